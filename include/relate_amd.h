@@ -1,0 +1,175 @@
+/*
+ * relate_amd.h -- C ABI of the MI355X-native Relate Paint -> BuildTopology path.
+ *
+ * Plain C types only (no torch, no C++ types).  Every entry point names the
+ * reference interface it replaces; paths are relative to
+ * /root/reference/include (MyersGroup/relate @ 2025-04-10).
+ *
+ * Conventions
+ *   - all functions return 0 on success and a negative RL_E* code on failure;
+ *     rl_last_error() returns a thread-local description of the last failure
+ *     (the reference asserts / exit(1)s instead: pipeline/Paint.cpp:24,78).
+ *   - caller owns every host buffer passed in or out; device memory is owned
+ *     by the rl_ctx / rl_window objects.
+ *   - one rl_ctx per host thread and GPU.  No CPU fallback exists: functions
+ *     that need the GPU fail with RL_ENODEVICE when none is visible.
+ */
+#ifndef RELATE_AMD_H
+#define RELATE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  RL_OK = 0,
+  RL_EINVAL = -1,    /* bad argument                                  */
+  RL_ENODEVICE = -2, /* no usable HIP device                          */
+  RL_EHIP = -3,      /* HIP runtime error (see rl_last_error)         */
+  RL_EIO = -4,       /* file could not be opened / read / written     */
+  RL_EFORMAT = -5,   /* malformed chunk / paint file                  */
+  RL_ESTATE = -6,    /* call sequence error (e.g. paint before load)  */
+  RL_ENOMEM = -7
+};
+
+/* Summation order of the per-site normalising constants.
+ *   RL_SUM_EXACT : left-to-right over donors n = 0..N-1, bit-identical to the
+ *                  reference's serial loops (src/fast_painting.cpp:300-303,
+ *                  495-503).  Paint files / .anc are byte-identical.
+ *   RL_SUM_LANES : per-lane partial sums + wavefront xor-butterfly.  Same
+ *                  arithmetic, different association: distances agree to
+ *                  ~1e-7 relative before min-subtraction, trees may differ
+ *                  where MinMatch breaks float ties.       */
+enum { RL_SUM_EXACT = 0, RL_SUM_LANES = 1 };
+
+typedef struct rl_ctx rl_ctx;
+typedef struct rl_window rl_window;
+
+const char *rl_last_error(void);
+const char *rl_version(void);
+/* number of visible HIP devices (0 when none; never initialises a context) */
+int rl_device_count(void);
+
+/* ---------------------------------------------------------------- context */
+rl_ctx *rl_create(int device);
+void rl_destroy(rl_ctx *ctx);
+
+/* Replaces `Data::Data(chunk files)` (src/data.cpp:86-97) + the parameter
+ * read of pipeline/Paint.cpp:23-31: loads <dir>/parameters_c<c>.bin and
+ * <dir>/chunk_<c>.{hap,r,rpos,bp,dist,state}. */
+int rl_load_chunk(rl_ctx *ctx, const char *dir, int chunk_index);
+
+/* Same, from memory (what a cgo/JNI-style binding of the reference's `Data`
+ * struct, src/data.hpp:44-103, would pass).  seq: L*N chars '0'/'1',
+ * SNP-major; r: L; rpos: L+1; wb: W+1 window boundaries (wb[W]==L). */
+int rl_set_chunk(rl_ctx *ctx, int N, int L, const uint8_t *seq,
+                 const double *r, const double *rpos, const int *wb, int W);
+/* Same, panel already bit-packed (bit n of row s = derived), row_words
+ * uint32 per row. */
+int rl_set_chunk_bits(rl_ctx *ctx, int N, int L, const uint32_t *bits,
+                      int row_words, const double *r, const double *rpos,
+                      const int *wb, int W);
+
+/* `--painting theta,rho` (pipeline/Paint.cpp:38-61): data.theta = theta,
+ * data.r[l] *= rho.  Must precede rl_paint / rl_window_open. */
+int rl_set_painting(rl_ctx *ctx, double theta, double rho);
+
+int rl_chunk_dims(const rl_ctx *ctx, int *N, int *L, int *W);
+/* sum_k D_k: visited (target, site) pairs of the chunk; 2*N*this is the
+ * number of directional haplotype-pair.SNP updates of one Paint. */
+long long rl_total_sites(rl_ctx *ctx);
+
+/* ------------------------------------------------------------------ Paint */
+/* Replaces the hot loop `for hap: FastPainting::PaintSteppingStones`
+ * (pipeline/Paint.cpp:81-87, src/fast_painting.cpp:18-618) for all N
+ * targets: forward/backward Li-Stephens over the bit-packed panel, stepping
+ * stones (alpha, beta, logscales at window boundaries) left in HBM.
+ * kernel_ms (optional) receives the GPU time of the kernels (HIP events). */
+int rl_paint(rl_ctx *ctx, int sum_mode, float *kernel_ms);
+
+/* Copy stepping stones of window w to the host: alpha, beta: N*N floats
+ * ([target][donor]); ls_alpha, ls_beta: N floats; bsnp_begin/end: N ints.
+ * Any pointer may be NULL. */
+int rl_get_stones(rl_ctx *ctx, int w, float *alpha, float *beta,
+                  float *ls_alpha, float *ls_beta, int *bsnp_begin,
+                  int *bsnp_end);
+
+/* Replaces the dump at src/fast_painting.cpp:589-601 +
+ * CollapsedMatrix::DumpToFile (src/collapsed_matrix.hpp:228-265): writes
+ * <paint_dir>/relate_<w>.bin for every window, byte-compatible with the
+ * reference (lossy RLE included). */
+int rl_write_paint_files(rl_ctx *ctx, const char *paint_dir);
+
+/* The whole `Relate --mode Paint` stage (pipeline/Paint.cpp:17-108): load,
+ * optional --painting, mkdir chunk_<c>/paint, paint, write files. */
+int rl_stage_paint(const char *out_dir, int chunk_index, int use_painting,
+                   double theta, double rho, int sum_mode, int device);
+
+/* ------------------------------------------------------- RePaint + matrix */
+/* Replaces DistanceMeasure::GetTopologyWithRepaint
+ * (src/anc_builder.cpp:49-106): decodes window w's stepping stones from
+ * paint_file (or, if NULL, from the stones resident after rl_paint, passed
+ * through the same float/RLE quantisation the file applies) and runs
+ * FastPainting::RePaintSection (src/fast_painting.cpp:621-1092) for all N
+ * targets.  The posterior rows (`topology`) and logscales stay in HBM.
+ * first_snp initialises the cursors v_snp_prev / v_rpos_prev / v_rpos_next
+ * (anc_builder.cpp:81-101). */
+rl_window *rl_window_open(rl_ctx *ctx, int w, const char *paint_file,
+                          int first_snp, int sum_mode, float *kernel_ms);
+void rl_window_close(rl_window *win);
+int rl_window_bounds(const rl_window *win, int *start, int *end);
+/* rows D_n of target n's topology and copies of it (tests / debugging):
+ * top: D_n*N floats in donor order, logscales: D_n floats. */
+int rl_window_rows(const rl_window *win, int n);
+int rl_window_get_topology(rl_window *win, int n, float *top,
+                           float *logscales);
+
+/* AncesTreeBuilder::BuildTopology's cursor update for the carriers of `snp`
+ * (src/anc_builder.cpp:487-495). */
+int rl_window_advance(rl_window *win, int snp);
+/* Replaces DistanceMeasure::GetMatrix(snp) (src/anc_builder.cpp:109-207):
+ * N*N float distance matrix at `snp`, row-min subtracted, into d_host
+ * (may be NULL to leave the result on the device only).
+ * kernel_ms optional. */
+int rl_window_matrix(rl_window *win, int snp, float *d_host, float *kernel_ms);
+
+/* --------------------------------------------------------------- host side */
+/* Replaces MinMatch::QuickBuild (src/tree_builder.cpp:1061-1303 without
+ * prior, :2358-2644 with prior) for sample_ages == empty: builds the tree
+ * from the asymmetric N*N matrix d (destroyed).  parent[2N-1] receives the
+ * parent of every node (-1 for the root); child_left/child_right (optional)
+ * the children of the N-1 internal nodes N..2N-2. */
+int rl_quickbuild(int N, double theta, float *d, const float *d_prior,
+                  int *parent, int *child_left, int *child_right);
+
+/* The whole `Relate --mode BuildTopology` stage
+ * (pipeline/BuildTopology.cpp:14-167) for sections first..last: writes
+ * <out>/chunk_<c>/<out>_<section>.anc and .mut.
+ * flags: bit0 = --no_consistency, fb = --fb value (0 = off). */
+int rl_stage_build_topology(const char *out_dir, int chunk_index,
+                            int first_section, int last_section,
+                            int use_painting, double theta, double rho,
+                            int flags, int fb, int sum_mode, int device);
+
+/* ------------------------------------------------------------------ tools */
+/* Synthetic block-coalescent panel (stand-in for MakeChunks input,
+ * SURVEY.md 8d).  seq_chars (L*N) and/or bits (L*row_words) may be NULL. */
+int rl_synth_panel(int N, int L, uint64_t seed, int block, int jitter,
+                   uint8_t *seq_chars, uint32_t *bits, int row_words, int *bp,
+                   double *r, double *rpos);
+/* the reference's window rule (src/data.cpp:213-229); returns W (<0 on error) */
+int rl_synth_windows(int N, int L, const uint8_t *seq_chars, double budget,
+                     int *wb, int max_windows);
+/* chunk files as Data::MakeChunks writes them (src/data.cpp:261-298,485-516) */
+int rl_write_chunk_files(const char *dir, int chunk, int N, int L,
+                         const uint8_t *seq_chars, const int *bp,
+                         const double *r, const double *rpos, const int *wb,
+                         int W);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

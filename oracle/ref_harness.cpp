@@ -1,0 +1,181 @@
+// ref_harness.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// A small driver that links the *reference's own* sources (compiled where
+// they lie under /root/reference by oracle/Makefile; nothing is copied) and
+// dumps intermediate results of the Paint -> BuildTopology path so that the
+// oracle restatement and the product can be pinned against the real thing:
+//
+//   ref_harness repaint  <outdir> <chunk> <window> <dump.bin>
+//       RePaintSection for every target of one window
+//       dump: int N; per target: int D; float logscales[D]; float top[D*N]
+//   ref_harness matrix   <outdir> <chunk> <window> <dump.bin> snp [snp ...]
+//       DistanceMeasure::GetMatrix at the window start and at each listed SNP
+//       (cursors advanced the way AncesTreeBuilder::BuildTopology does)
+//       dump: int N; per matrix: int snp; float d[N*N]
+//   ref_harness quickbuild <N> <d.bin> <parents.out> [<prior.bin>]
+//       MinMatch::QuickBuild on a raw N*N float matrix (with optional prior)
+//       output: int parent[2N-1]
+//   ref_harness treeseq  <outdir> <chunk> <window> <dump.bin>
+//       runs AncesTreeBuilder::BuildTopology and dumps, for every tree,
+//       int pos; int parent[2N-1]
+//
+// This file only exists in this container's workflow: /root/reference does
+// not travel to the GPU box; the fixtures it produces do (tests/golden/).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "anc.hpp"
+#include "anc_builder.hpp"
+#include "data.hpp"
+#include "fast_painting.hpp"
+#include "tree_builder.hpp"
+
+static void read_params(const std::string &out, int chunk, int &N, int &L,
+                        std::vector<int> &wb) {
+  FILE *fp = fopen((out + "/parameters_c" + std::to_string(chunk) + ".bin").c_str(), "rb");
+  if (!fp) { fprintf(stderr, "cannot open parameters\n"); exit(1); }
+  int nw;
+  if (fread(&N, 4, 1, fp) != 1 || fread(&L, 4, 1, fp) != 1 || fread(&nw, 4, 1, fp) != 1) exit(1);
+  wb.resize(nw);
+  if (fread(&wb[0], 4, nw, fp) != (size_t)nw) exit(1);
+  fclose(fp);
+}
+
+static Data *load(const std::string &out, int chunk) {
+  std::string b = out + "/chunk_" + std::to_string(chunk);
+  Data *d = new Data((b + ".hap").c_str(), (b + ".bp").c_str(), (b + ".dist").c_str(),
+                     (b + ".r").c_str(), (b + ".rpos").c_str(), (b + ".state").c_str());
+  d->name = b + "/paint/relate";
+  d->N = d->sequence.size() ? (int)d->sequence.subVectorSize(0) : 0;
+  d->L = (int)d->sequence.size();
+  return d;
+}
+
+static void apply_painting(Data &data) {
+  const char *p = getenv("REF_PAINTING");  // "theta,rho" like --painting
+  if (!p) return;
+  std::string s(p), a, b;
+  size_t c = s.find(',');
+  a = s.substr(0, c);
+  b = s.substr(c + 1);
+  data.theta = std::stof(a);
+  data.ntheta = 1.0 - data.theta;
+  double rho = std::stof(b);
+  for (auto &x : data.r) x *= rho;
+}
+
+int main(int argc, char **argv) {
+  if (argc < 2) return 2;
+  std::string mode = argv[1];
+
+  if (mode == "quickbuild") {
+    int N = atoi(argv[2]);
+    Data data(N, 1);
+    CollapsedMatrix<float> d, prior;
+    d.resize(N, N);
+    FILE *fp = fopen(argv[3], "rb");
+    if (!fp || fread(&d[0][0], 4, (size_t)N * N, fp) != (size_t)N * N) return 1;
+    fclose(fp);
+    MinMatch tb(data);
+    Tree tree;
+    std::vector<double> ages;
+    if (argc > 5) {
+      prior.resize(N, N);
+      fp = fopen(argv[5], "rb");
+      if (!fp || fread(&prior[0][0], 4, (size_t)N * N, fp) != (size_t)N * N) return 1;
+      fclose(fp);
+      tb.QuickBuild(d, tree, ages, prior);
+    } else {
+      tb.QuickBuild(d, tree, ages);
+    }
+    fp = fopen(argv[4], "wb");
+    for (int i = 0; i < 2 * N - 1; i++) {
+      int p = tree.nodes[i].parent ? (*tree.nodes[i].parent).label : -1;
+      fwrite(&p, 4, 1, fp);
+    }
+    fclose(fp);
+    return 0;
+  }
+
+  std::string out = argv[2];
+  int chunk = atoi(argv[3]);
+  int window = atoi(argv[4]);
+  int N, L;
+  std::vector<int> wb;
+  read_params(out, chunk, N, L, wb);
+  Data *pd = load(out, chunk);
+  Data &data = *pd;
+  apply_painting(data);
+  FILE *fo = fopen(argv[5], "wb");
+  if (!fo) return 1;
+
+  if (mode == "repaint") {
+    FastPainting painter(data);
+    char fn[2048];
+    snprintf(fn, sizeof fn, "%s_%i.bin", data.name.c_str(), window);
+    FILE *fp = fopen(fn, "rb");
+    if (!fp) return 1;
+    fwrite(&N, 4, 1, fo);
+    for (int n = 0; n < N; n++) {
+      int s0, s1, bb, be;
+      float la, lb;
+      CollapsedMatrix<float> ab, bend, top;
+      std::vector<float> ls;
+      if (fread(&s0, 4, 1, fp) != 1 || fread(&s1, 4, 1, fp) != 1) return 1;
+      ab.ReadFromFile(fp, bb, la);
+      bend.ReadFromFile(fp, be, lb);
+      painter.RePaintSection(data, top, ls, ab, bend, bb, be, la, lb, n);
+      int D = (int)ls.size();
+      fwrite(&D, 4, 1, fo);
+      fwrite(&ls[0], 4, D, fo);
+      for (int i = 0; i < D; i++) fwrite(&top[i][0], 4, N, fo);
+    }
+    fclose(fp);
+  } else if (mode == "matrix") {
+    int start = wb[window];
+    DistanceMeasure d(data, window);
+    fwrite(&N, 4, 1, fo);
+    d.GetMatrix(start);
+    fwrite(&start, 4, 1, fo);
+    fwrite(&d.matrix[0][0], 4, (size_t)N * N, fo);
+    int cur = start;
+    for (int a = 6; a < argc; a++) {
+      int snp = atoi(argv[a]);
+      for (int s = cur + 1; s <= snp; s++) {
+        for (int i = 0; i < N; i++) {
+          if (data.sequence[s][i] == '1') {
+            d.v_snp_prev[i]++;
+            d.v_rpos_prev[i] = data.rpos[s];
+          }
+        }
+      }
+      cur = snp;
+      d.GetMatrix(snp);
+      fwrite(&snp, 4, 1, fo);
+      fwrite(&d.matrix[0][0], 4, (size_t)N * N, fo);
+    }
+  } else if (mode == "treeseq") {
+    data.Ne = std::max(17.5f * data.N, 30000.0f);
+    std::vector<double> ages;
+    AncesTree anc;
+    AncesTreeBuilder ab(data, ages, 1);
+    int start = wb[window];
+    int end = (window < (int)wb.size() - 2) ? wb[window + 1] - 1 : data.L - 1;
+    ab.BuildTopology(window, start, end, data, anc, 1, true, 0);
+    fwrite(&N, 4, 1, fo);
+    for (auto &mt : anc.seq) {
+      fwrite(&mt.pos, 4, 1, fo);
+      for (int i = 0; i < 2 * N - 1; i++) {
+        int p = mt.tree.nodes[i].parent ? (*mt.tree.nodes[i].parent).label : -1;
+        fwrite(&p, 4, 1, fo);
+      }
+    }
+  } else {
+    return 2;
+  }
+  fclose(fo);
+  return 0;
+}
