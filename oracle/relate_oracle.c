@@ -128,42 +128,46 @@ int ro_plan_target(const ro_data *d, const int *wb, int W, int k, int *site,
 
 /* ------------------------------------------------------------------ */
 /* summation orders                                                   */
-static double sum_lanes(const double *t, int N, const ro_sum_order *o) {
-  double total = 0.0;
-  for (int w = 0; w < o->nwaves; w++) {
-    double lane[64];
-    for (int l = 0; l < 64; l++) {
-      double s = 0.0;
-      long base = ((long)w * 64 + l) * o->seg;
-      for (int i = 0; i < o->seg; i++) {
-        long n = base + i;
-        s += (n < N) ? t[n] : 0.0;
-      }
-      lane[l] = s;
+/* Order of the HIP RL_SUM_LANES kernels (relate_amd/csrc/paint_device.h):
+ * the P = N-1 donors n != k, in donor order, are cut into 64 contiguous runs
+ * (the first P%64 runs hold P/64+1 donors, the rest P/64); each run is summed
+ * left to right from 0.0, then an xor-butterfly (masks 1..32) combines the 64
+ * partial sums. */
+static double sum_lanes(const double *t, int N, int k) {
+  const int P = N - 1, q = P / 64, rem = P % 64;
+  double lane[64];
+  int p = 0;
+  for (int l = 0; l < 64; l++) {
+    const int len = q + (l < rem ? 1 : 0);
+    double s = 0.0;
+    for (int i = 0; i < len; i++, p++) {
+      const int n = p + (p >= k ? 1 : 0);
+      s += t[n];
     }
-    for (int m = 1; m < 64; m <<= 1) {
-      double nxt[64];
-      for (int l = 0; l < 64; l++) nxt[l] = lane[l] + lane[l ^ m];
-      memcpy(lane, nxt, sizeof lane);
-    }
-    total = (w == 0) ? lane[0] : total + lane[0];
+    lane[l] = s;
   }
-  return total;
+  for (int m = 1; m < 64; m <<= 1) {
+    double nxt[64];
+    for (int l = 0; l < 64; l++) nxt[l] = lane[l] + lane[l ^ m];
+    memcpy(lane, nxt, sizeof lane);
+  }
+  return lane[0];
 }
 
-static inline double sum_alpha(const double *a, int N, const ro_sum_order *o) {
+static inline double sum_alpha(const double *a, int N, int k, const ro_sum_order *o) {
   if (o == NULL || o->mode == RO_SUM_SERIAL) {
     double s = 0.0;
     for (int n = 0; n < N; n++) s += a[n]; /* :300-303 */
     return s;
   }
-  return sum_lanes(a, N, o);
+  return sum_lanes(a, N, k);
 }
 
 /* sum_n e(n)*b[n], e = theta if (seq_k > row[n]) else ntheta  (:495-503) */
-static inline double sum_beta(const double *b, const char *row, char seq_k,
+static inline double sum_beta(const double *b, const char *row, int k,
                               int N, const paint_consts *c,
                               const ro_sum_order *o, double *scratch) {
+  const char seq_k = row[k];
   if (o == NULL || o->mode == RO_SUM_SERIAL) {
     double s = 0.0;
     for (int n = 0; n < N; n++) {
@@ -176,7 +180,7 @@ static inline double sum_beta(const double *b, const char *row, char seq_k,
   }
   for (int n = 0; n < N; n++)
     scratch[n] = (seq_k > row[n]) ? c->theta * b[n] : c->ntheta * b[n];
-  return sum_lanes(scratch, N, o);
+  return sum_lanes(scratch, N, k);
 }
 
 /* ------------------------------------------------------------------ */
@@ -235,7 +239,7 @@ static int paint_target(const ro_data *d, const paint_consts *c, const int *wb,
     }
     a[k] = 0.0;
   }
-  double S = sum_alpha(a, N, order);
+  double S = sum_alpha(a, N, k, order);
   double ls = 0.0;
   while (wa < W && bsnp_begin[wa] == 0) { /* :233-253 */
     for (int n = 0; n < N; n++) alpha[(size_t)wa * N + n] = (float)a[n];
@@ -255,7 +259,7 @@ static int paint_target(const ro_data *d, const paint_consts *c, const int *wb,
       a[n] = v;
     }
     a[k] = 0.0;
-    S = sum_alpha(a, N, order);
+    S = sum_alpha(a, N, k, order);
     cfac = S;
     if (cfac < c->lower || cfac > c->upper) { /* :334-347 */
       const double tmp = cfac;
@@ -282,17 +286,13 @@ static int paint_target(const ro_data *d, const paint_consts *c, const int *wb,
     const char *row = seq + (size_t)(L - 1) * N;
     const char seq_k = row[k];
     for (int n = 0; n < N; n++) b[n] = 1.0;
-    if (order == NULL || order->mode == RO_SUM_SERIAL) {
-      for (int n = 0; n < N; n++) { /* :421-430 */
-        if (seq_k > row[n])
-          B += c->theta;
-        else
-          B += c->ntheta;
-      }
-    } else {
-      for (int n = 0; n < N; n++)
-        ws->scratch[n] = (seq_k > row[n]) ? c->theta : c->ntheta;
-      B = sum_lanes(ws->scratch, N, order);
+    /* a sum of constants: always serial (the HIP path takes it from the host
+     * plan, relate_amd/csrc/context.cpp build_plan step 3) */
+    for (int n = 0; n < N; n++) { /* :421-430 */
+      if (seq_k > row[n])
+        B += c->theta;
+      else
+        B += c->ntheta;
     }
     B -= c->ntheta; /* :431 */
   }
@@ -317,7 +317,7 @@ static int paint_target(const ro_data *d, const paint_consts *c, const int *wb,
     }
     b[k] = 0.0;
     const char *row = seq + (size_t)snp * N;
-    B = sum_beta(b, row, row[k], N, c, order, ws->scratch);
+    B = sum_beta(b, row, k, N, c, order, ws->scratch);
     cfac = B;
     if (cfac < c->lower || cfac > c->upper) { /* :538-551 */
       const double tmp = cfac;
@@ -595,7 +595,7 @@ int ro_repaint_section(const ro_data *d, const float *alpha_begin,
   double *a = alpha;
   for (int n = 0; n < N; n++) a[n] = alpha_begin[n];
   a[k] = 0.0;
-  double S = sum_alpha(a, N, order);
+  double S = sum_alpha(a, N, k, order);
   double cfac = trans_factor(c, r_prob[0]) * S;
   double prev_logscale = logscales[0];
   for (int i = 1; i < D; i++) {
@@ -612,7 +612,7 @@ int ro_repaint_section(const ro_data *d, const float *alpha_begin,
       a[n] = v;
     }
     a[k] = 0.0;
-    S = sum_alpha(a, N, order);
+    S = sum_alpha(a, N, k, order);
     cfac = S;
     if (cfac < c->lower || cfac > c->upper) { /* :865-877 */
       const double tmp = cfac;
@@ -630,7 +630,7 @@ int ro_repaint_section(const ro_data *d, const float *alpha_begin,
   b[k] = 0.0;
   {
     const char *row = seq + (size_t)last_snp * N;
-    double B0 = sum_beta(b, row, row[k], N, c, order, scratch);
+    double B0 = sum_beta(b, row, k, N, c, order, scratch);
     a = alpha + (size_t)(D - 1) * N;
     float *t = topology + (size_t)(D - 1) * N;
     for (int n = 0; n < N; n++) t[n] = (float)(a[n] * b[n]); /* :930 */
@@ -652,7 +652,7 @@ int ro_repaint_section(const ro_data *d, const float *alpha_begin,
     }
     b[k] = 0.0;
     const char *row = seq + (size_t)site[j] * N;
-    double B = sum_beta(b, row, row[k], N, c, order, scratch);
+    double B = sum_beta(b, row, k, N, c, order, scratch);
     cfac = B;
     a = alpha + (size_t)j * N;
     float *t = topology + (size_t)j * N;

@@ -38,18 +38,17 @@ typedef struct {
 /* How the per-site normalising sums are accumulated.
  *   RO_SUM_SERIAL : left-to-right over n = 0..N-1, as the reference does
  *                   (fast_painting.cpp:300-303, 495-503).
- *   RO_SUM_LANES  : the order of the HIP "fast" kernels: the N donors are cut
- *                   into 64*nwaves contiguous segments of `seg` donors, each
- *                   segment summed left to right, then an xor-butterfly over
- *                   the 64 lanes (masks 1,2,4,8,16,32) and a left-to-right
- *                   sum over waves.  Used to check the fast kernels bit for
- *                   bit; it is NOT the reference order. */
+ *   RO_SUM_LANES  : the order of the HIP RL_SUM_LANES kernels: the N-1 donors
+ *                   n != k are cut into 64 contiguous, balanced runs, each run
+ *                   summed left to right, then an xor-butterfly over the 64
+ *                   partial sums (masks 1,2,4,8,16,32).  Used to check those
+ *                   kernels bit for bit; it is NOT the reference order. */
 enum { RO_SUM_SERIAL = 0, RO_SUM_LANES = 1 };
 
 typedef struct {
   int mode;   /* RO_SUM_* */
-  int seg;    /* donors per lane (RO_SUM_LANES) */
-  int nwaves; /* waves per target (RO_SUM_LANES) */
+  int seg;    /* unused */
+  int nwaves; /* unused */
 } ro_sum_order;
 
 /* fast_log.hpp:6-21 */

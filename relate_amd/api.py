@@ -1,0 +1,212 @@
+"""ctypes binding of librelate_amd.so (include/relate_amd.h).
+
+This is the Python-side mirror of the C ABI: thin wrappers, numpy in / numpy
+out.  There is no CPU fallback: if the shared library is missing, or no GPU is
+visible when a GPU entry point is called, an exception is raised.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librelate_amd.so")
+
+RL_SUM_EXACT = 0
+RL_SUM_LANES = 1
+
+_lib = None
+
+
+class RelateError(RuntimeError):
+    pass
+
+
+def lib():
+    """the loaded shared library (raises if it has not been built)"""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RelateError(
+                "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(make -C relate_amd/csrc)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.rl_last_error.restype = C.c_char_p
+        L.rl_version.restype = C.c_char_p
+        L.rl_create.restype = C.c_void_p
+        L.rl_create.argtypes = [C.c_int]
+        L.rl_destroy.argtypes = [C.c_void_p]
+        L.rl_total_sites.restype = C.c_longlong
+        L.rl_total_sites.argtypes = [C.c_void_p]
+        L.rl_window_open.restype = C.c_void_p
+        L.rl_window_open.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_void_p]
+        L.rl_window_close.argtypes = [C.c_void_p]
+        L.rl_stage_paint.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int]
+        L.rl_stage_build_topology.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                                              C.c_double, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.rl_quickbuild.argtypes = [C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p]
+        L.rl_set_painting.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise RelateError("librelate_amd error %d: %s" % (rc, lib().rl_last_error().decode()))
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def device_count():
+    return lib().rl_device_count()
+
+
+class Context:
+    """One chunk on one GPU (rl_ctx)."""
+
+    def __init__(self, device=0):
+        self._h = lib().rl_create(device)
+        if not self._h:
+            raise RelateError(lib().rl_last_error().decode())
+        self.N = self.L = self.W = 0
+
+    def close(self):
+        if self._h:
+            lib().rl_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def _dims(self):
+        n, l, w = C.c_int(), C.c_int(), C.c_int()
+        _check(lib().rl_chunk_dims(C.c_void_p(self._h), C.byref(n), C.byref(l), C.byref(w)))
+        self.N, self.L, self.W = n.value, l.value, w.value
+
+    def load_chunk(self, out_dir, chunk_index=0):
+        _check(lib().rl_load_chunk(C.c_void_p(self._h), out_dir.encode(), chunk_index))
+        self._dims()
+
+    def set_chunk(self, seq, r, rpos, wb):
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        L, N = seq.shape
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        rpos = np.ascontiguousarray(rpos, dtype=np.float64)
+        wb = np.ascontiguousarray(wb, dtype=np.int32)
+        assert len(r) == L and len(rpos) == L + 1
+        _check(lib().rl_set_chunk(C.c_void_p(self._h), N, L, _p(seq), _p(r), _p(rpos), _p(wb), len(wb) - 1))
+        self._dims()
+
+    def set_chunk_bits(self, N, bits, r, rpos, wb):
+        bits = np.ascontiguousarray(bits, dtype=np.uint32)
+        L, rw = bits.shape
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        rpos = np.ascontiguousarray(rpos, dtype=np.float64)
+        wb = np.ascontiguousarray(wb, dtype=np.int32)
+        _check(lib().rl_set_chunk_bits(C.c_void_p(self._h), N, L, _p(bits), rw, _p(r), _p(rpos), _p(wb),
+                                       len(wb) - 1))
+        self._dims()
+
+    def set_painting(self, theta, rho):
+        _check(lib().rl_set_painting(C.c_void_p(self._h), theta, rho))
+
+    def total_sites(self):
+        v = lib().rl_total_sites(C.c_void_p(self._h))
+        if v < 0:
+            _check(int(v))
+        return v
+
+    def paint(self, sum_mode=RL_SUM_EXACT):
+        """-> kernel milliseconds"""
+        ms = C.c_float(0)
+        _check(lib().rl_paint(C.c_void_p(self._h), sum_mode, C.byref(ms)))
+        return ms.value
+
+    def stones(self, w):
+        N = self.N
+        out = dict(alpha=np.empty((N, N), np.float32), beta=np.empty((N, N), np.float32),
+                   ls_alpha=np.empty(N, np.float32), ls_beta=np.empty(N, np.float32),
+                   bsnp_begin=np.empty(N, np.int32), bsnp_end=np.empty(N, np.int32))
+        _check(lib().rl_get_stones(C.c_void_p(self._h), w, _p(out["alpha"]), _p(out["beta"]),
+                                   _p(out["ls_alpha"]), _p(out["ls_beta"]), _p(out["bsnp_begin"]),
+                                   _p(out["bsnp_end"])))
+        return out
+
+    def write_paint_files(self, paint_dir):
+        os.makedirs(paint_dir, exist_ok=True)
+        _check(lib().rl_write_paint_files(C.c_void_p(self._h), paint_dir.encode()))
+
+    def open_window(self, w, paint_file=None, first_snp=None, sum_mode=RL_SUM_EXACT):
+        return Window(self, w, paint_file, first_snp, sum_mode)
+
+
+class Window:
+    """DistanceMeasure for one window (rl_window): topology resident in HBM."""
+
+    def __init__(self, ctx, w, paint_file, first_snp, sum_mode):
+        self.ctx = ctx
+        ms = C.c_float(0)
+        fs = -1 if first_snp is None else int(first_snp)
+        self._h = lib().rl_window_open(C.c_void_p(ctx._h), w, paint_file.encode() if paint_file else None,
+                                       fs, sum_mode, C.byref(ms))
+        if not self._h:
+            raise RelateError(lib().rl_last_error().decode())
+        self.repaint_ms = ms.value
+        s, e = C.c_int(), C.c_int()
+        _check(lib().rl_window_bounds(C.c_void_p(self._h), C.byref(s), C.byref(e)))
+        self.start, self.end = s.value, e.value
+
+    def close(self):
+        if self._h:
+            lib().rl_window_close(C.c_void_p(self._h))
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def rows(self, n):
+        return lib().rl_window_rows(C.c_void_p(self._h), n)
+
+    def topology(self, n):
+        D, N = self.rows(n), self.ctx.N
+        top = np.empty((D, N), np.float32)
+        ls = np.empty(D, np.float32)
+        _check(lib().rl_window_get_topology(C.c_void_p(self._h), n, _p(top), _p(ls)))
+        return top, ls
+
+    def advance(self, snp):
+        _check(lib().rl_window_advance(C.c_void_p(self._h), snp))
+
+    def matrix(self, snp):
+        N = self.ctx.N
+        d = np.empty((N, N), np.float32)
+        ms = C.c_float(0)
+        _check(lib().rl_window_matrix(C.c_void_p(self._h), snp, _p(d), C.byref(ms)))
+        self.matrix_ms = ms.value
+        return d
+
+
+def quickbuild(d, theta=0.001, prior=None):
+    """MinMatch::QuickBuild on an N x N float matrix -> parent array (2N-1)"""
+    d = np.array(d, dtype=np.float32, order="C")
+    N = d.shape[0]
+    parent = np.empty(2 * N - 1, np.int32)
+    pr = None if prior is None else np.ascontiguousarray(prior, dtype=np.float32)
+    _check(lib().rl_quickbuild(N, theta, _p(d), _p(pr), _p(parent), None, None))
+    return parent
+
+
+def stage_paint(out_dir, chunk_index=0, painting=None, sum_mode=RL_SUM_EXACT, device=0):
+    th, rho = painting if painting else (0.001, 1.0)
+    _check(lib().rl_stage_paint(out_dir.encode(), chunk_index, 1 if painting else 0, th, rho, sum_mode, device))
+
+
+def stage_build_topology(out_dir, chunk_index, first_section, last_section, painting=None, no_consistency=False,
+                         fb=0, sum_mode=RL_SUM_EXACT, device=0):
+    th, rho = painting if painting else (0.001, 1.0)
+    _check(lib().rl_stage_build_topology(out_dir.encode(), chunk_index, first_section, last_section,
+                                         1 if painting else 0, th, rho, 1 if no_consistency else 0, fb,
+                                         sum_mode, device))

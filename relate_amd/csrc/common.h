@@ -1,0 +1,111 @@
+// common.h -- internal host-side declarations of librelate_amd.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "device_types.h"
+#include "launch.h"
+#include "relate_amd.h"
+
+namespace rl {
+
+void set_error(const char *fmt, ...);
+
+#define RL_HIP(call)                                                              \
+  do {                                                                            \
+    hipError_t e_ = (call);                                                       \
+    if (e_ != hipSuccess) {                                                       \
+      rl::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return RL_EHIP;                                                             \
+    }                                                                             \
+  } while (0)
+
+// owning device buffer
+struct DevBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+  ~DevBuf() { release(); }
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  int alloc(size_t n) {
+    if (n <= bytes && p) return RL_OK;
+    release();
+    if (n == 0) n = 16;
+    hipError_t e = hipMalloc(&p, n);
+    if (e != hipSuccess) {
+      p = nullptr;
+      set_error("hipMalloc(%zu bytes) failed: %s", n, hipGetErrorString(e));
+      return RL_ENOMEM;
+    }
+    bytes = n;
+    return RL_OK;
+  }
+  template <typename T>
+  int upload(const std::vector<T> &v) {
+    int rc = alloc(v.size() * sizeof(T));
+    if (rc) return rc;
+    if (!v.empty()) RL_HIP(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return RL_OK;
+  }
+  template <typename T>
+  T *as() const { return static_cast<T *>(p); }
+};
+
+// Per-target visited-site plan (fast_painting.cpp:41-157), host side.
+struct Plan {
+  std::vector<int64_t> off;      // [N+1]
+  std::vector<int32_t> sites;    // site | seq_k flag in bit 31
+  std::vector<double> cf, nxt;   // per visited site
+  std::vector<int32_t> ia, ie;   // [N][W] visited index of boundarySNP_begin/end
+  std::vector<int32_t> bb, be;   // [N][W] boundarySNP_begin/end
+  std::vector<double> binit;     // [N]
+  std::vector<int32_t> order;    // targets, longest first
+  bool valid = false;
+};
+
+PaintConsts make_consts(int N, double theta);
+// r_prob / nor_x_theta of one interval -> (cf, nxt) (fast_painting.cpp:72-80,260)
+void interval_coeffs(const PaintConsts &c, int N, double rho, double *cf, double *nxt);
+
+}  // namespace rl
+
+struct rl_ctx {
+  int device = 0;
+  hipStream_t s0 = nullptr, s1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+  int N = 0, L = 0, W = 0;
+  rl::Layout lay{};
+  int S = 0;
+  double theta = 0.001, rho = 1.0;
+  int row_words = 0;
+  std::vector<uint32_t> bits;  // host copy of the panel
+  std::vector<double> r, rpos; // r is the unscaled map; rho applied in the plan
+  std::vector<int> wb;
+  rl::Plan plan;
+  rl::PaintConsts consts{};
+  rl::DevBuf d_bits, d_off, d_sites, d_cf, d_nxt, d_ia, d_ie, d_binit, d_order;
+  rl::DevBuf d_alpha, d_beta, d_lsa, d_lsb;
+  bool have_chunk = false, plan_on_device = false, painted = false;
+  int paint_mode = -1;
+};
+
+namespace rl {
+int build_plan(rl_ctx *ctx);
+int upload_plan(rl_ctx *ctx);
+int host_threads();
+// paint-file codec (collapsed_matrix.hpp:228-296)
+size_t encode_stone(const float *v, int N, int bsnp, float logscale, unsigned char *out);
+size_t decode_stone(const unsigned char *in, size_t avail, int N, float *v, int *bsnp, float *logscale);
+float fast_log_host(float v);
+}  // namespace rl

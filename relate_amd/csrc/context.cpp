@@ -1,0 +1,686 @@
+// context.cpp -- chunk state, visited-site plan and the Paint stage host code.
+//
+// Host counterpart of pipeline/Paint.cpp:17-108 and of the O(L) per-target
+// precompute of fast_painting.cpp:41-157.  The precompute stays on the host
+// on purpose: it needs glibc's exp() and costs O(N*L)
+// additions against the kernels' O(N * sum_k D_k) updates.
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <thread>
+
+#include "common.h"
+
+namespace rl {
+
+static thread_local std::string g_err;
+
+void set_error(const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+
+int host_threads() {
+  const char *e = getenv("RELATE_AMD_THREADS");
+  int n = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+  if (n < 1) n = 1;
+  if (n > 256) n = 256;
+  return n;
+}
+
+template <typename F>
+static void parallel_for(int n, F f) {
+  int T = std::min(host_threads(), std::max(1, n));
+  if (T == 1) {
+    for (int i = 0; i < n; i++) f(i);
+    return;
+  }
+  std::vector<std::thread> th;
+  for (int t = 0; t < T; t++)
+    th.emplace_back([=]() {
+      for (int i = t; i < n; i += T) f(i);
+    });
+  for (auto &x : th) x.join();
+}
+
+// FastPainting::FastPainting (fast_painting.hpp:26-39)
+PaintConsts make_consts(int N, double theta) {
+  PaintConsts c;
+  const double ntheta = 1.0 - theta;
+  const double Nm1 = N - 1.0;
+  c.theta = theta;
+  c.ntheta = ntheta;
+  const double prior_theta = theta / Nm1 - ntheta / Nm1;
+  const double prior_ntheta = ntheta / Nm1;
+  const double theta_ratio = theta / (1.0 - theta) - 1.0;
+  c.K1 = theta_ratio + 1.0;
+  c.init0 = prior_ntheta;
+  c.init1 = prior_theta + prior_ntheta;
+  c.log_Nm1 = std::log(Nm1);
+  c.log_ntheta = std::log(ntheta);
+  c.lower = 1e-10;
+  c.upper = 1.0 / c.lower;
+  return c;
+}
+
+void interval_coeffs(const PaintConsts &c, int N, double rho, double *cf, double *nxt) {
+  double nx = -rho + c.log_ntheta;
+  double rp = 1.0 - std::exp(-rho);
+  if (rp > 0.99) {
+    rp = 0.99;
+    nx = std::log(0.01) + c.log_ntheta;
+  }
+  *nxt = nx;
+  *cf = rp / ((1.0 - rp) * (N - 1.0));
+}
+
+// ---------------------------------------------------------------------------
+// Visited-site plan for every target.
+int build_plan(rl_ctx *ctx) {
+  const int N = ctx->N, L = ctx->L, W = ctx->W, rw = ctx->row_words;
+  Plan &pl = ctx->plan;
+  const uint32_t *bits = ctx->bits.data();
+  ctx->consts = make_consts(N, ctx->theta);
+  const PaintConsts c = ctx->consts;
+  std::vector<double> r(ctx->r);
+  if (ctx->rho != 1.0)
+    for (auto &x : r) x *= ctx->rho;  // Paint.cpp:57-59
+
+  // 1. counts of derived sites per target over SNPs 1..L-2
+  std::vector<int64_t> cnt((size_t)N, 0);
+  const int words = (N + 31) / 32;
+  parallel_for(words, [&](int w) {
+    int64_t local[32] = {0};
+    for (int s = 1; s < L - 1; s++) {
+      uint32_t x = bits[(size_t)s * rw + w];
+      while (x) {
+        int b = __builtin_ctz(x);
+        local[b]++;
+        x &= x - 1;
+      }
+    }
+    for (int b = 0; b < 32 && w * 32 + b < N; b++) cnt[w * 32 + b] = local[b];
+  });
+  pl.off.assign((size_t)N + 1, 0);
+  for (int k = 0; k < N; k++) pl.off[k + 1] = pl.off[k] + cnt[k] + 2;
+  const int64_t total = pl.off[N];
+  pl.sites.assign((size_t)total, 0);
+  pl.cf.assign((size_t)total, 0.0);
+  pl.nxt.assign((size_t)total, 0.0);
+  pl.ia.assign((size_t)N * W, 0);
+  pl.ie.assign((size_t)N * W, 0);
+  pl.bb.assign((size_t)N * W, 0);
+  pl.be.assign((size_t)N * W, 0);
+  pl.binit.assign((size_t)N, 0.0);
+
+  // 2. visited-site lists (site | flag "target derived here")
+  parallel_for(words, [&](int w) {
+    int64_t pos[32];
+    for (int b = 0; b < 32 && w * 32 + b < N; b++) {
+      int k = w * 32 + b;
+      pos[b] = pl.off[k];
+      uint32_t x0 = bits[w];
+      pl.sites[pos[b]++] = 0 | (((x0 >> b) & 1u) ? (int32_t)0x80000000 : 0);
+    }
+    for (int s = 1; s < L - 1; s++) {
+      uint32_t x = bits[(size_t)s * rw + w];
+      while (x) {
+        int b = __builtin_ctz(x);
+        pl.sites[pos[b]++] = s | (int32_t)0x80000000;
+        x &= x - 1;
+      }
+    }
+    uint32_t xl = bits[(size_t)(L - 1) * rw + w];
+    for (int b = 0; b < 32 && w * 32 + b < N; b++)
+      pl.sites[pos[b]++] = (L - 1) | (((xl >> b) & 1u) ? (int32_t)0x80000000 : 0);
+  });
+
+  // 3. interval coefficients, window boundaries, initial beta sum
+  const std::vector<int> &wb = ctx->wb;
+  parallel_for(N, [&](int k) {
+    const int64_t o = pl.off[k];
+    const int D = (int)(pl.off[k + 1] - o);
+    int32_t *bb = &pl.bb[(size_t)k * W], *be = &pl.be[(size_t)k * W];
+    int32_t *ia = &pl.ia[(size_t)k * W], *ie = &pl.ie[(size_t)k * W];
+    int pb = 0, pe = 0, window_index = 1, window_end = wb[1];
+    bb[pb] = 0;
+    ia[pb++] = 0;
+    for (int i = 0; i < D; i++) {
+      const int s0 = pl.sites[o + i] & 0x7fffffff;
+      double acc = r[s0];
+      if (i + 1 < D) {
+        const int s1 = pl.sites[o + i + 1] & 0x7fffffff;
+        for (int s = s0 + 1; s < s1; s++) acc += r[s];  // :56-59, :93-96
+        if (s1 >= window_end && s0 < window_end) {      // :60-69, :98-107
+          while (window_end <= s1) {
+            be[pe] = s1;
+            ie[pe++] = i + 1;
+            bb[pb] = s0;
+            ia[pb++] = i;
+            window_index++;
+            window_end = wb[window_index];
+          }
+        }
+      }
+      interval_coeffs(c, N, acc, &pl.cf[o + i], &pl.nxt[o + i]);
+    }
+    be[pe] = L - 1;
+    ie[pe++] = D - 1;
+    // beta_sum at the last SNP: serial over n, including n == k (:421-431)
+    const bool seqk = pl.sites[o + D - 1] < 0;
+    const uint32_t *row = bits + (size_t)(L - 1) * rw;
+    double B = 0.0;
+    for (int n = 0; n < N; n++) {
+      const bool dn = (row[n >> 5] >> (n & 31)) & 1u;
+      if (seqk && !dn)
+        B += c.theta;
+      else
+        B += c.ntheta;
+    }
+    B -= c.ntheta;
+    pl.binit[k] = B;
+  });
+
+  // 4. launch order: longest target first
+  pl.order.resize(N);
+  std::iota(pl.order.begin(), pl.order.end(), 0);
+  std::stable_sort(pl.order.begin(), pl.order.end(), [&](int a, int b) {
+    return (pl.off[a + 1] - pl.off[a]) > (pl.off[b + 1] - pl.off[b]);
+  });
+  pl.valid = true;
+  ctx->plan_on_device = false;
+  return RL_OK;
+}
+
+int upload_plan(rl_ctx *ctx) {
+  if (ctx->plan_on_device) return RL_OK;
+  if (!ctx->plan.valid) {
+    int rc = build_plan(ctx);
+    if (rc) return rc;
+  }
+  Plan &pl = ctx->plan;
+  int rc;
+  if ((rc = ctx->d_bits.upload(ctx->bits))) return rc;
+  if ((rc = ctx->d_off.upload(pl.off))) return rc;
+  if ((rc = ctx->d_sites.upload(pl.sites))) return rc;
+  if ((rc = ctx->d_cf.upload(pl.cf))) return rc;
+  if ((rc = ctx->d_nxt.upload(pl.nxt))) return rc;
+  if ((rc = ctx->d_ia.upload(pl.ia))) return rc;
+  if ((rc = ctx->d_ie.upload(pl.ie))) return rc;
+  if ((rc = ctx->d_binit.upload(pl.binit))) return rc;
+  if ((rc = ctx->d_order.upload(pl.order))) return rc;
+  ctx->plan_on_device = true;
+  return RL_OK;
+}
+
+// ---------------------------------------------------------------------------
+// paint-file codec
+size_t encode_stone(const float *v, int N, int bsnp, float logscale, unsigned char *out) {
+  // collapsed_matrix.hpp:228-265: runs merge while |first - v| < 1e-3*min(first, v)
+  unsigned char *p = out;
+  const uint64_t isize = 1, isub = (uint64_t)N;
+  memcpy(p, &isize, 8); p += 8;
+  memcpy(p, &isub, 8); p += 8;
+  memcpy(p, &bsnp, 4); p += 4;
+  memcpy(p, &logscale, 4); p += 4;
+  unsigned char *pk = p;
+  p += 4;
+  float *uniq = reinterpret_cast<float *>(p);  // 4-byte aligned: 28-byte header
+  std::vector<int> times;
+  times.reserve(64);
+  float current = v[0];
+  int k = 0;
+  memcpy(&uniq[0], &current, 4);
+  times.push_back(1);
+  for (int j = 1; j < N; j++) {
+    const float diff = std::fabs(current - v[j]);
+    const float mn = std::min(current, v[j]);
+    if (diff < 1e-3 * mn) {
+      times[k]++;
+    } else {
+      current = v[j];
+      k++;
+      memcpy(&uniq[k], &current, 4);
+      times.push_back(1);
+    }
+  }
+  k++;
+  memcpy(pk, &k, 4);
+  p += (size_t)k * 4;
+  memcpy(p, times.data(), (size_t)k * 4);
+  p += (size_t)k * 4;
+  return (size_t)(p - out);
+}
+
+size_t decode_stone(const unsigned char *in, size_t avail, int N, float *v, int *bsnp, float *logscale) {
+  // collapsed_matrix.hpp:268-296
+  if (avail < 28) return 0;
+  uint64_t isize, isub;
+  int k;
+  memcpy(&isize, in, 8);
+  memcpy(&isub, in + 8, 8);
+  if (isize != 1 || isub != (uint64_t)N) return 0;
+  memcpy(bsnp, in + 16, 4);
+  memcpy(logscale, in + 20, 4);
+  memcpy(&k, in + 24, 4);
+  if (k < 0 || avail < 28 + (size_t)k * 8) return 0;
+  const unsigned char *pu = in + 28, *pt = pu + (size_t)k * 4;
+  int i = 0;
+  for (int j = 0; j < k; j++) {
+    float u;
+    int t;
+    memcpy(&u, pu + (size_t)j * 4, 4);
+    memcpy(&t, pt + (size_t)j * 4, 4);
+    if (t < 0 || i + t > N) return 0;
+    for (int q = 0; q < t; q++) v[i++] = u;
+  }
+  if (i != N) return 0;
+  return 28 + (size_t)k * 8;
+}
+
+float fast_log_host(float val) {
+  int32_t x;
+  memcpy(&x, &val, 4);
+  const int log_2 = ((x >> 23) & 255) - 128;
+  x &= ~(255 << 23);
+  x += 127 << 23;
+  memcpy(&val, &x, 4);
+  val = ((-1.0f / 3) * val + 2) * val - 2.0f / 3;
+  return (val + log_2) * 0.69314718f;
+}
+
+static int read_all(const std::string &fn, std::vector<unsigned char> &buf) {
+  FILE *fp = fopen(fn.c_str(), "rb");
+  if (!fp) {
+    set_error("cannot open %s", fn.c_str());
+    return RL_EIO;
+  }
+  fseek(fp, 0, SEEK_END);
+  long len = ftell(fp);
+  fseek(fp, 0, SEEK_SET);
+  buf.resize((size_t)len);
+  size_t got = len ? fread(buf.data(), 1, (size_t)len, fp) : 0;
+  fclose(fp);
+  if (got != (size_t)len) {
+    set_error("short read on %s", fn.c_str());
+    return RL_EIO;
+  }
+  return RL_OK;
+}
+
+template <typename T>
+static int read_vec(const std::string &fn, std::vector<T> &v) {
+  // Data::ReadVectorFromBin (data.hpp:90-99): u32 size, then size elements
+  std::vector<unsigned char> buf;
+  int rc = read_all(fn, buf);
+  if (rc) return rc;
+  if (buf.size() < 4) {
+    set_error("%s: truncated", fn.c_str());
+    return RL_EFORMAT;
+  }
+  uint32_t n;
+  memcpy(&n, buf.data(), 4);
+  if (buf.size() < 4 + (size_t)n * sizeof(T)) {
+    set_error("%s: truncated (%u elements expected)", fn.c_str(), n);
+    return RL_EFORMAT;
+  }
+  v.resize(n);
+  memcpy(v.data(), buf.data() + 4, (size_t)n * sizeof(T));
+  return RL_OK;
+}
+
+static int mkdir_p(const std::string &d) {
+  // filesys::MakeDir (filesystem.cpp:4-23): mkdir 0700 if absent
+  struct stat st;
+  if (stat(d.c_str(), &st) == 0) return RL_OK;
+  if (mkdir(d.c_str(), 0700) != 0 && stat(d.c_str(), &st) != 0) {
+    set_error("cannot create directory %s", d.c_str());
+    return RL_EIO;
+  }
+  return RL_OK;
+}
+
+}  // namespace rl
+
+using namespace rl;
+
+extern "C" {
+
+const char *rl_last_error(void) { return g_err.c_str(); }
+const char *rl_version(void) { return "relate_amd 0.1 (gfx950)"; }
+
+int rl_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+rl_ctx *rl_create(int device) {
+  int n = rl_device_count();
+  if (n <= 0 || device < 0 || device >= n) {
+    set_error("no usable HIP device (visible devices: %d, requested %d)", n, device);
+    return nullptr;
+  }
+  if (hipSetDevice(device) != hipSuccess) {
+    set_error("hipSetDevice(%d) failed", device);
+    return nullptr;
+  }
+  rl_ctx *ctx = new rl_ctx();
+  ctx->device = device;
+  if (hipStreamCreateWithFlags(&ctx->s0, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->s1, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
+      hipEventCreate(&ctx->ev2) != hipSuccess) {
+    set_error("stream/event creation failed");
+    delete ctx;
+    return nullptr;
+  }
+  return ctx;
+}
+
+void rl_destroy(rl_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->s0) (void)hipStreamDestroy(ctx->s0);
+  if (ctx->s1) (void)hipStreamDestroy(ctx->s1);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
+  delete ctx;
+}
+
+static int set_common(rl_ctx *ctx, int N, int L, const double *r, const double *rpos, const int *wb, int W) {
+  if (!ctx || N < 2 || L < 2 || W < 1 || !r || !rpos || !wb) {
+    set_error("rl_set_chunk: bad arguments");
+    return RL_EINVAL;
+  }
+  if (wb[0] != 0 || wb[W] != L) {
+    set_error("window boundaries must start at 0 and end at L=%d", L);
+    return RL_EINVAL;
+  }
+  for (int w = 0; w < W; w++)
+    if (wb[w + 1] <= wb[w]) {
+      set_error("window boundaries must be increasing");
+      return RL_EINVAL;
+    }
+  Layout lay = make_layout(N);
+  int S = choose_S(lay);
+  if (S == 0) {
+    set_error("N=%d exceeds the largest compiled register tile (N <= %d)", N, 160 * 64 + 1);
+    return RL_EINVAL;
+  }
+  ctx->N = N; ctx->L = L; ctx->W = W; ctx->lay = lay; ctx->S = S;
+  ctx->r.assign(r, r + L);
+  ctx->rpos.assign(rpos, rpos + L + 1);
+  ctx->wb.assign(wb, wb + W + 1);
+  ctx->row_words = ((N + 31) / 32 + 3 + 3) & ~3;  // >= 3 words of zero slack, 16-byte rows
+  ctx->theta = 0.001;  // data.cpp:95
+  ctx->rho = 1.0;
+  ctx->plan.valid = false;
+  ctx->plan_on_device = false;
+  ctx->painted = false;
+  ctx->have_chunk = true;
+  return RL_OK;
+}
+
+int rl_set_chunk(rl_ctx *ctx, int N, int L, const uint8_t *seq, const double *r, const double *rpos,
+                 const int *wb, int W) {
+  if (!seq) {
+    set_error("rl_set_chunk: seq is NULL");
+    return RL_EINVAL;
+  }
+  int rc = set_common(ctx, N, L, r, rpos, wb, W);
+  if (rc) return rc;
+  const int rw = ctx->row_words;
+  ctx->bits.assign((size_t)L * rw, 0u);
+  uint32_t *bits = ctx->bits.data();
+  parallel_for(L, [&](int s) {
+    const uint8_t *row = seq + (size_t)s * N;
+    uint32_t *o = bits + (size_t)s * rw;
+    for (int n = 0; n < N; n++)
+      if (row[n] == '1') o[n >> 5] |= 1u << (n & 31);
+  });
+  return RL_OK;
+}
+
+int rl_set_chunk_bits(rl_ctx *ctx, int N, int L, const uint32_t *bits, int row_words, const double *r,
+                      const double *rpos, const int *wb, int W) {
+  if (!bits || row_words < (N + 31) / 32) {
+    set_error("rl_set_chunk_bits: bad panel");
+    return RL_EINVAL;
+  }
+  int rc = set_common(ctx, N, L, r, rpos, wb, W);
+  if (rc) return rc;
+  const int rw = ctx->row_words, words = (N + 31) / 32;
+  ctx->bits.assign((size_t)L * rw, 0u);
+  uint32_t *o = ctx->bits.data();
+  const uint32_t lastmask = (N & 31) ? ((1u << (N & 31)) - 1u) : 0xffffffffu;
+  parallel_for(L, [&](int s) {
+    memcpy(o + (size_t)s * rw, bits + (size_t)s * row_words, (size_t)words * 4);
+    o[(size_t)s * rw + words - 1] &= lastmask;
+  });
+  return RL_OK;
+}
+
+int rl_load_chunk(rl_ctx *ctx, const char *dir, int chunk_index) {
+  if (!ctx || !dir) {
+    set_error("rl_load_chunk: bad arguments");
+    return RL_EINVAL;
+  }
+  const std::string d(dir), c = std::to_string(chunk_index);
+  // parameters_c<c>.bin: int N, L, W+1, wb[W+1]  (Paint.cpp:23-31)
+  std::vector<unsigned char> pbuf;
+  int rc = read_all(d + "/parameters_c" + c + ".bin", pbuf);
+  if (rc) return rc;
+  if (pbuf.size() < 12) {
+    set_error("parameters file truncated");
+    return RL_EFORMAT;
+  }
+  int N, L, nw;
+  memcpy(&N, pbuf.data(), 4);
+  memcpy(&L, pbuf.data() + 4, 4);
+  memcpy(&nw, pbuf.data() + 8, 4);
+  if (nw < 2 || pbuf.size() < 12 + (size_t)nw * 4) {
+    set_error("parameters file malformed");
+    return RL_EFORMAT;
+  }
+  std::vector<int> wb(nw);
+  memcpy(wb.data(), pbuf.data() + 12, (size_t)nw * 4);
+  // chunk_<c>.hap: u64 L, u64 N, L*N chars (collapsed_matrix.hpp:204-225)
+  std::vector<unsigned char> hap;
+  rc = read_all(d + "/chunk_" + c + ".hap", hap);
+  if (rc) return rc;
+  uint64_t hL, hN;
+  if (hap.size() < 16) {
+    set_error(".hap truncated");
+    return RL_EFORMAT;
+  }
+  memcpy(&hL, hap.data(), 8);
+  memcpy(&hN, hap.data() + 8, 8);
+  if ((int)hL != L || (int)hN != N || hap.size() < 16 + (size_t)L * N) {
+    set_error(".hap dimensions (%llu x %llu) disagree with parameters (%d x %d)",
+              (unsigned long long)hL, (unsigned long long)hN, L, N);
+    return RL_EFORMAT;
+  }
+  std::vector<double> r, rpos;
+  if ((rc = read_vec(d + "/chunk_" + c + ".r", r))) return rc;
+  if ((rc = read_vec(d + "/chunk_" + c + ".rpos", rpos))) return rc;
+  if ((int)r.size() != L || (int)rpos.size() != L + 1) {
+    set_error(".r/.rpos sizes disagree with L=%d", L);
+    return RL_EFORMAT;
+  }
+  return rl_set_chunk(ctx, N, L, hap.data() + 16, r.data(), rpos.data(), wb.data(), nw - 1);
+}
+
+int rl_set_painting(rl_ctx *ctx, double theta, double rho) {
+  if (!ctx || !ctx->have_chunk) {
+    set_error("rl_set_painting: no chunk loaded");
+    return RL_ESTATE;
+  }
+  if (!(theta > 0.0 && theta < 1.0)) {
+    set_error("theta must be in (0,1)");
+    return RL_EINVAL;
+  }
+  ctx->theta = theta;
+  ctx->rho = rho;
+  ctx->plan.valid = false;
+  ctx->plan_on_device = false;
+  ctx->painted = false;
+  return RL_OK;
+}
+
+int rl_chunk_dims(const rl_ctx *ctx, int *N, int *L, int *W) {
+  if (!ctx || !ctx->have_chunk) {
+    set_error("no chunk loaded");
+    return RL_ESTATE;
+  }
+  if (N) *N = ctx->N;
+  if (L) *L = ctx->L;
+  if (W) *W = ctx->W;
+  return RL_OK;
+}
+
+long long rl_total_sites(rl_ctx *ctx) {
+  if (!ctx || !ctx->have_chunk) return RL_ESTATE;
+  if (!ctx->plan.valid && build_plan(ctx)) return RL_EINVAL;
+  return ctx->plan.off[ctx->N];
+}
+
+int rl_paint(rl_ctx *ctx, int sum_mode, float *kernel_ms) {
+  if (!ctx || !ctx->have_chunk) {
+    set_error("rl_paint: no chunk loaded");
+    return RL_ESTATE;
+  }
+  if (sum_mode != RL_SUM_EXACT && sum_mode != RL_SUM_LANES) {
+    set_error("rl_paint: bad sum_mode");
+    return RL_EINVAL;
+  }
+  RL_HIP(hipSetDevice(ctx->device));
+  int rc = upload_plan(ctx);
+  if (rc) return rc;
+  const size_t N = ctx->N, W = ctx->W;
+  if ((rc = ctx->d_alpha.alloc(W * N * N * sizeof(float)))) return rc;
+  if ((rc = ctx->d_beta.alloc(W * N * N * sizeof(float)))) return rc;
+  if ((rc = ctx->d_lsa.alloc(W * N * sizeof(float)))) return rc;
+  if ((rc = ctx->d_lsb.alloc(W * N * sizeof(float)))) return rc;
+
+  PaintParams p;
+  p.lay = ctx->lay;
+  p.c = ctx->consts;
+  p.L = ctx->L;
+  p.W = ctx->W;
+  p.row_words = ctx->row_words;
+  p.bits = ctx->d_bits.as<uint32_t>();
+  p.plan_off = ctx->d_off.as<int64_t>();
+  p.sites = ctx->d_sites.as<int32_t>();
+  p.cf = ctx->d_cf.as<double>();
+  p.nxt = ctx->d_nxt.as<double>();
+  p.stone_ia = ctx->d_ia.as<int32_t>();
+  p.stone_ie = ctx->d_ie.as<int32_t>();
+  p.binit = ctx->d_binit.as<double>();
+  p.order = ctx->d_order.as<int32_t>();
+  p.alpha = ctx->d_alpha.as<float>();
+  p.beta = ctx->d_beta.as<float>();
+  p.ls_alpha = ctx->d_lsa.as<float>();
+  p.ls_beta = ctx->d_lsb.as<float>();
+  p.sum_mode = sum_mode;
+
+  // forward on s0, backward on s1; timed from ev0 to ev2 on s0
+  RL_HIP(hipEventRecord(ctx->ev0, ctx->s0));
+  RL_HIP(hipStreamWaitEvent(ctx->s1, ctx->ev0, 0));
+  RL_HIP(launch_paint(p, ctx->S, ctx->s0, ctx->s1));
+  RL_HIP(hipEventRecord(ctx->ev1, ctx->s1));
+  RL_HIP(hipStreamWaitEvent(ctx->s0, ctx->ev1, 0));
+  RL_HIP(hipEventRecord(ctx->ev2, ctx->s0));
+  RL_HIP(hipEventSynchronize(ctx->ev2));
+  if (kernel_ms) RL_HIP(hipEventElapsedTime(kernel_ms, ctx->ev0, ctx->ev2));
+  ctx->painted = true;
+  ctx->paint_mode = sum_mode;
+  return RL_OK;
+}
+
+int rl_get_stones(rl_ctx *ctx, int w, float *alpha, float *beta, float *ls_alpha, float *ls_beta,
+                  int *bsnp_begin, int *bsnp_end) {
+  if (!ctx || !ctx->painted) {
+    set_error("rl_get_stones: call rl_paint first");
+    return RL_ESTATE;
+  }
+  if (w < 0 || w >= ctx->W) {
+    set_error("window %d out of range", w);
+    return RL_EINVAL;
+  }
+  RL_HIP(hipSetDevice(ctx->device));
+  const size_t N = ctx->N, W = ctx->W;
+  if (alpha)
+    RL_HIP(hipMemcpy(alpha, ctx->d_alpha.as<float>() + w * N * N, N * N * 4, hipMemcpyDeviceToHost));
+  if (beta)
+    RL_HIP(hipMemcpy(beta, ctx->d_beta.as<float>() + w * N * N, N * N * 4, hipMemcpyDeviceToHost));
+  if (ls_alpha)
+    RL_HIP(hipMemcpy(ls_alpha, ctx->d_lsa.as<float>() + w * N, N * 4, hipMemcpyDeviceToHost));
+  if (ls_beta)
+    RL_HIP(hipMemcpy(ls_beta, ctx->d_lsb.as<float>() + w * N, N * 4, hipMemcpyDeviceToHost));
+  for (size_t k = 0; k < N; k++) {
+    if (bsnp_begin) bsnp_begin[k] = ctx->plan.bb[k * W + w];
+    if (bsnp_end) bsnp_end[k] = ctx->plan.be[k * W + w];
+  }
+  return RL_OK;
+}
+
+int rl_write_paint_files(rl_ctx *ctx, const char *paint_dir) {
+  if (!ctx || !ctx->painted || !paint_dir) {
+    set_error("rl_write_paint_files: call rl_paint first");
+    return RL_ESTATE;
+  }
+  const int N = ctx->N, W = ctx->W;
+  std::vector<float> a((size_t)N * N), b((size_t)N * N), la(N), lb(N);
+  std::vector<int> bb(N), be(N);
+  const size_t maxrec = 8 + 2 * (28 + (size_t)N * 8);
+  std::vector<unsigned char> recs((size_t)N * maxrec);
+  std::vector<size_t> lens(N);
+  for (int w = 0; w < W; w++) {
+    int rc = rl_get_stones(ctx, w, a.data(), b.data(), la.data(), lb.data(), bb.data(), be.data());
+    if (rc) return rc;
+    const int start = ctx->wb[w], end = ctx->wb[w + 1] - 1;  // fast_painting.cpp:591-594
+    parallel_for(N, [&](int k) {
+      unsigned char *p = recs.data() + (size_t)k * maxrec, *p0 = p;
+      memcpy(p, &start, 4); p += 4;
+      memcpy(p, &end, 4); p += 4;
+      p += encode_stone(a.data() + (size_t)k * N, N, bb[k], la[k], p);
+      p += encode_stone(b.data() + (size_t)k * N, N, be[k], lb[k], p);
+      lens[k] = (size_t)(p - p0);
+    });
+    const std::string fn = std::string(paint_dir) + "/relate_" + std::to_string(w) + ".bin";
+    FILE *fp = fopen(fn.c_str(), "wb");
+    if (!fp) {
+      set_error("cannot open %s for writing", fn.c_str());
+      return RL_EIO;
+    }
+    for (int k = 0; k < N; k++) fwrite(recs.data() + (size_t)k * maxrec, 1, lens[k], fp);
+    fclose(fp);
+  }
+  return RL_OK;
+}
+
+int rl_stage_paint(const char *out_dir, int chunk_index, int use_painting, double theta, double rho,
+                   int sum_mode, int device) {
+  rl_ctx *ctx = rl_create(device);
+  if (!ctx) return RL_ENODEVICE;
+  int rc = rl_load_chunk(ctx, out_dir, chunk_index);
+  if (!rc && use_painting) rc = rl_set_painting(ctx, theta, rho);
+  const std::string cdir = std::string(out_dir) + "/chunk_" + std::to_string(chunk_index);
+  if (!rc) rc = mkdir_p(cdir);
+  if (!rc) rc = mkdir_p(cdir + "/paint");
+  if (!rc) rc = rl_paint(ctx, sum_mode, nullptr);
+  if (!rc) rc = rl_write_paint_files(ctx, (cdir + "/paint").c_str());
+  rl_destroy(ctx);
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,88 @@
+// device_types.h -- parameter blocks shared by host code and HIP kernels.
+#pragma once
+#include <stdint.h>
+
+namespace rl {
+
+// Lane layout of one target's donors (DESIGN.md "register layout").
+// The wave of target k holds the P = N-1 donors n != k in "physical" order
+// p = n - (n > k); lane l owns the contiguous run
+//   [start_l, start_l + len_l),  start_l = l*q + min(l, rem),
+//   len_l = q + (l < rem),       q = P / 64, rem = P % 64
+// in registers 0..len_l-1; registers >= len_l hold +0.0 and stay +0.0.
+struct Layout {
+  int N, P, q, rem;
+};
+
+struct PaintConsts {
+  double theta, ntheta;
+  double K1;          // theta_ratio + 1.0           (fast_painting.hpp:36)
+  double init0;       // prior_ntheta                (fast_painting.hpp:35)
+  double init1;       // prior_theta + prior_ntheta  (fast_painting.cpp:219)
+  double log_Nm1;     // log(N-1)                    (fast_painting.cpp:399)
+  double log_ntheta;  // log(1-theta)
+  double lower, upper;  // rescaling thresholds 1e-10 / 1e10
+};
+
+struct PaintParams {
+  Layout lay;
+  PaintConsts c;
+  int L, W;
+  int row_words;            // uint32 per panel row
+  const uint32_t *bits;     // [L][row_words], bit n of row s = derived
+  const int64_t *plan_off;  // [N+1] offsets of target k's visited sites
+  const int32_t *sites;     // visited site | (seq_k derived ? 1<<31 : 0)
+  const double *cf;         // r_prob_i / ((1 - r_prob_i) * (N-1))
+  const double *nxt;        // nor_x_theta_i
+  const int32_t *stone_ia;  // [N][W] visited index of boundarySNP_begin[w]
+  const int32_t *stone_ie;  // [N][W] visited index of boundarySNP_end[w]
+  const double *binit;      // [N] beta_sum at the last SNP (serial, host)
+  const int32_t *order;     // [N] launch order -> target (longest first)
+  float *alpha, *beta;      // [W][N][N] stepping stones, donor order
+  float *ls_alpha, *ls_beta;  // [W][N]
+  int sum_mode;             // RL_SUM_EXACT / RL_SUM_LANES
+};
+
+// RePaintSection over one window, all targets.
+struct RepaintParams {
+  Layout lay;
+  PaintConsts c;
+  int L;
+  int row_words;
+  const uint32_t *bits;
+  const int64_t *plan_off;
+  const int32_t *sites;
+  const double *cf;
+  const double *nxt;
+  // per target: slice [ib, ie] of its visited list covered by this window and
+  // the coefficients of the window's last interval (r[last_snp] only,
+  // fast_painting.cpp:702-716)
+  const int32_t *ib, *ie;     // [N]
+  const double *cf_last;      // [N]
+  const double *nxt_last;     // [N]
+  const float *alpha_begin;   // [N][N] decoded stones, donor order
+  const float *beta_end;      // [N][N]
+  const float *ls_alpha;      // [N]
+  const float *ls_beta;       // [N]
+  const int64_t *top_off;     // [N+1] row offsets into topology/logscales
+  float *topology;            // [sum D][N] donor order
+  float *logscales;           // [sum D]
+  double *scratch;            // per-block alpha rows [maxD][S*64]
+  int64_t scratch_stride;     // doubles per block
+  const int32_t *order;       // [N]
+  int sum_mode;
+};
+
+struct MatrixParams {
+  int N;
+  const float *topology;
+  const float *logscales;
+  const int64_t *top_off;   // [N+1]
+  const int32_t *v_snp_prev;  // [N]
+  const uint8_t *direct;      // [N] 1: no interpolation
+  const double *wl, *wr;      // [N] interpolation weights
+  const float *e_pn, *e_np;   // [N] expf(ls_prev-ls_next), expf(ls_next-ls_prev)
+  float *matrix;              // [N][N]
+};
+
+}  // namespace rl
