@@ -1,3 +1,89 @@
+// matrix_kernels.hip -- K3: the N x N distance matrix at one SNP.
+//
+// Replaces the row loop of DistanceMeasure::GetMatrix (anc_builder.cpp:116-194).
+// One 256-thread block per target row n: reads one (derived at snp) or two
+// (interpolated) posterior rows of target n, applies fast_log (fast_log.hpp),
+// reduces the row minimum over all N computed entries (the diagonal's
+// fast_log(0) value included), writes d[n][j] - min (diagonal 0).
+// Traffic: <= 8N^2 B read + 4N^2 B written per call: HBM-bound.
 #include "paint_device.h"
 #include "launch.h"
-namespace rl { hipError_t launch_matrix(const MatrixParams &, const Layout &, int, hipStream_t) { return hipErrorNotSupported; } }
+
+namespace rl {
+
+// register-major index of donor j in target n's posterior row
+RL_DEV int phys_index(const Layout &lay, int n, int j) {
+  const int p = j - (j > n ? 1 : 0);
+  const int big = lay.rem * (lay.q + 1);
+  int l, i;
+  if (p < big) {
+    l = p / (lay.q + 1);
+    i = p - l * (lay.q + 1);
+  } else {
+    const int p2 = p - big;
+    l = lay.rem + p2 / lay.q;  // q > 0 here because p2 >= 0 implies lanes of length q exist
+    i = p2 - (l - lay.rem) * lay.q;
+  }
+  return i * 64 + l;
+}
+
+__global__ void __launch_bounds__(256) matrix_kernel(const MatrixParams p, const Layout lay, int S) {
+  extern __shared__ float vals[];  // N floats
+  __shared__ float red[256];
+  const int n = blockIdx.x;
+  const int N = p.N;
+  const int64_t stride = (int64_t)S * 64;
+  const int64_t r0 = p.top_off[n] + p.v_snp_prev[n];
+  const float *__restrict__ tp = p.topology + r0 * stride;
+  const float *__restrict__ tn = tp + stride;
+  const float ls_prev = p.logscales[r0];
+  const bool direct = p.direct[n] != 0;
+  const float ls_next = direct ? 0.0f : p.logscales[r0 + 1];
+  const double wl = p.wl[n], wr = p.wr[n];
+  const float e_pn = p.e_pn[n], e_np = p.e_np[n];
+  const float scale = -1.0f;
+
+  float mn = INFINITY;
+  for (int j = threadIdx.x; j < N; j += blockDim.x) {
+    float v;
+    if (direct) {
+      const float x = (j == n) ? 0.0f : tp[phys_index(lay, n, j)];
+      v = (fast_log_dev(x) + ls_prev) * scale;  // :128
+    } else {
+      float xp = 0.0f, xn = 0.0f;
+      if (j != n) {
+        const int idx = phys_index(lay, n, j);
+        xp = tp[idx];
+        xn = tn[idx];
+      }
+      if (ls_prev <= ls_next) {  // :172-178
+        const float x = (float)(wl * xp * e_pn + wr * xn);
+        v = (fast_log_dev(x) + ls_next) * scale;
+      } else {
+        const float x = (float)(wl * xp + wr * xn * e_np);
+        v = (fast_log_dev(x) + ls_prev) * scale;
+      }
+    }
+    vals[j] = v;
+    if (v < mn) mn = v;
+  }
+  red[threadIdx.x] = mn;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      const float o = red[threadIdx.x + s];
+      if (o < red[threadIdx.x]) red[threadIdx.x] = o;
+    }
+    __syncthreads();
+  }
+  mn = red[0];
+  float *__restrict__ out = p.matrix + (size_t)n * N;
+  for (int j = threadIdx.x; j < N; j += blockDim.x) out[j] = (j == n) ? 0.0f : vals[j] - mn;  // :190-192
+}
+
+hipError_t launch_matrix(const MatrixParams &p, const Layout &lay, int S, hipStream_t stream) {
+  hipLaunchKernelGGL(matrix_kernel, dim3(p.N), dim3(256), (size_t)p.N * sizeof(float), stream, p, lay, S);
+  return hipGetLastError();
+}
+
+}  // namespace rl

@@ -1,12 +1,370 @@
-// window.cpp -- placeholder, replaced below
+// window.cpp -- rl_window: DistanceMeasure for one window, topology in HBM.
+//
+// Host counterpart of DistanceMeasure (anc_builder.hpp:50-109):
+//   rl_window_open    = GetTopologyWithRepaint   (anc_builder.cpp:49-106)
+//   rl_window_advance = the cursor update of AncesTreeBuilder::BuildTopology
+//                       (anc_builder.cpp:487-495)
+//   rl_window_matrix  = GetMatrix                (anc_builder.cpp:109-207)
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
 #include "common.h"
+
 using namespace rl;
-extern "C" {
-rl_window *rl_window_open(rl_ctx *, int, const char *, int, int, float *) { set_error("not implemented"); return nullptr; }
-void rl_window_close(rl_window *) {}
-int rl_window_bounds(const rl_window *, int *, int *) { return RL_ESTATE; }
-int rl_window_rows(const rl_window *, int) { return RL_ESTATE; }
-int rl_window_get_topology(rl_window *, int, float *, float *) { return RL_ESTATE; }
-int rl_window_advance(rl_window *, int) { return RL_ESTATE; }
-int rl_window_matrix(rl_window *, int, float *, float *) { return RL_ESTATE; }
+
+struct rl_window {
+  rl_ctx *ctx = nullptr;
+  int w = 0;
+  int start = 0, end = 0;  // section_startpos / section_endpos as stored in the paint file
+  std::vector<int64_t> top_off;  // [N+1]
+  std::vector<float> logscales;  // host copy, [sum D]
+  std::vector<int32_t> v_snp_prev;
+  std::vector<double> v_rpos_prev, v_rpos_next;
+  DevBuf d_top, d_ls, d_top_off, d_matrix;
+  DevBuf d_vsp, d_direct, d_wl, d_wr, d_epn, d_enp;
+};
+
+static inline bool derived(const rl_ctx *ctx, int snp, int n) {
+  return (ctx->bits[(size_t)snp * ctx->row_words + (n >> 5)] >> (n & 31)) & 1u;
 }
+
+static int read_file(const char *fn, std::vector<unsigned char> &buf) {
+  FILE *fp = fopen(fn, "rb");
+  if (!fp) {
+    set_error("cannot open %s", fn);
+    return RL_EIO;
+  }
+  fseek(fp, 0, SEEK_END);
+  long len = ftell(fp);
+  fseek(fp, 0, SEEK_SET);
+  buf.resize((size_t)len);
+  size_t got = len ? fread(buf.data(), 1, (size_t)len, fp) : 0;
+  fclose(fp);
+  if (got != (size_t)len) {
+    set_error("short read on %s", fn);
+    return RL_EIO;
+  }
+  return RL_OK;
+}
+
+extern "C" {
+
+rl_window *rl_window_open(rl_ctx *ctx, int w, const char *paint_file, int first_snp, int sum_mode,
+                          float *kernel_ms) {
+  if (!ctx || !ctx->have_chunk || w < 0 || w >= ctx->W) {
+    set_error("rl_window_open: bad arguments");
+    return nullptr;
+  }
+  if (sum_mode != RL_SUM_EXACT && sum_mode != RL_SUM_LANES) {
+    set_error("rl_window_open: bad sum_mode");
+    return nullptr;
+  }
+  if (hipSetDevice(ctx->device) != hipSuccess) {
+    set_error("hipSetDevice failed");
+    return nullptr;
+  }
+  if (upload_plan(ctx)) return nullptr;
+  const int N = ctx->N, L = ctx->L, W = ctx->W, S = ctx->S;
+  const Plan &pl = ctx->plan;
+
+  // ---- stepping stones of this window, after the file's float/RLE quantisation
+  std::vector<float> ab((size_t)N * N), be((size_t)N * N), la(N), lb(N);
+  std::vector<int> bb(N), bend(N);
+  int start = ctx->wb[w], end = ctx->wb[w + 1] - 1;
+  if (paint_file) {
+    std::vector<unsigned char> buf;
+    if (read_file(paint_file, buf)) return nullptr;
+    size_t pos = 0;
+    for (int n = 0; n < N; n++) {  // anc_builder.cpp:61-73
+      if (pos + 8 > buf.size()) {
+        set_error("%s: truncated at target %d", paint_file, n);
+        return nullptr;
+      }
+      memcpy(&start, buf.data() + pos, 4);
+      memcpy(&end, buf.data() + pos + 4, 4);
+      pos += 8;
+      size_t u = decode_stone(buf.data() + pos, buf.size() - pos, N, &ab[(size_t)n * N], &bb[n], &la[n]);
+      if (!u) {
+        set_error("%s: malformed alpha record of target %d", paint_file, n);
+        return nullptr;
+      }
+      pos += u;
+      u = decode_stone(buf.data() + pos, buf.size() - pos, N, &be[(size_t)n * N], &bend[n], &lb[n]);
+      if (!u) {
+        set_error("%s: malformed beta record of target %d", paint_file, n);
+        return nullptr;
+      }
+      pos += u;
+    }
+  } else {
+    if (!ctx->painted) {
+      set_error("rl_window_open: no paint file given and rl_paint has not run");
+      return nullptr;
+    }
+    if (rl_get_stones(ctx, w, ab.data(), be.data(), la.data(), lb.data(), bb.data(), bend.data()))
+      return nullptr;
+    // decode(encode(x)): the file round trip is part of the numerics
+    std::vector<unsigned char> tmp(28 + (size_t)N * 8);
+    for (int n = 0; n < N; n++) {
+      int bs;
+      float ls;
+      encode_stone(&ab[(size_t)n * N], N, bb[n], la[n], tmp.data());
+      decode_stone(tmp.data(), tmp.size(), N, &ab[(size_t)n * N], &bs, &ls);
+      encode_stone(&be[(size_t)n * N], N, bend[n], lb[n], tmp.data());
+      decode_stone(tmp.data(), tmp.size(), N, &be[(size_t)n * N], &bs, &ls);
+    }
+  }
+
+  // ---- per-target slices of the visited-site plan
+  std::vector<int32_t> ib(N), ie(N);
+  std::vector<double> cf_last(N), nxt_last(N);
+  std::vector<double> r(ctx->r);
+  if (ctx->rho != 1.0)
+    for (auto &x : r) x *= ctx->rho;
+  rl_window *win = new rl_window();
+  win->ctx = ctx;
+  win->w = w;
+  win->start = start;
+  win->end = end;
+  win->top_off.assign((size_t)N + 1, 0);
+  int maxD = 0;
+  for (int n = 0; n < N; n++) {
+    ib[n] = pl.ia[(size_t)n * W + w];
+    ie[n] = pl.ie[(size_t)n * W + w];
+    if (pl.bb[(size_t)n * W + w] != bb[n] || pl.be[(size_t)n * W + w] != bend[n]) {
+      set_error("paint file boundary SNPs of target %d (%d,%d) disagree with the chunk (%d,%d)", n, bb[n],
+                bend[n], pl.bb[(size_t)n * W + w], pl.be[(size_t)n * W + w]);
+      delete win;
+      return nullptr;
+    }
+    const int D = ie[n] - ib[n] + 1;
+    maxD = std::max(maxD, D);
+    win->top_off[n + 1] = win->top_off[n] + D;
+    // last interval of RePaintSection: r[last_snp] only (fast_painting.cpp:702-716)
+    interval_coeffs(ctx->consts, N, r[bend[n]], &cf_last[n], &nxt_last[n]);
+  }
+  const int64_t rows = win->top_off[N];
+  std::vector<int32_t> order(N);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(),
+                   [&](int a, int b) { return (ie[a] - ib[a]) > (ie[b] - ib[b]); });
+
+  DevBuf d_ab, d_be, d_la, d_lb, d_ib, d_ie, d_cfl, d_nxl, d_order, d_scratch, d_counter;
+  const int nblocks = std::min(N, 2048);
+  const int64_t scratch_stride = (int64_t)maxD * (S + 1) * 64;
+  int rc = 0;
+  rc = rc ? rc : d_ab.upload(ab);
+  rc = rc ? rc : d_be.upload(be);
+  rc = rc ? rc : d_la.upload(la);
+  rc = rc ? rc : d_lb.upload(lb);
+  rc = rc ? rc : d_ib.upload(ib);
+  rc = rc ? rc : d_ie.upload(ie);
+  rc = rc ? rc : d_cfl.upload(cf_last);
+  rc = rc ? rc : d_nxl.upload(nxt_last);
+  rc = rc ? rc : d_order.upload(order);
+  rc = rc ? rc : win->d_top_off.upload(win->top_off);
+  rc = rc ? rc : win->d_top.alloc((size_t)rows * S * 64 * sizeof(float));
+  rc = rc ? rc : win->d_ls.alloc((size_t)rows * sizeof(float));
+  rc = rc ? rc : d_scratch.alloc((size_t)nblocks * scratch_stride * sizeof(double));
+  rc = rc ? rc : d_counter.alloc(sizeof(int));
+  rc = rc ? rc : win->d_matrix.alloc((size_t)N * N * sizeof(float));
+  if (rc) {
+    delete win;
+    return nullptr;
+  }
+
+  RepaintParams p;
+  p.lay = ctx->lay;
+  p.c = ctx->consts;
+  p.L = L;
+  p.row_words = ctx->row_words;
+  p.bits = ctx->d_bits.as<uint32_t>();
+  p.plan_off = ctx->d_off.as<int64_t>();
+  p.sites = ctx->d_sites.as<int32_t>();
+  p.cf = ctx->d_cf.as<double>();
+  p.nxt = ctx->d_nxt.as<double>();
+  p.ib = d_ib.as<int32_t>();
+  p.ie = d_ie.as<int32_t>();
+  p.cf_last = d_cfl.as<double>();
+  p.nxt_last = d_nxl.as<double>();
+  p.alpha_begin = d_ab.as<float>();
+  p.beta_end = d_be.as<float>();
+  p.ls_alpha = d_la.as<float>();
+  p.ls_beta = d_lb.as<float>();
+  p.top_off = win->d_top_off.as<int64_t>();
+  p.topology = win->d_top.as<float>();
+  p.logscales = win->d_ls.as<float>();
+  p.scratch = d_scratch.as<double>();
+  p.scratch_stride = scratch_stride;
+  p.order = d_order.as<int32_t>();
+  p.sum_mode = sum_mode;
+
+  bool ok = hipMemsetAsync(d_counter.p, 0, sizeof(int), ctx->s0) == hipSuccess;
+  ok = ok && hipEventRecord(ctx->ev0, ctx->s0) == hipSuccess;
+  hipError_t le = ok ? launch_repaint(p, S, nblocks, d_counter.as<int>(), ctx->s0) : hipErrorUnknown;
+  ok = ok && le == hipSuccess;
+  ok = ok && hipEventRecord(ctx->ev2, ctx->s0) == hipSuccess;
+  hipError_t se = hipEventSynchronize(ctx->ev2);
+  ok = ok && se == hipSuccess;
+  if (!ok) {
+    set_error("repaint launch failed: %s / %s", hipGetErrorString(le), hipGetErrorString(se));
+    delete win;
+    return nullptr;
+  }
+  if (kernel_ms) (void)hipEventElapsedTime(kernel_ms, ctx->ev0, ctx->ev2);
+  win->logscales.resize((size_t)rows);
+  if (hipMemcpy(win->logscales.data(), win->d_ls.p, (size_t)rows * sizeof(float), hipMemcpyDeviceToHost) !=
+      hipSuccess) {
+    set_error("copy of logscales failed");
+    delete win;
+    return nullptr;
+  }
+
+  // ---- cursors (anc_builder.cpp:81-101)
+  const int snp = first_snp < 0 ? ctx->wb[w] : first_snp;
+  win->v_snp_prev.assign(N, 0);
+  win->v_rpos_prev.assign(N, 0.0);
+  win->v_rpos_next.assign(N, 0.0);
+  if (snp > 0) {
+    for (int t = snp; t >= win->start; t--)
+      for (int n = 0; n < N; n++)
+        if (derived(ctx, t, n)) win->v_snp_prev[n]++;
+  }
+  for (int n = 0; n < N; n++) {
+    int t = snp;
+    while (!derived(ctx, t, n) && t > 0) t--;
+    win->v_rpos_prev[n] = ctx->rpos[t];
+    win->v_rpos_next[n] = win->v_rpos_prev[n];
+  }
+  return win;
+}
+
+void rl_window_close(rl_window *win) { delete win; }
+
+int rl_window_bounds(const rl_window *win, int *start, int *end) {
+  if (!win) return RL_EINVAL;
+  if (start) *start = win->start;
+  if (end) *end = win->end;
+  return RL_OK;
+}
+
+int rl_window_rows(const rl_window *win, int n) {
+  if (!win || n < 0 || n >= win->ctx->N) return RL_EINVAL;
+  return (int)(win->top_off[n + 1] - win->top_off[n]);
+}
+
+int rl_window_get_topology(rl_window *win, int n, float *top, float *logscales) {
+  if (!win || n < 0 || n >= win->ctx->N) {
+    set_error("rl_window_get_topology: bad arguments");
+    return RL_EINVAL;
+  }
+  const rl_ctx *ctx = win->ctx;
+  RL_HIP(hipSetDevice(ctx->device));
+  const int N = ctx->N, S = ctx->S;
+  const int D = (int)(win->top_off[n + 1] - win->top_off[n]);
+  const Layout &lay = ctx->lay;
+  if (logscales) memcpy(logscales, &win->logscales[win->top_off[n]], (size_t)D * sizeof(float));
+  if (top) {
+    std::vector<float> phys((size_t)D * S * 64);
+    RL_HIP(hipMemcpy(phys.data(), win->d_top.as<float>() + win->top_off[n] * (int64_t)S * 64,
+                     phys.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (int d = 0; d < D; d++) {
+      const float *row = &phys[(size_t)d * S * 64];
+      float *o = top + (size_t)d * N;
+      o[n] = 0.0f;  // alpha[n] = 0 for the target itself (fast_painting.cpp:781)
+      int p = 0;
+      for (int l = 0; l < 64; l++) {
+        const int len = lay.q + (l < lay.rem ? 1 : 0);
+        for (int i = 0; i < len; i++, p++) o[p + (p >= n ? 1 : 0)] = row[i * 64 + l];
+      }
+    }
+  }
+  return RL_OK;
+}
+
+int rl_window_advance(rl_window *win, int snp) {
+  if (!win || snp < 0 || snp >= win->ctx->L) {
+    set_error("rl_window_advance: bad arguments");
+    return RL_EINVAL;
+  }
+  const rl_ctx *ctx = win->ctx;
+  for (int n = 0; n < ctx->N; n++)
+    if (derived(ctx, snp, n)) {  // anc_builder.cpp:489-494
+      win->v_snp_prev[n]++;
+      win->v_rpos_prev[n] = ctx->rpos[snp];
+    }
+  return RL_OK;
+}
+
+int rl_window_matrix(rl_window *win, int snp, float *d_host, float *kernel_ms) {
+  if (!win || snp < 0 || snp >= win->ctx->L) {
+    set_error("rl_window_matrix: bad arguments");
+    return RL_EINVAL;
+  }
+  rl_ctx *ctx = win->ctx;
+  RL_HIP(hipSetDevice(ctx->device));
+  const int N = ctx->N, L = ctx->L;
+  std::vector<uint8_t> direct(N);
+  std::vector<double> wl(N, 0.5), wr(N, 0.5);
+  std::vector<float> epn(N, 1.0f), enp(N, 1.0f);
+  for (int n = 0; n < N; n++) {
+    const int p = win->v_snp_prev[n];
+    const int D = (int)(win->top_off[n + 1] - win->top_off[n]);
+    direct[n] = derived(ctx, snp, n) || snp == 0 || snp == L - 1;
+    if (p < 0 || p >= D || (!direct[n] && p + 1 >= D)) {
+      set_error("rl_window_matrix: cursor of target %d (%d) outside its %d posterior rows at SNP %d", n, p,
+                D, snp);
+      return RL_ESTATE;
+    }
+    if (direct[n]) continue;
+    if (win->v_rpos_next[n] <= win->v_rpos_prev[n]) {  // anc_builder.cpp:134-141
+      for (int l = snp; l < L; l++)
+        if (derived(ctx, l, n) || l == L - 1) {
+          win->v_rpos_next[n] = ctx->rpos[l];
+          break;
+        }
+    }
+    const double rp = win->v_rpos_prev[n], rn = win->v_rpos_next[n];
+    if (rp != rn) {  // :146-153
+      const double denom = rn - rp;
+      wl[n] = (rn - ctx->rpos[snp]) / denom;
+      wr[n] = (ctx->rpos[snp] - rp) / denom;
+    }
+    const float lsp = win->logscales[win->top_off[n] + p], lsn = win->logscales[win->top_off[n] + p + 1];
+    epn[n] = expf(lsp - lsn);  // float expf of a float difference (:167-168), glibc
+    enp[n] = expf(lsn - lsp);
+  }
+  int rc = 0;
+  rc = rc ? rc : win->d_vsp.upload(win->v_snp_prev);
+  rc = rc ? rc : win->d_direct.upload(direct);
+  rc = rc ? rc : win->d_wl.upload(wl);
+  rc = rc ? rc : win->d_wr.upload(wr);
+  rc = rc ? rc : win->d_epn.upload(epn);
+  rc = rc ? rc : win->d_enp.upload(enp);
+  if (rc) return rc;
+  MatrixParams p;
+  p.N = N;
+  p.topology = win->d_top.as<float>();
+  p.logscales = win->d_ls.as<float>();
+  p.top_off = win->d_top_off.as<int64_t>();
+  p.v_snp_prev = win->d_vsp.as<int32_t>();
+  p.direct = win->d_direct.as<uint8_t>();
+  p.wl = win->d_wl.as<double>();
+  p.wr = win->d_wr.as<double>();
+  p.e_pn = win->d_epn.as<float>();
+  p.e_np = win->d_enp.as<float>();
+  p.matrix = win->d_matrix.as<float>();
+  RL_HIP(hipEventRecord(ctx->ev0, ctx->s0));
+  RL_HIP(launch_matrix(p, ctx->lay, ctx->S, ctx->s0));
+  RL_HIP(hipEventRecord(ctx->ev2, ctx->s0));
+  if (d_host)
+    RL_HIP(hipMemcpyAsync(d_host, win->d_matrix.p, (size_t)N * N * sizeof(float), hipMemcpyDeviceToHost,
+                          ctx->s0));
+  RL_HIP(hipStreamSynchronize(ctx->s0));
+  if (kernel_ms) RL_HIP(hipEventElapsedTime(kernel_ms, ctx->ev0, ctx->ev2));
+  return RL_OK;
+}
+
+}  // extern "C"

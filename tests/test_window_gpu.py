@@ -1,0 +1,91 @@
+"""K2 (RePaintSection) and K3 (GetMatrix) parity: HIP vs the CPU oracle.
+
+The oracle paints the chunk to paint files (byte-identical to the reference's,
+see test_oracle_ref.py / test_oracle_golden.py); both sides then read the same
+file, repaint the window and build distance matrices at several SNPs.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import rlutil
+from relate_amd import api
+
+pytestmark = pytest.mark.gpu
+
+
+def u32(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def run_case(tmp_path, N, L, budget, seed, theta=0.001, rho=1.0, windows=None, via_gpu_paint=False):
+    o = rlutil.oracle()
+    ch = rlutil.synth_chunk(N, L, seed=seed, budget=budget)
+    ctx = api.Context()
+    ctx.set_chunk(ch.seq, ch.r, ch.rpos, ch.wb)
+    if theta != 0.001 or rho != 1.0:
+        ctx.set_painting(theta, rho)
+        ch.theta = theta
+        ch.r = ch.r * rho
+    d = ch.ro()
+    pdir = str(tmp_path)
+    if via_gpu_paint:
+        ctx.paint(api.RL_SUM_EXACT)
+        ctx.write_paint_files(pdir)
+    else:
+        rc = o.ro_paint_chunk(C.byref(d), ch.wb.ctypes.data_as(C.c_void_p), ch.W, pdir.encode(), 4, 0, None, None)
+        assert rc == 0
+    W = ch.W
+    for w in (windows if windows is not None else sorted(set([0, W // 2, W - 1]))):
+        pf = os.path.join(pdir, "relate_%d.bin" % w)
+        s0, s1 = int(ch.wb[w]), int(ch.wb[w + 1]) - 1
+        ow = o.ro_window_open(C.byref(d), pf.encode(), s0, 4)
+        assert ow
+        win = ctx.open_window(w, pf, s0, api.RL_SUM_EXACT)
+        assert (win.start, win.end) == (o.ro_window_start(C.c_void_p(ow)), o.ro_window_end(C.c_void_p(ow)))
+        for n in sorted(set([0, 1, N // 3, N - 1])):
+            D = o.ro_window_rows(C.c_void_p(ow), n)
+            assert win.rows(n) == D
+            top, ls = win.topology(n)
+            lso = np.ctypeslib.as_array(C.cast(o.ro_window_log(C.c_void_p(ow), n), C.POINTER(C.c_float)), (D,))
+            topo = np.ctypeslib.as_array(C.cast(o.ro_window_top(C.c_void_p(ow), n), C.POINTER(C.c_float)), (D, N))
+            assert np.array_equal(u32(ls), u32(lso)), (w, n, "logscales")
+            assert np.array_equal(u32(top), u32(topo)), (w, n, "topology")
+        # distance matrices at the window start and further in, cursors advanced
+        # the way AncesTreeBuilder::BuildTopology does (anc_builder.cpp:487-495)
+        M = np.zeros((N, N), np.float32)
+        snps = sorted(set([s0, s0 + 1, s0 + (s1 - s0) // 3, s0 + 2 * (s1 - s0) // 3, s1]))
+        cur = s0
+        for s in snps:
+            for t in range(cur + 1, s + 1):
+                o.ro_window_advance(C.c_void_p(ow), t)
+                win.advance(t)
+            cur = s
+            o.ro_window_matrix(C.c_void_p(ow), s, M.ctypes.data_as(C.c_void_p))
+            G = win.matrix(s)
+            assert np.array_equal(u32(G), u32(M)), (w, s, np.abs(G - M).max())
+        win.close()
+        o.ro_window_free(C.c_void_p(ow))
+    ctx.close()
+
+
+@pytest.mark.parametrize("N,L,budget,seed", [
+    (8, 600, 3000, 3),
+    (64, 1500, 30000, 1),
+    (65, 1200, 30000, 2),
+    (130, 1500, 200000, 5),
+    (600, 900, 3000000, 11),
+])
+def test_window_matches_oracle(tmp_path, N, L, budget, seed):
+    run_case(tmp_path, N, L, budget, seed)
+
+
+def test_window_painting_params(tmp_path):
+    run_case(tmp_path, 200, 1500, 400000, 7, theta=0.025, rho=3.0)
+
+
+def test_gpu_paint_files_feed_window(tmp_path):
+    # paint files written by the HIP Paint stage, read back by both sides
+    run_case(tmp_path, 96, 1400, 60000, 9, via_gpu_paint=True)
