@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py -- Paint (stepping-stone Li-Stephens forward/backward) throughput.
+
+One "step" = one pass of the Paint hot path over one synthetic chunk already
+resident in HBM: the backward kernel + the forward kernel for all N targets
+(replacing the loop of pipeline/Paint.cpp:81-87 in the reference).
+
+    python bench.py [--gpus N --steps K --warmup W] [--n 5000 --l 500000]
+
+With --gpus N > 1 the driver launches one rank per GPU with torch.distributed.run;
+ranks paint independent chunks (chunks are embarrassingly parallel in the
+reference too: scripts/RelateParallel/RelateParallel.sh:216) -> weak scaling,
+no data-path collective.  Rank 0 prints ONE JSON line.
+
+Metric (BASELINE.json): directional haplotype-pair.SNP updates per second,
+2 * N * sum_k D_k per Paint, D_k = sites visited by target k.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def make_chunk(N, L, seed, memory_gb):
+    """synthetic block-coalescent panel, bit-packed, + the reference's window rule"""
+    from relate_amd import api
+    lib = api.lib()
+    rw = (N + 31) // 32
+    bits = np.zeros((L, rw), dtype=np.uint32)
+    r = np.zeros(L)
+    rpos = np.zeros(L + 1)
+    rc = lib.rl_synth_panel(N, L, C.c_uint64(seed), 100, 1, None, bits.ctypes.data_as(C.c_void_p), rw, None,
+                            r.ctypes.data_as(C.c_void_p), rpos.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    # data.cpp:129: min_memory_size = mem*1e9/4 - (2N^2 + 3N) floats per window
+    budget = memory_gb * 1e9 / 4.0 - (2.0 * N * N + 3.0 * N)
+    wbuf = np.zeros(L + 2, dtype=np.int32)
+    W = lib.rl_synth_windows_bits(N, L, bits.ctypes.data_as(C.c_void_p), rw, C.c_double(budget),
+                                  wbuf.ctypes.data_as(C.c_void_p), 499)
+    assert W > 0, "window rule failed (raise --memory)"
+    return bits, r, rpos, wbuf[:W + 1].copy()
+
+
+def cpu_baseline(N, L, bits, r, rpos, wb, seconds_target=15.0):
+    """the oracle (plain-C port of the reference's PaintSteppingStones) timed on
+    the host cores on a bounded sample of targets of the SAME chunk"""
+    import rlutil
+    o = rlutil.oracle()
+    cores = min(os.cpu_count() or 1, 64)
+    seq = np.unpackbits(bits.view(np.uint8), axis=1, bitorder="little")[:, :N]
+    seq = np.ascontiguousarray(seq + ord("0"), dtype=np.uint8)
+    d = rlutil.RoData(N, L, seq.ctypes.data, r.ctypes.data, rpos.ctypes.data, 0.001)
+    # ~3.1e8 updates/s/core measured on the reference; one target
+    # costs 2*N*D_k ~ 2*N*0.11*L updates
+    per_target = 2.0 * N * 0.12 * L / 3.0e8
+    per_thread = max(1, int(seconds_target / max(per_target, 1e-3)))
+    count = min(N, cores * per_thread)
+    stride = max(1, N // count)
+    t0 = time.time()
+    sites = o.ro_paint_sample(C.byref(d), wb.ctypes.data_as(C.c_void_p), len(wb) - 1, 0, stride, count, cores)
+    dt = time.time() - t0
+    assert sites > 0
+    return dict(value=2.0 * N * sites / dt, unit="updates/s", cores=cores, kind="port",
+                sample="%d of %d targets (every %d-th) of the same chunk, oracle ro_paint_sample on %d threads, "
+                       "%.1f s wall" % (count, N, stride, cores, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=5000, help="haplotypes")
+    ap.add_argument("--l", type=int, default=500000, help="SNPs")
+    ap.add_argument("--memory", type=float, default=20.0, help="--memory of MakeChunks (window rule), GB")
+    ap.add_argument("--mode", default="exact", choices=["exact", "lanes"])
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-alt", action="store_true", help="skip timing the other summation mode")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+
+    from relate_amd import api
+    N, L = args.n, args.l
+    bits, r, rpos, wb = make_chunk(N, L, seed=1 + rank, memory_gb=args.memory)
+    ctx = api.Context(local_rank if world > 1 else 0)
+    ctx.set_chunk_bits(N, bits, r, rpos, wb)
+    sites = ctx.total_sites()
+    updates = 2.0 * N * sites
+    mode = api.RL_SUM_EXACT if args.mode == "exact" else api.RL_SUM_LANES
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(m, steps, warmup):
+        for _ in range(warmup):
+            ctx.paint(m)
+        barrier()
+        t0 = time.time()
+        fwd = bwd = 0.0
+        for _ in range(steps):
+            ctx.paint(m)  # returns after both kernels completed (HIP events)
+            f, b = ctx.paint_times()
+            fwd += f
+            bwd += b
+        barrier()
+        return time.time() - t0, fwd / steps, bwd / steps
+
+    dt, fwd_ms, bwd_ms = timed(mode, args.steps, args.warmup)
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        u = torch.tensor([updates], device="cuda", dtype=torch.float64)
+        dist.all_reduce(u, op=dist.ReduceOp.SUM)
+        total_updates = float(u.item())
+    else:
+        total_updates = updates
+
+    alt = None
+    if not args.no_alt:
+        other = api.RL_SUM_LANES if mode == api.RL_SUM_EXACT else api.RL_SUM_EXACT
+        adt, af, ab = timed(other, max(1, args.steps), 1 if other == api.RL_SUM_LANES else 0)
+        alt = dict(mode="lanes" if other == api.RL_SUM_LANES else "exact",
+                   value=updates * max(1, args.steps) / adt, ms_per_step=1e3 * adt / max(1, args.steps),
+                   fwd_kernel_ms=af, bwd_kernel_ms=ab,
+                   bwd_roofline_frac=(N * sites / 8.0) / (ab * 1e-3) / 1e9 / HBM_PEAK_GBS)
+
+    if rank == 0:
+        ms_per_step = 1e3 * dt / args.steps
+        # dominant kernel: the backward launch.  Algorithmic bytes = 1 bit per
+        # directional update: N * sum_k D_k / 8 per launch.
+        alg_bytes = N * sites / 8.0
+        achieved = alg_bytes / (bwd_ms * 1e-3) / 1e9
+        out = {
+            "metric": "haplotype-pair*SNP updates/sec (Paint)",
+            "value": total_updates * args.steps / dt,
+            "unit": "updates/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "synthetic block-coalescent panel, N=%d haplotypes x L=%d SNPs, 1 chunk per GPU, "
+                            "%d windows (--memory %g), Paint = PaintSteppingStones for all targets" %
+                            (N, L, len(wb) - 1, args.memory),
+                "sum_mode": args.mode,
+                "sum_k_D_k": int(sites),
+                "updates_per_step_per_gpu": updates,
+                "fwd_kernel_ms": fwd_ms,
+                "bwd_kernel_ms": bwd_ms,
+                "other_mode": alt,
+            },
+            "roofline": {"bound": "hbm", "kernel": "paint_kernel<backward>", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None},
+        }
+        if not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(N, L, bits, r, rpos, wb)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

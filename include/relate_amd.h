@@ -89,6 +89,9 @@ long long rl_total_sites(rl_ctx *ctx);
  * stones (alpha, beta, logscales at window boundaries) left in HBM.
  * kernel_ms (optional) receives the GPU time of the kernels (HIP events). */
 int rl_paint(rl_ctx *ctx, int sum_mode, float *kernel_ms);
+/* HIP-event durations of the last rl_paint's two launches (forward kernel,
+ * backward kernel), in milliseconds. */
+int rl_paint_times(const rl_ctx *ctx, float *fwd_ms, float *bwd_ms);
 
 /* Copy stepping stones of window w to the host: alpha, beta: N*N floats
  * ([target][donor]); ls_alpha, ls_beta: N floats; bsnp_begin/end: N ints.
@@ -163,6 +166,8 @@ int rl_synth_panel(int N, int L, uint64_t seed, int block, int jitter,
 /* the reference's window rule (src/data.cpp:213-229); returns W (<0 on error) */
 int rl_synth_windows(int N, int L, const uint8_t *seq_chars, double budget,
                      int *wb, int max_windows);
+int rl_synth_windows_bits(int N, int L, const uint32_t *bits, int row_words,
+                          double budget, int *wb, int max_windows);
 /* chunk files as Data::MakeChunks writes them (src/data.cpp:261-298,485-516) */
 int rl_write_chunk_files(const char *dir, int chunk, int N, int L,
                          const uint8_t *seq_chars, const int *bp,

@@ -125,6 +125,12 @@ class Context:
         _check(lib().rl_paint(C.c_void_p(self._h), sum_mode, C.byref(ms)))
         return ms.value
 
+    def paint_times(self):
+        """-> (forward kernel ms, backward kernel ms) of the last paint()"""
+        f, b = C.c_float(0), C.c_float(0)
+        _check(lib().rl_paint_times(C.c_void_p(self._h), C.byref(f), C.byref(b)))
+        return f.value, b.value
+
     def stones(self, w):
         N = self.N
         out = dict(alpha=np.empty((N, N), np.float32), beta=np.empty((N, N), np.float32),

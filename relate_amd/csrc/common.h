@@ -98,6 +98,7 @@ struct rl_ctx {
   rl::DevBuf d_alpha, d_beta, d_lsa, d_lsb;
   bool have_chunk = false, plan_on_device = false, painted = false;
   int paint_mode = -1;
+  float ms_fwd = 0.f, ms_bwd = 0.f;
 };
 
 namespace rl {

@@ -592,17 +592,28 @@ int rl_paint(rl_ctx *ctx, int sum_mode, float *kernel_ms) {
   p.ls_beta = ctx->d_lsb.as<float>();
   p.sum_mode = sum_mode;
 
-  // forward on s0, backward on s1; timed from ev0 to ev2 on s0
+  // backward then forward on one stream, each bracketed by HIP events
   RL_HIP(hipEventRecord(ctx->ev0, ctx->s0));
-  RL_HIP(hipStreamWaitEvent(ctx->s1, ctx->ev0, 0));
-  RL_HIP(launch_paint(p, ctx->S, ctx->s0, ctx->s1));
-  RL_HIP(hipEventRecord(ctx->ev1, ctx->s1));
-  RL_HIP(hipStreamWaitEvent(ctx->s0, ctx->ev1, 0));
+  RL_HIP(launch_paint(p, ctx->S, 1, ctx->s0));
+  RL_HIP(hipEventRecord(ctx->ev1, ctx->s0));
+  RL_HIP(launch_paint(p, ctx->S, 0, ctx->s0));
   RL_HIP(hipEventRecord(ctx->ev2, ctx->s0));
   RL_HIP(hipEventSynchronize(ctx->ev2));
-  if (kernel_ms) RL_HIP(hipEventElapsedTime(kernel_ms, ctx->ev0, ctx->ev2));
+  RL_HIP(hipEventElapsedTime(&ctx->ms_bwd, ctx->ev0, ctx->ev1));
+  RL_HIP(hipEventElapsedTime(&ctx->ms_fwd, ctx->ev1, ctx->ev2));
+  if (kernel_ms) *kernel_ms = ctx->ms_bwd + ctx->ms_fwd;
   ctx->painted = true;
   ctx->paint_mode = sum_mode;
+  return RL_OK;
+}
+
+int rl_paint_times(const rl_ctx *ctx, float *fwd_ms, float *bwd_ms) {
+  if (!ctx || !ctx->painted) {
+    set_error("rl_paint_times: call rl_paint first");
+    return RL_ESTATE;
+  }
+  if (fwd_ms) *fwd_ms = ctx->ms_fwd;
+  if (bwd_ms) *bwd_ms = ctx->ms_bwd;
   return RL_OK;
 }
 

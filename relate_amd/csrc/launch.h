@@ -33,7 +33,7 @@ inline Layout make_layout(int N) {
   return l;
 }
 
-hipError_t launch_paint(const PaintParams &p, int S, hipStream_t s_fwd, hipStream_t s_bwd);
+hipError_t launch_paint(const PaintParams &p, int S, int backward, hipStream_t stream);
 hipError_t launch_repaint(const RepaintParams &p, int S, int nblocks, int *counter, hipStream_t stream);
 hipError_t launch_matrix(const MatrixParams &p, const Layout &lay, int S, hipStream_t stream);
 

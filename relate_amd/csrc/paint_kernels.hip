@@ -2,8 +2,7 @@
 //
 // Replaces FastPainting::PaintSteppingStones (fast_painting.cpp:18-618).
 // Two launches of N wavefronts each (forward, backward: independent in this
-// stage, so they run concurrently on two streams); block b paints target
-// order[b].
+// stage); block b paints target order[b] (longest target first).
 #include "paint_device.h"
 #include "launch.h"
 
@@ -202,23 +201,27 @@ __global__ void __launch_bounds__(64) paint_kernel(const PaintParams p) {
 }
 
 template <int S, int TAIL>
-static hipError_t launch_paint_t(const PaintParams &p, hipStream_t s_fwd, hipStream_t s_bwd) {
+static hipError_t launch_paint_t(const PaintParams &p, int backward, hipStream_t stream) {
   const dim3 grid(p.lay.N), block(64);
   if (p.sum_mode == 0) {
-    hipLaunchKernelGGL((paint_kernel<S, TAIL, true, true>), grid, block, 0, s_bwd, p);
-    hipLaunchKernelGGL((paint_kernel<S, TAIL, true, false>), grid, block, 0, s_fwd, p);
+    if (backward)
+      hipLaunchKernelGGL((paint_kernel<S, TAIL, true, true>), grid, block, 0, stream, p);
+    else
+      hipLaunchKernelGGL((paint_kernel<S, TAIL, true, false>), grid, block, 0, stream, p);
   } else {
-    hipLaunchKernelGGL((paint_kernel<S, TAIL, false, true>), grid, block, 0, s_bwd, p);
-    hipLaunchKernelGGL((paint_kernel<S, TAIL, false, false>), grid, block, 0, s_fwd, p);
+    if (backward)
+      hipLaunchKernelGGL((paint_kernel<S, TAIL, false, true>), grid, block, 0, stream, p);
+    else
+      hipLaunchKernelGGL((paint_kernel<S, TAIL, false, false>), grid, block, 0, stream, p);
   }
   return hipGetLastError();
 }
 
-hipError_t launch_paint(const PaintParams &p, int S, hipStream_t s_fwd, hipStream_t s_bwd) {
+hipError_t launch_paint(const PaintParams &p, int S, int backward, hipStream_t stream) {
   switch (S) {
 #define RL_CASE(s, t) \
   case s:             \
-    return launch_paint_t<s, t>(p, s_fwd, s_bwd);
+    return launch_paint_t<s, t>(p, backward, stream);
     RL_FOR_EACH_S(RL_CASE)
 #undef RL_CASE
   }

@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "relate_amd.h"
@@ -55,13 +56,18 @@ int rl_synth_panel(int N, int L, uint64_t seed, int block, int jitter,
   if (N < 2 || L < 2 || block < 1) return -1;
   const int words = (N + 31) / 32;
   if (bits && row_words < words) return -1;
-  Rng rng(seed);
   const int nodes = 2 * N - 1;
+  const int nblocks = (L + block - 1) / block;
+  int T = (int)std::thread::hardware_concurrency();
+  if (const char *e = getenv("RELATE_AMD_THREADS")) T = atoi(e);
+  T = std::max(1, std::min(T, std::min(nblocks, 64)));
+  auto worker = [&](int tid) {
   std::vector<uint32_t> desc((size_t)nodes * words);
   std::vector<double> height(nodes), cum(nodes);
   std::vector<int> active(N);
-
-  for (int s0 = 0; s0 < L; s0 += block) {
+  for (int blk = tid; blk < nblocks; blk += T) {
+    const int s0 = blk * block;
+    Rng rng(seed * 0x9e3779b97f4a7c15ull + (uint64_t)blk + 1);  // one stream per block
     // Kingman tree
     std::fill(desc.begin(), desc.end(), 0u);
     for (int i = 0; i < N; i++) {
@@ -112,7 +118,14 @@ int rl_synth_panel(int N, int L, uint64_t seed, int block, int jitter,
       }
     }
   }
+  };
+  {
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; t++) th.emplace_back(worker, t);
+    for (auto &x : th) x.join();
+  }
   // positions: ~100 bp spacing, uniform 1 cM/Mb map (data.cpp:443-481)
+  Rng rng(seed ^ 0x5851f42d4c957f2dull);
   int pos = 1000;
   std::vector<int> bpv((size_t)L + 1);
   for (int s = 0; s <= L; s++) {
@@ -141,6 +154,29 @@ int rl_synth_windows(int N, int L, const uint8_t *seq_chars, double budget,
     int nd = 0;
     const uint8_t *row = seq_chars + (size_t)s * N;
     for (int n = 0; n < N; n++) nd += (row[n] == '1');
+    mem += (double)nd * (N + 1);
+    if (mem >= budget && in_window > 10) {
+      if (W >= max_windows) return -1;
+      in_window = 0;
+      mem = 0.0;
+      wb[W++] = s;
+    }
+    in_window++;
+  }
+  wb[W] = L;
+  return W;
+}
+
+int rl_synth_windows_bits(int N, int L, const uint32_t *bits, int row_words, double budget, int *wb,
+                          int max_windows) {
+  int W = 1, in_window = 0;
+  double mem = 0.0;
+  wb[0] = 0;
+  const int words = (N + 31) / 32;
+  for (int s = 0; s < L; s++) {
+    int nd = 0;
+    const uint32_t *row = bits + (size_t)s * row_words;
+    for (int w = 0; w < words; w++) nd += __builtin_popcount(row[w]);
     mem += (double)nd * (N + 1);
     if (mem >= budget && in_window > 10) {
       if (W >= max_windows) return -1;
