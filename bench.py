@@ -130,15 +130,8 @@ def main():
         return time.time() - t0, fwd / steps, bwd / steps
 
     dt, fwd_ms, bwd_ms = timed(mode, args.steps, args.warmup)
-    if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        u = torch.tensor([updates], device="cuda", dtype=torch.float64)
-        dist.all_reduce(u, op=dist.ReduceOp.SUM)
-        total_updates = float(u.item())
-    else:
-        total_updates = updates
+    from relate_amd import dist as rdist
+    total_updates, dt = rdist.job_stats(updates, dt)  # sum of units, max of seconds over ranks
 
     alt = None
     if not args.no_alt:

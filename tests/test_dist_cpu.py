@@ -1,0 +1,63 @@
+"""world_size-2 gloo test of the chunk-sharded multi-GPU path (CPU only).
+
+Each rank takes its share of the chunks and "paints" them -- with the oracle
+standing in as the per-chunk worker, since there is no GPU here -- and the
+job statistics are reduced exactly as bench.py does with RCCL."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import rlutil
+    from relate_amd import dist as rdist
+    o = rlutil.oracle()
+    chunks = list(range(5))
+    mine = rdist.shard(chunks, rank, world)
+    sites = 0
+    for c in mine:
+        ch = rlutil.synth_chunk(16, 300, seed=100 + c, budget=None)
+        d = ch.ro()
+        s = C.c_longlong(0)
+        assert o.ro_paint_chunk(C.byref(d), ch.wb.ctypes.data_as(C.c_void_p), ch.W, None, 1, 0, None,
+                                C.byref(s)) == 0
+        sites += s.value
+    total, tmax = rdist.job_stats(sites, 1.0 + rank)
+    q.put((rank, mine, sites, total, tmax))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_chunk_sharding_two_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, m0, s0, t0, x0), (r1, m1, s1, t1, x1) = res
+    assert m0 == [0, 2, 4] and m1 == [1, 3]          # disjoint cover of the chunks
+    assert t0 == t1 == s0 + s1                        # whole-job units
+    assert x0 == x1 == 2.0                            # max over ranks
+
+
+def test_shard_is_a_partition():
+    from relate_amd import dist as rdist
+    for world in (1, 2, 3, 8):
+        parts = [rdist.shard(list(range(11)), r, world) for r in range(world)]
+        assert sorted(sum(parts, [])) == list(range(11))

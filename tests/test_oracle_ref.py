@@ -1,0 +1,41 @@
+"""Live check of the oracle against the reference binary on fresh random
+chunks.  Needs oracle/_ref (built from /root/reference by `make -C oracle ref`),
+so it only runs in the build container; the committed fixtures
+(test_oracle_golden.py) carry the same evidence to the GPU box."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import rlutil
+
+pytestmark = [pytest.mark.ref,
+              pytest.mark.skipif(not rlutil.have_ref(), reason="oracle/_ref not built (no /root/reference)")]
+
+
+@pytest.mark.parametrize("N,L,budget,seed,painting", [
+    (33, 1500, 20000, 31, None),
+    (150, 2500, 500000, 32, None),
+    (90, 1200, 100000, 33, "0.01,40"),   # large rho: r_prob clamp at 0.99
+    (64, 4000, 60000, 34, "0.2,0.05"),   # large theta
+])
+def test_paint_files_match_reference_binary(tmp_path, oracle, N, L, budget, seed, painting):
+    ch = rlutil.synth_chunk(N, L, seed=seed, budget=budget)
+    ch.write(str(tmp_path / "out"))
+    args = ["--mode", "Paint", "--chunk_index", "0", "-o", "out"]
+    if painting:
+        args += ["--painting", painting]
+        th, rho = painting.split(",")
+        ch.theta = float(np.float32(th))
+        ch.r = ch.r * float(np.float32(rho))
+    rlutil.run_ref(args, cwd=str(tmp_path))
+    d = ch.ro()
+    out = tmp_path / "orc"
+    out.mkdir()
+    assert oracle.ro_paint_chunk(C.byref(d), ch.wb.ctypes.data_as(C.c_void_p), ch.W, str(out).encode(), 4, 0, None,
+                                 None) == 0
+    for w in range(ch.W):
+        a = open(tmp_path / "out" / "chunk_0" / "paint" / ("relate_%d.bin" % w), "rb").read()
+        b = open(out / ("relate_%d.bin" % w), "rb").read()
+        assert a == b, "window %d" % w

@@ -1,0 +1,122 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the REAL reference.
+
+Runs only in a container that has /root/reference: it needs oracle/_ref/Relate
+and oracle/_ref/ref_harness (`make -C oracle ref`).  The fixtures are data --
+inputs written by this repo's generator and outputs produced by the unmodified
+reference binary on them -- packed into compressed .npz files:
+
+  synth24.npz        N=24, L=900 synthetic chunk, ~6 windows: chunk files, every
+                     paint file, RePaintSection dump of one window, GetMatrix
+                     dumps at several SNPs, per-section .anc/.mut, tree dump
+  synth24_paint.npz  same chunk with --painting 0.025,2: paint files + matrices
+  example8.npz       first 3000 SNPs of the reference's bundled example/data
+                     (N=8) through MakeChunks (synthetic 1 cM/Mb map), Paint,
+                     BuildTopology: BASELINE.json config #1 (plumbing)
+  synth70.npz        N=70 (>64 lanes): paint files, matrices, .anc/.mut
+
+Usage: python tools/make_golden.py
+"""
+import gzip
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import rlutil  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def fbytes(path):
+    return np.frombuffer(open(path, "rb").read(), dtype=np.uint8)
+
+
+def run(cmd, cwd, env=None):
+    e = dict(os.environ)
+    if env:
+        e.update(env)
+    subprocess.run(cmd, cwd=cwd, check=True, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+
+
+def collect(work, out, W, painting=None, windows_dump=(1,), with_trees=True):
+    """run the reference stages in `work` (chunk files already in work/out)"""
+    pa = ["--painting", painting] if painting else []
+    env = {"REF_PAINTING": painting} if painting else None
+    run([rlutil.REF_RELATE, "--mode", "Paint", "--chunk_index", "0", "-o", out] + pa, work)
+    data = {}
+    for f in ["parameters_c0.bin", "chunk_0.hap", "chunk_0.r", "chunk_0.rpos", "chunk_0.bp", "chunk_0.dist",
+              "chunk_0.state"]:
+        data["in/" + f] = fbytes(os.path.join(work, out, f))
+    for w in range(W):
+        data["paint/relate_%d.bin" % w] = fbytes(os.path.join(work, out, "chunk_0", "paint", "relate_%d.bin" % w))
+    ch = rlutil.read_chunk(os.path.join(work, out))
+    for w in windows_dump:
+        run([rlutil.REF_HARNESS, "repaint", out, "0", str(w), "rp.bin"], work, env)
+        data["repaint/w%d" % w] = fbytes(os.path.join(work, "rp.bin"))
+        s0, s1 = int(ch.wb[w]), int(ch.wb[w + 1]) - 1
+        snps = sorted(set([s0 + 1, s0 + (s1 - s0) // 2, s1]) - {s0})
+        run([rlutil.REF_HARNESS, "matrix", out, "0", str(w), "mx.bin"] + [str(s) for s in snps], work, env)
+        data["matrix/w%d" % w] = fbytes(os.path.join(work, "mx.bin"))
+        data["matrix/w%d/snps" % w] = np.array([s0] + snps, dtype=np.int32)
+    if with_trees:
+        run([rlutil.REF_RELATE, "--mode", "BuildTopology", "--chunk_index", "0", "--first_section", "0",
+             "--last_section", str(W - 1), "-o", out] + pa, work)
+        for w in range(W):
+            data["anc/%d" % w] = fbytes(os.path.join(work, out, "chunk_0", "%s_%d.anc" % (out, w)))
+            data["mut/%d" % w] = fbytes(os.path.join(work, out, "chunk_0", "%s_%d.mut" % (out, w)))
+    return data
+
+
+def synth_fixture(name, N, L, seed, budget, painting=None, windows_dump=(1,), with_trees=True):
+    ch = rlutil.synth_chunk(N, L, seed=seed, budget=budget)
+    with tempfile.TemporaryDirectory() as work:
+        ch.write(os.path.join(work, "out"))
+        data = collect(work, "out", ch.W, painting, windows_dump, with_trees)
+    data["meta"] = np.array([N, L, ch.W, seed], dtype=np.int64)
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **data)
+    print(name, "N", N, "L", L, "W", ch.W, "%.1f KB" % (os.path.getsize(os.path.join(GOLD, name + ".npz")) / 1e3))
+
+
+def example_fixture(nsnps=3000):
+    src = "/root/reference/example/data"
+    with tempfile.TemporaryDirectory() as work:
+        lines = []
+        with gzip.open(os.path.join(src, "example.haps.gz"), "rt") as f:
+            for i, line in enumerate(f):
+                if i >= nsnps:
+                    break
+                lines.append(line)
+        open(os.path.join(work, "ex.haps"), "w").writelines(lines)
+        with gzip.open(os.path.join(src, "example.sample.gz"), "rt") as f:
+            open(os.path.join(work, "ex.sample"), "w").write(f.read())
+        first = int(lines[0].split()[2])
+        last = int(lines[-1].split()[2])
+        # synthetic uniform 1 cM/Mb map (the bundled map is a missing blob): docs/input_data.html
+        with open(os.path.join(work, "ex.map"), "w") as f:
+            f.write("pos COMBINED_rate Genetic_Map\n")
+            for bp in range(max(0, first - 50000), last + 100000, 50000):
+                f.write("%d 1.0 %.6f\n" % (bp, bp * 1e-6))
+        run([rlutil.REF_RELATE, "--mode", "MakeChunks", "--haps", "ex.haps", "--sample", "ex.sample", "--map",
+             "ex.map", "--memory", "0.0002", "-o", "example"], work)
+        p = np.fromfile(os.path.join(work, "example", "parameters_c0.bin"), dtype=np.int32)
+        W = int(p[2]) - 1
+        data = collect(work, "example", W, None, windows_dump=(0,), with_trees=True)
+        data["meta"] = np.array([p[0], p[1], W, 0], dtype=np.int64)
+    np.savez_compressed(os.path.join(GOLD, "example8.npz"), **data)
+    print("example8 N", p[0], "L", p[1], "W", W, "%.1f KB" % (os.path.getsize(os.path.join(GOLD, "example8.npz")) / 1e3))
+
+
+if __name__ == "__main__":
+    assert rlutil.have_ref(), "run `make -C oracle ref` first (needs /root/reference)"
+    os.makedirs(GOLD, exist_ok=True)
+    synth_fixture("synth24", 24, 900, seed=21, budget=4000)
+    synth_fixture("synth24_paint", 24, 900, seed=21, budget=4000, painting="0.025,2", with_trees=False)
+    synth_fixture("synth70", 70, 700, seed=5, budget=40000, windows_dump=(0, 2))
+    example_fixture()
