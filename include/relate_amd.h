@@ -148,6 +148,36 @@ int rl_window_matrix(rl_window *win, int snp, float *d_host, float *kernel_ms);
 int rl_quickbuild(int N, double theta, float *d, const float *d_prior,
                   int *parent, int *child_left, int *child_right);
 
+/* Tree-sequence loop of one section, AncesTreeBuilder::BuildTopology
+ * (src/anc_builder.cpp:398-656): first tree from the distance matrix at
+ * `start`, then for every SNP map its carriers onto the current tree
+ * (MapMutation, :1064-1139) and rebuild (carrier penalty + previous-tree clade
+ * prior, :555-606; MinMatch) when it does not map.  The distance matrices come
+ * from a provider: `matrix(user, snp, d)` must fill the N*N matrix of
+ * DistanceMeasure::GetMatrix(snp) and `advance(user, snp)` (may be NULL) is
+ * called for every SNP start < snp < end before its matrix can be requested
+ * (the cursor update of :487-495).  rl_stage_build_topology plugs rl_window
+ * in; any other DistanceMeasure implementation can be plugged the same way.
+ * bits/row_words: bit-packed panel as for rl_set_chunk_bits; bp_pos (L, only
+ * for --fb) and state (L, chunk_<c>.state) may be NULL.
+ * flags bit0 = --no_consistency; fb = --fb (0 = off). */
+typedef struct rl_treeseq rl_treeseq;
+typedef int (*rl_matrix_fn)(void *user, int snp, float *d);
+typedef int (*rl_advance_fn)(void *user, int snp);
+rl_treeseq *rl_treeseq_create(int N, int L, const uint32_t *bits, int row_words,
+                              const double *rpos, const int *bp_pos,
+                              const int *state, double theta);
+void rl_treeseq_destroy(rl_treeseq *ts);
+int rl_treeseq_build(rl_treeseq *ts, int start, int end, rl_matrix_fn matrix,
+                     rl_advance_fn advance, void *user, int flags, int fb);
+int rl_treeseq_num_trees(const rl_treeseq *ts);
+/* position (first SNP) and parent array (2N-1, root = -1) of tree t */
+int rl_treeseq_get_tree(const rl_treeseq *ts, int t, int *pos, int *parent);
+/* AncesTree::DumpBin (src/anc.cpp:1104-1167) and Mutations::DumpShortFormat
+ * (src/mutations.cpp:548-581); either path may be NULL. */
+int rl_treeseq_write(const rl_treeseq *ts, const char *anc_path,
+                     const char *mut_path);
+
 /* The whole `Relate --mode BuildTopology` stage
  * (pipeline/BuildTopology.cpp:14-167) for sections first..last: writes
  * <out>/chunk_<c>/<out>_<section>.anc and .mut.

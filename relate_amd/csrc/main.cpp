@@ -1,1 +1,135 @@
-int main() { return 0; }
+// main.cpp -- `Relate` drop-in for the two stages of this path:
+//   Relate --mode Paint         --chunk_index c -o out [--painting theta,rho]
+//   Relate --mode BuildTopology --chunk_index c --first_section a --last_section b -o out
+//          [--painting theta,rho] [--seed s] [--fb x] [--no_consistency]
+// Same options, files and stderr banners as include/pipeline/Relate.cpp:19-115,
+// Paint.cpp, BuildTopology.cpp of the reference; every other --mode is refused
+// (use the reference binary for them).  Extra options: --device n,
+// --sum_mode exact|lanes.
+#include <sys/resource.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iomanip>
+#include <iostream>
+#include <map>
+#include <string>
+
+#include "relate_amd.h"
+
+static void usage_line() {
+  rusage usage;
+  getrusage(RUSAGE_SELF, &usage);
+  std::cerr << "CPU Time spent: " << usage.ru_utime.tv_sec << "." << std::setfill('0') << std::setw(6)
+            << usage.ru_utime.tv_usec << "s; Max Memory usage: " << usage.ru_maxrss / 1000.0 << "Mb." << std::endl;
+  std::cerr << "---------------------------------------------------------" << std::endl << std::endl;
+}
+
+int main(int argc, char **argv) {
+  // option table of Relate.cpp:19-45 restricted to what the two modes read
+  const std::map<std::string, bool> known = {  // name -> takes a value
+      {"mode", true}, {"chunk_index", true}, {"first_section", true}, {"last_section", true},
+      {"output", true}, {"painting", true}, {"seed", true}, {"fb", true}, {"sample_ages", true},
+      {"no_consistency", false}, {"device", true}, {"sum_mode", true}, {"help", false},
+      // accepted and ignored by these two modes in the reference as well
+      {"haps", true}, {"sample", true}, {"map", true}, {"mutation_rate", true}, {"effectiveN", true},
+      {"memory", true}, {"dist", true}, {"annot", true}, {"coal", true}, {"transversion", false}};
+  std::map<std::string, std::string> opt;
+  for (int a = 1; a < argc; a++) {
+    std::string s = argv[a], name;
+    if (s == "-o") name = "output";
+    else if (s == "-m") name = "mutation_rate";
+    else if (s == "-N") name = "effectiveN";
+    else if (s == "-h") name = "help";
+    else if (s.rfind("--", 0) == 0) name = s.substr(2);
+    else {
+      std::cerr << "Unexpected argument " << s << std::endl;
+      return 1;
+    }
+    auto it = known.find(name);
+    if (it == known.end()) {  // cxxopts throws option_not_exists_exception (cxxopts.hpp:1041)
+      std::cerr << "Option '" << name << "' does not exist" << std::endl;
+      return 1;
+    }
+    if (it->second) {
+      if (a + 1 >= argc) {
+        std::cerr << "Option '" << name << "' is missing an argument" << std::endl;
+        return 1;
+      }
+      opt[name] = argv[++a];
+    } else {
+      opt[name] = "1";
+    }
+  }
+  if (opt.count("help") || !opt.count("mode")) {
+    std::cerr << "Usage: Relate --mode Paint|BuildTopology --chunk_index c -o out [options]" << std::endl;
+    return opt.count("help") ? 0 : 1;
+  }
+  const std::string mode = opt["mode"];
+  if (!opt.count("output") || !opt.count("chunk_index")) {
+    std::cerr << "Not enough arguments supplied." << std::endl;
+    std::cerr << "Needed: chunk_index, output." << std::endl;
+    return 1;
+  }
+  const std::string out = opt["output"];
+  if (out.find('/') != std::string::npos) {  // Relate.cpp:50-58
+    std::cerr << "Output needs to be in working directory." << std::endl;
+    return 1;
+  }
+  const int chunk = atoi(opt["chunk_index"].c_str());
+  const int device = opt.count("device") ? atoi(opt["device"].c_str()) : 0;
+  int sum_mode = RL_SUM_EXACT;
+  if (opt.count("sum_mode")) {
+    if (opt["sum_mode"] == "lanes") sum_mode = RL_SUM_LANES;
+    else if (opt["sum_mode"] != "exact") {
+      std::cerr << "--sum_mode must be exact or lanes" << std::endl;
+      return 1;
+    }
+  }
+  int use_painting = 0;
+  double theta = 0.001, rho = 1.0;
+  if (opt.count("painting")) {  // Paint.cpp:38-61: "theta,rho" parsed with std::stof
+    const std::string p = opt["painting"];
+    const size_t c = p.find(',');
+    if (c == std::string::npos) {
+      std::cerr << "--painting expects theta,rho" << std::endl;
+      return 1;
+    }
+    theta = std::stof(p.substr(0, c));
+    rho = std::stof(p.substr(c + 1));
+    use_painting = 1;
+  }
+  int rc;
+  if (mode == "Paint") {
+    std::cerr << "---------------------------------------------------------" << std::endl;
+    std::cerr << "Painting sequences..." << std::endl;
+    rc = rl_stage_paint(out.c_str(), chunk, use_painting, theta, rho, sum_mode, device);
+    if (rc == 0) usage_line();
+  } else if (mode == "BuildTopology") {
+    if (!opt.count("first_section") || !opt.count("last_section")) {
+      std::cerr << "Not enough arguments supplied." << std::endl;
+      std::cerr << "Needed: first_section, last_section." << std::endl;
+      return 1;
+    }
+    if (opt.count("sample_ages")) {
+      std::cerr << "--sample_ages is not supported by this build (use the reference binary)." << std::endl;
+      return 1;
+    }
+    const int flags = opt.count("no_consistency") ? 1 : 0;
+    const int fb = opt.count("fb") ? (int)std::stof(opt["fb"]) : 0;  // BuildTopology.cpp:111-114
+    rc = rl_stage_build_topology(out.c_str(), chunk, atoi(opt["first_section"].c_str()),
+                                 atoi(opt["last_section"].c_str()), use_painting, theta, rho, flags, fb, sum_mode,
+                                 device);
+    if (rc == 1) return 1;  // first_section >= num_windows (BuildTopology.cpp:45)
+  } else {
+    std::cerr << "Mode " << mode << " is not part of this build: it replaces --mode Paint and --mode BuildTopology "
+              << "only; run the reference Relate for the other stages." << std::endl;
+    return 1;
+  }
+  if (rc != 0) {
+    std::cerr << "Error: " << rl_last_error() << std::endl;
+    return 1;
+  }
+  return 0;
+}

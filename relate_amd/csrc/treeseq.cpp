@@ -1,3 +1,584 @@
+// treeseq.cpp -- the tree-sequence loop of one section and the BuildTopology stage.
+//
+// Host restatement of AncesTreeBuilder::BuildTopology (src/anc_builder.cpp:398-656),
+// MapMutation / ForceMapMutation / PropagateMutation* (:1064-1413), the .anc
+// writer AncesTree::DumpBin (src/anc.cpp:1104-1167) and the .mut writer
+// Mutations::DumpShortFormat (src/mutations.cpp:548-581), for the
+// configuration the stage driver uses (pipeline/BuildTopology.cpp:14-167):
+// ancestral_state = true, sample_ages empty.
+//
+// Distance matrices come from a provider (callbacks): the stage wires the GPU
+// rl_window in; nothing here computes painting on the CPU.
+#include <sys/resource.h>
+#include <sys/stat.h>
+#include <sys/time.h>
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstring>
+#include <iomanip>
+#include <iostream>
+#include <sstream>
+
 #include "common.h"
+#include "minmatch.h"
+
+namespace rl {
+
+struct SnpInfo {
+  int tree = 0;
+  std::vector<int> branch;
+  bool flipped = false;
+};
+
+struct PropGlobal {
+  int num_correct_carriers, num_correct_noncarriers;
+  int num_incorrect_carriers, num_incorrect_noncarriers;
+  int best_branch, best_flipped_branch;
+  int min, flipped_min;
+};
+struct PropLocal {
+  int num_carriers = 0, num_flipped_carriers = 0, best_branch = -1, best_flipped_branch = -1;
+};
+
+}  // namespace rl
+
+struct rl_treeseq {
+  int N = 0, L = 0;
+  double theta = 0.001;
+  std::vector<uint32_t> bits;  // panel
+  int row_words = 0;
+  std::vector<double> rpos;
+  std::vector<int> bp, state;
+  int thr = 0;
+  std::vector<rl::HostTree> trees;
+  std::vector<rl::SnpInfo> info;  // indexed by snp - start
+  int start = 0, end = 0;
+  std::vector<char> member;  // carriers of the current SNP
+  int num_carriers = 0;
+
+  bool derived(int snp, int n) const { return (bits[(size_t)snp * row_words + (n >> 5)] >> (n & 31)) & 1u; }
+};
+
+namespace rl {
+
+// ---- anc_builder.cpp:1237-1341
+static void propagate_global(const rl_treeseq &ts, const HostTree &t, int node, PropGlobal &report) {
+  const int N = ts.N;
+  const float total_carriers = ts.num_carriers;
+  const float total_noncarriers = N - total_carriers;
+  if (t.child_left[node] >= 0) {
+    PropGlobal report2;
+    propagate_global(ts, t, t.child_left[node], report);
+    propagate_global(ts, t, t.child_right[node], report2);
+    report.num_correct_carriers += report2.num_correct_carriers;
+    report.num_incorrect_noncarriers += report2.num_incorrect_noncarriers;
+    report.num_incorrect_carriers = total_carriers - report.num_correct_carriers;
+    report.num_correct_noncarriers = total_noncarriers - report.num_incorrect_noncarriers;
+
+    int sum = report.num_incorrect_carriers + report.num_incorrect_noncarriers;
+    bool cond = (((float)report.num_incorrect_carriers) / total_carriers < 0.3);
+    cond *= (((float)report.num_incorrect_noncarriers) / total_noncarriers < 0.3);
+    if (report.num_correct_carriers + report.num_incorrect_noncarriers > 0.0)
+      cond *= (((float)report.num_correct_carriers) /
+                   (report.num_correct_carriers + report.num_incorrect_noncarriers) > 0.7);
+    if (report.num_incorrect_carriers + report.num_correct_noncarriers > 0.0)
+      cond *= (((float)report.num_correct_noncarriers) /
+                   (report.num_incorrect_carriers + report.num_correct_noncarriers) > 0.7);
+    if (cond && report.min > sum && report2.min > sum) {
+      report.min = sum;
+      report.best_branch = node;
+    } else if (report.min > report2.min) {
+      report.min = report2.min;
+      report.best_branch = report2.best_branch;
+    }
+
+    sum = report.num_correct_carriers + report.num_correct_noncarriers;
+    cond = (((float)report.num_correct_carriers) / total_carriers < 0.3);
+    cond *= (((float)report.num_correct_noncarriers) / total_noncarriers < 0.3);
+    if (report.num_incorrect_carriers + report.num_correct_noncarriers > 0.0)
+      cond *= (((float)report.num_incorrect_carriers) /
+                   (report.num_incorrect_carriers + report.num_correct_noncarriers) > 0.7);
+    if (report.num_correct_carriers + report.num_incorrect_noncarriers > 0.0)
+      cond *= (((float)report.num_incorrect_noncarriers) /
+                   (report.num_correct_carriers + report.num_incorrect_noncarriers) > 0.7);
+    if (cond && report.flipped_min > sum && report2.flipped_min > sum) {
+      report.flipped_min = sum;
+      report.best_flipped_branch = node;
+    } else if (report.flipped_min > report2.flipped_min) {
+      report.flipped_min = report2.flipped_min;
+      report.best_flipped_branch = report2.best_flipped_branch;
+    }
+  } else {
+    if (ts.member[node] == 1) {
+      report.num_correct_carriers = 1;
+      report.num_incorrect_carriers = total_carriers - 1;
+      report.num_correct_noncarriers = total_noncarriers;
+      report.num_incorrect_noncarriers = 0;
+      if (report.num_incorrect_carriers / total_carriers < 0.3) {
+        report.min = report.num_incorrect_carriers;
+        report.best_branch = node;
+      } else {
+        report.min = INT_MAX;
+        report.best_branch = -1;
+      }
+      if (report.num_correct_carriers / total_carriers < 0.3 &&
+          report.num_correct_noncarriers / total_noncarriers < 0.3) {
+        report.flipped_min = report.num_correct_noncarriers + report.num_correct_carriers;
+        report.best_flipped_branch = node;
+      } else {
+        report.flipped_min = INT_MAX;
+        report.best_flipped_branch = -1;
+      }
+    } else {
+      report.num_correct_carriers = 0;
+      report.num_incorrect_carriers = total_carriers;
+      report.num_correct_noncarriers = total_noncarriers - 1;
+      report.num_incorrect_noncarriers = 1;
+      if (report.num_incorrect_carriers / total_carriers < 0.3 &&
+          report.num_incorrect_noncarriers / total_noncarriers < 0.3) {
+        report.min = report.num_incorrect_carriers + report.num_incorrect_noncarriers;
+        report.best_branch = node;
+      } else {
+        report.min = INT_MAX;
+        report.best_branch = -1;
+      }
+      if (report.num_correct_noncarriers / total_noncarriers < 0.3) {
+        report.flipped_min = report.num_correct_noncarriers;
+        report.best_flipped_branch = node;
+      } else {
+        report.flipped_min = INT_MAX;
+        report.best_flipped_branch = -1;
+      }
+    }
+  }
+}
+
+// ---- anc_builder.cpp:1344-1413
+static void propagate_local(const rl_treeseq &ts, const HostTree &t, int node, std::vector<int> &branches,
+                            std::vector<int> &branches_flipped, PropLocal &report) {
+  if (t.child_left[node] >= 0) {
+    PropLocal c1, c2;
+    propagate_local(ts, t, t.child_left[node], branches, branches_flipped, c1);
+    propagate_local(ts, t, t.child_right[node], branches, branches_flipped, c2);
+    report.num_carriers = c1.num_carriers + c2.num_carriers;
+    report.num_flipped_carriers = c1.num_flipped_carriers + c2.num_flipped_carriers;
+    const float num_leaves = report.num_carriers + report.num_flipped_carriers;
+    if (report.num_flipped_carriers / num_leaves < 0.03 && c1.best_branch != -1 && c2.best_branch != -1) {
+      if (c1.num_carriers > 0 && c2.num_carriers > 0)
+        report.best_branch = node;
+      else if (c1.num_carriers > 0)
+        report.best_branch = c1.best_branch;
+      else
+        report.best_branch = c2.best_branch;
+    } else {
+      if (c1.best_branch != -1) branches.push_back(c1.best_branch);
+      if (c2.best_branch != -1) branches.push_back(c2.best_branch);
+      report.best_branch = -1;
+    }
+    if (report.num_carriers / num_leaves < 0.03 && c1.best_flipped_branch != -1 && c2.best_flipped_branch != -1) {
+      if (c1.num_flipped_carriers > 0 && c2.num_flipped_carriers > 0)
+        report.best_flipped_branch = node;
+      else if (c1.num_flipped_carriers > 0)
+        report.best_flipped_branch = c1.best_flipped_branch;
+      else
+        report.best_flipped_branch = c2.best_flipped_branch;
+    } else {
+      if (c1.best_flipped_branch != -1) branches_flipped.push_back(c1.best_flipped_branch);
+      if (c2.best_flipped_branch != -1) branches_flipped.push_back(c2.best_flipped_branch);
+      report.best_flipped_branch = -1;
+    }
+  } else {
+    if (ts.member[node] == 1) {
+      report.num_carriers = 1;
+      report.num_flipped_carriers = 0;
+      report.best_branch = node;
+      report.best_flipped_branch = -1;
+    } else {
+      report.num_carriers = 0;
+      report.num_flipped_carriers = 1;
+      report.best_flipped_branch = node;
+      report.best_branch = -1;
+    }
+  }
+}
+
+// ---- anc_builder.cpp:1064-1139 (version without random flipping)
+static int map_mutation(rl_treeseq &ts, HostTree &t, SnpInfo &si, float &min_value, bool use) {
+  const int N = ts.N;
+  if (ts.num_carriers == N) {
+    min_value = 0.0f;
+    si.branch.resize(1);
+    si.flipped = false;
+    si.branch[0] = 2 * N - 2;
+    t.num_events[2 * N - 2] += 1.0f;
+    return 1;
+  }
+  if (ts.num_carriers == 0) {
+    min_value = 0.0f;
+    si.branch.resize(0);
+    si.flipped = false;
+    return 1;
+  }
+  PropGlobal report;
+  propagate_global(ts, t, 2 * N - 2, report);
+  if (report.min == report.flipped_min && report.min <= ts.thr) {
+    min_value = report.min;
+    si.branch.resize(1);
+    si.branch[0] = report.best_branch;
+    si.flipped = false;
+    if (use) t.num_events[report.best_branch] += 1.0f;
+    return 1;
+  } else if (report.min <= report.flipped_min) {
+    min_value = report.min;
+    if (report.min <= ts.thr) {
+      si.branch.resize(1);
+      si.branch[0] = report.best_branch;
+      si.flipped = false;
+      if (use) t.num_events[report.best_branch] += 1.0f;
+      return 1;
+    }
+    return 3;
+  } else {
+    min_value = report.flipped_min;
+    if (report.flipped_min <= ts.thr) {
+      si.branch.resize(1);
+      si.branch[0] = report.best_flipped_branch;
+      si.flipped = true;
+      if (use) t.num_events[report.best_flipped_branch] += 1.0f;
+      return 2;
+    }
+    return 3;
+  }
+}
+
+// ---- anc_builder.cpp:1143-1204
+static int force_map_mutation(rl_treeseq &ts, HostTree &t, SnpInfo &si, bool force) {
+  const int N = ts.N;
+  if (ts.num_carriers == 0 || ts.num_carriers == N) return 1;
+  std::vector<int> branches, branches_flipped;
+  PropLocal report;
+  propagate_local(ts, t, 2 * N - 2, branches, branches_flipped, report);
+  if (branches_flipped.size() == 0) {
+    if (branches.size() == 1 || force) si.branch = branches;
+    return (int)branches.size();
+  }
+  if (branches.size() <= branches_flipped.size() && branches.size() > 0) {
+    if (branches.size() == 1 || force) si.branch = branches;
+    return (int)branches.size();
+  }
+  if (branches_flipped.size() == 1 || force) {
+    si.flipped = true;
+    si.branch = branches_flipped;
+  }
+  return (int)branches_flipped.size();
+}
+
+// Prior `dist` from the previous tree's clades (anc_builder.cpp:583-606):
+// dist[i][j] = val added once per clade that contains i but not j.  Computed
+// here per pair from leaf depths and the depth of the pair's lowest common
+// ancestor; the repeated float additions of `val` are replayed through a table
+// (acc[c] = val added c times, left to right), so every entry is bit-identical
+// to the reference's accumulation.
+static void clade_prior(const HostTree &t, float val, std::vector<float> &dist) {
+  const int N = t.N, T = 2 * N - 1;
+  dist.assign((size_t)N * N, 0.0f);
+  std::vector<int> depth(T, 0);  // internal nodes on the path node..root, inclusive of node if internal
+  for (int v = T - 1; v >= N; v--) depth[v] = (t.parent[v] >= 0 ? depth[t.parent[v]] : 0) + 1;
+  std::vector<float> acc((size_t)N + 1, 0.0f);
+  for (int c = 1; c <= N; c++) acc[c] = acc[c - 1] + val;
+  // leaves below each node, children before parents (labels increase towards the root)
+  std::vector<std::vector<int>> leaves(T);
+  for (int i = 0; i < N; i++) leaves[i].push_back(i);
+  for (int v = N; v < T; v++) {
+    const std::vector<int> &A = leaves[t.child_left[v]], &B = leaves[t.child_right[v]];
+    const int dv = depth[v];
+    for (int a : A)
+      for (int b : B) {
+        // clades containing a but not b: internal ancestors of a strictly below v
+        dist[(size_t)a * N + b] = acc[depth[t.parent[a]] - dv];
+        dist[(size_t)b * N + a] = acc[depth[t.parent[b]] - dv];
+      }
+    leaves[v].reserve(A.size() + B.size());
+    leaves[v].insert(leaves[v].end(), A.begin(), A.end());
+    leaves[v].insert(leaves[v].end(), B.begin(), B.end());
+    std::vector<int>().swap(leaves[t.child_left[v]]);
+    std::vector<int>().swap(leaves[t.child_right[v]]);
+  }
+}
+
+}  // namespace rl
+
 using namespace rl;
-extern "C" int rl_stage_build_topology(const char *, int, int, int, int, double, double, int, int, int, int) { set_error("not implemented"); return RL_ESTATE; }
+
+extern "C" {
+
+rl_treeseq *rl_treeseq_create(int N, int L, const uint32_t *bits, int row_words, const double *rpos,
+                              const int *bp_pos, const int *state, double theta) {
+  if (N < 2 || L < 2 || !bits || row_words < (N + 31) / 32 || !rpos || !(theta > 0.0 && theta < 1.0)) {
+    set_error("rl_treeseq_create: bad arguments");
+    return nullptr;
+  }
+  rl_treeseq *ts = new rl_treeseq();
+  ts->N = N;
+  ts->L = L;
+  ts->theta = theta;
+  ts->row_words = row_words;
+  ts->bits.assign(bits, bits + (size_t)L * row_words);
+  ts->rpos.assign(rpos, rpos + L + 1);
+  if (bp_pos) ts->bp.assign(bp_pos, bp_pos + L);
+  if (state)
+    ts->state.assign(state, state + L);
+  else
+    ts->state.assign(L, 1);
+  ts->thr = (int)(0.03 * N);  // anc_builder.cpp:383
+  ts->member.assign(N, 0);
+  return ts;
+}
+
+void rl_treeseq_destroy(rl_treeseq *ts) { delete ts; }
+
+int rl_treeseq_build(rl_treeseq *ts, int start, int end, rl_matrix_fn matrix, rl_advance_fn advance, void *user,
+                     int flags, int fb) {
+  if (!ts || !matrix || start < 0 || end >= ts->L || start > end) {
+    set_error("rl_treeseq_build: bad arguments");
+    return RL_EINVAL;
+  }
+  if (fb > 0 && ts->bp.empty()) {
+    set_error("rl_treeseq_build: --fb needs bp positions");
+    return RL_EINVAL;
+  }
+  const int N = ts->N;
+  const bool consistency = !(flags & 1);
+  ts->start = start;
+  ts->end = end;
+  ts->trees.clear();
+  ts->info.assign((size_t)(end - start + 1), SnpInfo());
+  // carriers: the reference fills them for snp < section_endpos only, so the
+  // last SNP of a window is processed with none (anc_builder.cpp:407-414)
+  auto set_carriers = [&](int snp) {
+    ts->num_carriers = 0;
+    std::fill(ts->member.begin(), ts->member.end(), 0);
+    if (snp < end)
+      for (int i = 0; i < N; i++)
+        if (ts->derived(snp, i)) {
+          ts->member[i] = 1;
+          ts->num_carriers++;
+        }
+  };
+  MinMatch tb(N, ts->theta);
+  std::vector<float> d((size_t)N * N), dist;
+  float min_value = 0.f, min_value_alt = 0.f;
+  int rc;
+
+  ts->trees.emplace_back();
+  if ((rc = matrix(user, start, d.data()))) return rc;
+  tb.quick_build(d.data(), nullptr, ts->trees.back());  // :447, no prior for the first tree
+  ts->trees.back().pos = start;
+  std::fill(ts->trees.back().snp_begin.begin(), ts->trees.back().snp_begin.end(), start);
+  set_carriers(start);
+  ts->info[0].tree = 0;
+  int is_mapping = map_mutation(*ts, ts->trees.back(), ts->info[0], min_value, ts->state[start] != 0);
+  if (is_mapping > 2) force_map_mutation(*ts, ts->trees.back(), ts->info[0], true);
+
+  int num_tree = 1;
+  const float val = -std::log(ts->theta / (1.0 - ts->theta));  // :555
+  for (int snp = start + 1; snp <= end; snp++) {
+    SnpInfo &si = ts->info[(size_t)(snp - start)];
+    set_carriers(snp);
+    if (advance && snp < end && (rc = advance(user, snp))) return rc;  // :487-495 (carriers only)
+    si.tree = num_tree - 1;
+    const bool use = ts->state[snp] != 0;
+    is_mapping = map_mutation(*ts, ts->trees.back(), si, min_value, use);
+    bool force_new = false;
+    if (snp < end && fb > 0)
+      if (((int)(ts->bp[snp + 1] / fb)) - ((int)(ts->bp[snp] / fb)) >= 1) force_new = true;
+
+    if (is_mapping > 1 || force_new) {
+      int prev_branch = -1;
+      if (is_mapping == 2 || (is_mapping == 1 && force_new)) prev_branch = si.branch[0];
+      ts->trees.emplace_back();
+      HostTree &nt = ts->trees.back();
+      HostTree &pt = ts->trees[ts->trees.size() - 2];
+      if ((rc = matrix(user, snp, d.data()))) return rc;
+      if (consistency) {
+        // carrier penalty (:563-581): d[c][*] += val, then d[c][c'] -= val
+        for (int c = 0; c < N; c++)
+          if (ts->member[c]) {
+            float *row = &d[(size_t)c * N];
+            for (int col = 0; col < N; col++) row[col] += val;
+            for (int c2 = 0; c2 < N; c2++)
+              if (ts->member[c2]) row[c2] -= val;
+          }
+        clade_prior(pt, val, dist);
+        tb.quick_build(d.data(), dist.data(), nt);
+      } else {
+        tb.quick_build(d.data(), nullptr, nt);
+      }
+      nt.pos = snp;
+      const int is_mapping_alt = map_mutation(*ts, nt, si, min_value_alt, use);
+      if (is_mapping_alt > 1 && min_value_alt >= min_value && !force_new) {
+        // new tree is not better: keep the old one (:621-630)
+        if (is_mapping == 2) si.branch[0] = prev_branch;
+        ts->trees.pop_back();
+        if (is_mapping > 2) force_map_mutation(*ts, ts->trees.back(), si, true);
+      } else {
+        if (is_mapping == 2 || (is_mapping == 1 && force_new)) {
+          if (use) pt.num_events[prev_branch] -= 1.0f;
+        }
+        if (is_mapping_alt > 2) force_map_mutation(*ts, nt, si, true);
+        si.tree = num_tree;
+        std::fill(pt.snp_end.begin(), pt.snp_end.end(), snp);
+        std::fill(nt.snp_begin.begin(), nt.snp_begin.end(), snp);
+        num_tree++;
+      }
+    }
+  }
+  std::fill(ts->trees.back().snp_end.begin(), ts->trees.back().snp_end.end(), end);
+  return RL_OK;
+}
+
+int rl_treeseq_num_trees(const rl_treeseq *ts) { return ts ? (int)ts->trees.size() : RL_EINVAL; }
+
+int rl_treeseq_get_tree(const rl_treeseq *ts, int t, int *pos, int *parent) {
+  if (!ts || t < 0 || t >= (int)ts->trees.size()) return RL_EINVAL;
+  if (pos) *pos = ts->trees[t].pos;
+  if (parent) memcpy(parent, ts->trees[t].parent.data(), sizeof(int) * (2 * ts->N - 1));
+  return RL_OK;
+}
+
+// AncesTree::DumpBin (anc.cpp:1104-1167) and Mutations::DumpShortFormat (mutations.cpp:548-581)
+int rl_treeseq_write(const rl_treeseq *ts, const char *anc_path, const char *mut_path) {
+  if (!ts || ts->trees.empty()) {
+    set_error("rl_treeseq_write: nothing built");
+    return RL_ESTATE;
+  }
+  const int N = ts->N, T = 2 * N - 1;
+  if (anc_path) {
+    FILE *fp = fopen(anc_path, "wb");
+    if (!fp) {
+      set_error("cannot open %s for writing", anc_path);
+      return RL_EIO;
+    }
+    const unsigned char has_ages = 0;
+    const unsigned int uN = N, nt = (unsigned int)ts->trees.size();
+    fwrite(&has_ages, 1, 1, fp);
+    fwrite(&uN, 4, 1, fp);
+    fwrite(&nt, 4, 1, fp);
+    std::vector<unsigned char> buf((size_t)T * 24);
+    for (const HostTree &t : ts->trees) {
+      fwrite(&t.pos, 4, 1, fp);
+      const double bl = 0.0;
+      for (int i = 0; i < T; i++) {
+        unsigned char *p = &buf[(size_t)i * 24];
+        memcpy(p, &t.parent[i], 4);
+        memcpy(p + 4, &bl, 8);
+        memcpy(p + 12, &t.num_events[i], 4);
+        memcpy(p + 16, &t.snp_begin[i], 4);
+        memcpy(p + 20, &t.snp_end[i], 4);
+      }
+      fwrite(buf.data(), 1, buf.size(), fp);
+    }
+    fclose(fp);
+  }
+  if (mut_path) {
+    FILE *fp = fopen(mut_path, "w");
+    if (!fp) {
+      set_error("cannot open %s for writing", mut_path);
+      return RL_EIO;
+    }
+    fputs("tree_index;branch_index;is_mapping;is_flipped;age_of_mutation\n", fp);
+    for (const SnpInfo &si : ts->info) {
+      fprintf(fp, "%d;", si.tree);
+      for (size_t b = 0; b < si.branch.size(); b++) fprintf(fp, b ? " %d" : "%d", si.branch[b]);
+      fputs(si.branch.size() > 1 ? ";1;" : ";0;", fp);
+      fprintf(fp, "%d;0;0;\n", si.flipped ? 1 : 0);
+    }
+    fclose(fp);
+  }
+  return RL_OK;
+}
+
+// ---- the stage: pipeline/BuildTopology.cpp:14-167 -------------------------
+static int win_matrix(void *user, int snp, float *d) { return rl_window_matrix((rl_window *)user, snp, d, nullptr); }
+static int win_advance(void *user, int snp) { return rl_window_advance((rl_window *)user, snp); }
+
+int rl_stage_build_topology(const char *out_dir, int chunk_index, int first_section, int last_section,
+                            int use_painting, double theta, double rho, int flags, int fb, int sum_mode,
+                            int device) {
+  if (!out_dir) return RL_EINVAL;
+  rl_ctx *ctx = rl_create(device);
+  if (!ctx) return RL_ENODEVICE;
+  int rc = rl_load_chunk(ctx, out_dir, chunk_index);
+  if (!rc && use_painting) rc = rl_set_painting(ctx, theta, rho);
+  if (rc) {
+    rl_destroy(ctx);
+    return rc;
+  }
+  const int W = ctx->W, L = ctx->L;
+  if (first_section >= W) {  // BuildTopology.cpp:45
+    rl_destroy(ctx);
+    return 1;
+  }
+  last_section = std::min(W - 1, last_section);
+  const std::string od(out_dir), c = std::to_string(chunk_index);
+  // output name = basename of -o (Relate requires -o to be a bare name, Relate.cpp:50-58)
+  std::string base = od;
+  while (!base.empty() && base.back() == '/') base.pop_back();
+  const size_t sl = base.find_last_of('/');
+  if (sl != std::string::npos) base = base.substr(sl + 1);
+  std::vector<int> bp(L, 0), state(L, 1);
+  auto read_ints = [&](const std::string &fn, std::vector<int> &v) {
+    FILE *fp = fopen(fn.c_str(), "rb");
+    if (!fp) return;
+    int n = 0;
+    if (fread(&n, 4, 1, fp) == 1 && n == L) {
+      if (fread(v.data(), 4, (size_t)L, fp) != (size_t)L) v.assign(L, v[0]);
+    }
+    fclose(fp);
+  };
+  read_ints(od + "/chunk_" + c + ".bp", bp);
+  read_ints(od + "/chunk_" + c + ".state", state);
+  rl_treeseq *ts = rl_treeseq_create(ctx->N, L, ctx->bits.data(), ctx->row_words, ctx->rpos.data(), bp.data(),
+                                     state.data(), ctx->theta);
+  if (!ts) {
+    rl_destroy(ctx);
+    return RL_EINVAL;
+  }
+  std::cerr << "---------------------------------------------------------" << std::endl;
+  std::cerr << "Estimating topologies of AncesTrees in sections " << first_section << "-" << last_section << "..."
+            << std::endl;
+  for (int section = first_section; section <= last_section && !rc; section++) {
+    std::cerr << "[" << section << "/" << last_section << "]\r";
+    std::cerr.flush();
+    const int start = ctx->wb[section];
+    int end = (section < W - 1) ? ctx->wb[section + 1] - 1 : L - 1;
+    if (end >= L) end = L - 1;
+    const std::string pf = od + "/chunk_" + c + "/paint/relate_" + std::to_string(section) + ".bin";
+    rl_window *win = rl_window_open(ctx, section, pf.c_str(), start, sum_mode, nullptr);
+    if (!win) {
+      rc = RL_EIO;
+      break;
+    }
+    rc = rl_treeseq_build(ts, start, end, win_matrix, win_advance, win, flags, fb);
+    rl_window_close(win);
+    if (!rc) {
+      const std::string b = od + "/chunk_" + c + "/" + base + "_" + std::to_string(section);
+      rc = rl_treeseq_write(ts, (b + ".anc").c_str(), (b + ".mut").c_str());
+    }
+  }
+  rl_treeseq_destroy(ts);
+  rl_destroy(ctx);
+  if (!rc) {
+    rusage usage;
+    getrusage(RUSAGE_SELF, &usage);
+    std::cerr << "CPU Time spent: " << usage.ru_utime.tv_sec << "." << std::setfill('0') << std::setw(6)
+              << usage.ru_utime.tv_usec << "s; Max Memory usage: " << usage.ru_maxrss / 1000.0 << "Mb."
+              << std::endl;
+    std::cerr << "---------------------------------------------------------" << std::endl << std::endl;
+  }
+  return rc;
+}
+
+}  // extern "C"

@@ -39,3 +39,29 @@ def test_paint_files_match_reference_binary(tmp_path, oracle, N, L, budget, seed
         a = open(tmp_path / "out" / "chunk_0" / "paint" / ("relate_%d.bin" % w), "rb").read()
         b = open(out / ("relate_%d.bin" % w), "rb").read()
         assert a == b, "window %d" % w
+
+
+@pytest.mark.parametrize("N,L,budget,seed", [(160, 1800, 600000, 41), (300, 1200, 3000000, 42)])
+def test_treeseq_matches_reference_binary(tmp_path, oracle, N, L, budget, seed):
+    """host tree builder + tree-sequence loop (oracle as matrix provider) vs
+    `Relate --mode BuildTopology` of the reference, byte for byte"""
+    import test_treeseq_cpu as T
+
+    ch = rlutil.synth_chunk(N, L, seed=seed, budget=budget)
+    ch.write(str(tmp_path / "out"))
+    rlutil.run_ref(["--mode", "Paint", "--chunk_index", "0", "-o", "out"], cwd=str(tmp_path))
+    rlutil.run_ref(["--mode", "BuildTopology", "--chunk_index", "0", "--first_section", "0", "--last_section",
+                    str(ch.W - 1), "-o", "out"], cwd=str(tmp_path))
+
+    class Fx:  # the minimal Fixture interface build_section needs
+        pass
+    fx = Fx()
+    fx.chunk, fx.W, fx.dir = ch, ch.W, str(tmp_path / "out")
+    fx.write_paint_files = lambda d: os.makedirs(d, exist_ok=True) or [
+        os.replace(str(tmp_path / "out" / "chunk_0" / "paint" / ("relate_%d.bin" % w)),
+                   os.path.join(d, "relate_%d.bin" % w))
+        for w in range(ch.W) if not os.path.exists(os.path.join(d, "relate_%d.bin" % w))]
+    for w in range(ch.W):
+        anc, mut, nt = T.build_section(fx, w, tmp_path, oracle)
+        assert mut == open(tmp_path / "out" / "chunk_0" / ("out_%d.mut" % w), "rb").read(), w
+        assert anc == open(tmp_path / "out" / "chunk_0" / ("out_%d.anc" % w), "rb").read(), (w, nt)

@@ -1,0 +1,49 @@
+"""The drop-in CLI (relate_amd/Relate --mode Paint / --mode BuildTopology) on
+the GPU against the committed outputs of the reference binary: every paint
+file, .anc and .mut byte-identical."""
+import os
+import subprocess
+
+import pytest
+
+from golden_util import Fixture
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "relate_amd", "Relate")
+
+
+def run_cli(args, cwd):
+    p = subprocess.run([CLI] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr.decode()
+    return p.stderr.decode()
+
+
+@pytest.mark.parametrize("name", ["synth24", "synth70", "example8"])
+def test_cli_stages_byte_identical_to_reference(tmp_path, name):
+    work = tmp_path / "work"
+    (work / "out").mkdir(parents=True)
+    fx = Fixture(name, work / "out")
+    err = run_cli(["--mode", "Paint", "--chunk_index", "0", "-o", "out"], str(work))
+    assert "CPU Time spent" in err
+    for w in range(fx.W):
+        got = open(work / "out" / "chunk_0" / "paint" / ("relate_%d.bin" % w), "rb").read()
+        assert got == fx.paint_file(w), "paint window %d" % w
+    run_cli(["--mode", "BuildTopology", "--chunk_index", "0", "--first_section", "0", "--last_section",
+             str(fx.W - 1), "-o", "out"], str(work))
+    for w in range(fx.W):
+        assert open(work / "out" / "chunk_0" / ("out_%d.mut" % w), "rb").read() == fx.z["mut/%d" % w].tobytes(), w
+        assert open(work / "out" / "chunk_0" / ("out_%d.anc" % w), "rb").read() == fx.z["anc/%d" % w].tobytes(), w
+
+
+def test_cli_rejects_unknown_option_and_other_modes(tmp_path):
+    p = subprocess.run([CLI, "--mode", "Paint", "--bogus", "1", "-o", "out", "--chunk_index", "0"], cwd=str(tmp_path),
+                       stderr=subprocess.PIPE)
+    assert p.returncode != 0 and b"does not exist" in p.stderr
+    p = subprocess.run([CLI, "--mode", "Finalize", "-o", "out", "--chunk_index", "0"], cwd=str(tmp_path),
+                       stderr=subprocess.PIPE)
+    assert p.returncode != 0
+    p = subprocess.run([CLI, "--mode", "Paint", "-o", "a/b", "--chunk_index", "0"], cwd=str(tmp_path),
+                       stderr=subprocess.PIPE)
+    assert p.returncode != 0 and b"working directory" in p.stderr
