@@ -36,14 +36,19 @@ enum {
 };
 
 /* Summation order of the per-site normalising constants.
- *   RL_SUM_EXACT : left-to-right over donors n = 0..N-1, bit-identical to the
- *                  reference's serial loops (src/fast_painting.cpp:300-303,
- *                  495-503).  Paint files / .anc are byte-identical.
+ *   RL_SUM_EXACT : the reference's serial left-to-right order over donors
+ *                  n = 0..N-1 (src/fast_painting.cpp:300-303, 495-503),
+ *                  reproduced bit for bit by a parallel algorithm
+ *                  (relate_amd/csrc/exact_sum.h).  Paint files / .anc / .mut
+ *                  are byte-identical to the reference's.
+ *   RL_SUM_EXACT_SERIAL : the same result computed literally (one dependent
+ *                  add per donor); slower, kept as the in-kernel fallback of
+ *                  RL_SUM_EXACT and for cross-checking it.
  *   RL_SUM_LANES : per-lane partial sums + wavefront xor-butterfly.  Same
  *                  arithmetic, different association: distances agree to
  *                  ~1e-7 relative before min-subtraction, trees may differ
  *                  where MinMatch breaks float ties.       */
-enum { RL_SUM_EXACT = 0, RL_SUM_LANES = 1 };
+enum { RL_SUM_EXACT = 0, RL_SUM_LANES = 1, RL_SUM_EXACT_SERIAL = 2 };
 
 typedef struct rl_ctx rl_ctx;
 typedef struct rl_window rl_window;

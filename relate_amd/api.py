@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "librelate_amd.so")
 
 RL_SUM_EXACT = 0
 RL_SUM_LANES = 1
+RL_SUM_EXACT_SERIAL = 2
 
 _lib = None
 

@@ -558,7 +558,7 @@ int rl_paint(rl_ctx *ctx, int sum_mode, float *kernel_ms) {
     set_error("rl_paint: no chunk loaded");
     return RL_ESTATE;
   }
-  if (sum_mode != RL_SUM_EXACT && sum_mode != RL_SUM_LANES) {
+  if (sum_mode != RL_SUM_EXACT && sum_mode != RL_SUM_LANES && sum_mode != RL_SUM_EXACT_SERIAL) {
     set_error("rl_paint: bad sum_mode");
     return RL_EINVAL;
   }

@@ -33,8 +33,34 @@ inline Layout make_layout(int N) {
   return l;
 }
 
-hipError_t launch_paint(const PaintParams &p, int S, int backward, hipStream_t stream);
-hipError_t launch_repaint(const RepaintParams &p, int S, int nblocks, int *counter, hipStream_t stream);
+// kernel summation modes (template parameter MODE of the kernels)
+//   0 = lanes (RL_SUM_LANES), 1 = exact, parallel (RL_SUM_EXACT), 2 = exact, literal serial (RL_SUM_EXACT_SERIAL)
+template <int MODE>
+hipError_t launch_paint_mode(const PaintParams &p, int S, int backward, hipStream_t stream);
+template <int MODE>
+hipError_t launch_repaint_mode(const RepaintParams &p, int S, int nblocks, int *counter, hipStream_t stream);
+template <> hipError_t launch_paint_mode<0>(const PaintParams &, int, int, hipStream_t);
+template <> hipError_t launch_paint_mode<1>(const PaintParams &, int, int, hipStream_t);
+template <> hipError_t launch_paint_mode<2>(const PaintParams &, int, int, hipStream_t);
+template <> hipError_t launch_repaint_mode<0>(const RepaintParams &, int, int, int *, hipStream_t);
+template <> hipError_t launch_repaint_mode<1>(const RepaintParams &, int, int, int *, hipStream_t);
+template <> hipError_t launch_repaint_mode<2>(const RepaintParams &, int, int, int *, hipStream_t);
+
+inline int kernel_mode(int sum_mode) { return sum_mode == 0 ? 1 : (sum_mode == 1 ? 0 : 2); }
+inline hipError_t launch_paint(const PaintParams &p, int S, int backward, hipStream_t stream) {
+  switch (kernel_mode(p.sum_mode)) {
+    case 0: return launch_paint_mode<0>(p, S, backward, stream);
+    case 1: return launch_paint_mode<1>(p, S, backward, stream);
+    default: return launch_paint_mode<2>(p, S, backward, stream);
+  }
+}
+inline hipError_t launch_repaint(const RepaintParams &p, int S, int nblocks, int *counter, hipStream_t stream) {
+  switch (kernel_mode(p.sum_mode)) {
+    case 0: return launch_repaint_mode<0>(p, S, nblocks, counter, stream);
+    case 1: return launch_repaint_mode<1>(p, S, nblocks, counter, stream);
+    default: return launch_repaint_mode<2>(p, S, nblocks, counter, stream);
+  }
+}
 hipError_t launch_matrix(const MatrixParams &p, const Layout &lay, int S, hipStream_t stream);
 
 }  // namespace rl

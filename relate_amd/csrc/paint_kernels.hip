@@ -4,7 +4,12 @@
 // Two launches of N wavefronts each (forward, backward: independent in this
 // stage); block b paints target order[b] (longest target first).
 #include "paint_device.h"
+#include "exact_sum.h"
 #include "launch.h"
+
+#ifndef RL_MODE
+#error "compile with -DRL_MODE=0 (lanes), 1 (exact, parallel), 2 (exact, literal serial)"
+#endif
 
 namespace rl {
 
@@ -31,7 +36,7 @@ RL_DEV void emit_stone(const LaneCtx<S> &lc, const double (&v)[S], float *__rest
   if (lc.lane == 0) out[lc.k] = self_value;
 }
 
-template <int S, int TAIL, bool EXACT>
+template <int S, int TAIL, int MODE>
 RL_DEV void paint_forward(const PaintParams &p, int k, float *stage) {
   LaneCtx<S> lc;
   lc.init(p.lay, k);
@@ -43,7 +48,6 @@ RL_DEV void paint_forward(const PaintParams &p, int k, float *stage) {
   const double *__restrict__ cfp = p.cf + off;
   const double *__restrict__ nx = p.nxt + off;
   const int32_t *__restrict__ ia = p.stone_ia + (size_t)k * W;
-  constexpr bool exact = EXACT;
 
   double a[S];
   RawBits<S> raw;
@@ -59,8 +63,7 @@ RL_DEV void paint_forward(const PaintParams &p, int k, float *stage) {
     double v = mb.get(i) ? c.init1 : c.init0;
     a[i] = (i < lc.len) ? v : 0.0;
   }
-  double ssum = exact ? sum_exact<S>([&](int i) { return a[i]; })
-                      : sum_lanes<S>([&](int i) { return a[i]; });
+  double ssum = wave_sum<MODE, S>(RegTerm<S>{a});
   double ls = 0.0;
   int wa = 0;
   int next_stone = ia[0];
@@ -92,8 +95,7 @@ RL_DEV void paint_forward(const PaintParams &p, int k, float *stage) {
       if (j >= S - TAIL) v = (j < lc.len) ? v : 0.0;
       a[j] = v;
     }
-    ssum = exact ? sum_exact<S>([&](int j) { return a[j]; })
-                 : sum_lanes<S>([&](int j) { return a[j]; });
+    ssum = wave_sum<MODE, S>(RegTerm<S>{a});
     cfac = ssum;
     if (cfac < c.lower || cfac > c.upper) {  // :334-347
 #pragma unroll
@@ -111,7 +113,7 @@ RL_DEV void paint_forward(const PaintParams &p, int k, float *stage) {
   }
 }
 
-template <int S, int TAIL, bool EXACT>
+template <int S, int TAIL, int MODE>
 RL_DEV void paint_backward(const PaintParams &p, int k, float *stage) {
   LaneCtx<S> lc;
   lc.init(p.lay, k);
@@ -123,7 +125,6 @@ RL_DEV void paint_backward(const PaintParams &p, int k, float *stage) {
   const double *__restrict__ cfp = p.cf + off;
   const double *__restrict__ nx = p.nxt + off;
   const int32_t *__restrict__ ie = p.stone_ie + (size_t)k * W;
-  constexpr bool exact = EXACT;
 
   double b[S];
   RawBits<S> raw;
@@ -171,8 +172,8 @@ RL_DEV void paint_backward(const PaintParams &p, int k, float *stage) {
       if (i >= S - TAIL) v = (i < lc.len) ? v : 0.0;
       b[i] = v;
     }
-    auto term = [&](int i) { return (m_here.get(i) ? c.theta : c.ntheta) * b[i]; };
-    bsum = exact ? sum_exact<S>(term) : sum_lanes<S>(term);  // :495-503
+    const WeightedTerm<S> term{m_here, b, c.theta, c.ntheta};
+    bsum = wave_sum<MODE, S>(term);  // :495-503
     cfac = bsum;
     if (cfac < c.lower || cfac > c.upper) {  // :538-551
 #pragma unroll
@@ -190,34 +191,28 @@ RL_DEV void paint_backward(const PaintParams &p, int k, float *stage) {
   }
 }
 
-template <int S, int TAIL, bool EXACT, bool BACKWARD>
+template <int S, int TAIL, int MODE, bool BACKWARD>
 __global__ void __launch_bounds__(64) paint_kernel(const PaintParams p) {
   __shared__ float stage[16 * 64];
   const int k = p.order[blockIdx.x];
   if (BACKWARD)
-    paint_backward<S, TAIL, EXACT>(p, k, stage);
+    paint_backward<S, TAIL, MODE>(p, k, stage);
   else
-    paint_forward<S, TAIL, EXACT>(p, k, stage);
+    paint_forward<S, TAIL, MODE>(p, k, stage);
 }
 
 template <int S, int TAIL>
 static hipError_t launch_paint_t(const PaintParams &p, int backward, hipStream_t stream) {
   const dim3 grid(p.lay.N), block(64);
-  if (p.sum_mode == 0) {
-    if (backward)
-      hipLaunchKernelGGL((paint_kernel<S, TAIL, true, true>), grid, block, 0, stream, p);
-    else
-      hipLaunchKernelGGL((paint_kernel<S, TAIL, true, false>), grid, block, 0, stream, p);
-  } else {
-    if (backward)
-      hipLaunchKernelGGL((paint_kernel<S, TAIL, false, true>), grid, block, 0, stream, p);
-    else
-      hipLaunchKernelGGL((paint_kernel<S, TAIL, false, false>), grid, block, 0, stream, p);
-  }
+  if (backward)
+    hipLaunchKernelGGL((paint_kernel<S, TAIL, RL_MODE, true>), grid, block, 0, stream, p);
+  else
+    hipLaunchKernelGGL((paint_kernel<S, TAIL, RL_MODE, false>), grid, block, 0, stream, p);
   return hipGetLastError();
 }
 
-hipError_t launch_paint(const PaintParams &p, int S, int backward, hipStream_t stream) {
+template <>
+hipError_t launch_paint_mode<RL_MODE>(const PaintParams &p, int S, int backward, hipStream_t stream) {
   switch (S) {
 #define RL_CASE(s, t) \
   case s:             \

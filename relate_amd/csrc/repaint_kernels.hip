@@ -10,7 +10,12 @@
 // same register-major layout (4 B per donor per visited site: the kernel is
 // HBM-write-bound).
 #include "paint_device.h"
+#include "exact_sum.h"
 #include "launch.h"
+
+#ifndef RL_MODE
+#error "compile with -DRL_MODE=0|1|2"
+#endif
 
 namespace rl {
 
@@ -31,7 +36,7 @@ RL_DEV void load_stone(const LaneCtx<S> &lc, const float *__restrict__ in, doubl
   }
 }
 
-template <int S, int TAIL, bool EXACT>
+template <int S, int TAIL, int MODE>
 RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ scratch, float *stage) {
   LaneCtx<S> lc;
   lc.init(p.lay, n);
@@ -55,8 +60,7 @@ RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ s
 
   // ---------------- forward (fast_painting.cpp:769-885)
   load_stone<S>(lc, p.alpha_begin + (size_t)n * N, a, stage);
-  double ssum = EXACT ? sum_exact<S>([&](int i) { return a[i]; })
-                      : sum_lanes<S>([&](int i) { return a[i]; });
+  double ssum = wave_sum<MODE, S>(RegTerm<S>{a});
   float lsf = p.ls_alpha[n];
   double prev_ls = (double)lsf;
   {
@@ -85,8 +89,7 @@ RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ s
       if (j >= S - TAIL) v = (j < lc.len) ? v : 0.0;
       a[j] = v;
     }
-    ssum = EXACT ? sum_exact<S>([&](int j) { return a[j]; })
-                 : sum_lanes<S>([&](int j) { return a[j]; });
+    ssum = wave_sum<MODE, S>(RegTerm<S>{a});
     cfac = ssum;
     if (cfac < c.lower || cfac > c.upper) {  // :865-877
 #pragma unroll
@@ -112,8 +115,8 @@ RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ s
   raw.load(p.bits + (size_t)(sv & 0x7fffffff) * p.row_words, lc.w0);
   m_here.from_raw(raw, lc);
   m_here.to_mismatch(sv < 0);
-  auto term = [&](int i) { return (m_here.get(i) ? c.theta : c.ntheta) * b[i]; };
-  double bsum = EXACT ? sum_exact<S>(term) : sum_lanes<S>(term);
+  const WeightedTerm<S> term{m_here, b, c.theta, c.ntheta};
+  double bsum = wave_sum<MODE, S>(term);
   {
     // `a` still holds row D-1 (:930)
     float *trow = top + (int64_t)(D - 1) * (S * 64);
@@ -147,7 +150,7 @@ RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ s
       if (i >= S - TAIL) v = (i < lc.len) ? v : 0.0;
       b[i] = v;
     }
-    bsum = EXACT ? sum_exact<S>(term) : sum_lanes<S>(term);
+    bsum = wave_sum<MODE, S>(term);
     cfac = bsum;
     float *trow = top + (int64_t)j * (S * 64);
 #pragma unroll
@@ -165,7 +168,7 @@ RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ s
   }
 }
 
-template <int S, int TAIL, bool EXACT>
+template <int S, int TAIL, int MODE>
 __global__ void __launch_bounds__(64) repaint_kernel(const RepaintParams p, int *counter) {
   __shared__ float stage[16 * 64];
   __shared__ int s_t;
@@ -176,24 +179,17 @@ __global__ void __launch_bounds__(64) repaint_kernel(const RepaintParams p, int 
     const int t = s_t;
     __syncthreads();
     if (t >= p.lay.N) break;
-    repaint_target<S, TAIL, EXACT>(p, p.order[t], scratch, stage);
+    repaint_target<S, TAIL, MODE>(p, p.order[t], scratch, stage);
   }
 }
 
-template <int S, int TAIL>
-static hipError_t launch_repaint_t(const RepaintParams &p, int nblocks, int *counter, hipStream_t stream) {
-  if (p.sum_mode == 0)
-    hipLaunchKernelGGL((repaint_kernel<S, TAIL, true>), dim3(nblocks), dim3(64), 0, stream, p, counter);
-  else
-    hipLaunchKernelGGL((repaint_kernel<S, TAIL, false>), dim3(nblocks), dim3(64), 0, stream, p, counter);
-  return hipGetLastError();
-}
-
-hipError_t launch_repaint(const RepaintParams &p, int S, int nblocks, int *counter, hipStream_t stream) {
+template <>
+hipError_t launch_repaint_mode<RL_MODE>(const RepaintParams &p, int S, int nblocks, int *counter, hipStream_t stream) {
   switch (S) {
-#define RL_CASE(s, t) \
-  case s:             \
-    return launch_repaint_t<s, t>(p, nblocks, counter, stream);
+#define RL_CASE(s, t)                                                                                        \
+  case s:                                                                                                    \
+    hipLaunchKernelGGL((repaint_kernel<s, t, RL_MODE>), dim3(nblocks), dim3(64), 0, stream, p, counter); \
+    return hipGetLastError();
     RL_FOR_EACH_S(RL_CASE)
 #undef RL_CASE
   }

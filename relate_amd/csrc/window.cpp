@@ -57,7 +57,7 @@ rl_window *rl_window_open(rl_ctx *ctx, int w, const char *paint_file, int first_
     set_error("rl_window_open: bad arguments");
     return nullptr;
   }
-  if (sum_mode != RL_SUM_EXACT && sum_mode != RL_SUM_LANES) {
+  if (sum_mode != RL_SUM_EXACT && sum_mode != RL_SUM_LANES && sum_mode != RL_SUM_EXACT_SERIAL) {
     set_error("rl_window_open: bad sum_mode");
     return nullptr;
   }

@@ -39,7 +39,7 @@ def bits_equal(a, b):
     (600, 1200, 2000000, 11, 0.001, 1.0),   # S=16 tile
     (1100, 700, 4000000, 13, 0.001, 50.0),  # S=32 tile, r_prob clamp
 ])
-@pytest.mark.parametrize("mode", ["exact", "lanes"])
+@pytest.mark.parametrize("mode", ["exact", "lanes", "serial"])
 def test_paint_matches_oracle(N, L, budget, seed, theta, rho, mode):
     ch = rlutil.synth_chunk(N, L, seed=seed, budget=budget)
     ctx = api.Context()
@@ -48,7 +48,7 @@ def test_paint_matches_oracle(N, L, budget, seed, theta, rho, mode):
         ctx.set_painting(theta, rho)
         ch.theta = theta
         ch.r = ch.r * rho
-    ctx.paint(api.RL_SUM_EXACT if mode == "exact" else api.RL_SUM_LANES)
+    ctx.paint({"exact": api.RL_SUM_EXACT, "lanes": api.RL_SUM_LANES, "serial": api.RL_SUM_EXACT_SERIAL}[mode])
     W = ch.W
     st = [ctx.stones(w) for w in range(W)]
     targets = sorted(set([0, 1, N // 2, N - 1] + [int(x) for x in np.random.RandomState(seed).randint(0, N, 6)]))
