@@ -98,6 +98,10 @@ int rl_paint(rl_ctx *ctx, int sum_mode, float *kernel_ms);
  * backward kernel), in milliseconds. */
 int rl_paint_times(const rl_ctx *ctx, float *fwd_ms, float *bwd_ms);
 
+/* Experiment builds only (kernels compiled with -DRL_STATS and
+ * RELATE_AMD_STATS set): 16 event counters of the last rl_paint. */
+int rl_debug_stats(rl_ctx *ctx, unsigned long long *out16);
+
 /* Copy stepping stones of window w to the host: alpha, beta: N*N floats
  * ([target][donor]); ls_alpha, ls_beta: N floats; bsnp_begin/end: N ints.
  * Any pointer may be NULL. */

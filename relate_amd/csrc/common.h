@@ -95,7 +95,7 @@ struct rl_ctx {
   rl::Plan plan;
   rl::PaintConsts consts{};
   rl::DevBuf d_bits, d_off, d_sites, d_cf, d_nxt, d_ia, d_ie, d_binit, d_order;
-  rl::DevBuf d_alpha, d_beta, d_lsa, d_lsb;
+  rl::DevBuf d_alpha, d_beta, d_lsa, d_lsb, d_stats;
   bool have_chunk = false, plan_on_device = false, painted = false;
   int paint_mode = -1;
   float ms_fwd = 0.f, ms_bwd = 0.f;

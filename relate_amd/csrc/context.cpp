@@ -591,6 +591,12 @@ int rl_paint(rl_ctx *ctx, int sum_mode, float *kernel_ms) {
   p.ls_alpha = ctx->d_lsa.as<float>();
   p.ls_beta = ctx->d_lsb.as<float>();
   p.sum_mode = sum_mode;
+  p.stats = nullptr;
+  if (getenv("RELATE_AMD_STATS")) {  // experiment builds (-DRL_STATS): 16 counters, see tools/exp_stats.py
+    if ((rc = ctx->d_stats.alloc(16 * sizeof(unsigned long long)))) return rc;
+    RL_HIP(hipMemset(ctx->d_stats.p, 0, 16 * sizeof(unsigned long long)));
+    p.stats = ctx->d_stats.as<unsigned long long>();
+  }
 
   // backward then forward on one stream, each bracketed by HIP events
   RL_HIP(hipEventRecord(ctx->ev0, ctx->s0));
@@ -604,6 +610,12 @@ int rl_paint(rl_ctx *ctx, int sum_mode, float *kernel_ms) {
   if (kernel_ms) *kernel_ms = ctx->ms_bwd + ctx->ms_fwd;
   ctx->painted = true;
   ctx->paint_mode = sum_mode;
+  return RL_OK;
+}
+
+int rl_debug_stats(rl_ctx *ctx, unsigned long long *out16) {
+  if (!ctx || !ctx->d_stats.p || !out16) return RL_ESTATE;
+  RL_HIP(hipMemcpy(out16, ctx->d_stats.p, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return RL_OK;
 }
 

@@ -40,7 +40,8 @@ struct PaintParams {
   const int32_t *order;     // [N] launch order -> target (longest first)
   float *alpha, *beta;      // [W][N][N] stepping stones, donor order
   float *ls_alpha, *ls_beta;  // [W][N]
-  int sum_mode;             // RL_SUM_EXACT / RL_SUM_LANES
+  int sum_mode;             // RL_SUM_EXACT / RL_SUM_LANES / RL_SUM_EXACT_SERIAL
+  unsigned long long *stats;  // 16 event counters (experiment builds with -DRL_STATS), else null
 };
 
 // RePaintSection over one window, all targets.

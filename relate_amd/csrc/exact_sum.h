@@ -23,9 +23,9 @@
 //       terms;
 //   (3) r_0 and r_3 are placed 16384 ulp below / above P_l, so s_l lies between
 //       them; fl-addition is monotone in its start value, hence if the r_0 and
-//       r_3 runs show the same exponent after every term (checked through the
-//       sums of those exponents, equal iff pointwise equal) so does every run
-//       in between, the true one included.
+//       r_3 runs show the same exponent after every term (their high words are
+//       xor-ed and or-accumulated term by term) so does every run in between,
+//       the true one included.
 // What remains sequential is a walk over the few lanes whose run is not a pure
 // translation (a tie or a binade crossing happened inside): integer offsets
 // delta_l = (s_l - P_l)/ulp are pushed through 4-entry tables.  Lanes whose
@@ -92,6 +92,7 @@ struct RegTerm {  // forward: the terms are the alpha registers themselves
   static constexpr bool REG = true;
   const double (&a)[S];
   double th = 0.0, nth = 0.0;
+  unsigned long long *stats = nullptr;  // experiment builds (-DRL_STATS) only
   RL_DEV double get(int i, double, double) const { return a[i]; }
 };
 template <int S>
@@ -100,6 +101,7 @@ struct WeightedTerm {  // backward: e(i) * beta[i], e = theta on a mismatch else
   const LaneBits<S> &m;
   const double (&b)[S];
   double th, nth;
+  unsigned long long *stats = nullptr;
   RL_DEV double get(int i, double t, double n) const { return (m.get(i) ? t : n) * b[i]; }
 };
 
@@ -124,8 +126,7 @@ RL_DEV double sum_exact_fallback(const T &term) {
 }
 
 #ifdef RL_STATS
-__device__ unsigned long long rl_stats[8];
-#define RL_STAT(i, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&rl_stats[i], (unsigned long long)(v)); } while (0)
+#define RL_STAT(i, v) do { if (term.stats && (threadIdx.x & 63) == 0) atomicAdd(&term.stats[i], (unsigned long long)(v)); } while (0)
 #else
 #define RL_STAT(i, v) do { } while (0)
 #endif
@@ -164,7 +165,7 @@ RL_DEV double sum_exact_fast(const T &term) {
   const double r0 = c0, r1 = c1, r2 = c2, r3 = c3;
   const int e_in = expo_field(r0);
   const bool entry_ok = zero_entry || (e_in == expo_field(r3) && e_in > 64);
-  int E0 = 0, E3 = 0;
+  int exdiff = 0;  // OR over the terms of (high word of c0) xor (high word of c3)
   double thB = term.th, nthB = term.nth;
 #pragma unroll
   for (int i = 0; i < S; i++) {
@@ -173,11 +174,12 @@ RL_DEV double sum_exact_fast(const T &term) {
     c1 += x;
     c2 += x;
     c3 += x;
-    E0 += hi32(c0) >> 20;
-    E3 += hi32(c3) >> 20;
-    // tie each exponent read to its partial sum: otherwise the scheduler first
-    // runs both chains to the end and keeps all 2*S partial sums alive
-    asm volatile("" : "+v"(E0), "+v"(E3), "+v"(c0), "+v"(c3), "+v"(thB), "+v"(nthB));
+    // exponent fields of the two bracketing runs must agree after every term;
+    // one 3-input bit op per term (bits 20..30 of the accumulated xor)
+    exdiff |= hi32(c0) ^ hi32(c3);
+    // tie the check to its partial sums: otherwise the scheduler first runs
+    // the chains to the end and keeps all partial sums alive
+    asm volatile("" : "+v"(exdiff), "+v"(c0), "+v"(c3), "+v"(thB), "+v"(nthB));
   }
   const int e_out = expo_field(c0);
   // exit unit = entry unit of the next lane = ulp of the binade of Q
@@ -186,7 +188,7 @@ RL_DEV double sum_exact_fast(const T &term) {
 
   // ---- classification
   const double D0 = c0 - r0, D1 = c1 - r1, D2 = c2 - r2, D3 = c3 - r3;
-  const bool same_seq = E0 == E3;
+  const bool same_seq = (exdiff >> 20) == 0;
   const int sh = e_out - e_in;
   const bool pure_cand = (D0 == D1) && (D1 == D2) && (D2 == D3) && sh == 0;
   bool invalid = !entry_ok || !same_seq;
@@ -200,12 +202,13 @@ RL_DEV double sum_exact_fast(const T &term) {
   // offsets are in units of the exit ulp; for a pure lane delta_out = delta_in + cinc
   int cinc = 0;
   if (pure && !zero_entry) cinc = (int)((D0 - (Q - P)) * inv_u_out);
-  int A0 = 0, A1 = 0, A2 = 0, A3 = 0;
+  // exit offsets of the four runs, |A_h| < 2^15, packed two per word
+  int w01 = 0, w23 = 0;
   if (table) {
-    A0 = (int)((c0 - Q) * inv_u_out);
-    A1 = (int)((c1 - Q) * inv_u_out);
-    A2 = (int)((c2 - Q) * inv_u_out);
-    A3 = (int)((c3 - Q) * inv_u_out);
+    const int A0 = (int)((c0 - Q) * inv_u_out), A1 = (int)((c1 - Q) * inv_u_out);
+    const int A2 = (int)((c2 - Q) * inv_u_out), A3 = (int)((c3 - Q) * inv_u_out);
+    w01 = (A0 & 0xffff) | (A1 << 16);
+    w23 = (A2 & 0xffff) | (A3 << 16);
   }
   const int meta = p0 | (sh << 2) | (special ? 16 : 0);
 
@@ -233,13 +236,15 @@ RL_DEV double sum_exact_fast(const T &term) {
   RL_STAT(2, __builtin_popcountll(todo));
   RL_STAT(3, __builtin_popcountll(__ballot(special)));
   int delta = 0;  // offset at the exit of lane `prev`
-  int prev = 0;   // lane 0 enters at exactly 0: its local sum is exact and Q_0 == L_0
+  // lane 0 enters at exactly 0: its local sum is exact and Q_0 == L_0
   int cpre_prev = __builtin_amdgcn_readlane(cpre, 0);
   while (todo) {
     const int q = __builtin_ctzll(todo);
     todo &= todo - 1;
-    // pure lanes strictly between prev and q
-    delta += __builtin_amdgcn_readlane(cpre, q - 1) - cpre_prev;
+    // pure lanes strictly between prev and q (cinc of a non-pure lane is 0)
+    const int cq = __builtin_amdgcn_readlane(cpre, q);
+    delta += cq - cpre_prev;
+    cpre_prev = cq;
     const int m = __builtin_amdgcn_readlane(meta, q);
 #ifdef RL_X_NOSPECIAL
     if (false) {
@@ -261,17 +266,13 @@ RL_DEV double sum_exact_fast(const T &term) {
     } else {
       const int qp0 = m & 3, qsh = (m >> 2) & 3;
       const int h = (qp0 + delta) & 3;
-      const int a0 = __builtin_amdgcn_readlane(A0, q), a1 = __builtin_amdgcn_readlane(A1, q);
-      const int a2 = __builtin_amdgcn_readlane(A2, q), a3 = __builtin_amdgcn_readlane(A3, q);
-      const int A = h == 0 ? a0 : (h == 1 ? a1 : (h == 2 ? a2 : a3));
+      const int w = __builtin_amdgcn_readlane((h & 2) ? w23 : w01, q);
+      const int A = (int)(short)((h & 1) ? (w >> 16) : w);
       const int B = h == 0 ? (-qp0 - G4) : (h == 3 ? (3 - qp0 + G4) : (h - qp0));
       delta = A + ((delta - B) >> qsh);
     }
-    prev = q;
-    cpre_prev = __builtin_amdgcn_readlane(cpre, q);
   }
   delta += __builtin_amdgcn_readlane(cpre, 63) - cpre_prev;
-  (void)prev;
   return Qt + (double)delta * pow2_field(expo_field(Qt) - 52);
 }
 

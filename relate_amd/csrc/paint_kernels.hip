@@ -63,7 +63,7 @@ RL_DEV void paint_forward(const PaintParams &p, int k, float *stage) {
     double v = mb.get(i) ? c.init1 : c.init0;
     a[i] = (i < lc.len) ? v : 0.0;
   }
-  double ssum = wave_sum<MODE, S>(RegTerm<S>{a});
+  double ssum = wave_sum<MODE, S>(RegTerm<S>{a, 0.0, 0.0, p.stats});
   double ls = 0.0;
   int wa = 0;
   int next_stone = ia[0];
@@ -95,7 +95,7 @@ RL_DEV void paint_forward(const PaintParams &p, int k, float *stage) {
       if (j >= S - TAIL) v = (j < lc.len) ? v : 0.0;
       a[j] = v;
     }
-    ssum = wave_sum<MODE, S>(RegTerm<S>{a});
+    ssum = wave_sum<MODE, S>(RegTerm<S>{a, 0.0, 0.0, p.stats});
     cfac = ssum;
     if (cfac < c.lower || cfac > c.upper) {  // :334-347
 #pragma unroll
@@ -172,7 +172,7 @@ RL_DEV void paint_backward(const PaintParams &p, int k, float *stage) {
       if (i >= S - TAIL) v = (i < lc.len) ? v : 0.0;
       b[i] = v;
     }
-    const WeightedTerm<S> term{m_here, b, c.theta, c.ntheta};
+    const WeightedTerm<S> term{m_here, b, c.theta, c.ntheta, p.stats ? p.stats + 8 : nullptr};
     bsum = wave_sum<MODE, S>(term);  // :495-503
     cfac = bsum;
     if (cfac < c.lower || cfac > c.upper) {  // :538-551
@@ -191,8 +191,9 @@ RL_DEV void paint_backward(const PaintParams &p, int k, float *stage) {
   }
 }
 
+// S <= 80: hold the kernel to 256 registers so that two waves share a SIMD
 template <int S, int TAIL, int MODE, bool BACKWARD>
-__global__ void __launch_bounds__(64) paint_kernel(const PaintParams p) {
+__global__ void __launch_bounds__(64, (S <= 80 ? 2 : 1)) paint_kernel(const PaintParams p) {
   __shared__ float stage[16 * 64];
   const int k = p.order[blockIdx.x];
   if (BACKWARD)
