@@ -98,6 +98,12 @@ int rl_paint(rl_ctx *ctx, int sum_mode, float *kernel_ms);
  * backward kernel), in milliseconds. */
 int rl_paint_times(const rl_ctx *ctx, float *fwd_ms, float *bwd_ms);
 
+/* Test hook: `batch` arrays of n doubles each are summed, one wavefront per
+ * array, with the summation machinery of the painting kernels (sum_mode as
+ * for rl_paint); out[b] receives the sum of array b.  RL_SUM_EXACT and
+ * RL_SUM_EXACT_SERIAL must return the left-to-right IEEE sum bit for bit. */
+int rl_debug_wave_sum(const double *x, int n, int batch, int sum_mode, double *out);
+
 /* Experiment builds only (kernels compiled with -DRL_STATS and
  * RELATE_AMD_STATS set): 16 event counters of the last rl_paint. */
 int rl_debug_stats(rl_ctx *ctx, unsigned long long *out16);

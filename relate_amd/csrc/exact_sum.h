@@ -26,12 +26,16 @@
 //       r_3 runs show the same exponent after every term (their high words are
 //       xor-ed and or-accumulated term by term) so does every run in between,
 //       the true one included.
-// What remains sequential is a walk over the few lanes whose run is not a pure
-// translation (a tie or a binade crossing happened inside): integer offsets
-// delta_l = (s_l - P_l)/ulp are pushed through 4-entry tables.  Lanes whose
-// run jumps two or more binades (a donor much larger than the prefix) redo
-// their run from the exact entry value; anything irregular (P_l within 16384
-// ulp of a power of two, ...) falls back to sum_exact for that step.
+// In integer offsets delta_l = (s_l - P_l)/ulp a lane without a rounding tie
+// acts as delta -> ((delta + K) >> s) + C (s = binade crossings inside, 0 or 1);
+// such maps compose into maps of the same form, so a segmented wavefront scan
+// composes them all at once.  What remains sequential is a walk over the few
+// lanes (measured ~3.5 per sum at N = 5000) where a tie made the four runs
+// disagree (4-entry table) or where the run jumps two or more binades (a term
+// much larger than the prefix, ~0.9 per sum: that lane redoes its run from its
+// exact entry value).  Anything else irregular (P_l within 16384 ulp of a power
+// of two, ...) falls back to the literal serial sum for that step (measured:
+// < 1e-4 of the steps).
 // The result is ALWAYS the serial sum, bit for bit.
 #pragma once
 #include "paint_device.h"
@@ -131,24 +135,15 @@ RL_DEV double sum_exact_fallback(const T &term) {
 #define RL_STAT(i, v) do { } while (0)
 #endif
 
+// L: this lane's serial sum of its terms from +0.0 (the caller accumulates it
+// inside its update loop, where the dependent adds hide behind other work).
 template <int S, typename T>
-RL_DEV double sum_exact_fast(const T &term) {
+RL_DEV double sum_exact_fast(const T &term, double L) {
   constexpr bool REG_TERM = T::REG;
   const int lane = threadIdx.x & 63;
   constexpr int G4 = 16384;  // half-width of the bracket [r_0, r_3] in ulps
 
-  // ---- A. local serial sums and the approximate prefix
-  double L = 0.0;
-  {
-    double th = term.th, nth = term.nth;
-#pragma unroll
-    for (int i = 0; i < S; i++) {
-      // the fake dependency makes term i+1 wait for sum i: otherwise all S
-      // terms are computed up front and stay alive
-      if constexpr (!REG_TERM) asm volatile("" : "+v"(th), "+v"(nth), "+v"(L));
-      L += term.get(i, th, nth);
-    }
-  }
+  // ---- A. approximate prefix from the lanes' local serial sums
   const double Q = wave_scan_f64(L);          // ~ sum over lanes <= l
   double P = dpp_f64<DPP_WAVE_SHR1>(Q);       // ~ entry value of this lane (lane 0: +0.0)
   const long long pb = __double_as_longlong(P);
@@ -162,7 +157,7 @@ RL_DEV double sum_exact_fast(const T &term) {
   double c2 = __longlong_as_double(base + 2);
   double c3 = __longlong_as_double(base + 3 + G4);
   if (zero_entry) { c0 = 0.0; c1 = 0.0; c2 = 0.0; c3 = 0.0; }
-  const double r0 = c0, r1 = c1, r2 = c2, r3 = c3;
+  const double r0 = c0, r3 = c3;
   const int e_in = expo_field(r0);
   const bool entry_ok = zero_entry || (e_in == expo_field(r3) && e_in > 64);
   int exdiff = 0;  // OR over the terms of (high word of c0) xor (high word of c3)
@@ -179,7 +174,7 @@ RL_DEV double sum_exact_fast(const T &term) {
     exdiff |= hi32(c0) ^ hi32(c3);
     // tie the check to its partial sums: otherwise the scheduler first runs
     // the chains to the end and keeps all partial sums alive
-    asm volatile("" : "+v"(exdiff), "+v"(c0), "+v"(c3), "+v"(thB), "+v"(nthB));
+    asm volatile("" : "+v"(exdiff), "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(thB), "+v"(nthB));
   }
   const int e_out = expo_field(c0);
   // exit unit = entry unit of the next lane = ulp of the binade of Q
@@ -187,29 +182,47 @@ RL_DEV double sum_exact_fast(const T &term) {
   const double inv_u_out = pow2_field(1075 + 1023 - e_next);  // 1 / 2^(e_next - 1075)
 
   // ---- classification
-  const double D0 = c0 - r0, D1 = c1 - r1, D2 = c2 - r2, D3 = c3 - r3;
   const bool same_seq = (exdiff >> 20) == 0;
   const int sh = e_out - e_in;
-  const bool pure_cand = (D0 == D1) && (D1 == D2) && (D2 == D3) && sh == 0;
   bool invalid = !entry_ok || !same_seq;
   // the exit must sit in the binade the next lane (or the caller) measures in
   if (!zero_entry && e_out != e_next) invalid = true;
   if (zero_entry && expo_field(c0) != e_next) invalid = true;
+  // a run that jumps two or more binades (a term much larger than the prefix)
+  // does not fit the mod-4 argument: the walk redoes it from its exact entry
   const bool special = !zero_entry && !invalid && sh >= 2;
-  const bool pure = zero_entry || (!invalid && !special && pure_cand);
-  const bool table = !invalid && !special && !pure;
 
-  // offsets are in units of the exit ulp; for a pure lane delta_out = delta_in + cinc
-  int cinc = 0;
-  if (pure && !zero_entry) cinc = (int)((D0 - (Q - P)) * inv_u_out);
-  // exit offsets of the four runs, |A_h| < 2^15, packed two per word
-  int w01 = 0, w23 = 0;
-  if (table) {
-    const int A0 = (int)((c0 - Q) * inv_u_out), A1 = (int)((c1 - Q) * inv_u_out);
-    const int A2 = (int)((c2 - Q) * inv_u_out), A3 = (int)((c3 - Q) * inv_u_out);
-    w01 = (A0 & 0xffff) | (A1 << 16);
-    w23 = (A2 & 0xffff) | (A3 << 16);
+  // offsets are in units of the exit ulp.  Exit offsets of the four runs
+  // (|A_h| < 2^15) and entry offsets B_h = (r_h - P)/ulp_in of their starts:
+  int A0 = 0, A1 = 0, A2 = 0, A3 = 0;
+  if (!invalid && !special && !zero_entry) {
+    A0 = (int)((c0 - Q) * inv_u_out);
+    A1 = (int)((c1 - Q) * inv_u_out);
+    A2 = (int)((c2 - Q) * inv_u_out);
+    A3 = (int)((c3 - Q) * inv_u_out);
   }
+  const int B0 = -p0 - G4, B1 = 1 - p0, B2 = 2 - p0, B3 = 3 - p0 + G4;
+  // Is the lane's map delta -> A_h + ((delta - B_h) >> sh), h = (p0 + delta) & 3,
+  // of the tie-free form ((delta + K) >> sh) + C ?   (K in {0,1} when sh = 1)
+  int mK = 0, mC = 0;
+  bool affine = zero_entry;
+  if (!invalid && !special && !zero_entry) {
+    if (sh == 0) {
+      const int d = A0 - B0;
+      affine = (A1 - B1 == d) && (A2 - B2 == d) && (A3 - B3 == d);
+      mC = d;
+    } else {
+      const int d0 = A0 - (B0 >> 1), d1 = A0 - ((B0 + 1) >> 1);
+      const bool k0 = (A1 - (B1 >> 1) == d0) && (A2 - (B2 >> 1) == d0) && (A3 - (B3 >> 1) == d0);
+      const bool k1 = (A1 - ((B1 + 1) >> 1) == d1) && (A2 - ((B2 + 1) >> 1) == d1) && (A3 - ((B3 + 1) >> 1) == d1);
+      affine = k0 || k1;
+      mK = k0 ? 0 : 1;
+      mC = k0 ? d0 : d1;
+    }
+  }
+  const int mS = (affine && !zero_entry) ? sh : 0;
+  if (!affine) { mK = 0; mC = 0; }
+  const int w01 = (A0 & 0xffff) | (A1 << 16), w23 = (A2 & 0xffff) | (A3 << 16);
   const int meta = p0 | (sh << 2) | (special ? 16 : 0);
 
   // the caller's unit: the total is returned as Q_63 + delta * ulp(Q_63); Q_63
@@ -220,37 +233,60 @@ RL_DEV double sum_exact_fast(const T &term) {
     const int ea = expo_field(__longlong_as_double(qb - G4)), eb = expo_field(__longlong_as_double(qb + 3 + G4));
     if (ea != eb || ea <= 64) invalid = true;
   }
-  RL_STAT(0, 1);
-  if (__ballot(invalid) != 0ull) {
-    RL_STAT(1, 1);
-#ifdef RL_X_NOFALLBACK
-    return 0.0;
-#else
-    return sum_exact_fallback<S>(term);  // irregular step: literal serial sum
-#endif
+  // ---- C. compose the tie-free lanes with a segmented scan (segments end at
+  // the lanes that need the walk), then walk those lanes
+  int sK = mK, sC = mC, sS = mS | (affine ? 0 : 64);  // bit 6: segment head
+  auto combine = [&](int pK, int pC, int pS) {
+    // (pK,pC,pS) = composite of the lanes further left; no-op if a head lies in between
+    if (!(sS & 64)) {
+      const int ps = pS & 63;
+      sK = pK + ((pC + sK) << ps);
+      sS = (ps + (sS & 63)) | (pS & 64);
+      // sC unchanged
+    }
+  };
+#define RL_SCAN_STEP(CTRL, RM)                                              \
+  {                                                                         \
+    const int pK = __builtin_amdgcn_update_dpp(0, sK, CTRL, RM, 0xf, true); \
+    const int pC = __builtin_amdgcn_update_dpp(0, sC, CTRL, RM, 0xf, true); \
+    const int pS = __builtin_amdgcn_update_dpp(0, sS, CTRL, RM, 0xf, true); \
+    combine(pK, pC, pS);                                                    \
   }
-
-  // ---- C. walk the non-pure lanes
-  const int cpre = wave_scan_i32(cinc);
-  unsigned long long todo = __ballot(!pure);
+  RL_SCAN_STEP(DPP_ROW_SHR + 1, 0xf)
+  RL_SCAN_STEP(DPP_ROW_SHR + 2, 0xf)
+  RL_SCAN_STEP(DPP_ROW_SHR + 4, 0xf)
+  RL_SCAN_STEP(DPP_ROW_SHR + 8, 0xf)
+  RL_SCAN_STEP(DPP_ROW_BCAST15, 0xa)
+  RL_SCAN_STEP(DPP_ROW_BCAST31, 0xc)
+#undef RL_SCAN_STEP
+  // lanes not selected by a step read (0,0,0) = the identity map: harmless
+  RL_STAT(0, 1);
+  if (__ballot(invalid || (sS & 63) > 20) != 0ull) {
+    RL_STAT(1, 1);
+    return sum_exact_fallback<S>(term);  // irregular step: literal serial sum
+  }
+  unsigned long long todo = __ballot(!affine);
   RL_STAT(2, __builtin_popcountll(todo));
-  RL_STAT(3, __builtin_popcountll(__ballot(special)));
-  int delta = 0;  // offset at the exit of lane `prev`
-  // lane 0 enters at exactly 0: its local sum is exact and Q_0 == L_0
-  int cpre_prev = __builtin_amdgcn_readlane(cpre, 0);
+  {
+    const unsigned long long sp = __ballot(special), cv = __ballot(special && c0 == c3), s2 = __ballot(special && sh == 2), s3 = __ballot(special && sh == 3), s4 = __ballot(special && sh >= 4 && sh < 8);
+    (void)sp; (void)cv; (void)s2; (void)s3; (void)s4;
+    RL_STAT(3, __builtin_popcountll(sp));
+    RL_STAT(4, __builtin_popcountll(cv));
+    RL_STAT(5, __builtin_popcountll(s2));
+    RL_STAT(6, __builtin_popcountll(s3));
+    RL_STAT(7, __builtin_popcountll(s4));
+  }
+  int delta = 0;  // lane 0 enters at exactly 0 (its local sum is exact, Q_0 == L_0)
   while (todo) {
     const int q = __builtin_ctzll(todo);
     todo &= todo - 1;
-    // pure lanes strictly between prev and q (cinc of a non-pure lane is 0)
-    const int cq = __builtin_amdgcn_readlane(cpre, q);
-    delta += cq - cpre_prev;
-    cpre_prev = cq;
+    {  // tie-free lanes since the previous walked lane (composite sits in lane q-1)
+      const int K = __builtin_amdgcn_readlane(sK, q - 1), C = __builtin_amdgcn_readlane(sC, q - 1);
+      const int sft = __builtin_amdgcn_readlane(sS, q - 1) & 63;
+      delta = ((delta + K) >> sft) + C;
+    }
     const int m = __builtin_amdgcn_readlane(meta, q);
-#ifdef RL_X_NOSPECIAL
-    if (false) {
-#else
     if (m & 16) {
-#endif
       // multi-binade run: redo it from the exact entry value
       const double Pq = rd_lane_f64(P, q);
       const double uq = pow2_field(expo_field(Pq) - 52);
@@ -272,18 +308,31 @@ RL_DEV double sum_exact_fast(const T &term) {
       delta = A + ((delta - B) >> qsh);
     }
   }
-  delta += __builtin_amdgcn_readlane(cpre, 63) - cpre_prev;
+  {  // trailing tie-free lanes (lane 63 holds their composite; identity if it was walked)
+    const int K = __builtin_amdgcn_readlane(sK, 63), C = __builtin_amdgcn_readlane(sC, 63);
+    const int sft = __builtin_amdgcn_readlane(sS, 63) & 63;
+    delta = ((delta + K) >> sft) + C;
+  }
   return Qt + (double)delta * pow2_field(expo_field(Qt) - 52);
 }
 
+// L = the lane's local serial sum of its terms (see sum_exact_fast)
 template <int MODE, int S, typename T>
-RL_DEV double wave_sum(const T &term) {
+RL_DEV double wave_sum(const T &term, double L) {
   if constexpr (MODE == 1)
-    return sum_exact_fast<S>(term);
+    return sum_exact_fast<S>(term, L);
   else if constexpr (MODE == 2)
     return sum_exact<S>([&](int i) { return term.get(i, term.th, term.nth); });
   else
-    return sum_lanes<S>([&](int i) { return term.get(i, term.th, term.nth); });
+    return wave_sum_butterfly(L);
+}
+
+template <int S, typename T>
+RL_DEV double local_sum(const T &term) {
+  double L = 0.0;
+#pragma unroll
+  for (int i = 0; i < S; i++) L += term.get(i, term.th, term.nth);
+  return L;
 }
 
 }  // namespace rl

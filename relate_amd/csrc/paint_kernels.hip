@@ -26,7 +26,12 @@ RL_DEV void emit_stone(const LaneCtx<S> &lc, const double (&v)[S], float *__rest
 #pragma unroll
   for (int c = 0; c < S / R; c++) {
 #pragma unroll
-    for (int ii = 0; ii < R; ii++) stage[ii * 64 + lc.lane] = (float)v[c * R + ii];
+    for (int ii = 0; ii < R; ii++) {
+      // pin the conversion to its chunk: hoisted, all S floats would be live at once
+      double x = v[c * R + ii];
+      asm volatile("" : "+v"(x) : : "memory");
+      stage[ii * 64 + lc.lane] = (float)x;
+    }
 #pragma clang loop unroll(disable)
     for (int ii = 0; ii < R; ii++) {
       const int i = c * R + ii;
@@ -63,7 +68,7 @@ RL_DEV void paint_forward(const PaintParams &p, int k, float *stage) {
     double v = mb.get(i) ? c.init1 : c.init0;
     a[i] = (i < lc.len) ? v : 0.0;
   }
-  double ssum = wave_sum<MODE, S>(RegTerm<S>{a, 0.0, 0.0, p.stats});
+  double ssum = wave_sum<MODE, S>(RegTerm<S>{a, 0.0, 0.0, p.stats}, local_sum<S>(RegTerm<S>{a}));
   double ls = 0.0;
   int wa = 0;
   int next_stone = ia[0];
@@ -88,14 +93,16 @@ RL_DEV void paint_forward(const PaintParams &p, int k, float *stage) {
       raw.load(p.bits + (size_t)(sv_next & 0x7fffffff) * p.row_words, lc.w0);
     }
     ls += nx[i - 1];  // :281-282
+    double lsum = 0.0;
 #pragma unroll
     for (int j = 0; j < S; j++) {  // :288-295
       double t = a[j] + cfac;
       double v = mb.get(j) ? t * c.K1 : t;
       if (j >= S - TAIL) v = (j < lc.len) ? v : 0.0;
       a[j] = v;
+      lsum += v;  // the lane's share of the serial sum (:300-303)
     }
-    ssum = wave_sum<MODE, S>(RegTerm<S>{a, 0.0, 0.0, p.stats});
+    ssum = wave_sum<MODE, S>(RegTerm<S>{a, 0.0, 0.0, p.stats}, lsum);
     cfac = ssum;
     if (cfac < c.lower || cfac > c.upper) {  // :334-347
 #pragma unroll
@@ -164,6 +171,7 @@ RL_DEV void paint_backward(const PaintParams &p, int k, float *stage) {
     ls += nx[j + 1];                       // :471-472
     const double b1 = cfac / c.ntheta;     // :474
     const double bt = cfac / c.theta - b1; // :475
+    double lsum = 0.0;
 #pragma unroll
     for (int i = 0; i < S; i++) {
       const bool mn = m_next.get(i);
@@ -171,9 +179,10 @@ RL_DEV void paint_backward(const PaintParams &p, int k, float *stage) {
       v = mn ? v * c.K1 : v;
       if (i >= S - TAIL) v = (i < lc.len) ? v : 0.0;
       b[i] = v;
+      lsum += (m_here.get(i) ? c.theta : c.ntheta) * v;  // the lane's share of :495-503
     }
     const WeightedTerm<S> term{m_here, b, c.theta, c.ntheta, p.stats ? p.stats + 8 : nullptr};
-    bsum = wave_sum<MODE, S>(term);  // :495-503
+    bsum = wave_sum<MODE, S>(term, lsum);  // :495-503
     cfac = bsum;
     if (cfac < c.lower || cfac > c.upper) {  // :538-551
 #pragma unroll

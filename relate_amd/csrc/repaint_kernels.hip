@@ -60,7 +60,7 @@ RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ s
 
   // ---------------- forward (fast_painting.cpp:769-885)
   load_stone<S>(lc, p.alpha_begin + (size_t)n * N, a, stage);
-  double ssum = wave_sum<MODE, S>(RegTerm<S>{a});
+  double ssum = wave_sum<MODE, S>(RegTerm<S>{a}, local_sum<S>(RegTerm<S>{a}));
   float lsf = p.ls_alpha[n];
   double prev_ls = (double)lsf;
   {
@@ -82,14 +82,16 @@ RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ s
     }
     prev_ls += nx[i - 1];
     lsf = (float)prev_ls;  // :806-807
+    double lsum = 0.0;
 #pragma unroll
     for (int j = 0; j < S; j++) {
       double t = a[j] + cfac;
       double v = mb.get(j) ? t * c.K1 : t;
       if (j >= S - TAIL) v = (j < lc.len) ? v : 0.0;
       a[j] = v;
+      lsum += v;
     }
-    ssum = wave_sum<MODE, S>(RegTerm<S>{a});
+    ssum = wave_sum<MODE, S>(RegTerm<S>{a}, lsum);
     cfac = ssum;
     if (cfac < c.lower || cfac > c.upper) {  // :865-877
 #pragma unroll
@@ -116,7 +118,7 @@ RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ s
   m_here.from_raw(raw, lc);
   m_here.to_mismatch(sv < 0);
   const WeightedTerm<S> term{m_here, b, c.theta, c.ntheta};
-  double bsum = wave_sum<MODE, S>(term);
+  double bsum = wave_sum<MODE, S>(term, local_sum<S>(term));
   {
     // `a` still holds row D-1 (:930)
     float *trow = top + (int64_t)(D - 1) * (S * 64);
@@ -142,6 +144,7 @@ RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ s
     lsf = (float)(row[S * 64 + lc.lane] + prev_ls);  // :962-963
     const double b1 = cfac / c.ntheta;
     const double bt = cfac / c.theta - b1;
+    double lsum = 0.0;
 #pragma unroll
     for (int i = 0; i < S; i++) {
       const bool mn = m_next.get(i);
@@ -149,8 +152,9 @@ RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ s
       v = mn ? v * c.K1 : v;
       if (i >= S - TAIL) v = (i < lc.len) ? v : 0.0;
       b[i] = v;
+      lsum += (m_here.get(i) ? c.theta : c.ntheta) * v;  // the lane's share of :495-503
     }
-    bsum = wave_sum<MODE, S>(term);
+    bsum = wave_sum<MODE, S>(term, lsum);
     cfac = bsum;
     float *trow = top + (int64_t)j * (S * 64);
 #pragma unroll
