@@ -20,12 +20,30 @@ namespace rl {
 
 RL_DEV double wave_bcast(double v, int src_lane) { return __shfl(v, src_lane, 64); }
 
-// xor-butterfly, masks 1,2,4,8,16,32: every lane ends with the same bits
-// (IEEE addition is commutative), matching oracle RO_SUM_LANES.
+// DPP move of a double (two 32-bit DPP movs); lanes a control does not select read +0.0
+template <int CTRL, int ROW_MASK = 0xf>
+RL_DEV double dpp_mov_f64(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, ROW_MASK, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, true);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// Sum over the 64 lanes as a balanced binary tree in lane order -- the value an
+// xor-butterfly with masks 1,2,4,8,16,32 gives (IEEE addition is commutative),
+// which is what the oracle's RO_SUM_LANES reproduces -- but on the DPP
+// crossbar instead of six LDS round trips: quad swaps, half-row and row
+// mirrors, then the two row broadcasts; the total lands in lane 63.
 RL_DEV double wave_sum_butterfly(double v) {
-#pragma unroll
-  for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
-  return v;
+  v += dpp_mov_f64<0xB1>(v);         // quad_perm [1,0,3,2]
+  v += dpp_mov_f64<0x4E>(v);         // quad_perm [2,3,0,1]
+  v += dpp_mov_f64<0x141>(v);        // row_half_mirror
+  v += dpp_mov_f64<0x140>(v);        // row_mirror
+  v += dpp_mov_f64<0x142, 0xa>(v);   // row_bcast:15 -> rows 1,3
+  v += dpp_mov_f64<0x143, 0xc>(v);   // row_bcast:31 -> rows 2,3
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)b, 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
 // fast_log.hpp:6-21
