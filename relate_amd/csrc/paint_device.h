@@ -123,6 +123,17 @@ struct LaneBits {
   RL_DEV bool get(int i) const { return (w[i >> 5] >> (i & 31)) & 1u; }
 };
 
+// Lane-masked double ops: `if (lane in mask) t = t (op) k`, executed by
+// narrowing EXEC to the mask for one instruction instead of computing both
+// variants and selecting (2 x v_cndmask_b32 per double).  mask is a
+// wave-uniform 64-bit lane mask (one v_cmp away from the lanes' bits).
+RL_DEV void masked_mul(double &t, unsigned long long mask, double k) {
+  asm volatile("s_mov_b64 exec, %1\n\tv_mul_f64 %0, %0, %2\n\ts_mov_b64 exec, -1" : "+v"(t) : "s"(mask), "v"(k));
+}
+RL_DEV void masked_add(double &t, unsigned long long mask, double k) {
+  asm volatile("s_mov_b64 exec, %1\n\tv_add_f64 %0, %0, %2\n\ts_mov_b64 exec, -1" : "+v"(t) : "s"(mask), "v"(k));
+}
+
 // ---- normalising sums ---------------------------------------------------
 // EXACT: the donors are added left to right in physical order (= donor order
 // with the zero of donor k skipped, which is a no-op), lane 0's registers

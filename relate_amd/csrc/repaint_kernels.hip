@@ -85,8 +85,8 @@ RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ s
     double lsum = 0.0;
 #pragma unroll
     for (int j = 0; j < S; j++) {
-      double t = a[j] + cfac;
-      double v = mb.get(j) ? t * c.K1 : t;
+      double v = a[j] + cfac;
+      masked_mul(v, __ballot(mb.get(j)), c.K1);  // v *= (mismatch ? K1 : 1.0)
       if (j >= S - TAIL) v = (j < lc.len) ? v : 0.0;
       a[j] = v;
       lsum += v;
@@ -147,9 +147,11 @@ RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ s
     double lsum = 0.0;
 #pragma unroll
     for (int i = 0; i < S; i++) {
-      const bool mn = m_next.get(i);
-      double v = (b[i] + (mn ? bt : 0.0)) + b1;
-      v = mn ? v * c.K1 : v;
+      const unsigned long long mn = __ballot(m_next.get(i));
+      double v = b[i];
+      masked_add(v, mn, bt);      // b + mis*bt  (b + 0.0 == b)
+      v = v + b1;
+      masked_mul(v, mn, c.K1);    // *(mis ? K1 : 1.0)
       if (i >= S - TAIL) v = (i < lc.len) ? v : 0.0;
       b[i] = v;
       lsum += (m_here.get(i) ? c.theta : c.ntheta) * v;  // the lane's share of :495-503
