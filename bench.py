@@ -148,6 +148,15 @@ def main():
         # directional update: N * sum_k D_k / 8 per launch.
         alg_bytes = N * sites / 8.0
         achieved = alg_bytes / (bwd_ms * 1e-3) / 1e9
+        # HBM bytes of that launch from the PMC passes (FETCH_SIZE + WRITE_SIZE, collected by
+        # tools/gpu_profile_r01.sh in separate rocprofv3 runs, summary committed under profiles/)
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_c3.json")))
+            if pmc["N"] == N and pmc["L"] == L:
+                traffic = pmc["kernels"][args.mode + "_bwd"]["hbm_bytes_per_launch"]
+        except Exception:
+            pass
         out = {
             "metric": "haplotype-pair*SNP updates/sec (Paint)",
             "value": total_updates * args.steps / dt,
@@ -174,7 +183,7 @@ def main():
             },
             "roofline": {"bound": "hbm", "kernel": "paint_kernel<backward>", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None},
+                         "traffic": traffic},
         }
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(N, L, bits, r, rpos, wb)
