@@ -11,9 +11,9 @@
 // Idea.  Lane l owns a contiguous run of terms.  If lane l knew its exact
 // entry value s_l it could add its run serially on its own, and all lanes
 // could do so at once.  It does not, but:
-//   (1) an ordinary parallel scan gives P_l with |s_l - P_l| <= 2600 ulp
-//       (every rounding of either order is <= 1/2 ulp of a partial sum,
-//       <= 10240 + 86 additions);
+//   (1) an ordinary parallel scan gives P_l with |s_l - P_l| <= 10250 ulp
+//       (each of the <= 10240 additions of either order errs by <= 1/2 ulp
+//       of a partial sum; typically a few tens of ulp);
 //   (2) within one binade, fl(a + x) - a depends on `a` only through the
 //       parity of a/ulp (round-half-even), and across ONE binade crossing only
 //       through a mod 4 ulp.  So lane l runs its serial sum from four starts
