@@ -14,12 +14,15 @@
 #include <sys/time.h>
 
 #include <algorithm>
+#include <atomic>
 #include <climits>
 #include <cmath>
 #include <cstring>
 #include <iomanip>
 #include <iostream>
+#include <mutex>
 #include <sstream>
+#include <thread>
 
 #include "common.h"
 #include "minmatch.h"
@@ -501,7 +504,18 @@ int rl_treeseq_write(const rl_treeseq *ts, const char *anc_path, const char *mut
 }
 
 // ---- the stage: pipeline/BuildTopology.cpp:14-167 -------------------------
-static int win_matrix(void *user, int snp, float *d) { return rl_window_matrix((rl_window *)user, snp, d, nullptr); }
+// Sections are independent (the reference's scripts run them as separate
+// processes, scripts/RelateParallel/RelateParallel.sh:231-257): here a few host
+// threads each run one section's tree-sequence loop (MinMatch etc. on the
+// host) and share the GPU -- window opening / RePaint and every distance
+// matrix go through one mutex, the GPU work per call being milliseconds.
+namespace {
+std::mutex g_gpu_mutex;
+}
+static int win_matrix(void *user, int snp, float *d) {
+  std::lock_guard<std::mutex> lk(g_gpu_mutex);
+  return rl_window_matrix((rl_window *)user, snp, d, nullptr);
+}
 static int win_advance(void *user, int snp) { return rl_window_advance((rl_window *)user, snp); }
 
 int rl_stage_build_topology(const char *out_dir, int chunk_index, int first_section, int last_section,
@@ -540,35 +554,71 @@ int rl_stage_build_topology(const char *out_dir, int chunk_index, int first_sect
   };
   read_ints(od + "/chunk_" + c + ".bp", bp);
   read_ints(od + "/chunk_" + c + ".state", state);
-  rl_treeseq *ts = rl_treeseq_create(ctx->N, L, ctx->bits.data(), ctx->row_words, ctx->rpos.data(), bp.data(),
-                                     state.data(), ctx->theta);
-  if (!ts) {
-    rl_destroy(ctx);
-    return RL_EINVAL;
-  }
   std::cerr << "---------------------------------------------------------" << std::endl;
   std::cerr << "Estimating topologies of AncesTrees in sections " << first_section << "-" << last_section << "..."
             << std::endl;
-  for (int section = first_section; section <= last_section && !rc; section++) {
-    std::cerr << "[" << section << "/" << last_section << "]\r";
-    std::cerr.flush();
-    const int start = ctx->wb[section];
-    int end = (section < W - 1) ? ctx->wb[section + 1] - 1 : L - 1;
-    if (end >= L) end = L - 1;
-    const std::string pf = od + "/chunk_" + c + "/paint/relate_" + std::to_string(section) + ".bin";
-    rl_window *win = rl_window_open(ctx, section, pf.c_str(), start, sum_mode, nullptr);
-    if (!win) {
-      rc = RL_EIO;
-      break;
-    }
-    rc = rl_treeseq_build(ts, start, end, win_matrix, win_advance, win, flags, fb);
-    rl_window_close(win);
-    if (!rc) {
-      const std::string b = od + "/chunk_" + c + "/" + base + "_" + std::to_string(section);
-      rc = rl_treeseq_write(ts, (b + ".anc").c_str(), (b + ".mut").c_str());
+  // how many sections may be open at once: bounded by host threads and by the
+  // HBM their posterior rows need (sum_n D_n rows of S*64 floats per window)
+  int nthreads = std::max(1, std::min(host_threads() / 2, 16));
+  if (const char *e = getenv("RELATE_AMD_SECTION_THREADS")) nthreads = std::max(1, atoi(e));
+  nthreads = std::min(nthreads, last_section - first_section + 1);
+  {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+      const double per_window = 1.3 * (double)rl_total_sites(ctx) / std::max(1, W) * 4.0 * ctx->S * 64 * 2.0 + 4.0 * ctx->N * ctx->N;
+      const int fit = (int)std::max(1.0, 0.8 * (double)free_b / std::max(per_window, 1.0));
+      nthreads = std::min(nthreads, fit);
     }
   }
-  rl_treeseq_destroy(ts);
+  std::atomic<int> next(first_section);
+  std::atomic<int> first_error(0);
+  auto worker = [&]() {
+    rl_treeseq *ts = rl_treeseq_create(ctx->N, L, ctx->bits.data(), ctx->row_words, ctx->rpos.data(), bp.data(),
+                                       state.data(), ctx->theta);
+    if (!ts) {
+      first_error = RL_EINVAL;
+      return;
+    }
+    for (;;) {
+      const int section = next.fetch_add(1);
+      if (section > last_section || first_error.load()) break;
+      const int start = ctx->wb[section];
+      int end = (section < W - 1) ? ctx->wb[section + 1] - 1 : L - 1;
+      if (end >= L) end = L - 1;
+      const std::string pf = od + "/chunk_" + c + "/paint/relate_" + std::to_string(section) + ".bin";
+      rl_window *win;
+      {
+        std::lock_guard<std::mutex> lk(g_gpu_mutex);
+        win = rl_window_open(ctx, section, pf.c_str(), start, sum_mode, nullptr);
+      }
+      int r = win ? RL_OK : RL_EIO;
+      if (!r) r = rl_treeseq_build(ts, start, end, win_matrix, win_advance, win, flags, fb);
+      if (win) {
+        std::lock_guard<std::mutex> lk(g_gpu_mutex);
+        rl_window_close(win);
+      }
+      if (!r) {
+        const std::string b = od + "/chunk_" + c + "/" + base + "_" + std::to_string(section);
+        r = rl_treeseq_write(ts, (b + ".anc").c_str(), (b + ".mut").c_str());
+      }
+      if (r) {
+        int expected = 0;
+        first_error.compare_exchange_strong(expected, r);
+        break;
+      }
+      std::cerr << "[" << section << "/" << last_section << "]\r";
+      std::cerr.flush();
+    }
+    rl_treeseq_destroy(ts);
+  };
+  if (nthreads <= 1) {
+    worker();
+  } else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; t++) th.emplace_back(worker);
+    for (auto &x : th) x.join();
+  }
+  rc = first_error.load();
   rl_destroy(ctx);
   if (!rc) {
     rusage usage;
