@@ -5,7 +5,7 @@ One "step" = one pass of the Paint hot path over one synthetic chunk already
 resident in HBM: the backward kernel + the forward kernel for all N targets
 (replacing the loop of pipeline/Paint.cpp:81-87 in the reference).
 
-    python bench.py [--gpus N --steps K --warmup W] [--n 5000 --l 500000]
+    python bench.py [--gpus N --steps K --warmup W] [--haplotypes 5000 --snps 500000]
 
 With --gpus N > 1 the driver launches one rank per GPU with torch.distributed.run;
 ranks paint independent chunks (chunks are embarrassingly parallel in the
@@ -80,12 +80,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=5000, help="haplotypes")
-    ap.add_argument("--l", type=int, default=500000, help="SNPs")
+    ap.add_argument("--haplotypes", dest="n", type=int, default=5000, help="haplotypes")
+    ap.add_argument("--snps", dest="l", type=int, default=500000, help="SNPs")
     ap.add_argument("--memory", type=float, default=20.0, help="--memory of MakeChunks (window rule), GB")
     ap.add_argument("--mode", default="exact", choices=["exact", "lanes"])
-    ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-alt", action="store_true", help="skip timing the other summation mode")
+    ap.add_argument("--skip-cpu", dest="no_cpu", action="store_true")
+    ap.add_argument("--skip-alt", dest="no_alt", action="store_true", help="skip timing the other summation mode")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -93,7 +93,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
-    if world > 1:
+    if "RANK" in os.environ:  # launched by torch.distributed.run: one rank per GPU, RCCL for the bookkeeping
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -103,7 +103,7 @@ def main():
     from relate_amd import api
     N, L = args.n, args.l
     bits, r, rpos, wb = make_chunk(N, L, seed=1 + rank, memory_gb=args.memory)
-    ctx = api.Context(local_rank if world > 1 else 0)
+    ctx = api.Context(local_rank if dist is not None else 0)
     ctx.set_chunk_bits(N, bits, r, rpos, wb)
     sites = ctx.total_sites()
     updates = 2.0 * N * sites
