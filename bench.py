@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--mode", default="exact", choices=["exact", "lanes"])
     ap.add_argument("--skip-cpu", dest="no_cpu", action="store_true")
     ap.add_argument("--skip-alt", dest="no_alt", action="store_true", help="skip timing the other summation mode")
+    ap.add_argument("--skip-k23", dest="skip_k23", action="store_true", help="skip the RePaint / matrix measurement")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -105,6 +106,7 @@ def main():
     bits, r, rpos, wb = make_chunk(N, L, seed=1 + rank, memory_gb=args.memory)
     ctx = api.Context(local_rank if dist is not None else 0)
     ctx.set_chunk_bits(N, bits, r, rpos, wb)
+    ctx.prepare()  # plan on the host, panel + plan uploaded, stone buffers allocated: inputs resident in HBM
     sites = ctx.total_sites()
     updates = 2.0 * N * sites
     mode = api.RL_SUM_EXACT if args.mode == "exact" else api.RL_SUM_LANES
@@ -141,6 +143,24 @@ def main():
                    value=updates * max(1, args.steps) / adt, ms_per_step=1e3 * adt / max(1, args.steps),
                    fwd_kernel_ms=af, bwd_kernel_ms=ab,
                    bwd_roofline_frac=(N * sites / 8.0) / (ab * 1e-3) / 1e9 / HBM_PEAK_GBS)
+
+    # secondary kernels of the path on the same chunk (reported under config, not timed steps):
+    # K2 RePaintSection of one window for all targets, K3 one N x N distance matrix
+    extra = None
+    if rank == 0 and not args.skip_k23:
+        try:
+            w = (len(wb) - 1) // 2
+            win = ctx.open_window(w, None, int(wb[w]), mode)     # stones resident after the last paint
+            win.matrix(int(wb[w]))
+            rows = sum(win.rows(n) for n in range(0, N, 50)) * 50.0   # sampled row count
+            extra = {"window": w,
+                     "k2_repaint_ms": win.repaint_ms,
+                     "k2_topology_write_GBps": rows * N * 4.0 / (win.repaint_ms * 1e-3) / 1e9,
+                     "k3_matrix_ms": win.matrix_ms,
+                     "k3_GBps": 12.0 * N * N / (win.matrix_ms * 1e-3) / 1e9}
+            win.close()
+        except Exception as e:  # never let the secondary measurement break the bench line
+            extra = {"error": str(e)[:200]}
 
     if rank == 0:
         ms_per_step = 1e3 * dt / args.steps
@@ -180,6 +200,7 @@ def main():
                 "fwd_kernel_ms": fwd_ms,
                 "bwd_kernel_ms": bwd_ms,
                 "other_mode": alt,
+                "repaint_and_matrix": extra,
             },
             "roofline": {"bound": "hbm", "kernel": "paint_kernel<backward>", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

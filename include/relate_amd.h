@@ -88,6 +88,12 @@ int rl_chunk_dims(const rl_ctx *ctx, int *N, int *L, int *W);
 long long rl_total_sites(rl_ctx *ctx);
 
 /* ------------------------------------------------------------------ Paint */
+/* Builds the per-target visited-site plan (host; src/fast_painting.cpp:41-157),
+ * uploads panel + plan and allocates the stepping-stone buffers, so that a
+ * following rl_paint finds everything resident in HBM.  Optional: rl_paint
+ * does the same on first use. */
+int rl_prepare(rl_ctx *ctx);
+
 /* Replaces the hot loop `for hap: FastPainting::PaintSteppingStones`
  * (pipeline/Paint.cpp:81-87, src/fast_painting.cpp:18-618) for all N
  * targets: forward/backward Li-Stephens over the bit-packed panel, stepping

@@ -120,6 +120,10 @@ class Context:
             _check(int(v))
         return v
 
+    def prepare(self):
+        """plan + uploads + allocations, so that paint() times only the kernels"""
+        _check(lib().rl_prepare(C.c_void_p(self._h)))
+
     def paint(self, sum_mode=RL_SUM_EXACT):
         """-> kernel milliseconds"""
         ms = C.c_float(0)

@@ -553,6 +553,23 @@ long long rl_total_sites(rl_ctx *ctx) {
   return ctx->plan.off[ctx->N];
 }
 
+int rl_prepare(rl_ctx *ctx) {
+  if (!ctx || !ctx->have_chunk) {
+    set_error("rl_prepare: no chunk loaded");
+    return RL_ESTATE;
+  }
+  RL_HIP(hipSetDevice(ctx->device));
+  int rc = upload_plan(ctx);
+  if (rc) return rc;
+  const size_t N = ctx->N, W = ctx->W;
+  if ((rc = ctx->d_alpha.alloc(W * N * N * sizeof(float)))) return rc;
+  if ((rc = ctx->d_beta.alloc(W * N * N * sizeof(float)))) return rc;
+  if ((rc = ctx->d_lsa.alloc(W * N * sizeof(float)))) return rc;
+  if ((rc = ctx->d_lsb.alloc(W * N * sizeof(float)))) return rc;
+  RL_HIP(hipDeviceSynchronize());
+  return RL_OK;
+}
+
 int rl_paint(rl_ctx *ctx, int sum_mode, float *kernel_ms) {
   if (!ctx || !ctx->have_chunk) {
     set_error("rl_paint: no chunk loaded");
