@@ -130,8 +130,10 @@ RL_DEV double sum_exact_fallback(const T &term) {
 }
 
 #ifdef RL_STATS
+#define RL_CLK() __builtin_readcyclecounter()
 #define RL_STAT(i, v) do { if (term.stats && (threadIdx.x & 63) == 0) atomicAdd(&term.stats[i], (unsigned long long)(v)); } while (0)
 #else
+#define RL_CLK() 0ull
 #define RL_STAT(i, v) do { } while (0)
 #endif
 
@@ -143,12 +145,14 @@ RL_DEV double sum_exact_fast(const T &term, double L) {
   const int lane = threadIdx.x & 63;
   constexpr int G4 = 16384;  // half-width of the bracket [r_0, r_3] in ulps
 
+  const unsigned long long tk0 = RL_CLK();
   // ---- A. approximate prefix from the lanes' local serial sums
   const double Q = wave_scan_f64(L);          // ~ sum over lanes <= l
   double P = dpp_f64<DPP_WAVE_SHR1>(Q);       // ~ entry value of this lane (lane 0: +0.0)
   const long long pb = __double_as_longlong(P);
   const bool zero_entry = pb == 0;            // nothing but zeros before this lane: entry exactly 0
 
+  const unsigned long long tk1 = RL_CLK();
   // ---- B. four runs from r_h = h (mod 4 ulp), r_0 / r_3 bracketing the true entry
   const long long base = pb & ~3ll;
   const int p0 = (int)(pb & 3);
@@ -176,6 +180,7 @@ RL_DEV double sum_exact_fast(const T &term, double L) {
     // the chains to the end and keeps all partial sums alive
     asm volatile("" : "+v"(exdiff), "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(thB), "+v"(nthB));
   }
+  const unsigned long long tk2 = RL_CLK();
   const int e_out = expo_field(c0);
   // exit unit = entry unit of the next lane = ulp of the binade of Q
   const int e_next = expo_field(Q);
@@ -265,16 +270,13 @@ RL_DEV double sum_exact_fast(const T &term, double L) {
     RL_STAT(1, 1);
     return sum_exact_fallback<S>(term);  // irregular step: literal serial sum
   }
+  const unsigned long long tk3 = RL_CLK();
   unsigned long long todo = __ballot(!affine);
   RL_STAT(2, __builtin_popcountll(todo));
   {
-    const unsigned long long sp = __ballot(special), cv = __ballot(special && c0 == c3), s2 = __ballot(special && sh == 2), s3 = __ballot(special && sh == 3), s4 = __ballot(special && sh >= 4 && sh < 8);
-    (void)sp; (void)cv; (void)s2; (void)s3; (void)s4;
+    const unsigned long long sp = __ballot(special);
+    (void)sp;
     RL_STAT(3, __builtin_popcountll(sp));
-    RL_STAT(4, __builtin_popcountll(cv));
-    RL_STAT(5, __builtin_popcountll(s2));
-    RL_STAT(6, __builtin_popcountll(s3));
-    RL_STAT(7, __builtin_popcountll(s4));
   }
   int delta = 0;  // lane 0 enters at exactly 0 (its local sum is exact, Q_0 == L_0)
   while (todo) {
@@ -312,6 +314,14 @@ RL_DEV double sum_exact_fast(const T &term, double L) {
     const int K = __builtin_amdgcn_readlane(sK, 63), C = __builtin_amdgcn_readlane(sC, 63);
     const int sft = __builtin_amdgcn_readlane(sS, 63) & 63;
     delta = ((delta + K) >> sft) + C;
+  }
+  {
+    const unsigned long long tk4 = RL_CLK();
+    (void)tk0; (void)tk1; (void)tk2; (void)tk3; (void)tk4;
+    RL_STAT(4, tk1 - tk0);  // scan
+    RL_STAT(5, tk2 - tk1);  // four runs
+    RL_STAT(6, tk3 - tk2);  // classification + map scan
+    RL_STAT(7, tk4 - tk3);  // walk
   }
   return Qt + (double)delta * pow2_field(expo_field(Qt) - 52);
 }

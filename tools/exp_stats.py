@@ -20,4 +20,4 @@ for name, o in (("forward", 0), ("backward", 8)):
     calls, fb, nonpure, special = st[o], st[o + 1], st[o + 2], st[o + 3]
     print("%s: sum calls %d  fallback steps %d (%.3g)  non-pure lanes/call %.3f  special lanes/call %.3f" %
           (name, calls, fb, fb / max(calls, 1), nonpure / max(calls, 1), special / max(calls, 1)))
-    print("   special lanes: converged (c0==c3) %.3f/call  sh=2 %.3f  sh=3 %.3f  sh 4..7 %.3f" % tuple(st[o + k] / max(calls, 1) for k in (4, 5, 6, 7)))
+    print("   cycles per sum: scan %.0f  four runs %.0f  classification+map scan %.0f  walk %.0f" % tuple(st[o + k] / max(calls, 1) for k in (4, 5, 6, 7)))
