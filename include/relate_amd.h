@@ -208,6 +208,22 @@ int rl_stage_build_topology(const char *out_dir, int chunk_index,
                             int use_painting, double theta, double rho,
                             int flags, int fb, int sum_mode, int device);
 
+/* ------------------------------------------------------------ MakeChunks */
+/* Replaces Data::MakeChunks (src/data.cpp:117-518): parses .haps / .sample
+ * (plain or gzip) and the genetic map, decides chunks and windows from the
+ * memory allowance (GB, reference default 5) and writes parameters.bin,
+ * parameters_c<i>.bin, chunk_<i>.{hap,state,bp,dist,rpos,r} and props.bin into
+ * the existing directory out_dir, byte-identical to the reference.  dist_fn may
+ * be NULL ("unspecified").  use_transitions = 0 is --transversion. */
+int rl_make_chunks(const char *haps_fn, const char *sample_fn, const char *map_fn,
+                   const char *dist_fn, const char *out_dir, int use_transitions,
+                   float memory_gb);
+/* The `Relate --mode MakeChunks` stage (pipeline/MakeChunks.cpp:13-114):
+ * refuses an existing out_dir, creates it, then rl_make_chunks. */
+int rl_stage_make_chunks(const char *haps_fn, const char *sample_fn,
+                         const char *map_fn, const char *dist_fn,
+                         const char *out_dir, int transversion, float memory_gb);
+
 /* ------------------------------------------------------------------ tools */
 /* Synthetic block-coalescent panel (stand-in for MakeChunks input,
  * SURVEY.md 8d).  seq_chars (L*N) and/or bits (L*row_words) may be NULL. */

@@ -1,4 +1,5 @@
-// main.cpp -- `Relate` drop-in for the two stages of this path:
+// main.cpp -- `Relate` drop-in for the stages of this path (plus their input producer):
+//   Relate --mode MakeChunks    --haps x.haps --sample x.sample --map x.map [--memory 5] [--dist f] [--transversion] -o out
 //   Relate --mode Paint         --chunk_index c -o out [--painting theta,rho]
 //   Relate --mode BuildTopology --chunk_index c --first_section a --last_section b -o out
 //          [--painting theta,rho] [--seed s] [--fb x] [--no_consistency]
@@ -67,14 +68,38 @@ int main(int argc, char **argv) {
     return opt.count("help") ? 0 : 1;
   }
   const std::string mode = opt["mode"];
-  if (!opt.count("output") || !opt.count("chunk_index")) {
+  if (!opt.count("output")) {
     std::cerr << "Not enough arguments supplied." << std::endl;
-    std::cerr << "Needed: chunk_index, output." << std::endl;
+    std::cerr << "Needed: output." << std::endl;
     return 1;
   }
   const std::string out = opt["output"];
   if (out.find('/') != std::string::npos) {  // Relate.cpp:50-58
     std::cerr << "Output needs to be in working directory." << std::endl;
+    return 1;
+  }
+  if (mode == "MakeChunks") {  // pipeline/MakeChunks.cpp:13-114
+    if (!opt.count("haps") || !opt.count("sample") || !opt.count("map")) {
+      std::cerr << "Not enough arguments supplied." << std::endl;
+      std::cerr << "Needed: haps, sample, map, output. Optional: memory, dist, transversion." << std::endl;
+      return 1;
+    }
+    std::cerr << "---------------------------------------------------------" << std::endl;
+    std::cerr << "Parsing data.." << std::endl;
+    const float memory = opt.count("memory") ? std::stof(opt["memory"]) : 5.0f;
+    const int rc = rl_stage_make_chunks(opt["haps"].c_str(), opt["sample"].c_str(), opt["map"].c_str(),
+                                        opt.count("dist") ? opt["dist"].c_str() : nullptr, out.c_str(),
+                                        opt.count("transversion") ? 1 : 0, memory);
+    if (rc != 0) {
+      std::cerr << rl_last_error() << std::endl;
+      return 1;
+    }
+    usage_line();
+    return 0;
+  }
+  if (!opt.count("chunk_index")) {
+    std::cerr << "Not enough arguments supplied." << std::endl;
+    std::cerr << "Needed: chunk_index, output." << std::endl;
     return 1;
   }
   const int chunk = atoi(opt["chunk_index"].c_str());
@@ -123,7 +148,7 @@ int main(int argc, char **argv) {
                                  device);
     if (rc == 1) return 1;  // first_section >= num_windows (BuildTopology.cpp:45)
   } else {
-    std::cerr << "Mode " << mode << " is not part of this build: it replaces --mode Paint and --mode BuildTopology "
+    std::cerr << "Mode " << mode << " is not part of this build: it replaces --mode MakeChunks, Paint and BuildTopology "
               << "only; run the reference Relate for the other stages." << std::endl;
     return 1;
   }

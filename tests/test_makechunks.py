@@ -1,0 +1,116 @@
+"""MakeChunks (host) against the reference binary, byte for byte: every chunk
+file, parameter file and props.bin -- on the bundled example data and on a
+synthetic .haps that is cut into several overlapping chunks.  Needs
+oracle/_ref (build container); the committed example8 fixture carries the
+single-chunk case to the GPU box (its chunk files were written by the
+reference's MakeChunks)."""
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import rlutil
+from golden_util import Fixture
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "relate_amd", "Relate")
+
+
+def write_synth_haps(work, N, L, seed):
+    ch = rlutil.synth_chunk(N, L, seed=seed, budget=None)
+    with open(os.path.join(work, "s.haps"), "w") as f:
+        for s in range(L):
+            a, b = ("C", "T") if s % 3 else ("A", "C")
+            f.write("1 rs%d %d %s %s %s\n" % (s, ch.bp[s], a, b, " ".join(chr(c) for c in ch.seq[s])))
+    with open(os.path.join(work, "s.sample"), "w") as f:
+        f.write("ID_1 ID_2 missing\n0 0 0\n")
+        for i in range(N // 2):
+            f.write("id%d id%d 0\n" % (i, i))
+    with open(os.path.join(work, "s.map"), "w") as f:
+        f.write("pos COMBINED_rate Genetic_Map\n")
+        hi = int(ch.bp[-1]) + 200000
+        for bp in range(0, hi, 40000):
+            f.write("%d %.3f %.8f\n" % (bp, 1.0 + (bp // 40000) % 3, bp * 1.1e-6 + 0.003 * ((bp // 40000) % 5)))
+    return ch
+
+
+def compare_dirs(a, b):
+    fa, fb = sorted(os.listdir(a)), sorted(os.listdir(b))
+    assert fa == fb
+    for fn in fa:
+        assert open(os.path.join(a, fn), "rb").read() == open(os.path.join(b, fn), "rb").read(), fn
+    return fa
+
+
+@pytest.mark.ref
+@pytest.mark.skipif(not rlutil.have_ref(), reason="oracle/_ref not built (no /root/reference)")
+@pytest.mark.parametrize("N,L,memory,extra", [(6, 50000, "0.0005", []), (8, 3000, "0.0002", ["--transversion"])])
+def test_makechunks_matches_reference(tmp_path, N, L, memory, extra):
+    work = str(tmp_path)
+    write_synth_haps(work, N, L, seed=N)
+    args = ["--mode", "MakeChunks", "--haps", "s.haps", "--sample", "s.sample", "--map", "s.map", "--memory", memory]
+    subprocess.run([rlutil.REF_RELATE] + args + extra + ["-o", "ref"], cwd=work, check=True, stderr=subprocess.PIPE)
+    p = subprocess.run([CLI] + args + extra + ["-o", "ours"], cwd=work, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr.decode()
+    files = compare_dirs(os.path.join(work, "ref"), os.path.join(work, "ours"))
+    assert "parameters.bin" in files and "props.bin" in files
+    if L == 50000:
+        assert "chunk_2.hap" in files  # several overlapping chunks
+    # an existing output directory is refused, like the reference
+    p = subprocess.run([CLI] + args + ["-o", "ours"], cwd=work, stderr=subprocess.PIPE)
+    assert p.returncode != 0 and b"already exists" in p.stderr
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/example/data/example.haps.gz"),
+                    reason="reference example data not present")
+def test_makechunks_example_data_matches_fixture(tmp_path):
+    # the example8 fixture's chunk files were produced by the reference's MakeChunks
+    # from the first 3000 SNPs of example/data with a uniform 1 cM/Mb map (tools/make_golden.py)
+    src = "/root/reference/example/data"
+    work = str(tmp_path)
+    lines = []
+    with gzip.open(os.path.join(src, "example.haps.gz"), "rt") as f:
+        for i, line in enumerate(f):
+            if i >= 3000:
+                break
+            lines.append(line)
+    open(os.path.join(work, "ex.haps"), "w").writelines(lines)
+    subprocess.run("gunzip -c %s/example.sample.gz > %s/ex.sample" % (src, work), shell=True, check=True)
+    first, last = int(lines[0].split()[2]), int(lines[-1].split()[2])
+    with open(os.path.join(work, "ex.map"), "w") as f:
+        f.write("pos COMBINED_rate Genetic_Map\n")
+        for bp in range(max(0, first - 50000), last + 100000, 50000):
+            f.write("%d 1.0 %.6f\n" % (bp, bp * 1e-6))
+    p = subprocess.run([CLI, "--mode", "MakeChunks", "--haps", "ex.haps", "--sample", "ex.sample", "--map", "ex.map",
+                        "--memory", "0.0002", "-o", "example"], cwd=work, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr.decode()
+    (tmp_path / "fx").mkdir()
+    fx = Fixture("example8", tmp_path / "fx")
+    for fn in ["parameters_c0.bin", "chunk_0.hap", "chunk_0.r", "chunk_0.rpos", "chunk_0.bp", "chunk_0.dist", "chunk_0.state"]:
+        assert open(os.path.join(work, "example", fn), "rb").read() == fx.z["in/" + fn].tobytes(), fn
+
+
+@pytest.mark.ref
+@pytest.mark.skipif(not rlutil.have_ref() or not os.path.exists("/root/reference/example/data/example.haps.gz"),
+                    reason="oracle/_ref or the reference example data not present")
+def test_makechunks_gz_example_matches_reference(tmp_path):
+    # the full bundled example (gzip input, N=8), cut into several chunks by a small --memory
+    src = "/root/reference/example/data"
+    work = str(tmp_path)
+    with open(os.path.join(work, "ex.map"), "w") as f:
+        f.write("pos COMBINED_rate Genetic_Map\n")
+        for i, bp in enumerate(range(0, 60000000, 25000)):
+            f.write("%d %.4f %.8f\n" % (bp, 0.5 + (i % 7) * 0.25, bp * 1.2e-6 + 1e-4 * (i % 11)))
+    args = ["--mode", "MakeChunks", "--haps", src + "/example.haps.gz", "--sample", src + "/example.sample.gz",
+            "--map", "ex.map", "--memory", "0.001"]
+    subprocess.run([rlutil.REF_RELATE] + args + ["-o", "ref"], cwd=work, check=True, stderr=subprocess.PIPE)
+    p = subprocess.run([CLI] + args + ["-o", "ours"], cwd=work, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr.decode()
+    files = compare_dirs(os.path.join(work, "ref"), os.path.join(work, "ours"))
+    assert "chunk_1.hap" in files
+    # an allowance too small for the 20000-SNP overlap aborts in the reference (data.cpp:170); here it is an error
+    args[-1] = "0.0005"
+    p = subprocess.run([CLI] + args + ["-o", "small"], cwd=work, stderr=subprocess.PIPE)
+    assert p.returncode != 0 and p.stderr
