@@ -129,12 +129,15 @@ int ro_plan_target(const ro_data *d, const int *wb, int W, int k, int *site,
 /* ------------------------------------------------------------------ */
 /* summation orders                                                   */
 /* Order of the HIP RL_SUM_LANES kernels (relate_amd/csrc/paint_device.h):
- * the P = N-1 donors n != k, in donor order, are cut into 64 contiguous runs
- * (the first P%64 runs hold P/64+1 donors, the rest P/64); each run is summed
- * left to right from 0.0, then an xor-butterfly (masks 1..32) combines the 64
- * partial sums. */
-static double sum_lanes(const double *t, int N, int k) {
-  const int P = N - 1, q = P / 64, rem = P % 64;
+ * the donors, in donor order, are cut into 64 contiguous runs (the first P%64
+ * runs hold P/64+1 donors, the rest P/64); each run is summed left to right
+ * from 0.0, then an xor-butterfly (masks 1..32) combines the 64 partial sums.
+ * The RePaint kernel lays out the P = N-1 donors n != k (full = 0); the
+ * stepping-stone kernel all P = N donors, the target's own term being +0.0
+ * (full = 1). */
+static double sum_lanes(const double *t, int N, int k, int full) {
+  const int P = full ? N : N - 1, q = P / 64, rem = P % 64;
+  if (full) k = N; /* nothing is skipped */
   double lane[64];
   int p = 0;
   for (int l = 0; l < 64; l++) {
@@ -154,19 +157,19 @@ static double sum_lanes(const double *t, int N, int k) {
   return lane[0];
 }
 
-static inline double sum_alpha(const double *a, int N, int k, const ro_sum_order *o) {
+static inline double sum_alpha(const double *a, int N, int k, const ro_sum_order *o, int full) {
   if (o == NULL || o->mode == RO_SUM_SERIAL) {
     double s = 0.0;
     for (int n = 0; n < N; n++) s += a[n]; /* :300-303 */
     return s;
   }
-  return sum_lanes(a, N, k);
+  return sum_lanes(a, N, k, full);
 }
 
 /* sum_n e(n)*b[n], e = theta if (seq_k > row[n]) else ntheta  (:495-503) */
 static inline double sum_beta(const double *b, const char *row, int k,
                               int N, const paint_consts *c,
-                              const ro_sum_order *o, double *scratch) {
+                              const ro_sum_order *o, double *scratch, int full) {
   const char seq_k = row[k];
   if (o == NULL || o->mode == RO_SUM_SERIAL) {
     double s = 0.0;
@@ -180,7 +183,7 @@ static inline double sum_beta(const double *b, const char *row, int k,
   }
   for (int n = 0; n < N; n++)
     scratch[n] = (seq_k > row[n]) ? c->theta * b[n] : c->ntheta * b[n];
-  return sum_lanes(scratch, N, k);
+  return sum_lanes(scratch, N, k, full);
 }
 
 /* ------------------------------------------------------------------ */
@@ -239,7 +242,7 @@ static int paint_target(const ro_data *d, const paint_consts *c, const int *wb,
     }
     a[k] = 0.0;
   }
-  double S = sum_alpha(a, N, k, order);
+  double S = sum_alpha(a, N, k, order, 1);
   double ls = 0.0;
   while (wa < W && bsnp_begin[wa] == 0) { /* :233-253 */
     for (int n = 0; n < N; n++) alpha[(size_t)wa * N + n] = (float)a[n];
@@ -259,7 +262,7 @@ static int paint_target(const ro_data *d, const paint_consts *c, const int *wb,
       a[n] = v;
     }
     a[k] = 0.0;
-    S = sum_alpha(a, N, k, order);
+    S = sum_alpha(a, N, k, order, 1);
     cfac = S;
     if (cfac < c->lower || cfac > c->upper) { /* :334-347 */
       const double tmp = cfac;
@@ -317,7 +320,7 @@ static int paint_target(const ro_data *d, const paint_consts *c, const int *wb,
     }
     b[k] = 0.0;
     const char *row = seq + (size_t)snp * N;
-    B = sum_beta(b, row, k, N, c, order, ws->scratch);
+    B = sum_beta(b, row, k, N, c, order, ws->scratch, 1);
     cfac = B;
     if (cfac < c->lower || cfac > c->upper) { /* :538-551 */
       const double tmp = cfac;
@@ -595,7 +598,7 @@ int ro_repaint_section(const ro_data *d, const float *alpha_begin,
   double *a = alpha;
   for (int n = 0; n < N; n++) a[n] = alpha_begin[n];
   a[k] = 0.0;
-  double S = sum_alpha(a, N, k, order);
+  double S = sum_alpha(a, N, k, order, 0);
   double cfac = trans_factor(c, r_prob[0]) * S;
   double prev_logscale = logscales[0];
   for (int i = 1; i < D; i++) {
@@ -612,7 +615,7 @@ int ro_repaint_section(const ro_data *d, const float *alpha_begin,
       a[n] = v;
     }
     a[k] = 0.0;
-    S = sum_alpha(a, N, k, order);
+    S = sum_alpha(a, N, k, order, 0);
     cfac = S;
     if (cfac < c->lower || cfac > c->upper) { /* :865-877 */
       const double tmp = cfac;
@@ -630,7 +633,7 @@ int ro_repaint_section(const ro_data *d, const float *alpha_begin,
   b[k] = 0.0;
   {
     const char *row = seq + (size_t)last_snp * N;
-    double B0 = sum_beta(b, row, k, N, c, order, scratch);
+    double B0 = sum_beta(b, row, k, N, c, order, scratch, 0);
     a = alpha + (size_t)(D - 1) * N;
     float *t = topology + (size_t)(D - 1) * N;
     for (int n = 0; n < N; n++) t[n] = (float)(a[n] * b[n]); /* :930 */
@@ -652,7 +655,7 @@ int ro_repaint_section(const ro_data *d, const float *alpha_begin,
     }
     b[k] = 0.0;
     const char *row = seq + (size_t)site[j] * N;
-    double B = sum_beta(b, row, k, N, c, order, scratch);
+    double B = sum_beta(b, row, k, N, c, order, scratch, 0);
     cfac = B;
     a = alpha + (size_t)j * N;
     float *t = topology + (size_t)j * N;

@@ -85,8 +85,10 @@ struct rl_ctx {
   hipStream_t s0 = nullptr, s1 = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
   int N = 0, L = 0, W = 0;
-  rl::Layout lay{};
+  rl::Layout lay{};        // K2/K3: donors of a target, target deleted
   int S = 0;
+  rl::Layout paint_lay{};  // K1: all N donors
+  int paint_S = 0;
   double theta = 0.001, rho = 1.0;
   int row_words = 0;
   std::vector<uint32_t> bits;  // host copy of the panel
@@ -94,7 +96,7 @@ struct rl_ctx {
   std::vector<int> wb;
   rl::Plan plan;
   rl::PaintConsts consts{};
-  rl::DevBuf d_bits, d_off, d_sites, d_cf, d_nxt, d_ia, d_ie, d_binit, d_order;
+  rl::DevBuf d_bits, d_masks, d_off, d_sites, d_cf, d_nxt, d_ia, d_ie, d_binit, d_order;
   rl::DevBuf d_alpha, d_beta, d_lsa, d_lsb, d_stats;
   bool have_chunk = false, plan_on_device = false, painted = false;
   int paint_mode = -1;

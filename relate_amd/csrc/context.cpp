@@ -208,6 +208,11 @@ int upload_plan(rl_ctx *ctx) {
   Plan &pl = ctx->plan;
   int rc;
   if ((rc = ctx->d_bits.upload(ctx->bits))) return rc;
+  // lane-mask form of the panel for K1
+  if ((rc = ctx->d_masks.alloc(((size_t)ctx->L + 2) * ctx->paint_S * sizeof(unsigned long long)))) return rc;
+  RL_HIP(launch_lane_masks(ctx->d_bits.as<uint32_t>(), ctx->row_words, ctx->L, ctx->paint_lay, ctx->paint_S,
+                           ctx->d_masks.as<unsigned long long>(), nullptr));
+  RL_HIP(hipDeviceSynchronize());
   if ((rc = ctx->d_off.upload(pl.off))) return rc;
   if ((rc = ctx->d_sites.upload(pl.sites))) return rc;
   if ((rc = ctx->d_cf.upload(pl.cf))) return rc;
@@ -412,11 +417,13 @@ static int set_common(rl_ctx *ctx, int N, int L, const double *r, const double *
     }
   Layout lay = make_layout(N);
   int S = choose_S(lay);
-  if (S == 0) {
-    set_error("N=%d exceeds the largest compiled register tile (N <= %d)", N, 160 * 64 + 1);
+  const Layout paint_lay = make_paint_layout(N);
+  const int paint_S = choose_S(paint_lay);
+  if (S == 0 || paint_S == 0) {
+    set_error("N=%d exceeds the largest compiled register tile (N <= %d)", N, 160 * 64);
     return RL_EINVAL;
   }
-  ctx->N = N; ctx->L = L; ctx->W = W; ctx->lay = lay; ctx->S = S;
+  ctx->N = N; ctx->L = L; ctx->W = W; ctx->lay = lay; ctx->S = S; ctx->paint_lay = paint_lay; ctx->paint_S = paint_S;
   ctx->r.assign(r, r + L);
   ctx->rpos.assign(rpos, rpos + L + 1);
   ctx->wb.assign(wb, wb + W + 1);
@@ -589,12 +596,12 @@ int rl_paint(rl_ctx *ctx, int sum_mode, float *kernel_ms) {
   if ((rc = ctx->d_lsb.alloc(W * N * sizeof(float)))) return rc;
 
   PaintParams p;
-  p.lay = ctx->lay;
+  p.lay = ctx->paint_lay;
   p.c = ctx->consts;
   p.L = ctx->L;
   p.W = ctx->W;
-  p.row_words = ctx->row_words;
-  p.bits = ctx->d_bits.as<uint32_t>();
+  p.S = ctx->paint_S;
+  p.masks = ctx->d_masks.as<unsigned long long>();
   p.plan_off = ctx->d_off.as<int64_t>();
   p.sites = ctx->d_sites.as<int32_t>();
   p.cf = ctx->d_cf.as<double>();
@@ -617,9 +624,9 @@ int rl_paint(rl_ctx *ctx, int sum_mode, float *kernel_ms) {
 
   // backward then forward on one stream, each bracketed by HIP events
   RL_HIP(hipEventRecord(ctx->ev0, ctx->s0));
-  RL_HIP(launch_paint(p, ctx->S, 1, ctx->s0));
+  RL_HIP(launch_paint(p, ctx->paint_S, 1, ctx->s0));
   RL_HIP(hipEventRecord(ctx->ev1, ctx->s0));
-  RL_HIP(launch_paint(p, ctx->S, 0, ctx->s0));
+  RL_HIP(launch_paint(p, ctx->paint_S, 0, ctx->s0));
   RL_HIP(hipEventRecord(ctx->ev2, ctx->s0));
   RL_HIP(hipEventSynchronize(ctx->ev2));
   RL_HIP(hipEventElapsedTime(&ctx->ms_bwd, ctx->ev0, ctx->ev1));

@@ -25,11 +25,11 @@ struct PaintConsts {
 };
 
 struct PaintParams {
-  Layout lay;
+  Layout lay;               // over all N donors (P = N): the target keeps a slot, pinned to +0.0
   PaintConsts c;
   int L, W;
-  int row_words;            // uint32 per panel row
-  const uint32_t *bits;     // [L][row_words], bit n of row s = derived
+  int S;                    // words per row of the lane-mask panel (= register tile)
+  const unsigned long long *masks;  // [L+2][S] lane-mask panel (paint_device.h), built by panel_kernels.hip
   const int64_t *plan_off;  // [N+1] offsets of target k's visited sites
   const int32_t *sites;     // visited site | (seq_k derived ? 1<<31 : 0)
   const double *cf;         // r_prob_i / ((1 - r_prob_i) * (N-1))

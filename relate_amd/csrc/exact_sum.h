@@ -87,10 +87,11 @@ RL_DEV double rd_lane_f64(double v, int lane) {
 // 2^(k) for a biased exponent field f = k + 1023
 RL_DEV double pow2_field(int f) { return __longlong_as_double((long long)f << 52); }
 
-// Term generators.  get(i, th, nth) returns the i-th term of the lane; the two
-// weights are passed in so that each pass of sum_exact_fast can use its own
-// opaque copies: otherwise the compiler shares the S selected weights (or the
-// S products) between the passes and keeps them alive in registers.
+// Term generators.  for_each(th, nth, f) calls f(i, term_i) for the lane's S
+// terms in order; the two weights are passed in so that each pass of
+// sum_exact_fast can use its own opaque copies: otherwise the compiler shares
+// the S selected weights (or the S products) between the passes and keeps them
+// alive in registers.
 template <int S>
 struct RegTerm {  // forward: the terms are the alpha registers themselves
   static constexpr bool REG = true;
@@ -98,6 +99,11 @@ struct RegTerm {  // forward: the terms are the alpha registers themselves
   double th = 0.0, nth = 0.0;
   unsigned long long *stats = nullptr;  // experiment builds (-DRL_STATS) only
   RL_DEV double get(int i, double, double) const { return a[i]; }
+  template <typename F>
+  RL_DEV void for_each(double &, double &, F &&f) const {
+#pragma unroll
+    for (int i = 0; i < S; i++) f(i, a[i]);
+  }
 };
 template <int S>
 struct WeightedTerm {  // backward: e(i) * beta[i], e = theta on a mismatch else 1 - theta
@@ -107,23 +113,45 @@ struct WeightedTerm {  // backward: e(i) * beta[i], e = theta on a mismatch else
   double th, nth;
   unsigned long long *stats = nullptr;
   RL_DEV double get(int i, double t, double n) const { return (m.get(i) ? t : n) * b[i]; }
+  template <typename F>
+  RL_DEV void for_each(double &t, double &n, F &&f) const {
+#pragma unroll
+    for (int i = 0; i < S; i++) f(i, get(i, t, n));
+  }
+};
+
+template <int S>
+struct MaskTerm {  // backward, lane-mask panel: e(i) * beta[i] with the site's row words as EXEC masks
+  static constexpr bool REG = false;
+  MaskRow row;  // mismatch row of the site (S words)
+  const double (&b)[S];
+  double th, nth;
+  unsigned long long *stats = nullptr;
+  template <typename F>
+  RL_DEV void for_each(double &t, double &n, F &&f) const {
+    for_each_chunk<S, 4>(row, [&](int j0, const u64x4 &m) {
+      double x[4];
+      weighted4(x, b[j0], b[j0 + 1], b[j0 + 2], b[j0 + 3], m, t, n);
+#pragma unroll
+      for (int jj = 0; jj < 4; jj++) f(j0 + jj, x[jj]);
+    });
+  }
 };
 
 // The literal serial sum as the rare-path fallback of sum_exact_fast: same
-// result as sum_exact, but the terms are recomputed in every round (the
-// opaque multiply by 1.0 stops the compiler from hoisting S doubles of terms
-// out of the round loop, which would cost the hot path its registers).
+// result as sum_exact, but the terms are recomputed in every round (the empty
+// asm stops the compiler from hoisting S doubles of terms out of the round
+// loop, which would cost the hot path its registers).
 template <int S, typename T>
 RL_DEV double sum_exact_fallback(const T &term) {
   double s = 0.0;
   for (int l = 0; l < 64; l++) {
     double th = term.th, nth = term.nth;
     double tmp = s;
-#pragma unroll
-    for (int i = 0; i < S; i++) {
+    term.for_each(th, nth, [&](int, double x) {
+      tmp += x;
       if constexpr (!T::REG) asm volatile("" : "+v"(th), "+v"(nth), "+v"(tmp));
-      tmp += term.get(i, th, nth);
-    }
+    });
     s = wave_bcast(tmp, l);
   }
   return s;
@@ -166,20 +194,18 @@ RL_DEV double sum_exact_fast(const T &term, double L) {
   const bool entry_ok = zero_entry || (e_in == expo_field(r3) && e_in > 64);
   int exdiff = 0;  // OR over the terms of (high word of c0) xor (high word of c3)
   double thB = term.th, nthB = term.nth;
-#pragma unroll
-  for (int i = 0; i < S; i++) {
-    const double x = term.get(i, thB, nthB);
+  term.for_each(thB, nthB, [&](int, double x) {
     c0 += x;
     c1 += x;
     c2 += x;
     c3 += x;
-    // exponent fields of the two bracketing runs must agree after every term;
-    // one 3-input bit op per term (bits 20..30 of the accumulated xor)
-    exdiff |= hi32(c0) ^ hi32(c3);
+    // exponent fields of the two bracketing runs must agree after every term:
+    // exdiff |= hi(c0) ^ hi(c3), one v_bitop3_b32 per term (bits 20..30 count)
+    exdiff = __builtin_amdgcn_bitop3_b32(exdiff, hi32(c0), hi32(c3), 0xF6);
     // tie the check to its partial sums: otherwise the scheduler first runs
     // the chains to the end and keeps all partial sums alive
     asm volatile("" : "+v"(exdiff), "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(thB), "+v"(nthB));
-  }
+  });
   const unsigned long long tk2 = RL_CLK();
   const int e_out = expo_field(c0);
   // exit unit = entry unit of the next lane = ulp of the binade of Q
@@ -294,11 +320,10 @@ RL_DEV double sum_exact_fast(const T &term, double L) {
       const double uq = pow2_field(expo_field(Pq) - 52);
       double t = Pq + (double)delta * uq;  // exact
       double thC = term.th, nthC = term.nth;
-#pragma unroll
-      for (int i = 0; i < S; i++) {
+      term.for_each(thC, nthC, [&](int, double x) {
+        t += x;
         if constexpr (!REG_TERM) asm volatile("" : "+v"(thC), "+v"(nthC), "+v"(t));
-        t += term.get(i, thC, nthC);
-      }
+      });
       const double v = rd_lane_f64(t, q);
       delta = (int)((v - rd_lane_f64(Q, q)) * rd_lane_f64(inv_u_out, q));
     } else {
@@ -332,16 +357,15 @@ RL_DEV double wave_sum(const T &term, double L) {
   if constexpr (MODE == 1)
     return sum_exact_fast<S>(term, L);
   else if constexpr (MODE == 2)
-    return sum_exact<S>([&](int i) { return term.get(i, term.th, term.nth); });
+    return sum_exact_fallback<S>(term);
   else
     return wave_sum_butterfly(L);
 }
 
 template <int S, typename T>
 RL_DEV double local_sum(const T &term) {
-  double L = 0.0;
-#pragma unroll
-  for (int i = 0; i < S; i++) L += term.get(i, term.th, term.nth);
+  double L = 0.0, th = term.th, nth = term.nth;
+  term.for_each(th, nth, [&](int, double x) { L += x; });
   return L;
 }
 

@@ -24,6 +24,7 @@ inline int choose_S(const Layout &lay) {
   return 0;
 }
 
+// layout of K2/K3: the P = N-1 donors of a target, the target itself deleted
 inline Layout make_layout(int N) {
   Layout l;
   l.N = N;
@@ -32,6 +33,18 @@ inline Layout make_layout(int N) {
   l.rem = l.P % 64;
   return l;
 }
+
+// layout of K1: all N donors, the target keeps a slot that is pinned to +0.0
+inline Layout make_paint_layout(int N) {
+  Layout l;
+  l.N = N;
+  l.P = N;
+  l.q = N / 64;
+  l.rem = N % 64;
+  return l;
+}
+hipError_t launch_lane_masks(const uint32_t *bits, int row_words, int L, const Layout &lay, int S,
+                             unsigned long long *masks, hipStream_t stream);
 
 // kernel summation modes (template parameter MODE of the kernels)
 //   0 = lanes (RL_SUM_LANES), 1 = exact, parallel (RL_SUM_EXACT), 2 = exact, literal serial (RL_SUM_EXACT_SERIAL)

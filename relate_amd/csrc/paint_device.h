@@ -134,6 +134,265 @@ RL_DEV void masked_add(double &t, unsigned long long mask, double k) {
   asm volatile("s_mov_b64 exec, %1\n\tv_add_f64 %0, %0, %2\n\ts_mov_b64 exec, -1" : "+v"(t) : "s"(mask), "v"(k));
 }
 
+// ---- lane-mask panel (K1) -------------------------------------------------
+// The stepping-stone kernel reads the panel in "lane-mask" form: for site s and
+// register j one 64-bit word whose bit l says that the donor lane l holds in
+// register j is ANCESTRAL at s (layout over all N donors, the target included;
+// slots past a lane's run read 0).  At a site where the target is derived this
+// is exactly the mismatch mask "target derived, donor ancestral"
+// (fast_painting.cpp:290); where it is ancestral (only the first / last site
+// can be) the kernel reads the all-zero row L instead.  The words are
+// wave-uniform: they are fetched with scalar loads straight into SGPRs and
+// moved into EXEC -- no per-register v_cmp, no per-lane bit extraction.
+//
+// Each wave issues at most one instruction per issue slot, scalar or vector, so
+// the EXEC writes are batched: a chunk of registers does all its unmasked
+// vector work under one "exec = -1".
+typedef unsigned long long u64;
+typedef u64 u64x4 __attribute__((ext_vector_type(4)));
+typedef u64 u64x8 __attribute__((ext_vector_type(8)));
+// constant address space: uniform loads become s_load_dwordx8 / x16
+typedef const __attribute__((address_space(4))) u64 *MaskRow;
+template <int CH> struct MaskChunk;
+template <> struct MaskChunk<4> { typedef u64x4 type; };
+template <> struct MaskChunk<8> { typedef u64x8 type; };
+template <int CH>
+RL_DEV typename MaskChunk<CH>::type load_masks(MaskRow row, int c) {
+  typedef const __attribute__((address_space(4))) typename MaskChunk<CH>::type *P;
+  return ((P)row)[c];
+}
+
+// Walk the S masks of a row in chunks of CH: wait for chunk c, issue the load
+// of chunk c+1, then run f(j0, chunk) on chunk c.  (s_load results return out
+// of order, so the only wait is lgkmcnt(0): the next load must be issued AFTER
+// the wait for the current chunk, which the empty asm enforces.)
+template <int S, int CH, typename F>
+RL_DEV void for_each_chunk(MaskRow row, F &&f) {
+  static_assert(S % CH == 0, "S must be a multiple of the chunk");
+  auto cur = load_masks<CH>(row, 0);
+#pragma unroll
+  for (int c = 0; c < S / CH; c++) {
+    auto nxt = cur;
+    if (c + 1 < S / CH) {
+      asm volatile("" : "+s"(row) : "s"(cur[0]));
+      nxt = load_masks<CH>(row, c + 1);
+    }
+    f(c * CH, cur);
+    cur = nxt;
+  }
+}
+// The same with chunk 0 already requested by the caller (`first`), and with
+// the chunks of `vrow` -- per-register validity masks, the lanes whose run
+// reaches that register -- alongside for the chunks that touch the last TAIL
+// registers: f(j0, chunk, validity chunk).
+template <int S, int CH, int TAIL, typename C, typename F>
+RL_DEV void for_each_chunk_tail(MaskRow row, MaskRow vrow, C first, F &&f) {
+  static_assert(S % CH == 0, "S must be a multiple of the chunk");
+  C cur = first, va = first;
+  if (CH > S - TAIL) va = load_masks<CH>(vrow, 0);
+#pragma unroll
+  for (int c = 0; c < S / CH; c++) {
+    C nxt = cur, nva = va;
+    if (c + 1 < S / CH) {
+      asm volatile("" : "+s"(row), "+s"(vrow) : "s"(cur[0]));
+      nxt = load_masks<CH>(row, c + 1);
+      if ((c + 2) * CH > S - TAIL) nva = load_masks<CH>(vrow, c + 1);
+    }
+    f(c * CH, cur, va);
+    cur = nxt;
+    va = nva;
+  }
+}
+template <int S, int CH, int TAIL, typename C, typename F>
+RL_DEV void for_each_chunk2_tail(MaskRow rowa, MaskRow rowb, MaskRow vrow, C firsta, C firstb, F &&f) {
+  static_assert(S % CH == 0, "S must be a multiple of the chunk");
+  C ca = firsta, cb = firstb, va = firsta;
+  if (CH > S - TAIL) va = load_masks<CH>(vrow, 0);
+#pragma unroll
+  for (int c = 0; c < S / CH; c++) {
+    C na = ca, nb = cb, nva = va;
+    if (c + 1 < S / CH) {
+      asm volatile("" : "+s"(rowa), "+s"(rowb), "+s"(vrow) : "s"(ca[0]), "s"(cb[0]));
+      na = load_masks<CH>(rowa, c + 1);
+      nb = load_masks<CH>(rowb, c + 1);
+      if ((c + 2) * CH > S - TAIL) nva = load_masks<CH>(vrow, c + 1);
+    }
+    f(c * CH, ca, cb, va);
+    ca = na;
+    cb = nb;
+    va = nva;
+  }
+}
+
+// One target's view of the layout over all N donors.
+template <int S>
+struct PaintLane {
+  int lane, start, len, k;
+  int q;         // registers 0..q-1 are valid in every lane
+  u64 rem_mask;  // lanes in which register q is valid
+  int jk;        // donor k itself sits in register jk ...
+  u64 kbit;      // ... of this lane (mask): it is pinned to +0.0
+  RL_DEV void init(const Layout &lay, int k_) {
+    lane = threadIdx.x & 63;
+    k = k_;
+    q = lay.q;
+    start = lane * lay.q + (lane < lay.rem ? lane : lay.rem);
+    len = lay.q + (lane < lay.rem ? 1 : 0);
+    rem_mask = lay.rem ? (~0ull >> (64 - lay.rem)) : 0ull;
+    const int big = lay.rem * (lay.q + 1);
+    const int lk = k < big ? k / (lay.q + 1) : lay.rem + (k - big) / (lay.q > 0 ? lay.q : 1);
+    jk = k - (lk * lay.q + (lk < lay.rem ? lk : lay.rem));
+    kbit = 1ull << lk;
+  }
+  RL_DEV u64 valid(int j) const { return j < q ? ~0ull : (j == q ? rem_mask : 0ull); }
+};
+
+// ---- exec-masked vector ops ----------------------------------------------
+RL_DEV void masked_mov(double &t, u64 mask, double v) {
+  asm volatile("s_mov_b64 exec, %1\n\tv_mov_b64 %0, %2\n\ts_mov_b64 exec, -1" : "+v"(t) : "s"(mask), "v"(v));
+}
+// v[i] *= k in the lanes of m[i]
+template <typename M>
+RL_DEV void masked_mul8(double (&v)[8], const M &m, double k) {
+  asm volatile(
+      "s_mov_b64 exec, %8\n\tv_mul_f64 %0, %0, %16\n\t"
+      "s_mov_b64 exec, %9\n\tv_mul_f64 %1, %1, %16\n\t"
+      "s_mov_b64 exec, %10\n\tv_mul_f64 %2, %2, %16\n\t"
+      "s_mov_b64 exec, %11\n\tv_mul_f64 %3, %3, %16\n\t"
+      "s_mov_b64 exec, %12\n\tv_mul_f64 %4, %4, %16\n\t"
+      "s_mov_b64 exec, %13\n\tv_mul_f64 %5, %5, %16\n\t"
+      "s_mov_b64 exec, %14\n\tv_mul_f64 %6, %6, %16\n\t"
+      "s_mov_b64 exec, %15\n\tv_mul_f64 %7, %7, %16\n\t"
+      "s_mov_b64 exec, -1"
+      : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
+      : "s"(m[0]), "s"(m[1]), "s"(m[2]), "s"(m[3]), "s"(m[4]), "s"(m[5]), "s"(m[6]), "s"(m[7]), "v"(k));
+}
+// v[i] += k in the lanes of m[i]
+template <typename M>
+RL_DEV void masked_add8(double (&v)[8], const M &m, double k) {
+  asm volatile(
+      "s_mov_b64 exec, %8\n\tv_add_f64 %0, %0, %16\n\t"
+      "s_mov_b64 exec, %9\n\tv_add_f64 %1, %1, %16\n\t"
+      "s_mov_b64 exec, %10\n\tv_add_f64 %2, %2, %16\n\t"
+      "s_mov_b64 exec, %11\n\tv_add_f64 %3, %3, %16\n\t"
+      "s_mov_b64 exec, %12\n\tv_add_f64 %4, %4, %16\n\t"
+      "s_mov_b64 exec, %13\n\tv_add_f64 %5, %5, %16\n\t"
+      "s_mov_b64 exec, %14\n\tv_add_f64 %6, %6, %16\n\t"
+      "s_mov_b64 exec, %15\n\tv_add_f64 %7, %7, %16\n\t"
+      "s_mov_b64 exec, -1"
+      : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
+      : "s"(m[0]), "s"(m[1]), "s"(m[2]), "s"(m[3]), "s"(m[4]), "s"(m[5]), "s"(m[6]), "s"(m[7]), "v"(k));
+}
+// x[i] = (lane in m[i] ? th : nth) * b[i]   (fast_painting.cpp:495-503)
+template <typename M>
+RL_DEV void weighted4(double (&x)[4], double b0, double b1, double b2, double b3, const M &m, double th, double nth) {
+  asm volatile(
+      "v_mul_f64 %0, %4, %13\n\tv_mul_f64 %1, %5, %13\n\tv_mul_f64 %2, %6, %13\n\tv_mul_f64 %3, %7, %13\n\t"
+      "s_mov_b64 exec, %8\n\tv_mul_f64 %0, %4, %12\n\t"
+      "s_mov_b64 exec, %9\n\tv_mul_f64 %1, %5, %12\n\t"
+      "s_mov_b64 exec, %10\n\tv_mul_f64 %2, %6, %12\n\t"
+      "s_mov_b64 exec, %11\n\tv_mul_f64 %3, %7, %12\n\t"
+      "s_mov_b64 exec, -1"
+      : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3])
+      : "v"(b0), "v"(b1), "v"(b2), "v"(b3), "s"(m[0]), "s"(m[1]), "s"(m[2]), "s"(m[3]), "v"(th), "v"(nth));
+}
+// backward update of four registers (fast_painting.cpp:483-484):
+//   v = ((v + mis*bt) + b1) * (mis ? K1 : 1.0), mis = lanes of mn[i],
+// and their weighted terms x = (lanes of mh[i] ? th : nth) * v
+template <typename M>
+RL_DEV void backward4(double (&v)[4], double (&x)[4], const M &mn, const M &mh, double bt, double b1, double K1,
+                      double th, double nth) {
+  asm volatile(
+      "s_mov_b64 exec, %8\n\tv_add_f64 %0, %0, %16\n\t"
+      "s_mov_b64 exec, %9\n\tv_add_f64 %1, %1, %16\n\t"
+      "s_mov_b64 exec, %10\n\tv_add_f64 %2, %2, %16\n\t"
+      "s_mov_b64 exec, %11\n\tv_add_f64 %3, %3, %16\n\t"
+      "s_mov_b64 exec, -1\n\t"
+      "v_add_f64 %0, %0, %17\n\tv_add_f64 %1, %1, %17\n\tv_add_f64 %2, %2, %17\n\tv_add_f64 %3, %3, %17\n\t"
+      "s_mov_b64 exec, %8\n\tv_mul_f64 %0, %0, %18\n\t"
+      "s_mov_b64 exec, %9\n\tv_mul_f64 %1, %1, %18\n\t"
+      "s_mov_b64 exec, %10\n\tv_mul_f64 %2, %2, %18\n\t"
+      "s_mov_b64 exec, %11\n\tv_mul_f64 %3, %3, %18\n\t"
+      "s_mov_b64 exec, -1\n\t"
+      "v_mul_f64 %4, %0, %20\n\tv_mul_f64 %5, %1, %20\n\tv_mul_f64 %6, %2, %20\n\tv_mul_f64 %7, %3, %20\n\t"
+      "s_mov_b64 exec, %12\n\tv_mul_f64 %4, %0, %19\n\t"
+      "s_mov_b64 exec, %13\n\tv_mul_f64 %5, %1, %19\n\t"
+      "s_mov_b64 exec, %14\n\tv_mul_f64 %6, %2, %19\n\t"
+      "s_mov_b64 exec, %15\n\tv_mul_f64 %7, %3, %19\n\t"
+      "s_mov_b64 exec, -1"
+      : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3])
+      : "s"(mn[0]), "s"(mn[1]), "s"(mn[2]), "s"(mn[3]), "s"(mh[0]), "s"(mh[1]), "s"(mh[2]), "s"(mh[3]), "v"(bt),
+        "v"(b1), "v"(K1), "v"(th), "v"(nth));
+}
+// the same with the "+ b1" confined to the lanes of va[i] (registers of the TAIL)
+template <typename M>
+RL_DEV void backward4_tail(double (&v)[4], double (&x)[4], const M &mn, const M &mh, const M &va, double bt,
+                           double b1, double K1, double th, double nth) {
+  asm volatile(
+      "s_mov_b64 exec, %8\n\tv_add_f64 %0, %0, %16\n\t"
+      "s_mov_b64 exec, %9\n\tv_add_f64 %1, %1, %16\n\t"
+      "s_mov_b64 exec, %10\n\tv_add_f64 %2, %2, %16\n\t"
+      "s_mov_b64 exec, %11\n\tv_add_f64 %3, %3, %16\n\t"
+      "s_mov_b64 exec, %21\n\tv_add_f64 %0, %0, %17\n\t"
+      "s_mov_b64 exec, %22\n\tv_add_f64 %1, %1, %17\n\t"
+      "s_mov_b64 exec, %23\n\tv_add_f64 %2, %2, %17\n\t"
+      "s_mov_b64 exec, %24\n\tv_add_f64 %3, %3, %17\n\t"
+      "s_mov_b64 exec, %8\n\tv_mul_f64 %0, %0, %18\n\t"
+      "s_mov_b64 exec, %9\n\tv_mul_f64 %1, %1, %18\n\t"
+      "s_mov_b64 exec, %10\n\tv_mul_f64 %2, %2, %18\n\t"
+      "s_mov_b64 exec, %11\n\tv_mul_f64 %3, %3, %18\n\t"
+      "s_mov_b64 exec, -1\n\t"
+      "v_mul_f64 %4, %0, %20\n\tv_mul_f64 %5, %1, %20\n\tv_mul_f64 %6, %2, %20\n\tv_mul_f64 %7, %3, %20\n\t"
+      "s_mov_b64 exec, %12\n\tv_mul_f64 %4, %0, %19\n\t"
+      "s_mov_b64 exec, %13\n\tv_mul_f64 %5, %1, %19\n\t"
+      "s_mov_b64 exec, %14\n\tv_mul_f64 %6, %2, %19\n\t"
+      "s_mov_b64 exec, %15\n\tv_mul_f64 %7, %3, %19\n\t"
+      "s_mov_b64 exec, -1"
+      : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3])
+      : "s"(mn[0]), "s"(mn[1]), "s"(mn[2]), "s"(mn[3]), "s"(mh[0]), "s"(mh[1]), "s"(mh[2]), "s"(mh[3]), "v"(bt),
+        "v"(b1), "v"(K1), "v"(th), "v"(nth), "s"(va[0]), "s"(va[1]), "s"(va[2]), "s"(va[3]));
+}
+
+// a[j] = v in the lanes of `bit`, j wave-uniform but not a compile-time
+// constant: a branch tree over static cases, each one exec-masked v_mov_b64.
+// Written the obvious way ("+v"(a[J]) in every case) the cases define new
+// values of a[J] that merge after the switch, and the register allocator
+// settles the merges with up to S register copies per call.  So the cases
+// take a[J] as an INPUT and overwrite its register behind the compiler's
+// back; the empty asm statements before and after (every a[i] in and out,
+// same register) pin the array to registers across the switch and tell the
+// compiler that any element may have changed.
+RL_DEV void poke_slot(const double &t, u64 mask, double v) {
+  asm volatile("s_mov_b64 exec, %1\n\tv_mov_b64 %0, %2\n\ts_mov_b64 exec, -1" : : "v"(t), "s"(mask), "v"(v));
+}
+template <int S>
+RL_DEV void pin_registers(double (&a)[S]) {
+  static_assert(S % 8 == 0, "S must be a multiple of 8");
+#pragma unroll
+  for (int i = 0; i < S; i += 8)
+    asm volatile("" : "+v"(a[i]), "+v"(a[i + 1]), "+v"(a[i + 2]), "+v"(a[i + 3]), "+v"(a[i + 4]), "+v"(a[i + 5]),
+                 "+v"(a[i + 6]), "+v"(a[i + 7]));
+}
+#define RL_SLOT(J) \
+  case J:          \
+    if constexpr ((J) < S) poke_slot(a[(J) < S ? (J) : 0], bit, v); \
+    break;
+#define RL_SLOT8(B) RL_SLOT(B) RL_SLOT(B + 1) RL_SLOT(B + 2) RL_SLOT(B + 3) RL_SLOT(B + 4) RL_SLOT(B + 5) RL_SLOT(B + 6) RL_SLOT(B + 7)
+template <int S>
+RL_DEV void set_slot(double (&a)[S], int j, u64 bit, double v) {
+  static_assert(S <= 160, "extend the case list");
+  pin_registers<S>(a);
+  switch (j) {
+    RL_SLOT8(0) RL_SLOT8(8) RL_SLOT8(16) RL_SLOT8(24) RL_SLOT8(32) RL_SLOT8(40) RL_SLOT8(48) RL_SLOT8(56)
+    RL_SLOT8(64) RL_SLOT8(72) RL_SLOT8(80) RL_SLOT8(88) RL_SLOT8(96) RL_SLOT8(104) RL_SLOT8(112) RL_SLOT8(120)
+    RL_SLOT8(128) RL_SLOT8(136) RL_SLOT8(144) RL_SLOT8(152)
+    default: break;
+  }
+  pin_registers<S>(a);
+}
+#undef RL_SLOT8
+#undef RL_SLOT
+
 // ---- normalising sums ---------------------------------------------------
 // EXACT: the donors are added left to right in physical order (= donor order
 // with the zero of donor k skipped, which is a no-op), lane 0's registers

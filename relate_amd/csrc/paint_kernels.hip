@@ -18,8 +18,9 @@ namespace rl {
 // addresses out of the hot loop's register budget the registers are staged,
 // 16 at a time, through a 4 KiB LDS strip private to the wave and written by a
 // rolled loop (each lane reads back only what it wrote: no barrier needed).
+// The slot of donor k itself (held at +0.0) is written as self_value.
 template <int S>
-RL_DEV void emit_stone(const LaneCtx<S> &lc, const double (&v)[S], float *__restrict__ out,
+RL_DEV void emit_stone(const PaintLane<S> &pl, const double (&v)[S], float *__restrict__ out,
                        float self_value, float *stage) {
   static_assert(S % 8 == 0, "S must be a multiple of 8");
   constexpr int R = S % 16 == 0 ? 16 : 8;
@@ -30,78 +31,119 @@ RL_DEV void emit_stone(const LaneCtx<S> &lc, const double (&v)[S], float *__rest
       // pin the conversion to its chunk: hoisted, all S floats would be live at once
       double x = v[c * R + ii];
       asm volatile("" : "+v"(x) : : "memory");
-      stage[ii * 64 + lc.lane] = (float)x;
+      stage[ii * 64 + pl.lane] = (float)x;
     }
 #pragma clang loop unroll(disable)
     for (int ii = 0; ii < R; ii++) {
       const int i = c * R + ii;
-      if (i < lc.len) out[lc.donor(i)] = stage[ii * 64 + lc.lane];
+      const int n = pl.start + i;
+      if (i < pl.len) out[n] = (n == pl.k) ? self_value : stage[ii * 64 + pl.lane];
     }
   }
-  if (lc.lane == 0) out[lc.k] = self_value;
+}
+
+// The plan arrays are read-only and indexed uniformly: read them through the
+// constant address space so that they come in by scalar loads (lgkmcnt) and
+// the loop's only vector-memory traffic is the row prefetch below.
+typedef const __attribute__((address_space(4))) int32_t *ConstI32;
+typedef const __attribute__((address_space(4))) double *ConstF64;
+
+// Pull the row of a site that the NEXT step will read into L2 (one dword per
+// 16 bytes; the value is kept alive until then, which also parks the wait
+// for it a whole step later).  Scalar loads that miss L2 cost ~800 cycles per
+// chunk of masks; from L2 the other wave on the SIMD covers them.
+RL_DEV uint32_t touch_row(const PaintParams &p, int sv, int lane) {
+  sv = __builtin_amdgcn_readfirstlane(sv);
+  const uint32_t *row = (const uint32_t *)(p.masks + (size_t)(sv & 0x7fffffff) * p.S);
+  int o = lane * 4;
+  const int last = p.S * 2 - 1;
+  return row[o < last ? o : last];
+}
+RL_DEV void retire_touch(uint32_t t) { asm volatile("" : : "v"(t)); }
+
+// site word of the plan -> the row of mismatch masks the target sees there:
+// the site's row where the target is derived, the all-zero row L where it is not
+RL_DEV MaskRow validity_row(const PaintParams &p) { return (MaskRow)(p.masks + (size_t)(p.L + 1) * p.S); }
+RL_DEV MaskRow site_row(const PaintParams &p, int sv) {
+  sv = __builtin_amdgcn_readfirstlane(sv);
+  const int r = sv < 0 ? (sv & 0x7fffffff) : p.L;
+  return (MaskRow)(p.masks + (size_t)r * p.S);
 }
 
 template <int S, int TAIL, int MODE>
 RL_DEV void paint_forward(const PaintParams &p, int k, float *stage) {
-  LaneCtx<S> lc;
-  lc.init(p.lay, k);
+  PaintLane<S> pl;
+  pl.init(p.lay, k);
   const PaintConsts &c = p.c;
   const int N = p.lay.N, W = p.W;
   const int64_t off = p.plan_off[k];
   const int D = (int)(p.plan_off[k + 1] - off);
-  const int32_t *__restrict__ st = p.sites + off;
-  const double *__restrict__ cfp = p.cf + off;
-  const double *__restrict__ nx = p.nxt + off;
+  const ConstI32 st = (ConstI32)(p.sites + off);
+  const ConstF64 cfp = (ConstF64)(p.cf + off);
+  const ConstF64 nx = (ConstF64)(p.nxt + off);
   const int32_t *__restrict__ ia = p.stone_ia + (size_t)k * W;
 
   double a[S];
-  RawBits<S> raw;
-  LaneBits<S> mb;
 
   // ---- SNP 0 (fast_painting.cpp:207-253)
-  int sv = st[0];
-  raw.load(p.bits + (size_t)(sv & 0x7fffffff) * p.row_words, lc.w0);
-  mb.from_raw(raw, lc);
-  mb.to_mismatch(sv < 0);
+  for_each_chunk<S, 8>(site_row(p, st[0]), [&](int j0, const u64x8 &m) {
 #pragma unroll
-  for (int i = 0; i < S; i++) {
-    double v = mb.get(i) ? c.init1 : c.init0;
-    a[i] = (i < lc.len) ? v : 0.0;
-  }
+    for (int jj = 0; jj < 8; jj++) {
+      double v = c.init0;
+      masked_mov(v, m[jj], c.init1);
+      if (j0 + jj >= S - TAIL) masked_mov(v, ~pl.valid(j0 + jj), 0.0);
+      a[j0 + jj] = v;
+    }
+  });
+  set_slot<S>(a, pl.jk, pl.kbit, 0.0);
   double ssum = wave_sum<MODE, S>(RegTerm<S>{a, 0.0, 0.0, p.stats}, local_sum<S>(RegTerm<S>{a}));
   double ls = 0.0;
   int wa = 0;
   int next_stone = ia[0];
   while (next_stone == 0) {
-    emit_stone<S>(lc, a, p.alpha + ((size_t)wa * N + k) * N, 0.0f, stage);
-    if (lc.lane == 0) p.ls_alpha[(size_t)wa * N + k] = (float)ls;
+    emit_stone<S>(pl, a, p.alpha + ((size_t)wa * N + k) * N, 0.0f, stage);
+    if (pl.lane == 0) p.ls_alpha[(size_t)wa * N + k] = (float)ls;
     wa++;
     next_stone = wa < W ? ia[wa] : -1;
   }
   double cfac = cfp[0] * ssum;  // :260
 
-  // prefetch row of step 1
-  if (D > 1) raw.load(p.bits + (size_t)(st[1] & 0x7fffffff) * p.row_words, lc.w0);
-  int sv_next = D > 1 ? st[1] : 0;
-
+  // row pipeline: step i reads the row of s1 with scalar loads, its first
+  // chunk requested before the previous step's sum; the row of s2 (step i+1) is
+  // pulled into L2 by a vector load during step i
+  int s1 = D > 1 ? st[1] : 0, s2 = D > 2 ? st[2] : 0;
+  uint32_t touched = 0;
+  MaskRow row = site_row(p, s1);
+  u64x8 first = load_masks<8>(row, 0);
   for (int i = 1; i < D; i++) {
-    sv = sv_next;
-    mb.from_raw(raw, lc);
-    mb.to_mismatch(sv < 0);
-    if (i + 1 < D) {
-      sv_next = st[i + 1];
-      raw.load(p.bits + (size_t)(sv_next & 0x7fffffff) * p.row_words, lc.w0);
-    }
+    retire_touch(touched);
+    if (i + 1 < D) touched = touch_row(p, s2, pl.lane);
+    s1 = s2;
+    if (i + 2 < D) s2 = st[i + 2];
     ls += nx[i - 1];  // :281-282
+    set_slot<S>(a, pl.jk, pl.kbit, -cfac);  // donor k: (-c) + c = +0.0
     double lsum = 0.0;
+    MaskRow vrow = validity_row(p);
+    asm volatile("" : "+s"(vrow));  // reload the validity chunks every step instead of keeping 2*TAIL SGPRs
+    for_each_chunk_tail<S, 8, TAIL>(row, vrow, first, [&](int j0, const u64x8 &m, const u64x8 &va) {  // :288-295
+      double v[8];
 #pragma unroll
-    for (int j = 0; j < S; j++) {  // :288-295
-      double v = a[j] + cfac;
-      masked_mul(v, __ballot(mb.get(j)), c.K1);  // v *= (mismatch ? K1 : 1.0)
-      if (j >= S - TAIL) v = (j < lc.len) ? v : 0.0;
-      a[j] = v;
-      lsum += v;  // the lane's share of the serial sum (:300-303)
-    }
+      for (int jj = 0; jj < 8; jj++) v[jj] = a[j0 + jj];
+      if (j0 + 8 <= S - TAIL) {
+#pragma unroll
+        for (int jj = 0; jj < 8; jj++) v[jj] = v[jj] + cfac;
+      } else {
+        masked_add8(v, va, cfac);
+      }
+      masked_mul8(v, m, c.K1);  // v *= (mismatch ? K1 : 1.0)
+#pragma unroll
+      for (int jj = 0; jj < 8; jj++) {
+        a[j0 + jj] = v[jj];
+        lsum += v[jj];  // the lane's share of the serial sum (:300-303)
+      }
+    });
+    row = site_row(p, s1);
+    first = load_masks<8>(row, 0);
     ssum = wave_sum<MODE, S>(RegTerm<S>{a, 0.0, 0.0, p.stats}, lsum);
     cfac = ssum;
     if (cfac < c.lower || cfac > c.upper) {  // :334-347
@@ -112,79 +154,97 @@ RL_DEV void paint_forward(const PaintParams &p, int k, float *stage) {
     }
     cfac *= cfp[i];  // :349-352
     while (next_stone == i) {  // :354-374
-      emit_stone<S>(lc, a, p.alpha + ((size_t)wa * N + k) * N, 0.0f, stage);
-      if (lc.lane == 0) p.ls_alpha[(size_t)wa * N + k] = (float)ls;
+      emit_stone<S>(pl, a, p.alpha + ((size_t)wa * N + k) * N, 0.0f, stage);
+      if (pl.lane == 0) p.ls_alpha[(size_t)wa * N + k] = (float)ls;
       wa++;
       next_stone = wa < W ? ia[wa] : -1;
     }
   }
+  retire_touch(touched);
 }
 
 template <int S, int TAIL, int MODE>
 RL_DEV void paint_backward(const PaintParams &p, int k, float *stage) {
-  LaneCtx<S> lc;
-  lc.init(p.lay, k);
+  PaintLane<S> pl;
+  pl.init(p.lay, k);
   const PaintConsts &c = p.c;
   const int N = p.lay.N, W = p.W;
   const int64_t off = p.plan_off[k];
   const int D = (int)(p.plan_off[k + 1] - off);
-  const int32_t *__restrict__ st = p.sites + off;
-  const double *__restrict__ cfp = p.cf + off;
-  const double *__restrict__ nx = p.nxt + off;
+  const ConstI32 st = (ConstI32)(p.sites + off);
+  const ConstF64 cfp = (ConstF64)(p.cf + off);
+  const ConstF64 nx = (ConstF64)(p.nxt + off);
   const int32_t *__restrict__ ie = p.stone_ie + (size_t)k * W;
 
   double b[S];
-  RawBits<S> raw;
-  LaneBits<S> m_next, m_here;
 
   // ---- last SNP (:396-448)
   double ls = c.log_Nm1 - D * c.log_ntheta;  // normalizing_constant :399
 #pragma unroll
-  for (int i = 0; i < S; i++) b[i] = (i < lc.len) ? 1.0 : 0.0;
+  for (int i = 0; i < S; i++) {
+    double v = 1.0;
+    if (i >= S - TAIL) masked_mov(v, ~pl.valid(i), 0.0);
+    b[i] = v;
+  }
+  set_slot<S>(b, pl.jk, pl.kbit, 0.0);  // written as beta[k] = 1 below, +0.0 from then on
   double bsum = p.binit[k];  // serial sum of theta/ntheta minus ntheta (:421-431)
   int we = W - 1;
   int next_stone = ie[we];
   while (next_stone == D - 1) {
-    emit_stone<S>(lc, b, p.beta + ((size_t)we * N + k) * N, 1.0f, stage);  // beta[k] = 1 here
-    if (lc.lane == 0) p.ls_beta[(size_t)we * N + k] = (float)ls;
+    emit_stone<S>(pl, b, p.beta + ((size_t)we * N + k) * N, 1.0f, stage);
+    if (pl.lane == 0) p.ls_beta[(size_t)we * N + k] = (float)ls;
     we--;
     next_stone = we >= 0 ? ie[we] : -2;
   }
   double cfac = cfp[D - 1] * bsum;  // :454-455
 
-  int sv = st[D - 1];
-  raw.load(p.bits + (size_t)(sv & 0x7fffffff) * p.row_words, lc.w0);
-  m_here.from_raw(raw, lc);
-  m_here.to_mismatch(sv < 0);
-  int sv_prev = D > 1 ? st[D - 2] : 0;
-  if (D > 1) raw.load(p.bits + (size_t)(sv_prev & 0x7fffffff) * p.row_words, lc.w0);
-
+  // row pipeline as in paint_forward: step j reads the rows of s0 (site j+1)
+  // and s1 (site j); the row of s2 (site j-1) goes to L2 during the step
+  int s0 = st[D - 1], s1 = D > 1 ? st[D - 2] : 0, s2 = D > 2 ? st[D - 3] : 0;
+  uint32_t touched = 0;
+  MaskRow rown = site_row(p, s0);  // the later site's mismatches drive the update (:481-488)
+  MaskRow rowh = site_row(p, s1);
+  u64x4 firstn = load_masks<4>(rown, 0), firsth = load_masks<4>(rowh, 0);
   for (int j = D - 2; j >= 0; j--) {
-    m_next = m_here;  // the later site's mismatches drive the update (:481-488)
-    sv = sv_prev;
-    m_here.from_raw(raw, lc);
-    m_here.to_mismatch(sv < 0);
-    if (j > 0) {
-      sv_prev = st[j - 1];
-      raw.load(p.bits + (size_t)(sv_prev & 0x7fffffff) * p.row_words, lc.w0);
-    }
+    retire_touch(touched);
+    if (j > 0) touched = touch_row(p, s2, pl.lane);
+    s0 = s1;
+    s1 = s2;
+    if (j > 1) s2 = st[j - 2];
     ls += nx[j + 1];                       // :471-472
     const double b1 = cfac / c.ntheta;     // :474
     const double bt = cfac / c.theta - b1; // :475
+    set_slot<S>(b, pl.jk, pl.kbit, -b1);   // donor k: (-b1) + b1 = +0.0 (never a mismatch with itself)
     double lsum = 0.0;
+    MaskRow vrow = validity_row(p);
+    asm volatile("" : "+s"(vrow));
+    for_each_chunk2_tail<S, 4, TAIL>(rown, rowh, vrow, firstn, firsth,
+                                     [&](int j0, const u64x4 &mn, const u64x4 &mh, const u64x4 &va) {
+      double v[4], x[4];
 #pragma unroll
-    for (int i = 0; i < S; i++) {
-      const unsigned long long mn = __ballot(m_next.get(i));
-      double v = b[i];
-      masked_add(v, mn, bt);      // b + mis*bt  (b + 0.0 == b)
-      v = v + b1;
-      masked_mul(v, mn, c.K1);    // *(mis ? K1 : 1.0)
-      if (i >= S - TAIL) v = (i < lc.len) ? v : 0.0;
-      b[i] = v;
-      lsum += (m_here.get(i) ? c.theta : c.ntheta) * v;  // the lane's share of :495-503
+      for (int jj = 0; jj < 4; jj++) v[jj] = b[j0 + jj];
+      if (j0 + 4 <= S - TAIL)
+        backward4(v, x, mn, mh, bt, b1, c.K1, c.theta, c.ntheta);
+      else
+        backward4_tail(v, x, mn, mh, va, bt, b1, c.K1, c.theta, c.ntheta);
+#pragma unroll
+      for (int jj = 0; jj < 4; jj++) {
+        b[j0 + jj] = v[jj];
+        lsum += x[jj];  // the lane's share of :495-503
+      }
+    });
+    const MaskTerm<S> term{rowh, b, c.theta, c.ntheta, p.stats ? p.stats + 8 : nullptr};
+    rown = rowh;
+    rowh = site_row(p, s1);
+    if (MODE == 0) {  // lanes: the sum reads no masks, request the next step's first chunks across it
+      firstn = load_masks<4>(rown, 0);
+      firsth = load_masks<4>(rowh, 0);
     }
-    const WeightedTerm<S> term{m_here, b, c.theta, c.ntheta, p.stats ? p.stats + 8 : nullptr};
     bsum = wave_sum<MODE, S>(term, lsum);  // :495-503
+    if (MODE != 0) {
+      firstn = load_masks<4>(rown, 0);
+      firsth = load_masks<4>(rowh, 0);
+    }
     cfac = bsum;
     if (cfac < c.lower || cfac > c.upper) {  // :538-551
 #pragma unroll
@@ -194,12 +254,13 @@ RL_DEV void paint_backward(const PaintParams &p, int k, float *stage) {
     }
     cfac *= cfp[j];  // :553-556
     while (next_stone == j) {  // :559-578
-      emit_stone<S>(lc, b, p.beta + ((size_t)we * N + k) * N, 0.0f, stage);
-      if (lc.lane == 0) p.ls_beta[(size_t)we * N + k] = (float)ls;
+      emit_stone<S>(pl, b, p.beta + ((size_t)we * N + k) * N, 0.0f, stage);
+      if (pl.lane == 0) p.ls_beta[(size_t)we * N + k] = (float)ls;
       we--;
       next_stone = we >= 0 ? ie[we] : -2;
     }
   }
+  retire_touch(touched);
 }
 
 // S <= 80: hold the kernel to 256 registers so that two waves share a SIMD

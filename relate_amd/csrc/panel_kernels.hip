@@ -1,0 +1,39 @@
+// panel_kernels.hip -- bit-packed panel -> lane-mask panel of the stepping-stone
+// kernel (paint_device.h "lane-mask panel"): masks[s][j] bit l = the donor lane
+// l holds in register j (layout over all N donors) is ancestral at site s, 0
+// past the end of a lane's run; row L is all zero; row L+1 holds the validity
+// masks (bit l: register j lies inside lane l's run).  One wavefront per row,
+// once per chunk.
+#include "paint_device.h"
+#include "launch.h"
+
+namespace rl {
+
+__global__ void __launch_bounds__(64) lane_mask_kernel(const uint32_t *__restrict__ bits, int row_words, int L, Layout lay,
+                                                       int S, unsigned long long *__restrict__ masks) {
+  const int s = blockIdx.x;
+  const int lane = threadIdx.x;
+  const uint32_t *__restrict__ row = bits + (size_t)s * row_words;
+  const int start = lane * lay.q + (lane < lay.rem ? lane : lay.rem);
+  const int len = lay.q + (lane < lay.rem ? 1 : 0);
+  unsigned long long *__restrict__ out = masks + (size_t)s * S;
+  for (int j0 = 0; j0 < S; j0 += 64) {
+    unsigned long long mine = 0;
+    const int jn = S - j0 < 64 ? S - j0 : 64;
+    for (int jj = 0; jj < jn; jj++) {
+      const int j = j0 + jj, n = start + j;
+      const bool bit = s < L ? (j < len ? !((row[n >> 5] >> (n & 31)) & 1u) : false) : (s == L + 1 && j < len);
+      const unsigned long long m = __ballot(bit);
+      if (lane == jj) mine = m;
+    }
+    if (lane < jn) out[j0 + lane] = mine;
+  }
+}
+
+hipError_t launch_lane_masks(const uint32_t *bits, int row_words, int L, const Layout &lay, int S,
+                             unsigned long long *masks, hipStream_t stream) {
+  hipLaunchKernelGGL(lane_mask_kernel, dim3(L + 2), dim3(64), 0, stream, bits, row_words, L, lay, S, masks);
+  return hipGetLastError();
+}
+
+}  // namespace rl
