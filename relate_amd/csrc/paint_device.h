@@ -151,11 +151,13 @@ RL_DEV void masked_add(double &t, unsigned long long mask, double k) {
 typedef unsigned long long u64;
 typedef u64 u64x4 __attribute__((ext_vector_type(4)));
 typedef u64 u64x8 __attribute__((ext_vector_type(8)));
+typedef u64 u64x16 __attribute__((ext_vector_type(16)));
 // constant address space: uniform loads become s_load_dwordx8 / x16
 typedef const __attribute__((address_space(4))) u64 *MaskRow;
 template <int CH> struct MaskChunk;
 template <> struct MaskChunk<4> { typedef u64x4 type; };
 template <> struct MaskChunk<8> { typedef u64x8 type; };
+template <> struct MaskChunk<16> { typedef u64x16 type; };
 template <int CH>
 RL_DEV typename MaskChunk<CH>::type load_masks(MaskRow row, int c) {
   typedef const __attribute__((address_space(4))) typename MaskChunk<CH>::type *P;
@@ -173,6 +175,22 @@ RL_DEV void for_each_chunk(MaskRow row, F &&f) {
 #pragma unroll
   for (int c = 0; c < S / CH; c++) {
     auto nxt = cur;
+    if (c + 1 < S / CH) {
+      asm volatile("" : "+s"(row) : "s"(cur[0]));
+      nxt = load_masks<CH>(row, c + 1);
+    }
+    f(c * CH, cur);
+    cur = nxt;
+  }
+}
+// The same with chunk 0 already requested by the caller (`first`).
+template <int S, int CH, typename C, typename F>
+RL_DEV void for_each_chunk_from(MaskRow row, C first, F &&f) {
+  static_assert(S % CH == 0, "S must be a multiple of the chunk");
+  C cur = first;
+#pragma unroll
+  for (int c = 0; c < S / CH; c++) {
+    C nxt = cur;
     if (c + 1 < S / CH) {
       asm volatile("" : "+s"(row) : "s"(cur[0]));
       nxt = load_masks<CH>(row, c + 1);
@@ -251,9 +269,9 @@ struct PaintLane {
 RL_DEV void masked_mov(double &t, u64 mask, double v) {
   asm volatile("s_mov_b64 exec, %1\n\tv_mov_b64 %0, %2\n\ts_mov_b64 exec, -1" : "+v"(t) : "s"(mask), "v"(v));
 }
-// v[i] *= k in the lanes of m[i]
-template <typename M>
-RL_DEV void masked_mul8(double (&v)[8], const M &m, double k) {
+// v[i] *= k in the lanes of m[OFF + i]
+template <int OFF = 0, typename M>
+RL_DEV void masked_mul8(double *v, const M &m, double k) {
   asm volatile(
       "s_mov_b64 exec, %8\n\tv_mul_f64 %0, %0, %16\n\t"
       "s_mov_b64 exec, %9\n\tv_mul_f64 %1, %1, %16\n\t"
@@ -265,7 +283,17 @@ RL_DEV void masked_mul8(double (&v)[8], const M &m, double k) {
       "s_mov_b64 exec, %15\n\tv_mul_f64 %7, %7, %16\n\t"
       "s_mov_b64 exec, -1"
       : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
-      : "s"(m[0]), "s"(m[1]), "s"(m[2]), "s"(m[3]), "s"(m[4]), "s"(m[5]), "s"(m[6]), "s"(m[7]), "v"(k));
+      : "s"(m[OFF]), "s"(m[OFF + 1]), "s"(m[OFF + 2]), "s"(m[OFF + 3]), "s"(m[OFF + 4]), "s"(m[OFF + 5]),
+        "s"(m[OFF + 6]), "s"(m[OFF + 7]), "v"(k));
+}
+// v += k in the lanes whose run reaches register j (j < len; j a constant
+// after unrolling): the validity test of a TAIL register, one v_cmp from the
+// lane's run length
+RL_DEV void tail_add(double &v, int len, int j, double k) {
+  asm volatile("v_cmp_lt_i32 vcc, %2, %1\n\ts_mov_b64 exec, vcc\n\tv_add_f64 %0, %0, %3\n\ts_mov_b64 exec, -1"
+               : "+v"(v)
+               : "v"(len), "i"(j), "v"(k)
+               : "vcc");
 }
 // v[i] += k in the lanes of m[i]
 template <typename M>

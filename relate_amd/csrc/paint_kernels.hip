@@ -42,11 +42,21 @@ RL_DEV void emit_stone(const PaintLane<S> &pl, const double (&v)[S], float *__re
   }
 }
 
-// The plan arrays are read-only and indexed uniformly: read them through the
-// constant address space so that they come in by scalar loads (lgkmcnt) and
-// the loop's only vector-memory traffic is the row prefetch below.
-typedef const __attribute__((address_space(4))) int32_t *ConstI32;
-typedef const __attribute__((address_space(4))) double *ConstF64;
+// Kernel arguments that only the (rare) stepping-stone writes need are read
+// from the kernarg segment at the point of use, through a pointer the compiler
+// cannot see through: kept in SGPRs across the site loop they would crowd out
+// the mask chunks (and spill into VGPR lanes at every step).
+typedef const __attribute__((address_space(4))) PaintParams *ColdParams;
+RL_DEV ColdParams cold_params() {
+  ColdParams q = (ColdParams)__builtin_amdgcn_kernarg_segment_ptr();  // PaintParams is the first argument
+  asm volatile("" : "+s"(q));
+  return q;
+}
+// a loop constant that the exec-masked asm takes in a VGPR: keep it there
+RL_DEV double in_vgpr(double v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
 
 // Pull the row of a site that the NEXT step will read into L2 (one dword per
 // 16 bytes; the value is kept alive until then, which also parks the wait
@@ -75,13 +85,12 @@ RL_DEV void paint_forward(const PaintParams &p, int k, float *stage) {
   PaintLane<S> pl;
   pl.init(p.lay, k);
   const PaintConsts &c = p.c;
-  const int N = p.lay.N, W = p.W;
   const int64_t off = p.plan_off[k];
   const int D = (int)(p.plan_off[k + 1] - off);
-  const ConstI32 st = (ConstI32)(p.sites + off);
-  const ConstF64 cfp = (ConstF64)(p.cf + off);
-  const ConstF64 nx = (ConstF64)(p.nxt + off);
-  const int32_t *__restrict__ ia = p.stone_ia + (size_t)k * W;
+  // the plan arrays come in by vector loads (vmcnt), requested a step ahead
+  const int32_t *__restrict__ st = p.sites + off;
+  const double *__restrict__ cfp = p.cf + off;
+  const double *__restrict__ nx = p.nxt + off;
 
   double a[S];
 
@@ -99,12 +108,22 @@ RL_DEV void paint_forward(const PaintParams &p, int k, float *stage) {
   double ssum = wave_sum<MODE, S>(RegTerm<S>{a, 0.0, 0.0, p.stats}, local_sum<S>(RegTerm<S>{a}));
   double ls = 0.0;
   int wa = 0;
-  int next_stone = ia[0];
-  while (next_stone == 0) {
-    emit_stone<S>(pl, a, p.alpha + ((size_t)wa * N + k) * N, 0.0f, stage);
-    if (pl.lane == 0) p.ls_alpha[(size_t)wa * N + k] = (float)ls;
+  // stone wa of the target: written when the visited index reaches stone_ia[k][wa] (:354-374)
+  auto stone_index = [&](int w) {
+    const ColdParams cp = cold_params();
+    return w < cp->W ? cp->stone_ia[(size_t)k * cp->W + w] : -1;
+  };
+  auto write_stone = [&]() {
+    const ColdParams cp = cold_params();
+    const size_t N = cp->lay.N;
+    emit_stone<S>(pl, a, cp->alpha + ((size_t)wa * N + k) * N, 0.0f, stage);
+    if (pl.lane == 0) cp->ls_alpha[(size_t)wa * N + k] = (float)ls;
     wa++;
-    next_stone = wa < W ? ia[wa] : -1;
+  };
+  int next_stone = stone_index(0);
+  while (next_stone == 0) {
+    write_stone();
+    next_stone = stone_index(wa);
   }
   double cfac = cfp[0] * ssum;  // :260
 
@@ -113,38 +132,42 @@ RL_DEV void paint_forward(const PaintParams &p, int k, float *stage) {
   // pulled into L2 by a vector load during step i
   int s1 = D > 1 ? st[1] : 0, s2 = D > 2 ? st[2] : 0;
   uint32_t touched = 0;
+  const double K1 = in_vgpr(c.K1);
+  constexpr int CH = S % 16 == 0 ? 16 : 8;  // registers per chunk of masks
+  typedef typename MaskChunk<CH>::type Chunk;
   MaskRow row = site_row(p, s1);
-  u64x8 first = load_masks<8>(row, 0);
+  Chunk first = load_masks<CH>(row, 0);
   for (int i = 1; i < D; i++) {
     retire_touch(touched);
     if (i + 1 < D) touched = touch_row(p, s2, pl.lane);
     s1 = s2;
     if (i + 2 < D) s2 = st[i + 2];
-    ls += nx[i - 1];  // :281-282
+    // requested here, used after the sum: the chunk loop's waits cover the latency
+    const double nx_i = nx[i - 1], cf_i = cfp[i];
     set_slot<S>(a, pl.jk, pl.kbit, -cfac);  // donor k: (-c) + c = +0.0
     double lsum = 0.0;
-    MaskRow vrow = validity_row(p);
-    asm volatile("" : "+s"(vrow));  // reload the validity chunks every step instead of keeping 2*TAIL SGPRs
-    for_each_chunk_tail<S, 8, TAIL>(row, vrow, first, [&](int j0, const u64x8 &m, const u64x8 &va) {  // :288-295
-      double v[8];
+    for_each_chunk_from<S, CH>(row, first, [&](int j0, const Chunk &m) {  // :288-295
+      double v[CH];
 #pragma unroll
-      for (int jj = 0; jj < 8; jj++) v[jj] = a[j0 + jj];
-      if (j0 + 8 <= S - TAIL) {
-#pragma unroll
-        for (int jj = 0; jj < 8; jj++) v[jj] = v[jj] + cfac;
-      } else {
-        masked_add8(v, va, cfac);
+      for (int jj = 0; jj < CH; jj++) {
+        v[jj] = a[j0 + jj];
+        if (j0 + jj < S - TAIL)
+          v[jj] = v[jj] + cfac;
+        else
+          tail_add(v[jj], pl.len, j0 + jj, cfac);  // slots past the lane's run stay +0.0
       }
-      masked_mul8(v, m, c.K1);  // v *= (mismatch ? K1 : 1.0)
+      masked_mul8<0>(v, m, K1);  // v *= (mismatch ? K1 : 1.0)
+      if constexpr (CH == 16) masked_mul8<8>(v + 8, m, K1);
 #pragma unroll
-      for (int jj = 0; jj < 8; jj++) {
+      for (int jj = 0; jj < CH; jj++) {
         a[j0 + jj] = v[jj];
         lsum += v[jj];  // the lane's share of the serial sum (:300-303)
       }
     });
     row = site_row(p, s1);
-    first = load_masks<8>(row, 0);
+    first = load_masks<CH>(row, 0);
     ssum = wave_sum<MODE, S>(RegTerm<S>{a, 0.0, 0.0, p.stats}, lsum);
+    ls += nx_i;  // :281-282
     cfac = ssum;
     if (cfac < c.lower || cfac > c.upper) {  // :334-347
 #pragma unroll
@@ -152,12 +175,10 @@ RL_DEV void paint_forward(const PaintParams &p, int k, float *stage) {
       ls += log(ssum);
       cfac = 1.0;
     }
-    cfac *= cfp[i];  // :349-352
+    cfac *= cf_i;  // :349-352
     while (next_stone == i) {  // :354-374
-      emit_stone<S>(pl, a, p.alpha + ((size_t)wa * N + k) * N, 0.0f, stage);
-      if (pl.lane == 0) p.ls_alpha[(size_t)wa * N + k] = (float)ls;
-      wa++;
-      next_stone = wa < W ? ia[wa] : -1;
+      write_stone();
+      next_stone = stone_index(wa);
     }
   }
   retire_touch(touched);
@@ -168,13 +189,11 @@ RL_DEV void paint_backward(const PaintParams &p, int k, float *stage) {
   PaintLane<S> pl;
   pl.init(p.lay, k);
   const PaintConsts &c = p.c;
-  const int N = p.lay.N, W = p.W;
   const int64_t off = p.plan_off[k];
   const int D = (int)(p.plan_off[k + 1] - off);
-  const ConstI32 st = (ConstI32)(p.sites + off);
-  const ConstF64 cfp = (ConstF64)(p.cf + off);
-  const ConstF64 nx = (ConstF64)(p.nxt + off);
-  const int32_t *__restrict__ ie = p.stone_ie + (size_t)k * W;
+  const int32_t *__restrict__ st = p.sites + off;
+  const double *__restrict__ cfp = p.cf + off;
+  const double *__restrict__ nx = p.nxt + off;
 
   double b[S];
 
@@ -188,13 +207,22 @@ RL_DEV void paint_backward(const PaintParams &p, int k, float *stage) {
   }
   set_slot<S>(b, pl.jk, pl.kbit, 0.0);  // written as beta[k] = 1 below, +0.0 from then on
   double bsum = p.binit[k];  // serial sum of theta/ntheta minus ntheta (:421-431)
-  int we = W - 1;
-  int next_stone = ie[we];
-  while (next_stone == D - 1) {
-    emit_stone<S>(pl, b, p.beta + ((size_t)we * N + k) * N, 1.0f, stage);
-    if (pl.lane == 0) p.ls_beta[(size_t)we * N + k] = (float)ls;
+  int we = p.W - 1;
+  auto stone_index = [&](int w) {
+    const ColdParams cp = cold_params();
+    return w >= 0 ? cp->stone_ie[(size_t)k * cp->W + w] : -2;
+  };
+  auto write_stone = [&](float self_value) {
+    const ColdParams cp = cold_params();
+    const size_t N = cp->lay.N;
+    emit_stone<S>(pl, b, cp->beta + ((size_t)we * N + k) * N, self_value, stage);
+    if (pl.lane == 0) cp->ls_beta[(size_t)we * N + k] = (float)ls;
     we--;
-    next_stone = we >= 0 ? ie[we] : -2;
+  };
+  int next_stone = stone_index(we);
+  while (next_stone == D - 1) {
+    write_stone(1.0f);  // beta[k] = 1 at the last SNP
+    next_stone = stone_index(we);
   }
   double cfac = cfp[D - 1] * bsum;  // :454-455
 
@@ -205,15 +233,16 @@ RL_DEV void paint_backward(const PaintParams &p, int k, float *stage) {
   MaskRow rown = site_row(p, s0);  // the later site's mismatches drive the update (:481-488)
   MaskRow rowh = site_row(p, s1);
   u64x4 firstn = load_masks<4>(rown, 0), firsth = load_masks<4>(rowh, 0);
+  const double K1 = in_vgpr(c.K1), theta = in_vgpr(c.theta), ntheta = in_vgpr(c.ntheta);
   for (int j = D - 2; j >= 0; j--) {
     retire_touch(touched);
     if (j > 0) touched = touch_row(p, s2, pl.lane);
     s0 = s1;
     s1 = s2;
     if (j > 1) s2 = st[j - 2];
-    ls += nx[j + 1];                       // :471-472
-    const double b1 = cfac / c.ntheta;     // :474
-    const double bt = cfac / c.theta - b1; // :475
+    const double nx_j = nx[j + 1], cf_j = cfp[j];  // used after the sum (see paint_forward)
+    const double b1 = cfac / ntheta;     // :474
+    const double bt = cfac / theta - b1; // :475
     set_slot<S>(b, pl.jk, pl.kbit, -b1);   // donor k: (-b1) + b1 = +0.0 (never a mismatch with itself)
     double lsum = 0.0;
     MaskRow vrow = validity_row(p);
@@ -224,16 +253,16 @@ RL_DEV void paint_backward(const PaintParams &p, int k, float *stage) {
 #pragma unroll
       for (int jj = 0; jj < 4; jj++) v[jj] = b[j0 + jj];
       if (j0 + 4 <= S - TAIL)
-        backward4(v, x, mn, mh, bt, b1, c.K1, c.theta, c.ntheta);
+        backward4(v, x, mn, mh, bt, b1, K1, theta, ntheta);
       else
-        backward4_tail(v, x, mn, mh, va, bt, b1, c.K1, c.theta, c.ntheta);
+        backward4_tail(v, x, mn, mh, va, bt, b1, K1, theta, ntheta);
 #pragma unroll
       for (int jj = 0; jj < 4; jj++) {
         b[j0 + jj] = v[jj];
         lsum += x[jj];  // the lane's share of :495-503
       }
     });
-    const MaskTerm<S> term{rowh, b, c.theta, c.ntheta, p.stats ? p.stats + 8 : nullptr};
+    const MaskTerm<S> term{rowh, b, theta, ntheta, p.stats ? p.stats + 8 : nullptr};
     rown = rowh;
     rowh = site_row(p, s1);
     if (MODE == 0) {  // lanes: the sum reads no masks, request the next step's first chunks across it
@@ -245,6 +274,7 @@ RL_DEV void paint_backward(const PaintParams &p, int k, float *stage) {
       firstn = load_masks<4>(rown, 0);
       firsth = load_masks<4>(rowh, 0);
     }
+    ls += nx_j;  // :471-472
     cfac = bsum;
     if (cfac < c.lower || cfac > c.upper) {  // :538-551
 #pragma unroll
@@ -252,12 +282,10 @@ RL_DEV void paint_backward(const PaintParams &p, int k, float *stage) {
       ls += fast_log_dev((float)bsum);
       cfac = 1.0;
     }
-    cfac *= cfp[j];  // :553-556
+    cfac *= cf_j;  // :553-556
     while (next_stone == j) {  // :559-578
-      emit_stone<S>(pl, b, p.beta + ((size_t)we * N + k) * N, 0.0f, stage);
-      if (pl.lane == 0) p.ls_beta[(size_t)we * N + k] = (float)ls;
-      we--;
-      next_stone = we >= 0 ? ie[we] : -2;
+      write_stone(0.0f);
+      next_stone = stone_index(we);
     }
   }
   retire_touch(touched);
