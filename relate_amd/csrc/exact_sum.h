@@ -221,12 +221,20 @@ RL_DEV double sum_exact_fast(const T &term, double L) {
   if (zero_entry && expo_field(c0) != e_next) invalid = true;
   // a run that jumps two or more binades (a term much larger than the prefix)
   // does not fit the mod-4 argument: the walk redoes it from its exact entry
-  const bool special = !zero_entry && !invalid && sh >= 2;
+  const bool jump = !zero_entry && !invalid && sh >= 2;
+  // ... unless the two bracketing runs END on the same value: addition is
+  // monotone in its start, so every run started inside the bracket ends there
+  // too, the true one included -- the exit is known outright and nothing to
+  // the left of this lane matters any more (the usual case: the big term
+  // swamps the 2^15 ulp of the bracket)
+  const bool constant = jump && __double_as_longlong(c0) == __double_as_longlong(c3);
+  const bool special = jump && !constant;
 
   // offsets are in units of the exit ulp.  Exit offsets of the four runs
   // (|A_h| < 2^15) and entry offsets B_h = (r_h - P)/ulp_in of their starts:
   int A0 = 0, A1 = 0, A2 = 0, A3 = 0;
-  if (!invalid && !special && !zero_entry) {
+  if (constant) A0 = (int)((c0 - Q) * inv_u_out);
+  if (!invalid && !jump && !zero_entry) {
     A0 = (int)((c0 - Q) * inv_u_out);
     A1 = (int)((c1 - Q) * inv_u_out);
     A2 = (int)((c2 - Q) * inv_u_out);
@@ -237,7 +245,7 @@ RL_DEV double sum_exact_fast(const T &term, double L) {
   // of the tie-free form ((delta + K) >> sh) + C ?   (K in {0,1} when sh = 1)
   int mK = 0, mC = 0;
   bool affine = zero_entry;
-  if (!invalid && !special && !zero_entry) {
+  if (!invalid && !jump && !zero_entry) {
     if (sh == 0) {
       const int d = A0 - B0;
       affine = (A1 - B1 == d) && (A2 - B2 == d) && (A3 - B3 == d);
@@ -305,6 +313,14 @@ RL_DEV double sum_exact_fast(const T &term, double L) {
     RL_STAT(3, __builtin_popcountll(sp));
   }
   int delta = 0;  // lane 0 enters at exactly 0 (its local sum is exact, Q_0 == L_0)
+  {  // start behind the last lane whose exit is known outright
+    const unsigned long long cm = __ballot(constant);
+    if (cm) {
+      const int qc = 63 - __builtin_clzll(cm);
+      delta = (int)(short)__builtin_amdgcn_readlane(w01, qc);  // its A0
+      todo &= ~((2ull << qc) - 1ull);
+    }
+  }
   while (todo) {
     const int q = __builtin_ctzll(todo);
     todo &= todo - 1;

@@ -52,6 +52,14 @@ RL_DEV ColdParams cold_params() {
   asm volatile("" : "+s"(q));
   return q;
 }
+// experiment builds (-DRL_STATS): per-segment cycle counters of the forward step, lanes mode
+#ifdef RL_STATS
+#define RL_TICK(n) const unsigned long long tick##n = __builtin_readcyclecounter()
+#define RL_TOCK(acc, a, b) acc += tick##b - tick##a
+#else
+#define RL_TICK(n) do { } while (0)
+#define RL_TOCK(acc, a, b) do { } while (0)
+#endif
 // a loop constant that the exec-masked asm takes in a VGPR: keep it there
 RL_DEV double in_vgpr(double v) {
   asm volatile("" : "+v"(v));
@@ -137,8 +145,12 @@ RL_DEV void paint_forward(const PaintParams &p, int k, float *stage) {
   typedef typename MaskChunk<CH>::type Chunk;
   MaskRow row = site_row(p, s1);
   Chunk first = load_masks<CH>(row, 0);
+  unsigned long long seg1 = 0, seg2 = 0, seg3 = 0, seg4 = 0, seg5 = 0;
+  (void)seg1; (void)seg2; (void)seg3; (void)seg4; (void)seg5;
   for (int i = 1; i < D; i++) {
+    RL_TICK(0);
     retire_touch(touched);
+    RL_TICK(1);
     if (i + 1 < D) touched = touch_row(p, s2, pl.lane);
     s1 = s2;
     if (i + 2 < D) s2 = st[i + 2];
@@ -146,6 +158,7 @@ RL_DEV void paint_forward(const PaintParams &p, int k, float *stage) {
     const double nx_i = nx[i - 1], cf_i = cfp[i];
     set_slot<S>(a, pl.jk, pl.kbit, -cfac);  // donor k: (-c) + c = +0.0
     double lsum = 0.0;
+    RL_TICK(2);
     for_each_chunk_from<S, CH>(row, first, [&](int j0, const Chunk &m) {  // :288-295
       double v[CH];
 #pragma unroll
@@ -164,9 +177,11 @@ RL_DEV void paint_forward(const PaintParams &p, int k, float *stage) {
         lsum += v[jj];  // the lane's share of the serial sum (:300-303)
       }
     });
+    RL_TICK(3);
     row = site_row(p, s1);
     first = load_masks<CH>(row, 0);
     ssum = wave_sum<MODE, S>(RegTerm<S>{a, 0.0, 0.0, p.stats}, lsum);
+    RL_TICK(4);
     ls += nx_i;  // :281-282
     cfac = ssum;
     if (cfac < c.lower || cfac > c.upper) {  // :334-347
@@ -176,12 +191,21 @@ RL_DEV void paint_forward(const PaintParams &p, int k, float *stage) {
       cfac = 1.0;
     }
     cfac *= cf_i;  // :349-352
+    RL_TICK(5);
+    RL_TOCK(seg1, 0, 1); RL_TOCK(seg2, 1, 2); RL_TOCK(seg3, 2, 3); RL_TOCK(seg4, 3, 4); RL_TOCK(seg5, 4, 5);
     while (next_stone == i) {  // :354-374
       write_stone();
       next_stone = stone_index(wa);
     }
   }
   retire_touch(touched);
+#ifdef RL_STATS
+  if (MODE == 0 && p.stats && pl.lane == 0) {  // wait for prefetch | loads + slot | chunk loop | sum | rescale test
+    atomicAdd(&p.stats[0], (unsigned long long)(D - 1));
+    atomicAdd(&p.stats[1], seg1); atomicAdd(&p.stats[2], seg2); atomicAdd(&p.stats[3], seg3);
+    atomicAdd(&p.stats[4], seg4); atomicAdd(&p.stats[5], seg5);
+  }
+#endif
 }
 
 template <int S, int TAIL, int MODE>
