@@ -87,6 +87,10 @@ def main():
     ap.add_argument("--skip-cpu", dest="no_cpu", action="store_true")
     ap.add_argument("--skip-alt", dest="no_alt", action="store_true", help="skip timing the other summation mode")
     ap.add_argument("--skip-k23", dest="skip_k23", action="store_true", help="skip the RePaint / matrix measurement")
+    ap.add_argument("--shard", default="chunks", choices=["chunks", "targets"],
+                    help="chunks (default, the contract's weak scaling): one chunk per GPU, no collective. "
+                         "targets: ONE chunk for all ranks, each paints a range of target haplotypes (strong "
+                         "scaling; BASELINE.json config #5) and the ranks all-gather one distance matrix's rows")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -103,9 +107,13 @@ def main():
 
     from relate_amd import api
     N, L = args.n, args.l
-    bits, r, rpos, wb = make_chunk(N, L, seed=1 + rank, memory_gb=args.memory)
+    by_target = args.shard == "targets"
+    bits, r, rpos, wb = make_chunk(N, L, seed=1 if by_target else 1 + rank, memory_gb=args.memory)
     ctx = api.Context(local_rank if dist is not None else 0)
     ctx.set_chunk_bits(N, bits, r, rpos, wb)
+    if by_target:
+        from relate_amd import dist as rdist0
+        ctx.set_target_range(*rdist0.target_range(rank, world, N))
     ctx.prepare()  # plan on the host, panel + plan uploaded, stone buffers allocated: inputs resident in HBM
     sites = ctx.total_sites()
     updates = 2.0 * N * sites
@@ -146,8 +154,22 @@ def main():
 
     # secondary kernels of the path on the same chunk (reported under config, not timed steps):
     # K2 RePaintSection of one window for all targets, K3 one N x N distance matrix
+    gather = None
+    if by_target:  # every rank: rows of one distance matrix -> all-gather (RCCL) -> N x N on every rank
+        w = (len(wb) - 1) // 2
+        win = ctx.open_window(w, None, int(wb[w]), mode)
+        k0, k1 = ctx.target_range()
+        rows = torch.empty((k1 - k0, N), dtype=torch.float32, device="cuda")
+        win.matrix_rows_into(int(wb[w]), rows.data_ptr())
+        barrier()
+        t0 = time.time()
+        full = rdist.all_gather_rows(rows, N)
+        barrier()
+        gather = {"window": w, "k2_repaint_ms": win.repaint_ms, "k3_matrix_ms": win.matrix_ms,
+                  "all_gather_ms": 1e3 * (time.time() - t0), "matrix_shape": list(full.shape)}
+        win.close()
     extra = None
-    if rank == 0 and not args.skip_k23:
+    if rank == 0 and not args.skip_k23 and not by_target:
         try:
             w = (len(wb) - 1) // 2
             win = ctx.open_window(w, None, int(wb[w]), mode)     # stones resident after the last paint
@@ -173,7 +195,7 @@ def main():
         traffic = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_c3.json")))
-            if pmc["N"] == N and pmc["L"] == L:
+            if pmc["N"] == N and pmc["L"] == L and not by_target:
                 traffic = pmc["kernels"][args.mode + "_bwd"]["hbm_bytes_per_launch"]
         except Exception:
             pass
@@ -186,14 +208,15 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if by_target else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "synthetic block-coalescent panel, N=%d haplotypes x L=%d SNPs, 1 chunk per GPU, "
+                "workload": "synthetic block-coalescent panel, N=%d haplotypes x L=%d SNPs, %s, "
                             "%d windows (--memory %g), Paint = PaintSteppingStones for all targets" %
-                            (N, L, len(wb) - 1, args.memory),
+                            (N, L, "ONE chunk sharded by target haplotype over the GPUs" if by_target
+                             else "1 chunk per GPU", len(wb) - 1, args.memory),
                 "sum_mode": args.mode,
                 "sum_k_D_k": int(sites),
                 "updates_per_step_per_gpu": updates,
@@ -201,6 +224,8 @@ def main():
                 "bwd_kernel_ms": bwd_ms,
                 "other_mode": alt,
                 "repaint_and_matrix": extra,
+                "shard": args.shard,
+                "target_shard_matrix": gather,
             },
             "roofline": {"bound": "hbm", "kernel": "paint_kernel<backward>", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

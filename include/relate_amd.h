@@ -82,6 +82,18 @@ int rl_set_chunk_bits(rl_ctx *ctx, int N, int L, const uint32_t *bits,
  * data.r[l] *= rho.  Must precede rl_paint / rl_window_open. */
 int rl_set_painting(rl_ctx *ctx, double theta, double rho);
 
+/* Target-haplotype sharding of ONE chunk (BASELINE.json config #5):
+ * this context paints, re-paints and measures targets k_begin .. k_end-1 only
+ * (default: all).  The panel is replicated; stepping stones, posteriors and
+ * distance-matrix rows are held for those targets only (1/G of the memory on G
+ * GPUs).  Every per-target output below then has k_end-k_begin rows in target
+ * order; the caller all-gathers the distance rows (rl_window_matrix_rows_device
+ * + RCCL, relate_amd/dist.py) for the tree builder.  No reference counterpart:
+ * the reference shards a chunk by section only (RelateParallel.sh:231-257).
+ * Call after rl_set_chunk / rl_load_chunk and before rl_prepare / rl_paint. */
+int rl_set_target_range(rl_ctx *ctx, int k_begin, int k_end);
+int rl_target_range(const rl_ctx *ctx, int *k_begin, int *k_end);
+
 int rl_chunk_dims(const rl_ctx *ctx, int *N, int *L, int *W);
 /* sum_k D_k: visited (target, site) pairs of the chunk; 2*N*this is the
  * number of directional haplotype-pair.SNP updates of one Paint. */
@@ -155,10 +167,15 @@ int rl_window_get_topology(rl_window *win, int n, float *top,
  * (src/anc_builder.cpp:487-495). */
 int rl_window_advance(rl_window *win, int snp);
 /* Replaces DistanceMeasure::GetMatrix(snp) (src/anc_builder.cpp:109-207):
- * N*N float distance matrix at `snp`, row-min subtracted, into d_host
+ * N*N float distance matrix at `snp` (the rows of the context's targets, all
+ * by default), row-min subtracted, into d_host
  * (may be NULL to leave the result on the device only).
  * kernel_ms optional. */
 int rl_window_matrix(rl_window *win, int snp, float *d_host, float *kernel_ms);
+/* The same, written to a caller-owned DEVICE buffer of (targets of the
+ * context) * N floats -- the send buffer of the all-gather when the chunk is
+ * sharded by target (rl_set_target_range). */
+int rl_window_matrix_rows_device(rl_window *win, int snp, void *d_rows, float *kernel_ms);
 
 /* --------------------------------------------------------------- host side */
 /* Replaces MinMatch::QuickBuild (src/tree_builder.cpp:1061-1303 without

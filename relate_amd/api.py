@@ -48,6 +48,7 @@ def lib():
         L.rl_quickbuild.argtypes = [C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p]
         L.rl_set_painting.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        L.rl_window_matrix_rows_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -114,6 +115,15 @@ class Context:
     def set_painting(self, theta, rho):
         _check(lib().rl_set_painting(C.c_void_p(self._h), theta, rho))
 
+    def set_target_range(self, k_begin, k_end):
+        """shard ONE chunk by target haplotype: this context handles targets k_begin .. k_end-1"""
+        _check(lib().rl_set_target_range(C.c_void_p(self._h), int(k_begin), int(k_end)))
+
+    def target_range(self):
+        a, b = C.c_int(), C.c_int()
+        _check(lib().rl_target_range(C.c_void_p(self._h), C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def total_sites(self):
         v = lib().rl_total_sites(C.c_void_p(self._h))
         if v < 0:
@@ -137,10 +147,13 @@ class Context:
         return f.value, b.value
 
     def stones(self, w):
+        """stepping stones of window w: one row per target of the context (all N by default)"""
         N = self.N
-        out = dict(alpha=np.empty((N, N), np.float32), beta=np.empty((N, N), np.float32),
-                   ls_alpha=np.empty(N, np.float32), ls_beta=np.empty(N, np.float32),
-                   bsnp_begin=np.empty(N, np.int32), bsnp_end=np.empty(N, np.int32))
+        k0, k1 = self.target_range()
+        n = k1 - k0
+        out = dict(alpha=np.empty((n, N), np.float32), beta=np.empty((n, N), np.float32),
+                   ls_alpha=np.empty(n, np.float32), ls_beta=np.empty(n, np.float32),
+                   bsnp_begin=np.empty(n, np.int32), bsnp_end=np.empty(n, np.int32))
         _check(lib().rl_get_stones(C.c_void_p(self._h), w, _p(out["alpha"]), _p(out["beta"]),
                                    _p(out["ls_alpha"]), _p(out["ls_beta"]), _p(out["bsnp_begin"]),
                                    _p(out["bsnp_end"])))
@@ -192,12 +205,21 @@ class Window:
         _check(lib().rl_window_advance(C.c_void_p(self._h), snp))
 
     def matrix(self, snp):
+        """distance matrix at snp: the rows of the context's targets (the whole N x N matrix by default)"""
         N = self.ctx.N
-        d = np.empty((N, N), np.float32)
+        k0, k1 = self.ctx.target_range()
+        d = np.empty((k1 - k0, N), np.float32)
         ms = C.c_float(0)
         _check(lib().rl_window_matrix(C.c_void_p(self._h), snp, _p(d), C.byref(ms)))
         self.matrix_ms = ms.value
         return d
+
+    def matrix_rows_into(self, snp, device_ptr):
+        """the same rows written to a device buffer ((k_end-k_begin)*N floats), e.g. a torch tensor's
+        data_ptr(): the send buffer of relate_amd.dist.all_gather_rows"""
+        ms = C.c_float(0)
+        _check(lib().rl_window_matrix_rows_device(C.c_void_p(self._h), snp, C.c_void_p(device_ptr), C.byref(ms)))
+        self.matrix_ms = ms.value
 
 
 def quickbuild(d, theta=0.001, prior=None):

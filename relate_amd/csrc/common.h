@@ -85,6 +85,7 @@ struct rl_ctx {
   hipStream_t s0 = nullptr, s1 = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
   int N = 0, L = 0, W = 0;
+  int k0 = 0, nloc = 0;  // targets of this context (rl_set_target_range), default all
   rl::Layout lay{};        // K2/K3: donors of a target, target deleted
   int S = 0;
   rl::Layout paint_lay{};  // K1: all N donors

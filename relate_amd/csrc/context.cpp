@@ -108,8 +108,10 @@ int build_plan(rl_ctx *ctx) {
     }
     for (int b = 0; b < 32 && w * 32 + b < N; b++) cnt[w * 32 + b] = local[b];
   });
+  // only the targets of this context (rl_set_target_range) get a list
+  const int k0 = ctx->k0, k1 = ctx->k0 + ctx->nloc;
   pl.off.assign((size_t)N + 1, 0);
-  for (int k = 0; k < N; k++) pl.off[k + 1] = pl.off[k] + cnt[k] + 2;
+  for (int k = 0; k < N; k++) pl.off[k + 1] = pl.off[k] + ((k >= k0 && k < k1) ? cnt[k] + 2 : 0);
   const int64_t total = pl.off[N];
   pl.sites.assign((size_t)total, 0);
   pl.cf.assign((size_t)total, 0.0);
@@ -123,14 +125,18 @@ int build_plan(rl_ctx *ctx) {
   // 2. visited-site lists (site | flag "target derived here")
   parallel_for(words, [&](int w) {
     int64_t pos[32];
+    uint32_t mine = 0;  // targets of this word that belong to this context
     for (int b = 0; b < 32 && w * 32 + b < N; b++) {
       int k = w * 32 + b;
+      if (k < k0 || k >= k1) continue;
+      mine |= 1u << b;
       pos[b] = pl.off[k];
       uint32_t x0 = bits[w];
       pl.sites[pos[b]++] = 0 | (((x0 >> b) & 1u) ? (int32_t)0x80000000 : 0);
     }
+    if (!mine) return;
     for (int s = 1; s < L - 1; s++) {
-      uint32_t x = bits[(size_t)s * rw + w];
+      uint32_t x = bits[(size_t)s * rw + w] & mine;
       while (x) {
         int b = __builtin_ctz(x);
         pl.sites[pos[b]++] = s | (int32_t)0x80000000;
@@ -139,12 +145,13 @@ int build_plan(rl_ctx *ctx) {
     }
     uint32_t xl = bits[(size_t)(L - 1) * rw + w];
     for (int b = 0; b < 32 && w * 32 + b < N; b++)
-      pl.sites[pos[b]++] = (L - 1) | (((xl >> b) & 1u) ? (int32_t)0x80000000 : 0);
+      if ((mine >> b) & 1u) pl.sites[pos[b]++] = (L - 1) | (((xl >> b) & 1u) ? (int32_t)0x80000000 : 0);
   });
 
   // 3. interval coefficients, window boundaries, initial beta sum
   const std::vector<int> &wb = ctx->wb;
   parallel_for(N, [&](int k) {
+    if (k < k0 || k >= k1) return;
     const int64_t o = pl.off[k];
     const int D = (int)(pl.off[k + 1] - o);
     int32_t *bb = &pl.bb[(size_t)k * W], *be = &pl.be[(size_t)k * W];
@@ -189,8 +196,8 @@ int build_plan(rl_ctx *ctx) {
   });
 
   // 4. launch order: longest target first
-  pl.order.resize(N);
-  std::iota(pl.order.begin(), pl.order.end(), 0);
+  pl.order.resize(ctx->nloc);
+  std::iota(pl.order.begin(), pl.order.end(), k0);
   std::stable_sort(pl.order.begin(), pl.order.end(), [&](int a, int b) {
     return (pl.off[a + 1] - pl.off[a]) > (pl.off[b + 1] - pl.off[b]);
   });
@@ -424,6 +431,7 @@ static int set_common(rl_ctx *ctx, int N, int L, const double *r, const double *
     return RL_EINVAL;
   }
   ctx->N = N; ctx->L = L; ctx->W = W; ctx->lay = lay; ctx->S = S; ctx->paint_lay = paint_lay; ctx->paint_S = paint_S;
+  ctx->k0 = 0; ctx->nloc = N;  // all targets until rl_set_target_range
   ctx->r.assign(r, r + L);
   ctx->rpos.assign(rpos, rpos + L + 1);
   ctx->wb.assign(wb, wb + W + 1);
@@ -543,6 +551,33 @@ int rl_set_painting(rl_ctx *ctx, double theta, double rho) {
   return RL_OK;
 }
 
+int rl_set_target_range(rl_ctx *ctx, int k_begin, int k_end) {
+  if (!ctx || !ctx->have_chunk) {
+    set_error("rl_set_target_range: no chunk loaded");
+    return RL_ESTATE;
+  }
+  if (k_begin < 0 || k_end > ctx->N || k_begin >= k_end) {
+    set_error("rl_set_target_range: [%d, %d) is not a range of the %d haplotypes", k_begin, k_end, ctx->N);
+    return RL_EINVAL;
+  }
+  ctx->k0 = k_begin;
+  ctx->nloc = k_end - k_begin;
+  ctx->plan.valid = false;
+  ctx->plan_on_device = false;
+  ctx->painted = false;
+  return RL_OK;
+}
+
+int rl_target_range(const rl_ctx *ctx, int *k_begin, int *k_end) {
+  if (!ctx || !ctx->have_chunk) {
+    set_error("no chunk loaded");
+    return RL_ESTATE;
+  }
+  if (k_begin) *k_begin = ctx->k0;
+  if (k_end) *k_end = ctx->k0 + ctx->nloc;
+  return RL_OK;
+}
+
 int rl_chunk_dims(const rl_ctx *ctx, int *N, int *L, int *W) {
   if (!ctx || !ctx->have_chunk) {
     set_error("no chunk loaded");
@@ -568,11 +603,11 @@ int rl_prepare(rl_ctx *ctx) {
   RL_HIP(hipSetDevice(ctx->device));
   int rc = upload_plan(ctx);
   if (rc) return rc;
-  const size_t N = ctx->N, W = ctx->W;
-  if ((rc = ctx->d_alpha.alloc(W * N * N * sizeof(float)))) return rc;
-  if ((rc = ctx->d_beta.alloc(W * N * N * sizeof(float)))) return rc;
-  if ((rc = ctx->d_lsa.alloc(W * N * sizeof(float)))) return rc;
-  if ((rc = ctx->d_lsb.alloc(W * N * sizeof(float)))) return rc;
+  const size_t N = ctx->N, W = ctx->W, nloc = ctx->nloc;  // stones: this context's target rows only
+  if ((rc = ctx->d_alpha.alloc(W * nloc * N * sizeof(float)))) return rc;
+  if ((rc = ctx->d_beta.alloc(W * nloc * N * sizeof(float)))) return rc;
+  if ((rc = ctx->d_lsa.alloc(W * nloc * sizeof(float)))) return rc;
+  if ((rc = ctx->d_lsb.alloc(W * nloc * sizeof(float)))) return rc;
   RL_HIP(hipDeviceSynchronize());
   return RL_OK;
 }
@@ -589,17 +624,19 @@ int rl_paint(rl_ctx *ctx, int sum_mode, float *kernel_ms) {
   RL_HIP(hipSetDevice(ctx->device));
   int rc = upload_plan(ctx);
   if (rc) return rc;
-  const size_t N = ctx->N, W = ctx->W;
-  if ((rc = ctx->d_alpha.alloc(W * N * N * sizeof(float)))) return rc;
-  if ((rc = ctx->d_beta.alloc(W * N * N * sizeof(float)))) return rc;
-  if ((rc = ctx->d_lsa.alloc(W * N * sizeof(float)))) return rc;
-  if ((rc = ctx->d_lsb.alloc(W * N * sizeof(float)))) return rc;
+  const size_t N = ctx->N, W = ctx->W, nloc = ctx->nloc;  // stones: this context's target rows only
+  if ((rc = ctx->d_alpha.alloc(W * nloc * N * sizeof(float)))) return rc;
+  if ((rc = ctx->d_beta.alloc(W * nloc * N * sizeof(float)))) return rc;
+  if ((rc = ctx->d_lsa.alloc(W * nloc * sizeof(float)))) return rc;
+  if ((rc = ctx->d_lsb.alloc(W * nloc * sizeof(float)))) return rc;
 
   PaintParams p;
   p.lay = ctx->paint_lay;
   p.c = ctx->consts;
   p.L = ctx->L;
   p.W = ctx->W;
+  p.k0 = ctx->k0;
+  p.nloc = ctx->nloc;
   p.S = ctx->paint_S;
   p.masks = ctx->d_masks.as<unsigned long long>();
   p.plan_off = ctx->d_off.as<int64_t>();
@@ -664,18 +701,18 @@ int rl_get_stones(rl_ctx *ctx, int w, float *alpha, float *beta, float *ls_alpha
     return RL_EINVAL;
   }
   RL_HIP(hipSetDevice(ctx->device));
-  const size_t N = ctx->N, W = ctx->W;
+  const size_t N = ctx->N, W = ctx->W, nloc = ctx->nloc, k0 = ctx->k0;  // rows of targets k0 .. k0+nloc-1
   if (alpha)
-    RL_HIP(hipMemcpy(alpha, ctx->d_alpha.as<float>() + w * N * N, N * N * 4, hipMemcpyDeviceToHost));
+    RL_HIP(hipMemcpy(alpha, ctx->d_alpha.as<float>() + w * nloc * N, nloc * N * 4, hipMemcpyDeviceToHost));
   if (beta)
-    RL_HIP(hipMemcpy(beta, ctx->d_beta.as<float>() + w * N * N, N * N * 4, hipMemcpyDeviceToHost));
+    RL_HIP(hipMemcpy(beta, ctx->d_beta.as<float>() + w * nloc * N, nloc * N * 4, hipMemcpyDeviceToHost));
   if (ls_alpha)
-    RL_HIP(hipMemcpy(ls_alpha, ctx->d_lsa.as<float>() + w * N, N * 4, hipMemcpyDeviceToHost));
+    RL_HIP(hipMemcpy(ls_alpha, ctx->d_lsa.as<float>() + w * nloc, nloc * 4, hipMemcpyDeviceToHost));
   if (ls_beta)
-    RL_HIP(hipMemcpy(ls_beta, ctx->d_lsb.as<float>() + w * N, N * 4, hipMemcpyDeviceToHost));
-  for (size_t k = 0; k < N; k++) {
-    if (bsnp_begin) bsnp_begin[k] = ctx->plan.bb[k * W + w];
-    if (bsnp_end) bsnp_end[k] = ctx->plan.be[k * W + w];
+    RL_HIP(hipMemcpy(ls_beta, ctx->d_lsb.as<float>() + w * nloc, nloc * 4, hipMemcpyDeviceToHost));
+  for (size_t t = 0; t < nloc; t++) {
+    if (bsnp_begin) bsnp_begin[t] = ctx->plan.bb[(k0 + t) * W + w];
+    if (bsnp_end) bsnp_end[t] = ctx->plan.be[(k0 + t) * W + w];
   }
   return RL_OK;
 }
@@ -683,6 +720,11 @@ int rl_get_stones(rl_ctx *ctx, int w, float *alpha, float *beta, float *ls_alpha
 int rl_write_paint_files(rl_ctx *ctx, const char *paint_dir) {
   if (!ctx || !ctx->painted || !paint_dir) {
     set_error("rl_write_paint_files: call rl_paint first");
+    return RL_ESTATE;
+  }
+  if (ctx->nloc != ctx->N) {
+    set_error("rl_write_paint_files: a paint file holds every target; this context paints targets %d..%d only",
+              ctx->k0, ctx->k0 + ctx->nloc - 1);
     return RL_ESTATE;
   }
   const int N = ctx->N, W = ctx->W;

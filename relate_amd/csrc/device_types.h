@@ -28,6 +28,7 @@ struct PaintParams {
   Layout lay;               // over all N donors (P = N): the target keeps a slot, pinned to +0.0
   PaintConsts c;
   int L, W;
+  int k0, nloc;             // this context's targets are k0 .. k0+nloc-1 (rl_set_target_range); stones hold those rows
   int S;                    // words per row of the lane-mask panel (= register tile)
   const unsigned long long *masks;  // [L+2][S] lane-mask panel (paint_device.h), built by panel_kernels.hip
   const int64_t *plan_off;  // [N+1] offsets of target k's visited sites
@@ -37,9 +38,9 @@ struct PaintParams {
   const int32_t *stone_ia;  // [N][W] visited index of boundarySNP_begin[w]
   const int32_t *stone_ie;  // [N][W] visited index of boundarySNP_end[w]
   const double *binit;      // [N] beta_sum at the last SNP (serial, host)
-  const int32_t *order;     // [N] launch order -> target (longest first)
-  float *alpha, *beta;      // [W][N][N] stepping stones, donor order
-  float *ls_alpha, *ls_beta;  // [W][N]
+  const int32_t *order;     // [nloc] launch order -> target (longest first)
+  float *alpha, *beta;      // [W][nloc][N] stepping stones, donor order
+  float *ls_alpha, *ls_beta;  // [W][nloc]
   int sum_mode;             // RL_SUM_EXACT / RL_SUM_LANES / RL_SUM_EXACT_SERIAL
   unsigned long long *stats;  // 16 event counters (experiment builds with -DRL_STATS), else null
 };
@@ -49,6 +50,7 @@ struct RepaintParams {
   Layout lay;
   PaintConsts c;
   int L;
+  int k0, nloc;  // targets k0 .. k0+nloc-1; the per-target arrays below are indexed by t = n - k0
   int row_words;
   const uint32_t *bits;
   const int64_t *plan_off;
@@ -58,32 +60,33 @@ struct RepaintParams {
   // per target: slice [ib, ie] of its visited list covered by this window and
   // the coefficients of the window's last interval (r[last_snp] only,
   // fast_painting.cpp:702-716)
-  const int32_t *ib, *ie;     // [N]
-  const double *cf_last;      // [N]
-  const double *nxt_last;     // [N]
-  const float *alpha_begin;   // [N][N] decoded stones, donor order
-  const float *beta_end;      // [N][N]
-  const float *ls_alpha;      // [N]
-  const float *ls_beta;       // [N]
-  const int64_t *top_off;     // [N+1] row offsets into topology/logscales
+  const int32_t *ib, *ie;     // [nloc]
+  const double *cf_last;      // [nloc]
+  const double *nxt_last;     // [nloc]
+  const float *alpha_begin;   // [nloc][N] decoded stones, donor order
+  const float *beta_end;      // [nloc][N]
+  const float *ls_alpha;      // [nloc]
+  const float *ls_beta;       // [nloc]
+  const int64_t *top_off;     // [nloc+1] row offsets into topology/logscales
   float *topology;            // [sum D][N] donor order
   float *logscales;           // [sum D]
   double *scratch;            // per-block alpha rows [maxD][S*64]
   int64_t scratch_stride;     // doubles per block
-  const int32_t *order;       // [N]
+  const int32_t *order;       // [nloc] targets (global index), longest first
   int sum_mode;
 };
 
 struct MatrixParams {
   int N;
+  int k0, nloc;  // rows of targets k0 .. k0+nloc-1; per-row arrays and `matrix` are indexed by t = n - k0
   const float *topology;
   const float *logscales;
-  const int64_t *top_off;   // [N+1]
-  const int32_t *v_snp_prev;  // [N]
-  const uint8_t *direct;      // [N] 1: no interpolation
-  const double *wl, *wr;      // [N] interpolation weights
-  const float *e_pn, *e_np;   // [N] expf(ls_prev-ls_next), expf(ls_next-ls_prev)
-  float *matrix;              // [N][N]
+  const int64_t *top_off;   // [nloc+1]
+  const int32_t *v_snp_prev;  // [nloc]
+  const uint8_t *direct;      // [nloc] 1: no interpolation
+  const double *wl, *wr;      // [nloc] interpolation weights
+  const float *e_pn, *e_np;   // [nloc] expf(ls_prev-ls_next), expf(ls_next-ls_prev)
+  float *matrix;              // [nloc][N]
 };
 
 }  // namespace rl

@@ -30,17 +30,18 @@ RL_DEV int phys_index(const Layout &lay, int n, int j) {
 __global__ void __launch_bounds__(256) matrix_kernel(const MatrixParams p, const Layout lay, int S) {
   extern __shared__ float vals[];  // N floats
   __shared__ float red[256];
-  const int n = blockIdx.x;
+  const int t = blockIdx.x;   // row of this context
+  const int n = p.k0 + t;     // its target
   const int N = p.N;
   const int64_t stride = (int64_t)S * 64;
-  const int64_t r0 = p.top_off[n] + p.v_snp_prev[n];
+  const int64_t r0 = p.top_off[t] + p.v_snp_prev[t];
   const float *__restrict__ tp = p.topology + r0 * stride;
   const float *__restrict__ tn = tp + stride;
   const float ls_prev = p.logscales[r0];
-  const bool direct = p.direct[n] != 0;
+  const bool direct = p.direct[t] != 0;
   const float ls_next = direct ? 0.0f : p.logscales[r0 + 1];
-  const double wl = p.wl[n], wr = p.wr[n];
-  const float e_pn = p.e_pn[n], e_np = p.e_np[n];
+  const double wl = p.wl[t], wr = p.wr[t];
+  const float e_pn = p.e_pn[t], e_np = p.e_np[t];
   const float scale = -1.0f;
 
   float mn = INFINITY;
@@ -77,12 +78,12 @@ __global__ void __launch_bounds__(256) matrix_kernel(const MatrixParams p, const
     __syncthreads();
   }
   mn = red[0];
-  float *__restrict__ out = p.matrix + (size_t)n * N;
+  float *__restrict__ out = p.matrix + (size_t)t * N;
   for (int j = threadIdx.x; j < N; j += blockDim.x) out[j] = (j == n) ? 0.0f : vals[j] - mn;  // :190-192
 }
 
 hipError_t launch_matrix(const MatrixParams &p, const Layout &lay, int S, hipStream_t stream) {
-  hipLaunchKernelGGL(matrix_kernel, dim3(p.N), dim3(256), (size_t)p.N * sizeof(float), stream, p, lay, S);
+  hipLaunchKernelGGL(matrix_kernel, dim3(p.nloc), dim3(256), (size_t)p.N * sizeof(float), stream, p, lay, S);
   return hipGetLastError();
 }
 

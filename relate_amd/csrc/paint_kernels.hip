@@ -123,9 +123,9 @@ RL_DEV void paint_forward(const PaintParams &p, int k, float *stage) {
   };
   auto write_stone = [&]() {
     const ColdParams cp = cold_params();
-    const size_t N = cp->lay.N;
-    emit_stone<S>(pl, a, cp->alpha + ((size_t)wa * N + k) * N, 0.0f, stage);
-    if (pl.lane == 0) cp->ls_alpha[(size_t)wa * N + k] = (float)ls;
+    const size_t N = cp->lay.N, row = (size_t)wa * cp->nloc + (k - cp->k0);
+    emit_stone<S>(pl, a, cp->alpha + row * N, 0.0f, stage);
+    if (pl.lane == 0) cp->ls_alpha[row] = (float)ls;
     wa++;
   };
   int next_stone = stone_index(0);
@@ -238,9 +238,9 @@ RL_DEV void paint_backward(const PaintParams &p, int k, float *stage) {
   };
   auto write_stone = [&](float self_value) {
     const ColdParams cp = cold_params();
-    const size_t N = cp->lay.N;
-    emit_stone<S>(pl, b, cp->beta + ((size_t)we * N + k) * N, self_value, stage);
-    if (pl.lane == 0) cp->ls_beta[(size_t)we * N + k] = (float)ls;
+    const size_t N = cp->lay.N, row = (size_t)we * cp->nloc + (k - cp->k0);
+    emit_stone<S>(pl, b, cp->beta + row * N, self_value, stage);
+    if (pl.lane == 0) cp->ls_beta[row] = (float)ls;
     we--;
   };
   int next_stone = stone_index(we);
@@ -328,7 +328,7 @@ __global__ void __launch_bounds__(64, (S <= 80 ? 2 : 1)) paint_kernel(const Pain
 
 template <int S, int TAIL>
 static hipError_t launch_paint_t(const PaintParams &p, int backward, hipStream_t stream) {
-  const dim3 grid(p.lay.N), block(64);
+  const dim3 grid(p.nloc), block(64);
   if (backward)
     hipLaunchKernelGGL((paint_kernel<S, TAIL, RL_MODE, true>), grid, block, 0, stream, p);
   else

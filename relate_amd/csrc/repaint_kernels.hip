@@ -42,15 +42,16 @@ RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ s
   lc.init(p.lay, n);
   const PaintConsts &c = p.c;
   const int N = p.lay.N;
-  const int ib = p.ib[n], ie = p.ie[n];
+  const int t = n - p.k0;  // index into the per-target arrays of this context
+  const int ib = p.ib[t], ie = p.ie[t];
   const int D = ie - ib + 1;
   const int64_t off = p.plan_off[n] + ib;
   const int32_t *__restrict__ st = p.sites + off;
   const double *__restrict__ cfp = p.cf + off;
   const double *__restrict__ nx = p.nxt + off;
-  const double cf_last = p.cf_last[n], nxt_last = p.nxt_last[n];
+  const double cf_last = p.cf_last[t], nxt_last = p.nxt_last[t];
   constexpr int ROW = (S + 1) * 64;  // doubles per scratch row (+64: per-lane logscale copy)
-  const int64_t trow0 = p.top_off[n];
+  const int64_t trow0 = p.top_off[t];
   float *__restrict__ top = p.topology + trow0 * (int64_t)(S * 64);
   float *__restrict__ lsout = p.logscales + trow0;
 
@@ -59,9 +60,9 @@ RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ s
   LaneBits<S> mb;
 
   // ---------------- forward (fast_painting.cpp:769-885)
-  load_stone<S>(lc, p.alpha_begin + (size_t)n * N, a, stage);
+  load_stone<S>(lc, p.alpha_begin + (size_t)t * N, a, stage);
   double ssum = wave_sum<MODE, S>(RegTerm<S>{a}, local_sum<S>(RegTerm<S>{a}));
-  float lsf = p.ls_alpha[n];
+  float lsf = p.ls_alpha[t];
   double prev_ls = (double)lsf;
   {
     double *row = scratch;
@@ -111,8 +112,8 @@ RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ s
   // ---------------- backward (:887-1073)
   double b[S];
   LaneBits<S> m_next, m_here;
-  lsf = lsf + p.ls_beta[n];  // float += float (:895)
-  load_stone<S>(lc, p.beta_end + (size_t)n * N, b, stage);
+  lsf = lsf + p.ls_beta[t];  // float += float (:895)
+  load_stone<S>(lc, p.beta_end + (size_t)t * N, b, stage);
   int sv = st[D - 1];
   raw.load(p.bits + (size_t)(sv & 0x7fffffff) * p.row_words, lc.w0);
   m_here.from_raw(raw, lc);
@@ -127,7 +128,7 @@ RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ s
     if (lc.lane == 0) lsout[D - 1] = lsf;
   }
   cfac = cf_last * bsum;
-  prev_ls = (double)p.ls_beta[n];  // :951
+  prev_ls = (double)p.ls_beta[t];  // :951
   int sv_prev = D > 1 ? st[D - 2] : 0;
   if (D > 1) raw.load(p.bits + (size_t)(sv_prev & 0x7fffffff) * p.row_words, lc.w0);
   for (int j = D - 2; j >= 0; j--) {
@@ -184,7 +185,7 @@ __global__ void __launch_bounds__(64) repaint_kernel(const RepaintParams p, int 
     __syncthreads();
     const int t = s_t;
     __syncthreads();
-    if (t >= p.lay.N) break;
+    if (t >= p.nloc) break;
     repaint_target<S, TAIL, MODE>(p, p.order[t], scratch, stage);
   }
 }

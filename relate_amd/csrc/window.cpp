@@ -18,7 +18,8 @@ struct rl_window {
   rl_ctx *ctx = nullptr;
   int w = 0;
   int start = 0, end = 0;  // section_startpos / section_endpos as stored in the paint file
-  std::vector<int64_t> top_off;  // [N+1]
+  int k0 = 0, nloc = 0;          // targets of the context when the window was opened; arrays below are [nloc]
+  std::vector<int64_t> top_off;  // [nloc+1]
   std::vector<float> logscales;  // host copy, [sum D]
   std::vector<int32_t> v_snp_prev;
   std::vector<double> v_rpos_prev, v_rpos_next;
@@ -67,17 +68,19 @@ rl_window *rl_window_open(rl_ctx *ctx, int w, const char *paint_file, int first_
   }
   if (upload_plan(ctx)) return nullptr;
   const int N = ctx->N, L = ctx->L, W = ctx->W, S = ctx->S;
+  const int k0 = ctx->k0, nloc = ctx->nloc;  // this context's targets; t = n - k0 indexes the per-target arrays
   const Plan &pl = ctx->plan;
 
   // ---- stepping stones of this window, after the file's float/RLE quantisation
-  std::vector<float> ab((size_t)N * N), be((size_t)N * N), la(N), lb(N);
-  std::vector<int> bb(N), bend(N);
+  std::vector<float> ab((size_t)nloc * N), be((size_t)nloc * N), la(nloc), lb(nloc);
+  std::vector<int> bb(nloc), bend(nloc);
   int start = ctx->wb[w], end = ctx->wb[w + 1] - 1;
   if (paint_file) {
     std::vector<unsigned char> buf;
     if (read_file(paint_file, buf)) return nullptr;
     size_t pos = 0;
-    for (int n = 0; n < N; n++) {  // anc_builder.cpp:61-73
+    std::vector<float> skip(N);
+    for (int n = 0; n < k0 + nloc; n++) {  // anc_builder.cpp:61-73; records of other contexts' targets are skipped
       if (pos + 8 > buf.size()) {
         set_error("%s: truncated at target %d", paint_file, n);
         return nullptr;
@@ -85,13 +88,19 @@ rl_window *rl_window_open(rl_ctx *ctx, int w, const char *paint_file, int first_
       memcpy(&start, buf.data() + pos, 4);
       memcpy(&end, buf.data() + pos + 4, 4);
       pos += 8;
-      size_t u = decode_stone(buf.data() + pos, buf.size() - pos, N, &ab[(size_t)n * N], &bb[n], &la[n]);
+      const bool mine = n >= k0;
+      const int t = mine ? n - k0 : 0;
+      int bs = 0;
+      float ls = 0.f;
+      size_t u = decode_stone(buf.data() + pos, buf.size() - pos, N, mine ? &ab[(size_t)t * N] : skip.data(),
+                              mine ? &bb[t] : &bs, mine ? &la[t] : &ls);
       if (!u) {
         set_error("%s: malformed alpha record of target %d", paint_file, n);
         return nullptr;
       }
       pos += u;
-      u = decode_stone(buf.data() + pos, buf.size() - pos, N, &be[(size_t)n * N], &bend[n], &lb[n]);
+      u = decode_stone(buf.data() + pos, buf.size() - pos, N, mine ? &be[(size_t)t * N] : skip.data(),
+                       mine ? &bend[t] : &bs, mine ? &lb[t] : &ls);
       if (!u) {
         set_error("%s: malformed beta record of target %d", paint_file, n);
         return nullptr;
@@ -107,19 +116,19 @@ rl_window *rl_window_open(rl_ctx *ctx, int w, const char *paint_file, int first_
       return nullptr;
     // decode(encode(x)): the file round trip is part of the numerics
     std::vector<unsigned char> tmp(28 + (size_t)N * 8);
-    for (int n = 0; n < N; n++) {
+    for (int t = 0; t < nloc; t++) {
       int bs;
       float ls;
-      encode_stone(&ab[(size_t)n * N], N, bb[n], la[n], tmp.data());
-      decode_stone(tmp.data(), tmp.size(), N, &ab[(size_t)n * N], &bs, &ls);
-      encode_stone(&be[(size_t)n * N], N, bend[n], lb[n], tmp.data());
-      decode_stone(tmp.data(), tmp.size(), N, &be[(size_t)n * N], &bs, &ls);
+      encode_stone(&ab[(size_t)t * N], N, bb[t], la[t], tmp.data());
+      decode_stone(tmp.data(), tmp.size(), N, &ab[(size_t)t * N], &bs, &ls);
+      encode_stone(&be[(size_t)t * N], N, bend[t], lb[t], tmp.data());
+      decode_stone(tmp.data(), tmp.size(), N, &be[(size_t)t * N], &bs, &ls);
     }
   }
 
   // ---- per-target slices of the visited-site plan
-  std::vector<int32_t> ib(N), ie(N);
-  std::vector<double> cf_last(N), nxt_last(N);
+  std::vector<int32_t> ib(nloc), ie(nloc);
+  std::vector<double> cf_last(nloc), nxt_last(nloc);
   std::vector<double> r(ctx->r);
   if (ctx->rho != 1.0)
     for (auto &x : r) x *= ctx->rho;
@@ -128,31 +137,35 @@ rl_window *rl_window_open(rl_ctx *ctx, int w, const char *paint_file, int first_
   win->w = w;
   win->start = start;
   win->end = end;
-  win->top_off.assign((size_t)N + 1, 0);
+  win->k0 = k0;
+  win->nloc = nloc;
+  win->top_off.assign((size_t)nloc + 1, 0);
   int maxD = 0;
-  for (int n = 0; n < N; n++) {
-    ib[n] = pl.ia[(size_t)n * W + w];
-    ie[n] = pl.ie[(size_t)n * W + w];
-    if (pl.bb[(size_t)n * W + w] != bb[n] || pl.be[(size_t)n * W + w] != bend[n]) {
-      set_error("paint file boundary SNPs of target %d (%d,%d) disagree with the chunk (%d,%d)", n, bb[n],
-                bend[n], pl.bb[(size_t)n * W + w], pl.be[(size_t)n * W + w]);
+  for (int t = 0; t < nloc; t++) {
+    const int n = k0 + t;
+    ib[t] = pl.ia[(size_t)n * W + w];
+    ie[t] = pl.ie[(size_t)n * W + w];
+    if (pl.bb[(size_t)n * W + w] != bb[t] || pl.be[(size_t)n * W + w] != bend[t]) {
+      set_error("paint file boundary SNPs of target %d (%d,%d) disagree with the chunk (%d,%d)", n, bb[t],
+                bend[t], pl.bb[(size_t)n * W + w], pl.be[(size_t)n * W + w]);
       delete win;
       return nullptr;
     }
-    const int D = ie[n] - ib[n] + 1;
+    const int D = ie[t] - ib[t] + 1;
     maxD = std::max(maxD, D);
-    win->top_off[n + 1] = win->top_off[n] + D;
+    win->top_off[t + 1] = win->top_off[t] + D;
     // last interval of RePaintSection: r[last_snp] only (fast_painting.cpp:702-716)
-    interval_coeffs(ctx->consts, N, r[bend[n]], &cf_last[n], &nxt_last[n]);
+    interval_coeffs(ctx->consts, N, r[bend[t]], &cf_last[t], &nxt_last[t]);
   }
-  const int64_t rows = win->top_off[N];
-  std::vector<int32_t> order(N);
-  std::iota(order.begin(), order.end(), 0);
-  std::stable_sort(order.begin(), order.end(),
-                   [&](int a, int b) { return (ie[a] - ib[a]) > (ie[b] - ib[b]); });
+  const int64_t rows = win->top_off[nloc];
+  std::vector<int32_t> order(nloc);  // targets (global index), longest slice first
+  std::iota(order.begin(), order.end(), k0);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+    return (ie[a - k0] - ib[a - k0]) > (ie[b - k0] - ib[b - k0]);
+  });
 
   DevBuf d_ab, d_be, d_la, d_lb, d_ib, d_ie, d_cfl, d_nxl, d_order, d_scratch, d_counter;
-  const int nblocks = std::min(N, 2048);
+  const int nblocks = std::min(nloc, 2048);
   const int64_t scratch_stride = (int64_t)maxD * (S + 1) * 64;
   int rc = 0;
   rc = rc ? rc : d_ab.upload(ab);
@@ -169,7 +182,7 @@ rl_window *rl_window_open(rl_ctx *ctx, int w, const char *paint_file, int first_
   rc = rc ? rc : win->d_ls.alloc((size_t)rows * sizeof(float));
   rc = rc ? rc : d_scratch.alloc((size_t)nblocks * scratch_stride * sizeof(double));
   rc = rc ? rc : d_counter.alloc(sizeof(int));
-  rc = rc ? rc : win->d_matrix.alloc((size_t)N * N * sizeof(float));
+  rc = rc ? rc : win->d_matrix.alloc((size_t)nloc * N * sizeof(float));
   if (rc) {
     delete win;
     return nullptr;
@@ -179,6 +192,8 @@ rl_window *rl_window_open(rl_ctx *ctx, int w, const char *paint_file, int first_
   p.lay = ctx->lay;
   p.c = ctx->consts;
   p.L = L;
+  p.k0 = k0;
+  p.nloc = nloc;
   p.row_words = ctx->row_words;
   p.bits = ctx->d_bits.as<uint32_t>();
   p.plan_off = ctx->d_off.as<int64_t>();
@@ -224,19 +239,19 @@ rl_window *rl_window_open(rl_ctx *ctx, int w, const char *paint_file, int first_
 
   // ---- cursors (anc_builder.cpp:81-101)
   const int snp = first_snp < 0 ? ctx->wb[w] : first_snp;
-  win->v_snp_prev.assign(N, 0);
-  win->v_rpos_prev.assign(N, 0.0);
-  win->v_rpos_next.assign(N, 0.0);
+  win->v_snp_prev.assign(nloc, 0);
+  win->v_rpos_prev.assign(nloc, 0.0);
+  win->v_rpos_next.assign(nloc, 0.0);
   if (snp > 0) {
-    for (int t = snp; t >= win->start; t--)
-      for (int n = 0; n < N; n++)
-        if (derived(ctx, t, n)) win->v_snp_prev[n]++;
+    for (int s = snp; s >= win->start; s--)
+      for (int t = 0; t < nloc; t++)
+        if (derived(ctx, s, k0 + t)) win->v_snp_prev[t]++;
   }
-  for (int n = 0; n < N; n++) {
-    int t = snp;
-    while (!derived(ctx, t, n) && t > 0) t--;
-    win->v_rpos_prev[n] = ctx->rpos[t];
-    win->v_rpos_next[n] = win->v_rpos_prev[n];
+  for (int t = 0; t < nloc; t++) {
+    int s = snp;
+    while (!derived(ctx, s, k0 + t) && s > 0) s--;
+    win->v_rpos_prev[t] = ctx->rpos[s];
+    win->v_rpos_next[t] = win->v_rpos_prev[t];
   }
   return win;
 }
@@ -251,24 +266,26 @@ int rl_window_bounds(const rl_window *win, int *start, int *end) {
 }
 
 int rl_window_rows(const rl_window *win, int n) {
-  if (!win || n < 0 || n >= win->ctx->N) return RL_EINVAL;
-  return (int)(win->top_off[n + 1] - win->top_off[n]);
+  if (!win || n < win->k0 || n >= win->k0 + win->nloc) return RL_EINVAL;
+  const int t = n - win->k0;
+  return (int)(win->top_off[t + 1] - win->top_off[t]);
 }
 
 int rl_window_get_topology(rl_window *win, int n, float *top, float *logscales) {
-  if (!win || n < 0 || n >= win->ctx->N) {
-    set_error("rl_window_get_topology: bad arguments");
+  if (!win || n < win->k0 || n >= win->k0 + win->nloc) {
+    set_error("rl_window_get_topology: bad arguments (target outside the window's range)");
     return RL_EINVAL;
   }
   const rl_ctx *ctx = win->ctx;
   RL_HIP(hipSetDevice(ctx->device));
   const int N = ctx->N, S = ctx->S;
-  const int D = (int)(win->top_off[n + 1] - win->top_off[n]);
+  const int t = n - win->k0;
+  const int D = (int)(win->top_off[t + 1] - win->top_off[t]);
   const Layout &lay = ctx->lay;
-  if (logscales) memcpy(logscales, &win->logscales[win->top_off[n]], (size_t)D * sizeof(float));
+  if (logscales) memcpy(logscales, &win->logscales[win->top_off[t]], (size_t)D * sizeof(float));
   if (top) {
     std::vector<float> phys((size_t)D * S * 64);
-    RL_HIP(hipMemcpy(phys.data(), win->d_top.as<float>() + win->top_off[n] * (int64_t)S * 64,
+    RL_HIP(hipMemcpy(phys.data(), win->d_top.as<float>() + win->top_off[t] * (int64_t)S * 64,
                      phys.size() * sizeof(float), hipMemcpyDeviceToHost));
     for (int d = 0; d < D; d++) {
       const float *row = &phys[(size_t)d * S * 64];
@@ -290,51 +307,53 @@ int rl_window_advance(rl_window *win, int snp) {
     return RL_EINVAL;
   }
   const rl_ctx *ctx = win->ctx;
-  for (int n = 0; n < ctx->N; n++)
-    if (derived(ctx, snp, n)) {  // anc_builder.cpp:489-494
-      win->v_snp_prev[n]++;
-      win->v_rpos_prev[n] = ctx->rpos[snp];
+  for (int t = 0; t < win->nloc; t++)
+    if (derived(ctx, snp, win->k0 + t)) {  // anc_builder.cpp:489-494
+      win->v_snp_prev[t]++;
+      win->v_rpos_prev[t] = ctx->rpos[snp];
     }
   return RL_OK;
 }
 
-int rl_window_matrix(rl_window *win, int snp, float *d_host, float *kernel_ms) {
+// rows of the window's targets: [nloc][N] (the whole matrix for a context with all targets)
+static int window_matrix(rl_window *win, int snp, float *d_host, void *d_dev, float *kernel_ms) {
   if (!win || snp < 0 || snp >= win->ctx->L) {
     set_error("rl_window_matrix: bad arguments");
     return RL_EINVAL;
   }
   rl_ctx *ctx = win->ctx;
   RL_HIP(hipSetDevice(ctx->device));
-  const int N = ctx->N, L = ctx->L;
-  std::vector<uint8_t> direct(N);
-  std::vector<double> wl(N, 0.5), wr(N, 0.5);
-  std::vector<float> epn(N, 1.0f), enp(N, 1.0f);
-  for (int n = 0; n < N; n++) {
-    const int p = win->v_snp_prev[n];
-    const int D = (int)(win->top_off[n + 1] - win->top_off[n]);
-    direct[n] = derived(ctx, snp, n) || snp == 0 || snp == L - 1;
-    if (p < 0 || p >= D || (!direct[n] && p + 1 >= D)) {
+  const int N = ctx->N, L = ctx->L, k0 = win->k0, nloc = win->nloc;
+  std::vector<uint8_t> direct(nloc);
+  std::vector<double> wl(nloc, 0.5), wr(nloc, 0.5);
+  std::vector<float> epn(nloc, 1.0f), enp(nloc, 1.0f);
+  for (int t = 0; t < nloc; t++) {
+    const int n = k0 + t;
+    const int p = win->v_snp_prev[t];
+    const int D = (int)(win->top_off[t + 1] - win->top_off[t]);
+    direct[t] = derived(ctx, snp, n) || snp == 0 || snp == L - 1;
+    if (p < 0 || p >= D || (!direct[t] && p + 1 >= D)) {
       set_error("rl_window_matrix: cursor of target %d (%d) outside its %d posterior rows at SNP %d", n, p,
                 D, snp);
       return RL_ESTATE;
     }
-    if (direct[n]) continue;
-    if (win->v_rpos_next[n] <= win->v_rpos_prev[n]) {  // anc_builder.cpp:134-141
+    if (direct[t]) continue;
+    if (win->v_rpos_next[t] <= win->v_rpos_prev[t]) {  // anc_builder.cpp:134-141
       for (int l = snp; l < L; l++)
         if (derived(ctx, l, n) || l == L - 1) {
-          win->v_rpos_next[n] = ctx->rpos[l];
+          win->v_rpos_next[t] = ctx->rpos[l];
           break;
         }
     }
-    const double rp = win->v_rpos_prev[n], rn = win->v_rpos_next[n];
+    const double rp = win->v_rpos_prev[t], rn = win->v_rpos_next[t];
     if (rp != rn) {  // :146-153
       const double denom = rn - rp;
-      wl[n] = (rn - ctx->rpos[snp]) / denom;
-      wr[n] = (ctx->rpos[snp] - rp) / denom;
+      wl[t] = (rn - ctx->rpos[snp]) / denom;
+      wr[t] = (ctx->rpos[snp] - rp) / denom;
     }
-    const float lsp = win->logscales[win->top_off[n] + p], lsn = win->logscales[win->top_off[n] + p + 1];
-    epn[n] = expf(lsp - lsn);  // float expf of a float difference (:167-168), glibc
-    enp[n] = expf(lsn - lsp);
+    const float lsp = win->logscales[win->top_off[t] + p], lsn = win->logscales[win->top_off[t] + p + 1];
+    epn[t] = expf(lsp - lsn);  // float expf of a float difference (:167-168), glibc
+    enp[t] = expf(lsn - lsp);
   }
   int rc = 0;
   rc = rc ? rc : win->d_vsp.upload(win->v_snp_prev);
@@ -346,6 +365,8 @@ int rl_window_matrix(rl_window *win, int snp, float *d_host, float *kernel_ms) {
   if (rc) return rc;
   MatrixParams p;
   p.N = N;
+  p.k0 = k0;
+  p.nloc = nloc;
   p.topology = win->d_top.as<float>();
   p.logscales = win->d_ls.as<float>();
   p.top_off = win->d_top_off.as<int64_t>();
@@ -355,16 +376,27 @@ int rl_window_matrix(rl_window *win, int snp, float *d_host, float *kernel_ms) {
   p.wr = win->d_wr.as<double>();
   p.e_pn = win->d_epn.as<float>();
   p.e_np = win->d_enp.as<float>();
-  p.matrix = win->d_matrix.as<float>();
+  p.matrix = d_dev ? static_cast<float *>(d_dev) : win->d_matrix.as<float>();
   RL_HIP(hipEventRecord(ctx->ev0, ctx->s0));
   RL_HIP(launch_matrix(p, ctx->lay, ctx->S, ctx->s0));
   RL_HIP(hipEventRecord(ctx->ev2, ctx->s0));
   if (d_host)
-    RL_HIP(hipMemcpyAsync(d_host, win->d_matrix.p, (size_t)N * N * sizeof(float), hipMemcpyDeviceToHost,
-                          ctx->s0));
+    RL_HIP(hipMemcpyAsync(d_host, p.matrix, (size_t)nloc * N * sizeof(float), hipMemcpyDeviceToHost, ctx->s0));
   RL_HIP(hipStreamSynchronize(ctx->s0));
   if (kernel_ms) RL_HIP(hipEventElapsedTime(kernel_ms, ctx->ev0, ctx->ev2));
   return RL_OK;
+}
+
+int rl_window_matrix(rl_window *win, int snp, float *d_host, float *kernel_ms) {
+  return window_matrix(win, snp, d_host, nullptr, kernel_ms);
+}
+
+int rl_window_matrix_rows_device(rl_window *win, int snp, void *d_rows, float *kernel_ms) {
+  if (!d_rows) {
+    set_error("rl_window_matrix_rows_device: null device pointer");
+    return RL_EINVAL;
+  }
+  return window_matrix(win, snp, nullptr, d_rows, kernel_ms);
 }
 
 }  // extern "C"

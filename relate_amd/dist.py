@@ -5,7 +5,13 @@ collective): chunks are independent after MakeChunks, exactly as the
 reference's cluster scripts run them (scripts/RelateParallel/RelateParallel.sh:216,
 scripts/RelateSGE/RelateSGE.sh:324-401).  Within a chunk, BuildTopology shards
 by section (window) the same way (RelateParallel.sh:231-257).  The only
-collectives are the bookkeeping ones below (job statistics)."""
+collectives on that route are the bookkeeping ones below (job statistics).
+
+A single chunk too large for one GPU (BASELINE.json config #5) shards by TARGET
+haplotype instead: every rank holds the bit panel, paints / re-paints its own
+contiguous range of targets (rl_set_target_range) and owns those rows of every
+distance matrix; one all-gather (RCCL over xGMI) assembles the N x N matrix for
+the tree builder (target_range, all_gather_rows)."""
 import torch
 import torch.distributed as dist
 
@@ -25,3 +31,31 @@ def job_stats(units, seconds, device=None):
     dist.all_reduce(u, op=dist.ReduceOp.SUM)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(u.item()), float(t.item())
+
+
+def target_range(rank, world, N):
+    """contiguous, balanced range [k_begin, k_end) of targets for a rank (the first N % world ranks get one more)"""
+    q, r = divmod(N, world)
+    k0 = rank * q + min(rank, r)
+    return k0, k0 + q + (1 if rank < r else 0)
+
+
+def all_gather_rows(rows, N):
+    """rows: this rank's (k_end-k_begin) x N block of a distance matrix, a tensor on the backend's device.
+    Returns the N x N matrix (every rank).  Row counts may differ by one between ranks, so blocks are
+    padded to the largest and the padding dropped after the gather."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return rows
+    world = dist.get_world_size()
+    maxrows = -(-N // world)
+    send = rows
+    if rows.shape[0] < maxrows:
+        send = torch.zeros((maxrows, N), dtype=rows.dtype, device=rows.device)
+        send[: rows.shape[0]] = rows
+    out = torch.empty((world * maxrows, N), dtype=rows.dtype, device=rows.device)
+    dist.all_gather_into_tensor(out, send.contiguous())
+    blocks = []
+    for r in range(world):
+        k0, k1 = target_range(r, world, N)
+        blocks.append(out[r * maxrows: r * maxrows + (k1 - k0)])
+    return torch.cat(blocks, 0)

@@ -61,3 +61,46 @@ def test_shard_is_a_partition():
     for world in (1, 2, 3, 8):
         parts = [rdist.shard(list(range(11)), r, world) for r in range(world)]
         assert sorted(sum(parts, [])) == list(range(11))
+
+
+def _rows_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import torch
+    from relate_amd import dist as rdist
+    N = 11  # not a multiple of the world size: uneven blocks
+    full = torch.arange(N * N, dtype=torch.float32).reshape(N, N) * 0.5
+    k0, k1 = rdist.target_range(rank, world, N)
+    got = rdist.all_gather_rows(full[k0:k1].clone(), N)  # each rank contributes only its own rows
+    q.put((rank, k0, k1, bool(torch.equal(got, full))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_target_sharding_all_gather_three_ranks():
+    """the single-chunk route (config #5): ranks own target ranges and all-gather their distance rows"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 3
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_rows_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [(r[1], r[2]) for r in res] == [(0, 4), (4, 8), (8, 11)]
+    assert all(r[3] for r in res)
+
+
+def test_target_range_is_a_partition():
+    from relate_amd import dist as rdist
+    for world in (1, 2, 3, 8):
+        for N in (8, 11, 5000):
+            rs = [rdist.target_range(r, world, N) for r in range(world)]
+            assert rs[0][0] == 0 and rs[-1][1] == N
+            assert all(rs[i][1] == rs[i + 1][0] for i in range(world - 1))
+            assert max(b - a for a, b in rs) - min(b - a for a, b in rs) <= 1

@@ -1,0 +1,67 @@
+"""One chunk sharded by target haplotype (BASELINE.json config #5): contexts that
+each paint a range of targets reproduce, row for row and bit for bit, what a
+context with all targets computes -- stepping stones, posteriors, distance
+rows -- including through the device-buffer path that feeds the all-gather."""
+import numpy as np
+import pytest
+
+import rlutil
+from relate_amd import api, dist as rdist
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("N,L,budget,parts", [(130, 900, 200000, 2), (70, 700, 40000, 3)])
+@pytest.mark.parametrize("mode", ["exact", "lanes"])
+def test_target_ranges_reproduce_the_full_chunk(N, L, budget, parts, mode):
+    sm = api.RL_SUM_EXACT if mode == "exact" else api.RL_SUM_LANES
+    ch = rlutil.synth_chunk(N, L, seed=4, budget=budget)
+    full = api.Context()
+    full.set_chunk(ch.seq, ch.r, ch.rpos, ch.wb)
+    full.paint(sm)
+    W = ch.W
+    w = W // 2
+    snp = int(ch.wb[w]) + 3
+    fst = full.stones(w)
+    fwin = full.open_window(w, None, int(ch.wb[w]), sm)
+    for s in range(int(ch.wb[w]) + 1, snp + 1):
+        fwin.advance(s)
+    fd = fwin.matrix(snp)
+    total = 0
+    rows = []
+    for r in range(parts):
+        k0, k1 = rdist.target_range(r, parts, N)
+        ctx = api.Context()
+        ctx.set_chunk(ch.seq, ch.r, ch.rpos, ch.wb)
+        ctx.set_target_range(k0, k1)
+        assert ctx.target_range() == (k0, k1)
+        total += ctx.total_sites()
+        ctx.paint(sm)
+        st = ctx.stones(w)
+        for key in ("alpha", "beta", "ls_alpha", "ls_beta", "bsnp_begin", "bsnp_end"):
+            assert st[key].shape[0] == k1 - k0
+            assert np.array_equal(st[key].view(np.uint32) if st[key].dtype == np.float32 else st[key],
+                                  fst[key][k0:k1].view(np.uint32) if fst[key].dtype == np.float32 else fst[key][k0:k1]), key
+        win = ctx.open_window(w, None, int(ch.wb[w]), sm)
+        for s in range(int(ch.wb[w]) + 1, snp + 1):
+            win.advance(s)
+        d = win.matrix(snp)
+        assert d.shape == (k1 - k0, N)
+        assert np.array_equal(d.view(np.uint32), fd[k0:k1].view(np.uint32))
+        top, ls = win.topology(k0)
+        ftop, fls = fwin.topology(k0)
+        assert np.array_equal(top.view(np.uint32), ftop.view(np.uint32)) and np.array_equal(ls, fls)
+        with pytest.raises(api.RelateError):
+            ctx.write_paint_files("/tmp/never_written")
+        # the device-buffer path (send buffer of the all-gather)
+        import torch
+        buf = torch.empty((k1 - k0, N), dtype=torch.float32, device="cuda")
+        win.matrix_rows_into(snp, buf.data_ptr())
+        torch.cuda.synchronize()
+        rows.append(buf.cpu().numpy())
+        win.close()
+        ctx.close()
+    assert total == full.total_sites()
+    assert np.array_equal(np.concatenate(rows, 0).view(np.uint32), fd.view(np.uint32))
+    fwin.close()
+    full.close()
