@@ -132,9 +132,8 @@ int ro_plan_target(const ro_data *d, const int *wb, int W, int k, int *site,
  * the donors, in donor order, are cut into 64 contiguous runs (the first P%64
  * runs hold P/64+1 donors, the rest P/64); each run is summed left to right
  * from 0.0, then an xor-butterfly (masks 1..32) combines the 64 partial sums.
- * The RePaint kernel lays out the P = N-1 donors n != k (full = 0); the
- * stepping-stone kernel all P = N donors, the target's own term being +0.0
- * (full = 1). */
+ * The kernels lay out all P = N donors, the target's own term being +0.0
+ * (full = 1; full = 0, the donors n != k only, is kept for experiments). */
 static double sum_lanes(const double *t, int N, int k, int full) {
   const int P = full ? N : N - 1, q = P / 64, rem = P % 64;
   if (full) k = N; /* nothing is skipped */
@@ -598,7 +597,7 @@ int ro_repaint_section(const ro_data *d, const float *alpha_begin,
   double *a = alpha;
   for (int n = 0; n < N; n++) a[n] = alpha_begin[n];
   a[k] = 0.0;
-  double S = sum_alpha(a, N, k, order, 0);
+  double S = sum_alpha(a, N, k, order, 1);
   double cfac = trans_factor(c, r_prob[0]) * S;
   double prev_logscale = logscales[0];
   for (int i = 1; i < D; i++) {
@@ -615,7 +614,7 @@ int ro_repaint_section(const ro_data *d, const float *alpha_begin,
       a[n] = v;
     }
     a[k] = 0.0;
-    S = sum_alpha(a, N, k, order, 0);
+    S = sum_alpha(a, N, k, order, 1);
     cfac = S;
     if (cfac < c->lower || cfac > c->upper) { /* :865-877 */
       const double tmp = cfac;
@@ -633,7 +632,7 @@ int ro_repaint_section(const ro_data *d, const float *alpha_begin,
   b[k] = 0.0;
   {
     const char *row = seq + (size_t)last_snp * N;
-    double B0 = sum_beta(b, row, k, N, c, order, scratch, 0);
+    double B0 = sum_beta(b, row, k, N, c, order, scratch, 1);
     a = alpha + (size_t)(D - 1) * N;
     float *t = topology + (size_t)(D - 1) * N;
     for (int n = 0; n < N; n++) t[n] = (float)(a[n] * b[n]); /* :930 */
@@ -655,7 +654,7 @@ int ro_repaint_section(const ro_data *d, const float *alpha_begin,
     }
     b[k] = 0.0;
     const char *row = seq + (size_t)site[j] * N;
-    double B = sum_beta(b, row, k, N, c, order, scratch, 0);
+    double B = sum_beta(b, row, k, N, c, order, scratch, 1);
     cfac = B;
     a = alpha + (size_t)j * N;
     float *t = topology + (size_t)j * N;

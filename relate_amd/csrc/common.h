@@ -86,10 +86,8 @@ struct rl_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
   int N = 0, L = 0, W = 0;
   int k0 = 0, nloc = 0;  // targets of this context (rl_set_target_range), default all
-  rl::Layout lay{};        // K2/K3: donors of a target, target deleted
-  int S = 0;
-  rl::Layout paint_lay{};  // K1: all N donors
-  int paint_S = 0;
+  rl::Layout lay{};  // all N donors in 64 balanced runs
+  int S = 0;         // register tile (doubles per lane) = words per row of the lane-mask panel
   double theta = 0.001, rho = 1.0;
   int row_words = 0;
   std::vector<uint32_t> bits;  // host copy of the panel

@@ -216,8 +216,8 @@ int upload_plan(rl_ctx *ctx) {
   int rc;
   if ((rc = ctx->d_bits.upload(ctx->bits))) return rc;
   // lane-mask form of the panel for K1
-  if ((rc = ctx->d_masks.alloc(((size_t)ctx->L + 2) * ctx->paint_S * sizeof(unsigned long long)))) return rc;
-  RL_HIP(launch_lane_masks(ctx->d_bits.as<uint32_t>(), ctx->row_words, ctx->L, ctx->paint_lay, ctx->paint_S,
+  if ((rc = ctx->d_masks.alloc(((size_t)ctx->L + 2) * ctx->S * sizeof(unsigned long long)))) return rc;
+  RL_HIP(launch_lane_masks(ctx->d_bits.as<uint32_t>(), ctx->row_words, ctx->L, ctx->lay, ctx->S,
                            ctx->d_masks.as<unsigned long long>(), nullptr));
   RL_HIP(hipDeviceSynchronize());
   if ((rc = ctx->d_off.upload(pl.off))) return rc;
@@ -424,13 +424,11 @@ static int set_common(rl_ctx *ctx, int N, int L, const double *r, const double *
     }
   Layout lay = make_layout(N);
   int S = choose_S(lay);
-  const Layout paint_lay = make_paint_layout(N);
-  const int paint_S = choose_S(paint_lay);
-  if (S == 0 || paint_S == 0) {
+  if (S == 0) {
     set_error("N=%d exceeds the largest compiled register tile (N <= %d)", N, 160 * 64);
     return RL_EINVAL;
   }
-  ctx->N = N; ctx->L = L; ctx->W = W; ctx->lay = lay; ctx->S = S; ctx->paint_lay = paint_lay; ctx->paint_S = paint_S;
+  ctx->N = N; ctx->L = L; ctx->W = W; ctx->lay = lay; ctx->S = S;
   ctx->k0 = 0; ctx->nloc = N;  // all targets until rl_set_target_range
   ctx->r.assign(r, r + L);
   ctx->rpos.assign(rpos, rpos + L + 1);
@@ -631,13 +629,13 @@ int rl_paint(rl_ctx *ctx, int sum_mode, float *kernel_ms) {
   if ((rc = ctx->d_lsb.alloc(W * nloc * sizeof(float)))) return rc;
 
   PaintParams p;
-  p.lay = ctx->paint_lay;
+  p.lay = ctx->lay;
   p.c = ctx->consts;
   p.L = ctx->L;
   p.W = ctx->W;
   p.k0 = ctx->k0;
   p.nloc = ctx->nloc;
-  p.S = ctx->paint_S;
+  p.S = ctx->S;
   p.masks = ctx->d_masks.as<unsigned long long>();
   p.plan_off = ctx->d_off.as<int64_t>();
   p.sites = ctx->d_sites.as<int32_t>();
@@ -661,9 +659,9 @@ int rl_paint(rl_ctx *ctx, int sum_mode, float *kernel_ms) {
 
   // backward then forward on one stream, each bracketed by HIP events
   RL_HIP(hipEventRecord(ctx->ev0, ctx->s0));
-  RL_HIP(launch_paint(p, ctx->paint_S, 1, ctx->s0));
+  RL_HIP(launch_paint(p, ctx->S, 1, ctx->s0));
   RL_HIP(hipEventRecord(ctx->ev1, ctx->s0));
-  RL_HIP(launch_paint(p, ctx->paint_S, 0, ctx->s0));
+  RL_HIP(launch_paint(p, ctx->S, 0, ctx->s0));
   RL_HIP(hipEventRecord(ctx->ev2, ctx->s0));
   RL_HIP(hipEventSynchronize(ctx->ev2));
   RL_HIP(hipEventElapsedTime(&ctx->ms_bwd, ctx->ev0, ctx->ev1));

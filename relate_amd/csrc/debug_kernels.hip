@@ -14,16 +14,15 @@ template <int S, int MODE>
 __global__ void __launch_bounds__(64) sum_kernel(const double *__restrict__ x, int n, double *__restrict__ out) {
   __shared__ __attribute__((aligned(16))) float stage[16 * 64];
   (void)stage;
-  const Layout lay{n + 1, n, n / 64, n % 64};
-  LaneCtx<S> lc;
-  lc.init(lay, n);  // "target" = one past the last term: nothing is deleted
+  const int lane = threadIdx.x & 63, q = n / 64, rem = n % 64;  // the kernels' layout over n terms
+  const int start = lane * q + (lane < rem ? lane : rem), len = q + (lane < rem ? 1 : 0);
   const double *xb = x + (size_t)blockIdx.x * n;
   double a[S];
 #pragma unroll
-  for (int i = 0; i < S; i++) a[i] = (i < lc.len) ? xb[lc.start + i] : 0.0;
+  for (int i = 0; i < S; i++) a[i] = (i < len) ? xb[start + i] : 0.0;
   const RegTerm<S> t{a};
   const double r = wave_sum<MODE, S>(t, local_sum<S>(t));
-  if (lc.lane == 0) out[blockIdx.x] = r;
+  if (lane == 0) out[blockIdx.x] = r;
 }
 
 template <int MODE>
@@ -44,7 +43,7 @@ static hipError_t launch_sum(const double *x, int n, int batch, double *out, int
 extern "C" int rl_debug_wave_sum(const double *x, int n, int batch, int sum_mode, double *out) {
   using namespace rl;
   if (!x || !out || n < 1 || batch < 1) return RL_EINVAL;
-  const Layout lay = make_layout(n + 1);
+  const Layout lay = make_layout(n);
   const int S = choose_S(lay);
   if (!S) {
     set_error("rl_debug_wave_sum: n too large");

@@ -4,9 +4,9 @@
 
 namespace rl {
 
-// Lane layout of one target's donors (DESIGN.md "register layout").
-// The wave of target k holds the P = N-1 donors n != k in "physical" order
-// p = n - (n > k); lane l owns the contiguous run
+// Lane layout of the donors (DESIGN.md "register layout").
+// The wave of target k holds all P = N donors in donor order (the slot of k
+// itself is pinned to +0.0); lane l owns the contiguous run
 //   [start_l, start_l + len_l),  start_l = l*q + min(l, rem),
 //   len_l = q + (l < rem),       q = P / 64, rem = P % 64
 // in registers 0..len_l-1; registers >= len_l hold +0.0 and stay +0.0.
@@ -25,7 +25,7 @@ struct PaintConsts {
 };
 
 struct PaintParams {
-  Layout lay;               // over all N donors (P = N): the target keeps a slot, pinned to +0.0
+  Layout lay;
   PaintConsts c;
   int L, W;
   int k0, nloc;             // this context's targets are k0 .. k0+nloc-1 (rl_set_target_range); stones hold those rows
@@ -51,8 +51,7 @@ struct RepaintParams {
   PaintConsts c;
   int L;
   int k0, nloc;  // targets k0 .. k0+nloc-1; the per-target arrays below are indexed by t = n - k0
-  int row_words;
-  const uint32_t *bits;
+  const unsigned long long *masks;  // [L+2][S] lane-mask panel, as in PaintParams
   const int64_t *plan_off;
   const int32_t *sites;
   const double *cf;
@@ -68,7 +67,7 @@ struct RepaintParams {
   const float *ls_alpha;      // [nloc]
   const float *ls_beta;       // [nloc]
   const int64_t *top_off;     // [nloc+1] row offsets into topology/logscales
-  float *topology;            // [sum D][N] donor order
+  float *topology;            // [sum D][S*64] register-major: row[i*64 + lane] = donor start_lane + i
   float *logscales;           // [sum D]
   double *scratch;            // per-block alpha rows [maxD][S*64]
   int64_t scratch_stride;     // doubles per block

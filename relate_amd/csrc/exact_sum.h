@@ -106,21 +106,6 @@ struct RegTerm {  // forward: the terms are the alpha registers themselves
   }
 };
 template <int S>
-struct WeightedTerm {  // backward: e(i) * beta[i], e = theta on a mismatch else 1 - theta
-  static constexpr bool REG = false;
-  const LaneBits<S> &m;
-  const double (&b)[S];
-  double th, nth;
-  unsigned long long *stats = nullptr;
-  RL_DEV double get(int i, double t, double n) const { return (m.get(i) ? t : n) * b[i]; }
-  template <typename F>
-  RL_DEV void for_each(double &t, double &n, F &&f) const {
-#pragma unroll
-    for (int i = 0; i < S; i++) f(i, get(i, t, n));
-  }
-};
-
-template <int S>
 struct MaskTerm {  // backward, lane-mask panel: e(i) * beta[i] with the site's row words as EXEC masks
   static constexpr bool REG = false;
   MaskRow row;  // mismatch row of the site (S words)

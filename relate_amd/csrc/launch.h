@@ -24,18 +24,8 @@ inline int choose_S(const Layout &lay) {
   return 0;
 }
 
-// layout of K2/K3: the P = N-1 donors of a target, the target itself deleted
+// the layout of all kernels: all N donors, the target keeps a slot that is pinned to +0.0
 inline Layout make_layout(int N) {
-  Layout l;
-  l.N = N;
-  l.P = N - 1;
-  l.q = l.P / 64;
-  l.rem = l.P % 64;
-  return l;
-}
-
-// layout of K1: all N donors, the target keeps a slot that is pinned to +0.0
-inline Layout make_paint_layout(int N) {
   Layout l;
   l.N = N;
   l.P = N;

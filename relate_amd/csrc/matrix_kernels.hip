@@ -11,9 +11,10 @@
 
 namespace rl {
 
-// register-major index of donor j in target n's posterior row
-RL_DEV int phys_index(const Layout &lay, int n, int j) {
-  const int p = j - (j > n ? 1 : 0);
+// register-major index of donor j in a posterior row (layout over all N donors;
+// the target's own entry holds 0 = alpha[n]*beta[n])
+RL_DEV int phys_index(const Layout &lay, int j) {
+  const int p = j;
   const int big = lay.rem * (lay.q + 1);
   int l, i;
   if (p < big) {
@@ -48,15 +49,11 @@ __global__ void __launch_bounds__(256) matrix_kernel(const MatrixParams p, const
   for (int j = threadIdx.x; j < N; j += blockDim.x) {
     float v;
     if (direct) {
-      const float x = (j == n) ? 0.0f : tp[phys_index(lay, n, j)];
+      const float x = tp[phys_index(lay, j)];
       v = (fast_log_dev(x) + ls_prev) * scale;  // :128
     } else {
-      float xp = 0.0f, xn = 0.0f;
-      if (j != n) {
-        const int idx = phys_index(lay, n, j);
-        xp = tp[idx];
-        xn = tn[idx];
-      }
+      const int idx = phys_index(lay, j);
+      const float xp = tp[idx], xn = tn[idx];
       if (ls_prev <= ls_next) {  // :172-178
         const float x = (float)(wl * xp * e_pn + wr * xn);
         v = (fast_log_dev(x) + ls_next) * scale;

@@ -1,11 +1,11 @@
 // paint_device.h -- device-side building blocks of the Li-Stephens kernels.
 //
-// One 64-lane wavefront paints one target haplotype k.  The P = N-1 donors
-// live in registers, S doubles per lane (rl::Layout); one forward or backward
-// step is
+// One 64-lane wavefront paints one target haplotype k.  The N donors (the
+// target itself keeps a slot that is pinned to +0.0) live in registers, S
+// doubles per lane (rl::Layout); one forward or backward step is
 //   elementwise update (lane-local, fast_painting.cpp:288-295 / 481-488)
 //   + one normalising sum over all donors (fast_painting.cpp:300-303 / 495-503)
-// and the only data read per step is the site's N-bit panel row.
+// and the only data read per step is the site's row of lane masks.
 //
 // Compiled with -ffp-contract=off: every operator is one IEEE operation, in
 // the operand order of the reference.
@@ -57,85 +57,8 @@ RL_DEV float fast_log_dev(float val) {
   return (val + log_2) * 0.69314718f;
 }
 
-template <int S>
-struct LaneCtx {
-  static constexpr int NW = (S + 31) / 32;  // words of lane bits
-  int lane;
-  int start;  // first physical donor index of this lane
-  int len;    // valid registers
-  int k;      // target
-  int w0;     // first panel word this lane reads
-  int sh;     // bit shift of `start` inside w0
-  uint32_t lowmask[NW];  // bit i set: register i maps to donor start+i (< k)
-
-  RL_DEV void init(const Layout &lay, int k_) {
-    lane = threadIdx.x & 63;
-    k = k_;
-    start = lane * lay.q + (lane < lay.rem ? lane : lay.rem);
-    len = lay.q + (lane < lay.rem ? 1 : 0);
-    w0 = start >> 5;
-    sh = start & 31;
-    int t = k - start;  // registers [0,t) are donors below k
-    t = t < 0 ? 0 : (t > S ? S : t);
-#pragma unroll
-    for (int w = 0; w < NW; w++) {
-      int r = t - 32 * w;
-      lowmask[w] = r >= 32 ? 0xffffffffu : (r <= 0 ? 0u : ((1u << r) - 1u));
-    }
-  }
-  // donor index of register i
-  RL_DEV int donor(int i) const {
-    int p = start + i;
-    return p + (p >= k ? 1 : 0);
-  }
-};
-
-// Raw panel words of one row for this lane (prefetchable).
-template <int S>
-struct RawBits {
-  static constexpr int NR = (S + 31) / 32 + 1;
-  uint32_t r[NR];
-  RL_DEV void load(const uint32_t *__restrict__ row, int w0) {
-#pragma unroll
-    for (int t = 0; t < NR; t++) r[t] = row[w0 + t];
-  }
-};
-
-// Donor bits of the lane in register order, donor k deleted.
-template <int S>
-struct LaneBits {
-  static constexpr int NW = (S + 31) / 32;
-  uint32_t w[NW];
-  RL_DEV void from_raw(const RawBits<S> &raw, const LaneCtx<S> &lc) {
-#pragma unroll
-    for (int t = 0; t < NW; t++) {
-      uint64_t lo = ((uint64_t)raw.r[t + 1] << 32) | raw.r[t];
-      uint32_t a = (uint32_t)(lo >> lc.sh);        // donors start+32t+j
-      uint32_t b = (uint32_t)(lo >> (lc.sh + 1));  // donors start+32t+j+1
-      w[t] = (a & lc.lowmask[t]) | (b & ~lc.lowmask[t]);
-    }
-  }
-  // mismatch mask "target derived, donor ancestral" (fast_painting.cpp:290)
-  RL_DEV void to_mismatch(bool seqk) {
-#pragma unroll
-    for (int t = 0; t < NW; t++) w[t] = seqk ? ~w[t] : 0u;
-  }
-  RL_DEV bool get(int i) const { return (w[i >> 5] >> (i & 31)) & 1u; }
-};
-
-// Lane-masked double ops: `if (lane in mask) t = t (op) k`, executed by
-// narrowing EXEC to the mask for one instruction instead of computing both
-// variants and selecting (2 x v_cndmask_b32 per double).  mask is a
-// wave-uniform 64-bit lane mask (one v_cmp away from the lanes' bits).
-RL_DEV void masked_mul(double &t, unsigned long long mask, double k) {
-  asm volatile("s_mov_b64 exec, %1\n\tv_mul_f64 %0, %0, %2\n\ts_mov_b64 exec, -1" : "+v"(t) : "s"(mask), "v"(k));
-}
-RL_DEV void masked_add(double &t, unsigned long long mask, double k) {
-  asm volatile("s_mov_b64 exec, %1\n\tv_add_f64 %0, %0, %2\n\ts_mov_b64 exec, -1" : "+v"(t) : "s"(mask), "v"(k));
-}
-
-// ---- lane-mask panel (K1) -------------------------------------------------
-// The stepping-stone kernel reads the panel in "lane-mask" form: for site s and
+// ---- lane-mask panel -------------------------------------------------------
+// The Li-Stephens kernels (K1 stepping stones, K2 RePaint) read the panel in "lane-mask" form: for site s and
 // register j one 64-bit word whose bit l says that the donor lane l holds in
 // register j is ANCESTRAL at s (layout over all N donors, the target included;
 // slots past a lane's run read 0).  At a site where the target is derived this
@@ -264,6 +187,43 @@ struct PaintLane {
   }
   RL_DEV u64 valid(int j) const { return j < q ? ~0ull : (j == q ? rem_mask : 0ull); }
 };
+
+// ---- helpers shared by K1 and K2 -------------------------------------------
+// Kernel arguments that only rare code needs (stone / bookkeeping writes) are
+// read from the kernarg segment at the point of use, through a pointer the
+// compiler cannot see through: kept in SGPRs across the site loop they would
+// crowd out the mask chunks (and spill into VGPR lanes at every step).  P is the
+// kernel's FIRST argument.
+template <typename P>
+RL_DEV const __attribute__((address_space(4))) P *cold_params() {
+  typedef const __attribute__((address_space(4))) P *Q;
+  Q q = (Q)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(q));
+  return q;
+}
+// a loop constant that the exec-masked asm takes in a VGPR: keep it there
+RL_DEV double in_vgpr(double v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+// site word of the plan (bit 31: the target is derived there) -> the row of
+// mismatch masks the target sees: the site's row, or the all-zero row L
+RL_DEV MaskRow site_row(const u64 *masks, int S, int L, int sv) {
+  sv = __builtin_amdgcn_readfirstlane(sv);
+  const int r = sv < 0 ? (sv & 0x7fffffff) : L;
+  return (MaskRow)(masks + (size_t)r * S);
+}
+// Pull the row of a site that the NEXT step will read into L2 (one dword per
+// 16 bytes; the value is kept alive until then, which also parks the wait
+// for it a whole step later).  Scalar loads that miss L2 cost ~800 cycles per
+// chunk of masks; from L2 the other wave on the SIMD covers them.
+RL_DEV uint32_t touch_row(const u64 *masks, int S, int sv, int lane) {
+  sv = __builtin_amdgcn_readfirstlane(sv);
+  const uint32_t *row = (const uint32_t *)(masks + (size_t)(sv & 0x7fffffff) * S);
+  const int o = lane * 4, last = S * 2 - 1;
+  return row[o < last ? o : last];
+}
+RL_DEV void retire_touch(uint32_t t) { asm volatile("" : : "v"(t)); }
 
 // ---- exec-masked vector ops ----------------------------------------------
 RL_DEV void masked_mov(double &t, u64 mask, double v) {
@@ -420,29 +380,5 @@ RL_DEV void set_slot(double (&a)[S], int j, u64 bit, double v) {
 }
 #undef RL_SLOT8
 #undef RL_SLOT
-
-// ---- normalising sums ---------------------------------------------------
-// EXACT: the donors are added left to right in physical order (= donor order
-// with the zero of donor k skipped, which is a no-op), lane 0's registers
-// first.  Lane l continues from the running sum handed over by lane l-1.
-template <int S, typename F>
-RL_DEV double sum_exact(F term) {
-  double s = 0.0;
-  for (int l = 0; l < 64; l++) {
-    double tmp = s;
-#pragma unroll
-    for (int i = 0; i < S; i++) tmp += term(i);
-    s = wave_bcast(tmp, l);
-  }
-  return s;
-}
-
-template <int S, typename F>
-RL_DEV double sum_lanes(F term) {
-  double s = 0.0;
-#pragma unroll
-  for (int i = 0; i < S; i++) s += term(i);
-  return wave_sum_butterfly(s);
-}
 
 }  // namespace rl

@@ -42,16 +42,6 @@ RL_DEV void emit_stone(const PaintLane<S> &pl, const double (&v)[S], float *__re
   }
 }
 
-// Kernel arguments that only the (rare) stepping-stone writes need are read
-// from the kernarg segment at the point of use, through a pointer the compiler
-// cannot see through: kept in SGPRs across the site loop they would crowd out
-// the mask chunks (and spill into VGPR lanes at every step).
-typedef const __attribute__((address_space(4))) PaintParams *ColdParams;
-RL_DEV ColdParams cold_params() {
-  ColdParams q = (ColdParams)__builtin_amdgcn_kernarg_segment_ptr();  // PaintParams is the first argument
-  asm volatile("" : "+s"(q));
-  return q;
-}
 // experiment builds (-DRL_STATS): per-segment cycle counters of the forward step, lanes mode
 #ifdef RL_STATS
 #define RL_TICK(n) const unsigned long long tick##n = __builtin_readcyclecounter()
@@ -60,33 +50,8 @@ RL_DEV ColdParams cold_params() {
 #define RL_TICK(n) do { } while (0)
 #define RL_TOCK(acc, a, b) do { } while (0)
 #endif
-// a loop constant that the exec-masked asm takes in a VGPR: keep it there
-RL_DEV double in_vgpr(double v) {
-  asm volatile("" : "+v"(v));
-  return v;
-}
 
-// Pull the row of a site that the NEXT step will read into L2 (one dword per
-// 16 bytes; the value is kept alive until then, which also parks the wait
-// for it a whole step later).  Scalar loads that miss L2 cost ~800 cycles per
-// chunk of masks; from L2 the other wave on the SIMD covers them.
-RL_DEV uint32_t touch_row(const PaintParams &p, int sv, int lane) {
-  sv = __builtin_amdgcn_readfirstlane(sv);
-  const uint32_t *row = (const uint32_t *)(p.masks + (size_t)(sv & 0x7fffffff) * p.S);
-  int o = lane * 4;
-  const int last = p.S * 2 - 1;
-  return row[o < last ? o : last];
-}
-RL_DEV void retire_touch(uint32_t t) { asm volatile("" : : "v"(t)); }
-
-// site word of the plan -> the row of mismatch masks the target sees there:
-// the site's row where the target is derived, the all-zero row L where it is not
-RL_DEV MaskRow validity_row(const PaintParams &p) { return (MaskRow)(p.masks + (size_t)(p.L + 1) * p.S); }
-RL_DEV MaskRow site_row(const PaintParams &p, int sv) {
-  sv = __builtin_amdgcn_readfirstlane(sv);
-  const int r = sv < 0 ? (sv & 0x7fffffff) : p.L;
-  return (MaskRow)(p.masks + (size_t)r * p.S);
-}
+typedef const __attribute__((address_space(4))) PaintParams *ColdParams;
 
 template <int S, int TAIL, int MODE>
 RL_DEV void paint_forward(const PaintParams &p, int k, float *stage) {
@@ -103,7 +68,7 @@ RL_DEV void paint_forward(const PaintParams &p, int k, float *stage) {
   double a[S];
 
   // ---- SNP 0 (fast_painting.cpp:207-253)
-  for_each_chunk<S, 8>(site_row(p, st[0]), [&](int j0, const u64x8 &m) {
+  for_each_chunk<S, 8>(site_row(p.masks, S, p.L, st[0]), [&](int j0, const u64x8 &m) {
 #pragma unroll
     for (int jj = 0; jj < 8; jj++) {
       double v = c.init0;
@@ -118,11 +83,11 @@ RL_DEV void paint_forward(const PaintParams &p, int k, float *stage) {
   int wa = 0;
   // stone wa of the target: written when the visited index reaches stone_ia[k][wa] (:354-374)
   auto stone_index = [&](int w) {
-    const ColdParams cp = cold_params();
+    const ColdParams cp = cold_params<PaintParams>();
     return w < cp->W ? cp->stone_ia[(size_t)k * cp->W + w] : -1;
   };
   auto write_stone = [&]() {
-    const ColdParams cp = cold_params();
+    const ColdParams cp = cold_params<PaintParams>();
     const size_t N = cp->lay.N, row = (size_t)wa * cp->nloc + (k - cp->k0);
     emit_stone<S>(pl, a, cp->alpha + row * N, 0.0f, stage);
     if (pl.lane == 0) cp->ls_alpha[row] = (float)ls;
@@ -143,7 +108,7 @@ RL_DEV void paint_forward(const PaintParams &p, int k, float *stage) {
   const double K1 = in_vgpr(c.K1);
   constexpr int CH = S % 16 == 0 ? 16 : 8;  // registers per chunk of masks
   typedef typename MaskChunk<CH>::type Chunk;
-  MaskRow row = site_row(p, s1);
+  MaskRow row = site_row(p.masks, S, p.L, s1);
   Chunk first = load_masks<CH>(row, 0);
   unsigned long long seg1 = 0, seg2 = 0, seg3 = 0, seg4 = 0, seg5 = 0;
   (void)seg1; (void)seg2; (void)seg3; (void)seg4; (void)seg5;
@@ -151,7 +116,7 @@ RL_DEV void paint_forward(const PaintParams &p, int k, float *stage) {
     RL_TICK(0);
     retire_touch(touched);
     RL_TICK(1);
-    if (i + 1 < D) touched = touch_row(p, s2, pl.lane);
+    if (i + 1 < D) touched = touch_row(p.masks, S, s2, pl.lane);
     s1 = s2;
     if (i + 2 < D) s2 = st[i + 2];
     // requested here, used after the sum: the chunk loop's waits cover the latency
@@ -178,7 +143,7 @@ RL_DEV void paint_forward(const PaintParams &p, int k, float *stage) {
       }
     });
     RL_TICK(3);
-    row = site_row(p, s1);
+    row = site_row(p.masks, S, p.L, s1);
     first = load_masks<CH>(row, 0);
     ssum = wave_sum<MODE, S>(RegTerm<S>{a, 0.0, 0.0, p.stats}, lsum);
     RL_TICK(4);
@@ -233,11 +198,11 @@ RL_DEV void paint_backward(const PaintParams &p, int k, float *stage) {
   double bsum = p.binit[k];  // serial sum of theta/ntheta minus ntheta (:421-431)
   int we = p.W - 1;
   auto stone_index = [&](int w) {
-    const ColdParams cp = cold_params();
+    const ColdParams cp = cold_params<PaintParams>();
     return w >= 0 ? cp->stone_ie[(size_t)k * cp->W + w] : -2;
   };
   auto write_stone = [&](float self_value) {
-    const ColdParams cp = cold_params();
+    const ColdParams cp = cold_params<PaintParams>();
     const size_t N = cp->lay.N, row = (size_t)we * cp->nloc + (k - cp->k0);
     emit_stone<S>(pl, b, cp->beta + row * N, self_value, stage);
     if (pl.lane == 0) cp->ls_beta[row] = (float)ls;
@@ -254,13 +219,13 @@ RL_DEV void paint_backward(const PaintParams &p, int k, float *stage) {
   // and s1 (site j); the row of s2 (site j-1) goes to L2 during the step
   int s0 = st[D - 1], s1 = D > 1 ? st[D - 2] : 0, s2 = D > 2 ? st[D - 3] : 0;
   uint32_t touched = 0;
-  MaskRow rown = site_row(p, s0);  // the later site's mismatches drive the update (:481-488)
-  MaskRow rowh = site_row(p, s1);
+  MaskRow rown = site_row(p.masks, S, p.L, s0);  // the later site's mismatches drive the update (:481-488)
+  MaskRow rowh = site_row(p.masks, S, p.L, s1);
   u64x4 firstn = load_masks<4>(rown, 0), firsth = load_masks<4>(rowh, 0);
   const double K1 = in_vgpr(c.K1), theta = in_vgpr(c.theta), ntheta = in_vgpr(c.ntheta);
   for (int j = D - 2; j >= 0; j--) {
     retire_touch(touched);
-    if (j > 0) touched = touch_row(p, s2, pl.lane);
+    if (j > 0) touched = touch_row(p.masks, S, s2, pl.lane);
     s0 = s1;
     s1 = s2;
     if (j > 1) s2 = st[j - 2];
@@ -269,7 +234,7 @@ RL_DEV void paint_backward(const PaintParams &p, int k, float *stage) {
     const double bt = cfac / theta - b1; // :475
     set_slot<S>(b, pl.jk, pl.kbit, -b1);   // donor k: (-b1) + b1 = +0.0 (never a mismatch with itself)
     double lsum = 0.0;
-    MaskRow vrow = validity_row(p);
+    MaskRow vrow = (MaskRow)(p.masks + (size_t)(p.L + 1) * S);
     asm volatile("" : "+s"(vrow));
     for_each_chunk2_tail<S, 4, TAIL>(rown, rowh, vrow, firstn, firsth,
                                      [&](int j0, const u64x4 &mn, const u64x4 &mh, const u64x4 &va) {
@@ -288,7 +253,7 @@ RL_DEV void paint_backward(const PaintParams &p, int k, float *stage) {
     });
     const MaskTerm<S> term{rowh, b, theta, ntheta, p.stats ? p.stats + 8 : nullptr};
     rown = rowh;
-    rowh = site_row(p, s1);
+    rowh = site_row(p.masks, S, p.L, s1);
     if (MODE == 0) {  // lanes: the sum reads no masks, request the next step's first chunks across it
       firstn = load_masks<4>(rown, 0);
       firsth = load_masks<4>(rowh, 0);

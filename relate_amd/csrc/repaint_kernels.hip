@@ -3,12 +3,13 @@
 // Replaces FastPainting::RePaintSection (fast_painting.cpp:621-1092) as it is
 // driven by DistanceMeasure::GetTopologyWithRepaint (anc_builder.cpp:49-106).
 // One wavefront per target; persistent blocks pull targets from an atomic
-// counter (longest first).  The forward pass keeps every alpha row (double) in
-// a per-block HBM scratch strip laid out [row][register][lane] so that every
-// store/load instruction moves 512 contiguous bytes; the backward pass reads
-// it back and writes the posterior rows `topology = float(alpha*beta)` in the
-// same register-major layout (4 B per donor per visited site: the kernel is
-// HBM-write-bound).
+// counter (longest first).  Same register layout and lane-mask panel as the
+// stepping-stone kernel (paint_device.h).  The forward pass keeps every alpha
+// row (double) in a per-block HBM scratch strip laid out [row][register][lane]
+// so that every store/load instruction moves 512 contiguous bytes; the backward
+// pass reads it back, two chunks of registers ahead of their use, and writes the
+// posterior rows `topology = float(alpha*beta)` in the same register-major
+// layout (4 B per donor per visited site: the kernel is HBM-bound).
 #include "paint_device.h"
 #include "exact_sum.h"
 #include "launch.h"
@@ -19,29 +20,30 @@
 
 namespace rl {
 
+typedef const __attribute__((address_space(4))) RepaintParams *ColdRepaint;
+
 // Load N floats in donor order into the lane's registers (as doubles),
 // 16 registers at a time through the wave-private LDS strip.
 template <int S>
-RL_DEV void load_stone(const LaneCtx<S> &lc, const float *__restrict__ in, double (&v)[S], float *stage) {
+RL_DEV void load_stone(const PaintLane<S> &pl, const float *__restrict__ in, double (&v)[S], float *stage) {
   constexpr int R = S % 16 == 0 ? 16 : 8;
 #pragma unroll
   for (int c = 0; c < S / R; c++) {
 #pragma clang loop unroll(disable)
     for (int ii = 0; ii < R; ii++) {
       const int i = c * R + ii;
-      stage[ii * 64 + lc.lane] = (i < lc.len) ? in[lc.donor(i)] : 0.0f;
+      stage[ii * 64 + pl.lane] = (i < pl.len) ? in[pl.start + i] : 0.0f;
     }
 #pragma unroll
-    for (int ii = 0; ii < R; ii++) v[c * R + ii] = (double)stage[ii * 64 + lc.lane];
+    for (int ii = 0; ii < R; ii++) v[c * R + ii] = (double)stage[ii * 64 + pl.lane];
   }
 }
 
 template <int S, int TAIL, int MODE>
 RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ scratch, float *stage) {
-  LaneCtx<S> lc;
-  lc.init(p.lay, n);
+  PaintLane<S> pl;
+  pl.init(p.lay, n);
   const PaintConsts &c = p.c;
-  const int N = p.lay.N;
   const int t = n - p.k0;  // index into the per-target arrays of this context
   const int ib = p.ib[t], ie = p.ie[t];
   const int D = ie - ib + 1;
@@ -51,117 +53,179 @@ RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ s
   const double *__restrict__ nx = p.nxt + off;
   const double cf_last = p.cf_last[t], nxt_last = p.nxt_last[t];
   constexpr int ROW = (S + 1) * 64;  // doubles per scratch row (+64: per-lane logscale copy)
-  const int64_t trow0 = p.top_off[t];
-  float *__restrict__ top = p.topology + trow0 * (int64_t)(S * 64);
-  float *__restrict__ lsout = p.logscales + trow0;
+  constexpr int CH = S % 16 == 0 ? 16 : 8;  // registers per chunk of masks (forward)
+  typedef typename MaskChunk<CH>::type Chunk;
+  const double K1 = in_vgpr(c.K1);
 
   double a[S];
-  RawBits<S> raw;
-  LaneBits<S> mb;
 
   // ---------------- forward (fast_painting.cpp:769-885)
-  load_stone<S>(lc, p.alpha_begin + (size_t)t * N, a, stage);
+  {
+    const ColdRepaint cp = cold_params<RepaintParams>();
+    load_stone<S>(pl, cp->alpha_begin + (size_t)t * cp->lay.N, a, stage);
+  }
+  set_slot<S>(a, pl.jk, pl.kbit, 0.0);  // alpha[n] = 0 for the target itself (:781)
   double ssum = wave_sum<MODE, S>(RegTerm<S>{a}, local_sum<S>(RegTerm<S>{a}));
   float lsf = p.ls_alpha[t];
   double prev_ls = (double)lsf;
   {
     double *row = scratch;
 #pragma unroll
-    for (int i = 0; i < S; i++) row[i * 64 + lc.lane] = a[i];
-    row[S * 64 + lc.lane] = (double)lsf;
+    for (int i = 0; i < S; i++) row[i * 64 + pl.lane] = a[i];
+    row[S * 64 + pl.lane] = (double)lsf;
   }
   double cfac = (D == 1 ? cf_last : cfp[0]) * ssum;
-  int sv_next = D > 1 ? st[1] : 0;
-  if (D > 1) raw.load(p.bits + (size_t)(sv_next & 0x7fffffff) * p.row_words, lc.w0);
-  for (int i = 1; i < D; i++) {
-    const int sv = sv_next;
-    mb.from_raw(raw, lc);
-    mb.to_mismatch(sv < 0);
-    if (i + 1 < D) {
-      sv_next = st[i + 1];
-      raw.load(p.bits + (size_t)(sv_next & 0x7fffffff) * p.row_words, lc.w0);
-    }
-    prev_ls += nx[i - 1];
-    lsf = (float)prev_ls;  // :806-807
-    double lsum = 0.0;
+  {
+    int s1 = D > 1 ? st[1] : 0, s2 = D > 2 ? st[2] : 0;  // row pipeline as in paint_forward
+    uint32_t touched = 0;
+    MaskRow row = site_row(p.masks, S, p.L, s1);
+    Chunk first = load_masks<CH>(row, 0);
+    for (int i = 1; i < D; i++) {
+      retire_touch(touched);
+      if (i + 1 < D) touched = touch_row(p.masks, S, s2, pl.lane);
+      s1 = s2;
+      if (i + 2 < D) s2 = st[i + 2];
+      const double nx_i = nx[i - 1], cf_i = (i == D - 1 ? cf_last : cfp[i]);
+      set_slot<S>(a, pl.jk, pl.kbit, -cfac);  // the target's own slot: (-c) + c = +0.0
+      double lsum = 0.0;
+      for_each_chunk_from<S, CH>(row, first, [&](int j0, const Chunk &m) {
+        double v[CH];
 #pragma unroll
-    for (int j = 0; j < S; j++) {
-      double v = a[j] + cfac;
-      masked_mul(v, __ballot(mb.get(j)), c.K1);  // v *= (mismatch ? K1 : 1.0)
-      if (j >= S - TAIL) v = (j < lc.len) ? v : 0.0;
-      a[j] = v;
-      lsum += v;
-    }
-    ssum = wave_sum<MODE, S>(RegTerm<S>{a}, lsum);
-    cfac = ssum;
-    if (cfac < c.lower || cfac > c.upper) {  // :865-877
+        for (int jj = 0; jj < CH; jj++) {
+          v[jj] = a[j0 + jj];
+          if (j0 + jj < S - TAIL)
+            v[jj] = v[jj] + cfac;
+          else
+            tail_add(v[jj], pl.len, j0 + jj, cfac);
+        }
+        masked_mul8<0>(v, m, K1);  // v *= (mismatch ? K1 : 1.0)
+        if constexpr (CH == 16) masked_mul8<8>(v + 8, m, K1);
 #pragma unroll
-      for (int j = 0; j < S; j++) a[j] /= ssum;
-      const double lg = log(ssum);
-      prev_ls += lg;
-      lsf = (float)((double)lsf + lg);
-      cfac = 1.0;
-    }
-    cfac *= (i == D - 1 ? cf_last : cfp[i]);
-    double *row = scratch + (int64_t)i * ROW;
+        for (int jj = 0; jj < CH; jj++) {
+          a[j0 + jj] = v[jj];
+          lsum += v[jj];
+        }
+      });
+      row = site_row(p.masks, S, p.L, s1);
+      first = load_masks<CH>(row, 0);
+      ssum = wave_sum<MODE, S>(RegTerm<S>{a}, lsum);
+      prev_ls += nx_i;
+      lsf = (float)prev_ls;  // :806-807
+      cfac = ssum;
+      if (cfac < c.lower || cfac > c.upper) {  // :865-877
 #pragma unroll
-    for (int j = 0; j < S; j++) row[j * 64 + lc.lane] = a[j];
-    row[S * 64 + lc.lane] = (double)lsf;
+        for (int j = 0; j < S; j++) a[j] /= ssum;
+        const double lg = log(ssum);
+        prev_ls += lg;
+        lsf = (float)((double)lsf + lg);
+        cfac = 1.0;
+      }
+      cfac *= cf_i;
+      double *srow = scratch + (int64_t)i * ROW;
+#pragma unroll
+      for (int j = 0; j < S; j++) srow[j * 64 + pl.lane] = a[j];
+      srow[S * 64 + pl.lane] = (double)lsf;
+    }
+    retire_touch(touched);
   }
 
   // ---------------- backward (:887-1073)
+  const int64_t trow0 = p.top_off[t];
+  float *__restrict__ top = p.topology + trow0 * (int64_t)(S * 64);
+  float *__restrict__ lsout = p.logscales + trow0;
+  const double theta = in_vgpr(c.theta), ntheta = in_vgpr(c.ntheta);
   double b[S];
-  LaneBits<S> m_next, m_here;
   lsf = lsf + p.ls_beta[t];  // float += float (:895)
-  load_stone<S>(lc, p.beta_end + (size_t)t * N, b, stage);
-  int sv = st[D - 1];
-  raw.load(p.bits + (size_t)(sv & 0x7fffffff) * p.row_words, lc.w0);
-  m_here.from_raw(raw, lc);
-  m_here.to_mismatch(sv < 0);
-  const WeightedTerm<S> term{m_here, b, c.theta, c.ntheta};
-  double bsum = wave_sum<MODE, S>(term, local_sum<S>(term));
   {
-    // `a` still holds row D-1 (:930)
+    const ColdRepaint cp = cold_params<RepaintParams>();
+    load_stone<S>(pl, cp->beta_end + (size_t)t * cp->lay.N, b, stage);
+  }
+  {
+    // row D-1 (:930), alpha re-read from the scratch strip so that `a` is dead by now (a and b together
+    // do not fit the register file).  beta[n] of the stone is 1 at the last SNP of the chunk and 0
+    // elsewhere: either way alpha[n] = 0 makes the target's own product 0
+    const double *__restrict__ arow = scratch + (int64_t)(D - 1) * ROW;
     float *trow = top + (int64_t)(D - 1) * (S * 64);
 #pragma unroll
-    for (int i = 0; i < S; i++) trow[i * 64 + lc.lane] = (float)(a[i] * b[i]);
-    if (lc.lane == 0) lsout[D - 1] = lsf;
+    for (int i = 0; i < S; i++) trow[i * 64 + pl.lane] = (float)(arow[i * 64 + pl.lane] * b[i]);
+    if (pl.lane == 0) lsout[D - 1] = lsf;
+  }
+  set_slot<S>(b, pl.jk, pl.kbit, 0.0);  // from here on the target's own slot is +0.0
+  int s0 = st[D - 1], s1 = D > 1 ? st[D - 2] : 0, s2 = D > 2 ? st[D - 3] : 0;
+  MaskRow rown = site_row(p.masks, S, p.L, s0);
+  double bsum;
+  {
+    const MaskTerm<S> term{rown, b, theta, ntheta};
+    bsum = wave_sum<MODE, S>(term, local_sum<S>(term));
   }
   cfac = cf_last * bsum;
   prev_ls = (double)p.ls_beta[t];  // :951
-  int sv_prev = D > 1 ? st[D - 2] : 0;
-  if (D > 1) raw.load(p.bits + (size_t)(sv_prev & 0x7fffffff) * p.row_words, lc.w0);
+  MaskRow rowh = site_row(p.masks, S, p.L, s1);
+  u64x4 firstn = load_masks<4>(rown, 0), firsth = load_masks<4>(rowh, 0);
+  uint32_t touched = 0;
   for (int j = D - 2; j >= 0; j--) {
-    m_next = m_here;
-    sv = sv_prev;
-    m_here.from_raw(raw, lc);
-    m_here.to_mismatch(sv < 0);
-    if (j > 0) {
-      sv_prev = st[j - 1];
-      raw.load(p.bits + (size_t)(sv_prev & 0x7fffffff) * p.row_words, lc.w0);
-    }
-    const double *row = scratch + (int64_t)j * ROW;
-    prev_ls += (j + 1 == D - 1 ? nxt_last : nx[j + 1]);
-    lsf = (float)(row[S * 64 + lc.lane] + prev_ls);  // :962-963
-    const double b1 = cfac / c.ntheta;
-    const double bt = cfac / c.theta - b1;
+    retire_touch(touched);
+    if (j > 0) touched = touch_row(p.masks, S, s2, pl.lane);
+    s0 = s1;
+    s1 = s2;
+    if (j > 1) s2 = st[j - 2];
+    const double nx_j = (j + 1 == D - 1 ? nxt_last : nx[j + 1]), cf_j = cfp[j];
+    const double *__restrict__ arow = scratch + (int64_t)j * ROW;  // alpha of this site, re-read below
+    const double als = arow[S * 64 + pl.lane];
+    const double b1 = cfac / ntheta;
+    const double bt = cfac / theta - b1;
+    set_slot<S>(b, pl.jk, pl.kbit, -b1);
     double lsum = 0.0;
+    MaskRow vrow = (MaskRow)(p.masks + (size_t)(p.L + 1) * S);
+    asm volatile("" : "+s"(vrow));
+    for_each_chunk2_tail<S, 4, TAIL>(rown, rowh, vrow, firstn, firsth,
+                                     [&](int j0, const u64x4 &mn, const u64x4 &mh, const u64x4 &va) {
+      double v[4], x[4];
 #pragma unroll
-    for (int i = 0; i < S; i++) {
-      const unsigned long long mn = __ballot(m_next.get(i));
-      double v = b[i];
-      masked_add(v, mn, bt);      // b + mis*bt  (b + 0.0 == b)
-      v = v + b1;
-      masked_mul(v, mn, c.K1);    // *(mis ? K1 : 1.0)
-      if (i >= S - TAIL) v = (i < lc.len) ? v : 0.0;
-      b[i] = v;
-      lsum += (m_here.get(i) ? c.theta : c.ntheta) * v;  // the lane's share of :495-503
+      for (int jj = 0; jj < 4; jj++) v[jj] = b[j0 + jj];
+      if (j0 + 4 <= S - TAIL)
+        backward4(v, x, mn, mh, bt, b1, K1, theta, ntheta);
+      else
+        backward4_tail(v, x, mn, mh, va, bt, b1, K1, theta, ntheta);
+#pragma unroll
+      for (int jj = 0; jj < 4; jj++) {
+        b[j0 + jj] = v[jj];
+        lsum += x[jj];
+      }
+    });
+    const MaskTerm<S> term{rowh, b, theta, ntheta};
+    rown = rowh;
+    rowh = site_row(p.masks, S, p.L, s1);
+    // the first chunks of this site's alpha row: requested across the sum
+    constexpr int PC = 8;  // registers per product chunk
+    double ac[PC], an[PC];
+#pragma unroll
+    for (int jj = 0; jj < PC; jj++) ac[jj] = arow[jj * 64 + pl.lane];
+    if (MODE == 0) {
+      firstn = load_masks<4>(rown, 0);
+      firsth = load_masks<4>(rowh, 0);
     }
     bsum = wave_sum<MODE, S>(term, lsum);
+    if (MODE != 0) {
+      firstn = load_masks<4>(rown, 0);
+      firsth = load_masks<4>(rowh, 0);
+    }
+    prev_ls += nx_j;
+    lsf = (float)(als + prev_ls);  // :962-963
     cfac = bsum;
-    float *trow = top + (int64_t)j * (S * 64);
+    // topology = float(alpha * beta) before the rescale of this step (:1039 vs :1047)
+    float *__restrict__ trow = top + (int64_t)j * (S * 64);
 #pragma unroll
-    for (int i = 0; i < S; i++) trow[i * 64 + lc.lane] = (float)(row[i * 64 + lc.lane] * b[i]);  // :1039
+    for (int c0 = 0; c0 < S / PC; c0++) {
+      if (c0 + 1 < S / PC) {
+#pragma unroll
+        for (int jj = 0; jj < PC; jj++) an[jj] = arow[((c0 + 1) * PC + jj) * 64 + pl.lane];
+      }
+#pragma unroll
+      for (int jj = 0; jj < PC; jj++) trow[(c0 * PC + jj) * 64 + pl.lane] = (float)(ac[jj] * b[c0 * PC + jj]);
+#pragma unroll
+      for (int jj = 0; jj < PC; jj++) ac[jj] = an[jj];
+    }
     if (cfac < c.lower || cfac > c.upper) {  // :1047-1061
 #pragma unroll
       for (int i = 0; i < S; i++) b[i] /= bsum;
@@ -170,13 +234,14 @@ RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ s
       lsf = (float)((double)lsf + lg);
       cfac = 1.0;
     }
-    cfac *= cfp[j];
-    if (lc.lane == 0) lsout[j] = lsf;
+    cfac *= cf_j;
+    if (pl.lane == 0) lsout[j] = lsf;
   }
+  retire_touch(touched);
 }
 
 template <int S, int TAIL, int MODE>
-__global__ void __launch_bounds__(64) repaint_kernel(const RepaintParams p, int *counter) {
+__global__ void __launch_bounds__(64, (S <= 80 ? 2 : 1)) repaint_kernel(const RepaintParams p, int *counter) {
   __shared__ float stage[16 * 64];
   __shared__ int s_t;
   double *scratch = p.scratch + (int64_t)blockIdx.x * p.scratch_stride;

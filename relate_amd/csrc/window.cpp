@@ -194,8 +194,7 @@ rl_window *rl_window_open(rl_ctx *ctx, int w, const char *paint_file, int first_
   p.L = L;
   p.k0 = k0;
   p.nloc = nloc;
-  p.row_words = ctx->row_words;
-  p.bits = ctx->d_bits.as<uint32_t>();
+  p.masks = ctx->d_masks.as<unsigned long long>();
   p.plan_off = ctx->d_off.as<int64_t>();
   p.sites = ctx->d_sites.as<int32_t>();
   p.cf = ctx->d_cf.as<double>();
@@ -290,11 +289,10 @@ int rl_window_get_topology(rl_window *win, int n, float *top, float *logscales) 
     for (int d = 0; d < D; d++) {
       const float *row = &phys[(size_t)d * S * 64];
       float *o = top + (size_t)d * N;
-      o[n] = 0.0f;  // alpha[n] = 0 for the target itself (fast_painting.cpp:781)
-      int p = 0;
+      int p = 0;  // donor order = lane runs in order (the target's own entry is 0: alpha[n] = 0, fast_painting.cpp:781)
       for (int l = 0; l < 64; l++) {
         const int len = lay.q + (l < lay.rem ? 1 : 0);
-        for (int i = 0; i < len; i++, p++) o[p + (p >= n ? 1 : 0)] = row[i * 64 + l];
+        for (int i = 0; i < len; i++, p++) o[p] = row[i * 64 + l];
       }
     }
   }
