@@ -16,6 +16,8 @@
 
 namespace rl {
 
+static constexpr size_t PREFETCH_AHEAD = 12;  // clusters; see MinMatch::coalesce
+
 static const float INF = std::numeric_limits<float>::infinity();
 
 MinMatch::MinMatch(int N_, double theta) : N(N_) {
@@ -124,6 +126,13 @@ void MinMatch::coalesce(int i, int j) {
   const size_t n = cluster_index.size();
   for (size_t ik = 0; ik < n; ik++) {
     const int k = cluster_index[ik];
+    // the two column reads below walk the matrix with a stride of one row (a new cache line and,
+    // without huge pages, a new page each): request them a few clusters ahead
+    if (ik + PREFETCH_AHEAD < n) {
+      const float *nxt = D + (size_t)cluster_index[ik + PREFETCH_AHEAD] * N;
+      __builtin_prefetch(nxt + j, 1);
+      __builtin_prefetch(nxt + i, 0);
+    }
     if (k == j || k == i) continue;
     const float dkj = d(k, j), dki = d(k, i), dik = d(i, k), djk = d(j, k);
     min_value_k = min_values[k];
@@ -208,7 +217,14 @@ void MinMatch::coalesce_sym(int i, int j) {
   auto s = [&](int a, int b) -> float & { return sym_d[(size_t)a * N + b]; };
   best_sym.dist = INF;
   mc_sym[j].dist = INF;
-  for (int k : cluster_index) {
+  const size_t n = cluster_index.size();
+  for (size_t ik = 0; ik < n; ik++) {
+    const int k = cluster_index[ik];
+    if (ik + PREFETCH_AHEAD < n) {
+      const float *nxt = sym_d.data() + (size_t)cluster_index[ik + PREFETCH_AHEAD] * N;
+      __builtin_prefetch(nxt + j, 1);
+      __builtin_prefetch(nxt + i, 0);
+    }
     if (k == j || k == i) continue;
     const float dkj = s(k, j), dki = s(k, i), dik = s(i, k), djk = s(j, k);
     min_value_k = min_values_sym[k];
@@ -249,7 +265,14 @@ void MinMatch::coalesce_cf(int i, int j) {
   float *cf = d_CF.data();
   min_values_CF[j] = INF;
   const float added = cluster_size[i] + cluster_size[j];
-  for (int k : cluster_index) {
+  const size_t n = cluster_index.size();
+  for (size_t ik = 0; ik < n; ik++) {
+    const int k = cluster_index[ik];
+    if (ik + PREFETCH_AHEAD < n) {
+      const float *nxt = cf + (size_t)cluster_index[ik + PREFETCH_AHEAD] * N;
+      __builtin_prefetch(nxt + j, 1);
+      __builtin_prefetch(nxt + i, 0);
+    }
     if (k == j || k == i) continue;
     const float dkj = cf[(size_t)k * N + j], dki = cf[(size_t)k * N + i];
     const float dik = cf[(size_t)i * N + k], djk = cf[(size_t)j * N + k];
