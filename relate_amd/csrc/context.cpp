@@ -8,6 +8,10 @@
 
 #include <algorithm>
 #include <cmath>
+#include <atomic>
+#include <mutex>
+#include <string>
+#include <chrono>
 #include <cstring>
 #include <numeric>
 #include <thread>
@@ -726,46 +730,93 @@ int rl_write_paint_files(rl_ctx *ctx, const char *paint_dir) {
     return RL_ESTATE;
   }
   const int N = ctx->N, W = ctx->W;
-  std::vector<float> a((size_t)N * N), b((size_t)N * N), la(N), lb(N);
-  std::vector<int> bb(N), be(N);
   const size_t maxrec = 8 + 2 * (28 + (size_t)N * 8);
-  std::vector<unsigned char> recs((size_t)N * maxrec);
-  std::vector<size_t> lens(N);
-  for (int w = 0; w < W; w++) {
-    int rc = rl_get_stones(ctx, w, a.data(), b.data(), la.data(), lb.data(), bb.data(), be.data());
-    if (rc) return rc;
-    const int start = ctx->wb[w], end = ctx->wb[w + 1] - 1;  // fast_painting.cpp:591-594
-    parallel_for(N, [&](int k) {
-      unsigned char *p = recs.data() + (size_t)k * maxrec, *p0 = p;
-      memcpy(p, &start, 4); p += 4;
-      memcpy(p, &end, 4); p += 4;
-      p += encode_stone(a.data() + (size_t)k * N, N, bb[k], la[k], p);
-      p += encode_stone(b.data() + (size_t)k * N, N, be[k], lb[k], p);
-      lens[k] = (size_t)(p - p0);
-    });
-    const std::string fn = std::string(paint_dir) + "/relate_" + std::to_string(w) + ".bin";
-    FILE *fp = fopen(fn.c_str(), "wb");
-    if (!fp) {
-      set_error("cannot open %s for writing", fn.c_str());
-      return RL_EIO;
+  // Windows are independent files: a few writer threads each take windows round-robin (download of
+  // the stones under a mutex, RLE of the N targets, one sequential write), so that encoding and the
+  // file system work of different windows overlap.  Each holds ~ (2*4 + 8) * N^2 bytes of buffers.
+  const size_t per_thread = (size_t)N * N * 8 + (size_t)N * maxrec;
+  int nthreads = (int)std::max<size_t>(1, std::min<size_t>({(size_t)W, (size_t)4, ((size_t)6 << 30) / per_thread}));
+  if (const char *e = getenv("RELATE_AMD_WRITER_THREADS")) nthreads = std::max(1, atoi(e));
+  std::mutex gpu_mutex;
+  std::atomic<int> failed{0};
+  std::string first_error;
+  auto worker = [&](int tid) {
+    std::vector<float> a((size_t)N * N), b((size_t)N * N), la(N), lb(N);
+    std::vector<int> bb(N), be(N);
+    std::vector<unsigned char> recs((size_t)N * maxrec);
+    std::vector<size_t> lens(N);
+    for (int w = tid; w < W && !failed; w += nthreads) {
+      int rc;
+      {
+        std::lock_guard<std::mutex> lk(gpu_mutex);
+        rc = rl_get_stones(ctx, w, a.data(), b.data(), la.data(), lb.data(), bb.data(), be.data());
+        if (rc && !failed.exchange(rc)) first_error = rl_last_error();
+      }
+      if (rc) return;
+      const int start = ctx->wb[w], end = ctx->wb[w + 1] - 1;  // fast_painting.cpp:591-594
+      auto encode = [&](int k) {
+        unsigned char *p = recs.data() + (size_t)k * maxrec, *p0 = p;
+        memcpy(p, &start, 4); p += 4;
+        memcpy(p, &end, 4); p += 4;
+        p += encode_stone(a.data() + (size_t)k * N, N, bb[k], la[k], p);
+        p += encode_stone(b.data() + (size_t)k * N, N, be[k], lb[k], p);
+        lens[k] = (size_t)(p - p0);
+      };
+      parallel_for(N, encode);
+      const std::string fn = std::string(paint_dir) + "/relate_" + std::to_string(w) + ".bin";
+      FILE *fp = fopen(fn.c_str(), "wb");
+      if (!fp) {
+        std::lock_guard<std::mutex> lk(gpu_mutex);
+        if (!failed.exchange(RL_EIO)) first_error = "cannot open " + fn + " for writing";
+        return;
+      }
+      for (int k = 0; k < N; k++) fwrite(recs.data() + (size_t)k * maxrec, 1, lens[k], fp);
+      fclose(fp);
     }
-    for (int k = 0; k < N; k++) fwrite(recs.data() + (size_t)k * maxrec, 1, lens[k], fp);
-    fclose(fp);
+  };
+  if (nthreads == 1) {
+    worker(0);
+  } else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; t++) th.emplace_back(worker, t);
+    for (auto &t : th) t.join();
+  }
+  if (failed) {
+    set_error("%s", first_error.c_str());
+    return failed;
   }
   return RL_OK;
 }
 
 int rl_stage_paint(const char *out_dir, int chunk_index, int use_painting, double theta, double rho,
                    int sum_mode, int device) {
+  // RELATE_AMD_TIMING=1: wall-clock of the stage's phases on stderr
+  const bool timing = getenv("RELATE_AMD_TIMING") != nullptr;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t0 = now();
+  auto lap = [&](const char *what) {
+    const double t1 = now();
+    if (timing) fprintf(stderr, "[paint stage] %-28s %8.3f s\n", what, t1 - t0);
+    t0 = t1;
+  };
   rl_ctx *ctx = rl_create(device);
   if (!ctx) return RL_ENODEVICE;
+  lap("device context");
   int rc = rl_load_chunk(ctx, out_dir, chunk_index);
+  lap("read chunk files");
   if (!rc && use_painting) rc = rl_set_painting(ctx, theta, rho);
   const std::string cdir = std::string(out_dir) + "/chunk_" + std::to_string(chunk_index);
   if (!rc) rc = mkdir_p(cdir);
   if (!rc) rc = mkdir_p(cdir + "/paint");
-  if (!rc) rc = rl_paint(ctx, sum_mode, nullptr);
+  if (!rc) rc = build_plan(ctx);
+  lap("visited-site plan (host)");
+  if (!rc) rc = rl_prepare(ctx);
+  lap("uploads + lane-mask panel");
+  float ms = 0.f;
+  if (!rc) rc = rl_paint(ctx, sum_mode, &ms);
+  lap("paint kernels");
   if (!rc) rc = rl_write_paint_files(ctx, (cdir + "/paint").c_str());
+  lap("stones -> RLE -> paint files");
   rl_destroy(ctx);
   return rc;
 }

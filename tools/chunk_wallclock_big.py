@@ -36,15 +36,19 @@ with tempfile.TemporaryDirectory() as work:
     del seq
     exe = os.path.join(ROOT, "relate_amd", "Relate")
     t0 = time.time()
-    p = subprocess.run([exe, "--mode", "Paint", "--chunk_index", "0", "-o", "out"], cwd=work, stderr=subprocess.PIPE)
+    p = subprocess.run([exe, "--mode", "Paint", "--chunk_index", "0", "-o", "out"], cwd=work, stderr=subprocess.PIPE,
+                       env=dict(os.environ, RELATE_AMD_TIMING="1"))
     assert p.returncode == 0, p.stderr.decode()[-400:]
+    out["paint_stage_phases"] = [l.strip() for l in p.stderr.decode().split("\n") if l.startswith("[paint stage]")]
     t1 = time.time()
     out["paint_stage_s"] = t1 - t0
     out["paint_files_GB"] = sum(os.path.getsize(os.path.join(d, "chunk_0", "paint", f))
                                 for f in os.listdir(os.path.join(d, "chunk_0", "paint"))) / 1e9
-    p = subprocess.run([exe, "--mode", "BuildTopology", "--chunk_index", "0", "--first_section", "0", "--last_section",
-                        str(min(sections, W) - 1), "-o", "out"], cwd=work, stderr=subprocess.PIPE)
-    assert p.returncode == 0, p.stderr.decode()[-400:]
+    t1 = time.time()
+    if sections > 0:
+        p = subprocess.run([exe, "--mode", "BuildTopology", "--chunk_index", "0", "--first_section", "0", "--last_section",
+                            str(min(sections, W) - 1), "-o", "out"], cwd=work, stderr=subprocess.PIPE)
+        assert p.returncode == 0, p.stderr.decode()[-400:]
     t2 = time.time()
     out["build_topology_s"] = t2 - t1
     trees = snps = 0
