@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP64_PEAK_TINSTR = 39.3  # FP64 vector peak 78.6 TFLOP/s (256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz x 2 for an FMA): 39.3e12 lane-instructions/s
 
 
 def make_chunk(N, L, seed, memory_gb):
@@ -220,6 +221,7 @@ def main():
                 "sum_mode": args.mode,
                 "sum_k_D_k": int(sites),
                 "updates_per_step_per_gpu": updates,
+                "nominal_updates_per_s_2NNL": 2.0 * N * N * L * world / (dt / args.steps),
                 "fwd_kernel_ms": fwd_ms,
                 "bwd_kernel_ms": bwd_ms,
                 "other_mode": alt,
@@ -229,7 +231,16 @@ def main():
             },
             "roofline": {"bound": "hbm", "kernel": "paint_kernel<backward>", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic},
+                         "traffic": traffic,
+                         # SURVEY.md 8d caveat H5: at 1 bit per update the FP64 vector pipe, not HBM, is the
+                         # resource that binds.  Algorithmic f64 instructions per directional update of the
+                         # backward kernel: 6 (update + weighted lane sum), + 7 for the exact sum.
+                         "fp64_valu": {"instr_per_update": 13 if args.mode == "exact" else 6,
+                                       "achieved_Tinstr_per_s": (13 if args.mode == "exact" else 6) * N * sites
+                                       / (bwd_ms * 1e-3) / 1e12,
+                                       "peak_Tinstr_per_s": FP64_PEAK_TINSTR,
+                                       "frac": (13 if args.mode == "exact" else 6) * N * sites / (bwd_ms * 1e-3) / 1e12
+                                       / FP64_PEAK_TINSTR}},
         }
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(N, L, bits, r, rpos, wb)
