@@ -241,6 +241,14 @@ int rl_stage_make_chunks(const char *haps_fn, const char *sample_fn,
                          const char *map_fn, const char *dist_fn,
                          const char *out_dir, int transversion, float memory_gb);
 
+/* ------------------------------------------------- FindEquivalentBranches */
+/* The stage after BuildTopology (pipeline/FindEquivalentBranches.cpp:13-167;
+ * AncesTreeBuilder::BranchAssociation / AssociateTrees, src/anc_builder.cpp:
+ * 1454-1613, 658-800): reads <out_dir>/chunk_<c>/<name>_<w>.anc of every window,
+ * finds equivalent branches in neighbouring trees and rewrites the files with
+ * num_events / SNP_begin / SNP_end carried along them.  Host code. */
+int rl_stage_find_equivalent_branches(const char *out_dir, int chunk_index);
+
 /* ------------------------------------------------------------------ tools */
 /* Synthetic block-coalescent panel (stand-in for MakeChunks input,
  * SURVEY.md 8d).  seq_chars (L*N) and/or bits (L*row_words) may be NULL. */

@@ -1,4 +1,5 @@
 // main.cpp -- `Relate` drop-in for the stages of this path (plus their input producer):
+//   Relate --mode FindEquivalentBranches --chunk_index c -o out
 //   Relate --mode MakeChunks    --haps x.haps --sample x.sample --map x.map [--memory 5] [--dist f] [--transversion] -o out
 //   Relate --mode Paint         --chunk_index c -o out [--painting theta,rho]
 //   Relate --mode BuildTopology --chunk_index c --first_section a --last_section b -o out
@@ -102,6 +103,16 @@ int main(int argc, char **argv) {
     std::cerr << "Needed: chunk_index, output." << std::endl;
     return 1;
   }
+  if (mode == "FindEquivalentBranches") {  // pipeline/FindEquivalentBranches.cpp:13-167
+    std::cerr << "---------------------------------------------------------" << std::endl;
+    std::cerr << "Propagating mutations across AncesTrees..." << std::endl;
+    if (rl_stage_find_equivalent_branches(out.c_str(), std::stoi(opt["chunk_index"])) != 0) {
+      std::cerr << rl_last_error() << std::endl;
+      return 1;
+    }
+    usage_line();
+    return 0;
+  }
   const int chunk = atoi(opt["chunk_index"].c_str());
   const int device = opt.count("device") ? atoi(opt["device"].c_str()) : 0;
   int sum_mode = RL_SUM_EXACT;
@@ -148,7 +159,7 @@ int main(int argc, char **argv) {
                                  device);
     if (rc == 1) return 1;  // first_section >= num_windows (BuildTopology.cpp:45)
   } else {
-    std::cerr << "Mode " << mode << " is not part of this build: it replaces --mode MakeChunks, Paint and BuildTopology "
+    std::cerr << "Mode " << mode << " is not part of this build: it replaces --mode MakeChunks, Paint, BuildTopology and FindEquivalentBranches "
               << "only; run the reference Relate for the other stages." << std::endl;
     return 1;
   }

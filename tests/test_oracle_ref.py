@@ -65,3 +65,28 @@ def test_treeseq_matches_reference_binary(tmp_path, oracle, N, L, budget, seed):
         anc, mut, nt = T.build_section(fx, w, tmp_path, oracle)
         assert mut == open(tmp_path / "out" / "chunk_0" / ("out_%d.mut" % w), "rb").read(), w
         assert anc == open(tmp_path / "out" / "chunk_0" / ("out_%d.anc" % w), "rb").read(), (w, nt)
+
+
+@pytest.mark.parametrize("N,L,budget,seed", [(160, 1800, 600000, 41), (300, 1200, 3000000, 42)])
+def test_find_equivalent_branches_matches_reference_binary(tmp_path, N, L, budget, seed):
+    """the stage after BuildTopology (host code): same .anc files in, byte-identical .anc files out"""
+    import shutil
+    import subprocess
+
+    ch = rlutil.synth_chunk(N, L, seed=seed, budget=budget)
+    ch.write(str(tmp_path / "out"))
+    rlutil.run_ref(["--mode", "Paint", "--chunk_index", "0", "-o", "out"], cwd=str(tmp_path))
+    rlutil.run_ref(["--mode", "BuildTopology", "--chunk_index", "0", "--first_section", "0", "--last_section",
+                    str(ch.W - 1), "-o", "out"], cwd=str(tmp_path))
+    ours = tmp_path / "ours"
+    ours.mkdir()
+    shutil.copytree(str(tmp_path / "out"), str(ours / "out"))
+    rlutil.run_ref(["--mode", "FindEquivalentBranches", "--chunk_index", "0", "-o", "out"], cwd=str(tmp_path))
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "relate_amd", "Relate")
+    p = subprocess.run([cli, "--mode", "FindEquivalentBranches", "--chunk_index", "0", "-o", "out"], cwd=str(ours),
+                       stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr.decode()
+    for w in range(ch.W):
+        a = open(ours / "out" / "chunk_0" / ("out_%d.anc" % w), "rb").read()
+        b = open(tmp_path / "out" / "chunk_0" / ("out_%d.anc" % w), "rb").read()
+        assert a == b, "window %d" % w

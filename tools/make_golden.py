@@ -71,6 +71,11 @@ def collect(work, out, W, painting=None, windows_dump=(1,), with_trees=True):
         for w in range(W):
             data["anc/%d" % w] = fbytes(os.path.join(work, out, "chunk_0", "%s_%d.anc" % (out, w)))
             data["mut/%d" % w] = fbytes(os.path.join(work, out, "chunk_0", "%s_%d.mut" % (out, w)))
+        # the next stage downstream rewrites the .anc files in place (num_events, SNP_begin/end carried
+        # along equivalent branches)
+        run([rlutil.REF_RELATE, "--mode", "FindEquivalentBranches", "--chunk_index", "0", "-o", out], work)
+        for w in range(W):
+            data["feb_anc/%d" % w] = fbytes(os.path.join(work, out, "chunk_0", "%s_%d.anc" % (out, w)))
     return data
 
 
