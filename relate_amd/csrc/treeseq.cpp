@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <atomic>
 #include <climits>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <iomanip>
@@ -387,13 +388,25 @@ int rl_treeseq_build(rl_treeseq *ts, int start, int end, rl_matrix_fn matrix, rl
 
   int num_tree = 1;
   const float val = -std::log(ts->theta / (1.0 - ts->theta));  // :555
+  // RELATE_AMD_TIMING=1: where a section's wall-clock goes (stderr)
+  const bool timing = getenv("RELATE_AMD_TIMING") != nullptr;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_matrix = 0, t_prior = 0, t_build = 0, t_map = 0, t_mark = 0;
+  int builds = 0;
+  auto lap = [&](double &acc) {
+    const double t = now();
+    acc += t - t_mark;
+    t_mark = t;
+  };
   for (int snp = start + 1; snp <= end; snp++) {
     SnpInfo &si = ts->info[(size_t)(snp - start)];
     set_carriers(snp);
     if (advance && snp < end && (rc = advance(user, snp))) return rc;  // :487-495 (carriers only)
     si.tree = num_tree - 1;
     const bool use = ts->state[snp] != 0;
+    t_mark = now();
     is_mapping = map_mutation(*ts, ts->trees.back(), si, min_value, use);
+    lap(t_map);
     bool force_new = false;
     if (snp < end && fb > 0)
       if (((int)(ts->bp[snp + 1] / fb)) - ((int)(ts->bp[snp] / fb)) >= 1) force_new = true;
@@ -404,7 +417,10 @@ int rl_treeseq_build(rl_treeseq *ts, int start, int end, rl_matrix_fn matrix, rl
       ts->trees.emplace_back();
       HostTree &nt = ts->trees.back();
       HostTree &pt = ts->trees[ts->trees.size() - 2];
+      t_mark = now();
+      builds++;
       if ((rc = matrix(user, snp, d.data()))) return rc;
+      lap(t_matrix);
       if (consistency) {
         // carrier penalty (:563-581): d[c][*] += val, then d[c][c'] -= val
         for (int c = 0; c < N; c++)
@@ -415,12 +431,15 @@ int rl_treeseq_build(rl_treeseq *ts, int start, int end, rl_matrix_fn matrix, rl
               if (ts->member[c2]) row[c2] -= val;
           }
         clade_prior(pt, val, dist);
+        lap(t_prior);
         tb.quick_build(d.data(), dist.data(), nt);
       } else {
         tb.quick_build(d.data(), nullptr, nt);
       }
+      lap(t_build);
       nt.pos = snp;
       const int is_mapping_alt = map_mutation(*ts, nt, si, min_value_alt, use);
+      lap(t_map);
       if (is_mapping_alt > 1 && min_value_alt >= min_value && !force_new) {
         // new tree is not better: keep the old one (:621-630)
         if (is_mapping == 2) si.branch[0] = prev_branch;
@@ -439,6 +458,11 @@ int rl_treeseq_build(rl_treeseq *ts, int start, int end, rl_matrix_fn matrix, rl
     }
   }
   std::fill(ts->trees.back().snp_end.begin(), ts->trees.back().snp_end.end(), end);
+  if (timing)
+    fprintf(stderr,
+            "[tree sequence] SNPs %d..%d: %d trees kept of %d built; distance matrices %.2f s, penalty + clade prior "
+            "%.2f s, MinMatch %.2f s, mutation mapping %.2f s\n",
+            start, end, num_tree, builds + 1, t_matrix, t_prior, t_build, t_map);
   return RL_OK;
 }
 

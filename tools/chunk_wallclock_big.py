@@ -6,7 +6,7 @@
 Synthetic chunk (the bench's generator) -> chunk files -> `Relate --mode Paint` (whole chunk) and
 `Relate --mode BuildTopology` for the first `sections` windows; prints one JSON line.  BuildTopology's
 host tree building (MinMatch, O(N^2) per tree) dominates at this N, so only a few sections are timed."""
-import ctypes as C, json, os, subprocess, sys, tempfile, time
+import ctypes as C, hashlib, json, os, subprocess, sys, tempfile, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -35,6 +35,8 @@ with tempfile.TemporaryDirectory() as work:
                                     wb.ctypes.data_as(C.c_void_p), W) == 0
     del seq
     exe = os.path.join(ROOT, "relate_amd", "Relate")
+    if len(sys.argv) > 5 and sys.argv[5] == "ref":  # the unmodified reference binary on the same chunk (container only)
+        exe = rlutil.REF_RELATE
     t0 = time.time()
     p = subprocess.run([exe, "--mode", "Paint", "--chunk_index", "0", "-o", "out"], cwd=work, stderr=subprocess.PIPE,
                        env=dict(os.environ, RELATE_AMD_TIMING="1"))
@@ -47,8 +49,10 @@ with tempfile.TemporaryDirectory() as work:
     t1 = time.time()
     if sections > 0:
         p = subprocess.run([exe, "--mode", "BuildTopology", "--chunk_index", "0", "--first_section", "0", "--last_section",
-                            str(min(sections, W) - 1), "-o", "out"], cwd=work, stderr=subprocess.PIPE)
+                            str(min(sections, W) - 1), "-o", "out"], cwd=work, stderr=subprocess.PIPE,
+                           env=dict(os.environ, RELATE_AMD_TIMING="1"))
         assert p.returncode == 0, p.stderr.decode()[-400:]
+        out["build_topology_phases"] = [l.strip() for l in p.stderr.decode().split("\n") if l.startswith("[tree sequence]")]
     t2 = time.time()
     out["build_topology_s"] = t2 - t1
     trees = snps = 0
@@ -56,6 +60,11 @@ with tempfile.TemporaryDirectory() as work:
         trees += len(rlutil.parse_anc(os.path.join(d, "chunk_0", "out_%d.anc" % w))[1])
         snps += int(wb[w + 1] - wb[w])
     out["trees"] = trees
+    md5 = lambda fn: hashlib.md5(open(os.path.join(d, "chunk_0", fn), "rb").read()).hexdigest()
+    out["md5"] = {"paint/relate_0.bin": md5("paint/relate_0.bin")}
+    for w in range(min(sections, W)):
+        out["md5"]["out_%d.anc" % w] = md5("out_%d.anc" % w)
+        out["md5"]["out_%d.mut" % w] = md5("out_%d.mut" % w)
     out["snps_in_timed_sections"] = snps
     out["host_threads"] = os.cpu_count()
 print(json.dumps(out))
