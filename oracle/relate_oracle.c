@@ -129,46 +129,45 @@ int ro_plan_target(const ro_data *d, const int *wb, int W, int k, int *site,
 /* ------------------------------------------------------------------ */
 /* summation orders                                                   */
 /* Order of the HIP RL_SUM_LANES kernels (relate_amd/csrc/paint_device.h):
- * the donors, in donor order, are cut into 64 contiguous runs (the first P%64
- * runs hold P/64+1 donors, the rest P/64); each run is summed left to right
- * from 0.0, then an xor-butterfly (masks 1..32) combines the 64 partial sums.
- * The kernels lay out all P = N donors, the target's own term being +0.0
- * (full = 1; full = 0, the donors n != k only, is kept for experiments). */
-static double sum_lanes(const double *t, int N, int k, int full) {
-  const int P = full ? N : N - 1, q = P / 64, rem = P % 64;
-  if (full) k = N; /* nothing is skipped */
-  double lane[64];
+ * all N donors (the target's own term is +0.0), in donor order, are cut into
+ * nl contiguous runs (the first N%nl runs hold N/nl+1 donors, the rest N/nl);
+ * each run is summed left to right from 0.0, then an xor-butterfly (masks
+ * 1..nl/2) combines the partial sums.  nl = 64 lanes, except in the
+ * stepping-stone kernel for N > 5120, which gives a target two wavefronts
+ * (nl = 128; relate_amd/csrc/launch.h paint_waves). */
+static double sum_lanes(const double *t, int N, int k, int nl) {
+  const int q = N / nl, rem = N % nl;
+  double lane[128];
   int p = 0;
-  for (int l = 0; l < 64; l++) {
+  (void)k;
+  for (int l = 0; l < nl; l++) {
     const int len = q + (l < rem ? 1 : 0);
     double s = 0.0;
-    for (int i = 0; i < len; i++, p++) {
-      const int n = p + (p >= k ? 1 : 0);
-      s += t[n];
-    }
+    for (int i = 0; i < len; i++, p++) s += t[p];
     lane[l] = s;
   }
-  for (int m = 1; m < 64; m <<= 1) {
-    double nxt[64];
-    for (int l = 0; l < 64; l++) nxt[l] = lane[l] + lane[l ^ m];
+  for (int m = 1; m < nl; m <<= 1) {
+    double nxt[128];
+    for (int l = 0; l < nl; l++) nxt[l] = lane[l] + lane[l ^ m];
     memcpy(lane, nxt, sizeof lane);
   }
   return lane[0];
 }
+static inline int paint_lanes(int N) { return N > 80 * 64 ? 128 : 64; }
 
-static inline double sum_alpha(const double *a, int N, int k, const ro_sum_order *o, int full) {
+static inline double sum_alpha(const double *a, int N, int k, const ro_sum_order *o, int nl) {
   if (o == NULL || o->mode == RO_SUM_SERIAL) {
     double s = 0.0;
     for (int n = 0; n < N; n++) s += a[n]; /* :300-303 */
     return s;
   }
-  return sum_lanes(a, N, k, full);
+  return sum_lanes(a, N, k, nl);
 }
 
 /* sum_n e(n)*b[n], e = theta if (seq_k > row[n]) else ntheta  (:495-503) */
 static inline double sum_beta(const double *b, const char *row, int k,
                               int N, const paint_consts *c,
-                              const ro_sum_order *o, double *scratch, int full) {
+                              const ro_sum_order *o, double *scratch, int nl) {
   const char seq_k = row[k];
   if (o == NULL || o->mode == RO_SUM_SERIAL) {
     double s = 0.0;
@@ -182,7 +181,7 @@ static inline double sum_beta(const double *b, const char *row, int k,
   }
   for (int n = 0; n < N; n++)
     scratch[n] = (seq_k > row[n]) ? c->theta * b[n] : c->ntheta * b[n];
-  return sum_lanes(scratch, N, k, full);
+  return sum_lanes(scratch, N, k, nl);
 }
 
 /* ------------------------------------------------------------------ */
@@ -241,7 +240,7 @@ static int paint_target(const ro_data *d, const paint_consts *c, const int *wb,
     }
     a[k] = 0.0;
   }
-  double S = sum_alpha(a, N, k, order, 1);
+  double S = sum_alpha(a, N, k, order, paint_lanes(N));
   double ls = 0.0;
   while (wa < W && bsnp_begin[wa] == 0) { /* :233-253 */
     for (int n = 0; n < N; n++) alpha[(size_t)wa * N + n] = (float)a[n];
@@ -261,7 +260,7 @@ static int paint_target(const ro_data *d, const paint_consts *c, const int *wb,
       a[n] = v;
     }
     a[k] = 0.0;
-    S = sum_alpha(a, N, k, order, 1);
+    S = sum_alpha(a, N, k, order, paint_lanes(N));
     cfac = S;
     if (cfac < c->lower || cfac > c->upper) { /* :334-347 */
       const double tmp = cfac;
@@ -319,7 +318,7 @@ static int paint_target(const ro_data *d, const paint_consts *c, const int *wb,
     }
     b[k] = 0.0;
     const char *row = seq + (size_t)snp * N;
-    B = sum_beta(b, row, k, N, c, order, ws->scratch, 1);
+    B = sum_beta(b, row, k, N, c, order, ws->scratch, paint_lanes(N));
     cfac = B;
     if (cfac < c->lower || cfac > c->upper) { /* :538-551 */
       const double tmp = cfac;
@@ -597,7 +596,7 @@ int ro_repaint_section(const ro_data *d, const float *alpha_begin,
   double *a = alpha;
   for (int n = 0; n < N; n++) a[n] = alpha_begin[n];
   a[k] = 0.0;
-  double S = sum_alpha(a, N, k, order, 1);
+  double S = sum_alpha(a, N, k, order, 64);
   double cfac = trans_factor(c, r_prob[0]) * S;
   double prev_logscale = logscales[0];
   for (int i = 1; i < D; i++) {
@@ -614,7 +613,7 @@ int ro_repaint_section(const ro_data *d, const float *alpha_begin,
       a[n] = v;
     }
     a[k] = 0.0;
-    S = sum_alpha(a, N, k, order, 1);
+    S = sum_alpha(a, N, k, order, 64);
     cfac = S;
     if (cfac < c->lower || cfac > c->upper) { /* :865-877 */
       const double tmp = cfac;
@@ -632,7 +631,7 @@ int ro_repaint_section(const ro_data *d, const float *alpha_begin,
   b[k] = 0.0;
   {
     const char *row = seq + (size_t)last_snp * N;
-    double B0 = sum_beta(b, row, k, N, c, order, scratch, 1);
+    double B0 = sum_beta(b, row, k, N, c, order, scratch, 64);
     a = alpha + (size_t)(D - 1) * N;
     float *t = topology + (size_t)(D - 1) * N;
     for (int n = 0; n < N; n++) t[n] = (float)(a[n] * b[n]); /* :930 */
@@ -654,7 +653,7 @@ int ro_repaint_section(const ro_data *d, const float *alpha_begin,
     }
     b[k] = 0.0;
     const char *row = seq + (size_t)site[j] * N;
-    double B = sum_beta(b, row, k, N, c, order, scratch, 1);
+    double B = sum_beta(b, row, k, N, c, order, scratch, 64);
     cfac = B;
     a = alpha + (size_t)j * N;
     float *t = topology + (size_t)j * N;

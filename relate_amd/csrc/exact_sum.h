@@ -123,13 +123,34 @@ struct MaskTerm {  // backward, lane-mask panel: e(i) * beta[i] with the site's 
   }
 };
 
+// ---- targets spread over several waves ------------------------------------
+// For N > 5120 the stepping-stone kernel gives a target to a workgroup of
+// WAVES = 2 waves (virtual lanes 0..127, wave w holds lanes 64w..64w+63) so
+// that each lane keeps S <= 80 registers.  A sum then runs over the waves in
+// order; they meet in LDS (WaveLink) at workgroup barriers.  With WAVES = 1
+// every exchange below compiles away.
+struct WaveLinkStorage {
+  double tot[2][2];  // [phase][wave]: approximate total of the wave's lane sums
+  double result;     // the finished sum / the hand-over value of the serial fallback
+  int bad[2];        // wave w needs the fallback
+  int delta;         // exact offset at the exit of wave 0 (units: ulp of its exit binade)
+};
+template <int WAVES>
+struct WaveLink {
+  WaveLinkStorage *s = nullptr;
+  int w = 0;          // this wave
+  unsigned phase = 0;  // alternates per sum: a wave may run one sum ahead of the other
+  RL_DEV void barrier() const {
+    if constexpr (WAVES > 1) __syncthreads();
+  }
+};
+
 // The literal serial sum as the rare-path fallback of sum_exact_fast: same
 // result as sum_exact, but the terms are recomputed in every round (the empty
 // asm stops the compiler from hoisting S doubles of terms out of the round
 // loop, which would cost the hot path its registers).
 template <int S, typename T>
-RL_DEV double sum_exact_fallback(const T &term) {
-  double s = 0.0;
+RL_DEV double sum_exact_fallback(const T &term, double s = 0.0) {
   for (int l = 0; l < 64; l++) {
     double th = term.th, nth = term.nth;
     double tmp = s;
@@ -140,6 +161,29 @@ RL_DEV double sum_exact_fallback(const T &term) {
     s = wave_bcast(tmp, l);
   }
   return s;
+}
+// the same over the waves of a workgroup, in order; every wave returns the total
+template <int S, int WAVES, typename T>
+RL_DEV double sum_exact_fallback_linked(const T &term, const WaveLink<WAVES> &lk) {
+  if constexpr (WAVES == 1) {
+    return sum_exact_fallback<S>(term);
+  } else {
+    double r = 0.0;
+    if (lk.w == 0) {
+      r = sum_exact_fallback<S>(term);
+      if ((threadIdx.x & 63) == 0) lk.s->result = r;
+    }
+    lk.barrier();
+    if (lk.w == 1) {
+      r = sum_exact_fallback<S>(term, lk.s->result);
+    }
+    lk.barrier();  // wave 0 has handed over; wave 1 may now overwrite
+    if (lk.w == 1 && (threadIdx.x & 63) == 0) lk.s->result = r;
+    lk.barrier();
+    r = lk.s->result;
+    lk.barrier();  // everyone has read it before the next sum writes
+    return r;
+  }
 }
 
 #ifdef RL_STATS
@@ -152,16 +196,28 @@ RL_DEV double sum_exact_fallback(const T &term) {
 
 // L: this lane's serial sum of its terms from +0.0 (the caller accumulates it
 // inside its update loop, where the dependent adds hide behind other work).
-template <int S, typename T>
-RL_DEV double sum_exact_fast(const T &term, double L) {
+template <int S, int WAVES, typename T>
+RL_DEV double sum_exact_fast(const T &term, double L, WaveLink<WAVES> &lk) {
   constexpr bool REG_TERM = T::REG;
-  const int lane = threadIdx.x & 63;
   constexpr int G4 = 16384;  // half-width of the bracket [r_0, r_3] in ulps
 
   const unsigned long long tk0 = RL_CLK();
   // ---- A. approximate prefix from the lanes' local serial sums
-  const double Q = wave_scan_f64(L);          // ~ sum over lanes <= l
+  double Q = wave_scan_f64(L);                // ~ sum over lanes <= l (of this wave)
   double P = dpp_f64<DPP_WAVE_SHR1>(Q);       // ~ entry value of this lane (lane 0: +0.0)
+  if constexpr (WAVES > 1) {
+    // wave 1 continues where wave 0 ends: shift its prefixes by wave 0's (approximate) total
+    const int lane = threadIdx.x & 63;
+    const unsigned ph = lk.phase & 1u;
+    if (lane == 63) lk.s->tot[ph][lk.w] = Q;
+    lk.barrier();
+    if (lk.w == 1) {
+      const double before = lk.s->tot[ph][0];
+      Q = before + Q;
+      P = dpp_f64<DPP_WAVE_SHR1>(Q);
+      if (lane == 0) P = before;
+    }
+  }
   const long long pb = __double_as_longlong(P);
   const bool zero_entry = pb == 0;            // nothing but zeros before this lane: entry exactly 0
 
@@ -285,9 +341,15 @@ RL_DEV double sum_exact_fast(const T &term, double L) {
 #undef RL_SCAN_STEP
   // lanes not selected by a step read (0,0,0) = the identity map: harmless
   RL_STAT(0, 1);
-  if (__ballot(invalid || (sS & 63) > 20) != 0ull) {
+  bool fallback = __ballot(invalid || (sS & 63) > 20) != 0ull;
+  if constexpr (WAVES > 1) {  // the waves agree on the path
+    if ((threadIdx.x & 63) == 0) lk.s->bad[lk.w] = fallback;
+    lk.barrier();
+    fallback = lk.s->bad[0] | lk.s->bad[1];
+  }
+  if (fallback) {
     RL_STAT(1, 1);
-    return sum_exact_fallback<S>(term);  // irregular step: literal serial sum
+    return sum_exact_fallback_linked<S, WAVES>(term, lk);  // irregular step: literal serial sum
   }
   const unsigned long long tk3 = RL_CLK();
   unsigned long long todo = __ballot(!affine);
@@ -298,6 +360,14 @@ RL_DEV double sum_exact_fast(const T &term, double L) {
     RL_STAT(3, __builtin_popcountll(sp));
   }
   int delta = 0;  // lane 0 enters at exactly 0 (its local sum is exact, Q_0 == L_0)
+  if constexpr (WAVES > 1) {
+    // wave 1 walks after wave 0 and enters at wave 0's exact exit offset (same unit: the entry
+    // value of its lane 0 IS wave 0's Q_63)
+    if (lk.w == 1) {
+      lk.barrier();
+      delta = lk.s->delta;
+    }
+  }
   {  // start behind the last lane whose exit is known outright
     const unsigned long long cm = __ballot(constant);
     if (cm) {
@@ -349,18 +419,48 @@ RL_DEV double sum_exact_fast(const T &term, double L) {
     RL_STAT(6, tk3 - tk2);  // classification + map scan
     RL_STAT(7, tk4 - tk3);  // walk
   }
+  if constexpr (WAVES > 1) {
+    const int lane = threadIdx.x & 63;
+    if (lk.w == 0) {
+      if (lane == 0) lk.s->delta = delta;
+      lk.barrier();  // wave 1 starts its walk
+      lk.barrier();  // ... and has finished it
+    } else {
+      if (lane == 0) lk.s->result = Qt + (double)delta * pow2_field(expo_field(Qt) - 52);
+      lk.barrier();
+    }
+    const double r = lk.s->result;
+    lk.barrier();  // read by everyone before the next sum's hand-over may overwrite it
+    return r;
+  }
   return Qt + (double)delta * pow2_field(expo_field(Qt) - 52);
 }
 
 // L = the lane's local serial sum of its terms (see sum_exact_fast)
+template <int MODE, int S, int WAVES, typename T>
+RL_DEV double wave_sum(const T &term, double L, WaveLink<WAVES> &lk) {
+  lk.phase++;
+  if constexpr (MODE == 1) {
+    return sum_exact_fast<S, WAVES>(term, L, lk);
+  } else if constexpr (MODE == 2) {
+    return sum_exact_fallback_linked<S, WAVES>(term, lk);
+  } else {
+    const double t = wave_sum_butterfly(L);
+    if constexpr (WAVES == 1) {
+      return t;
+    } else {  // the top level of the balanced tree over 128 lane sums
+      const unsigned ph = lk.phase & 1u;
+      if ((threadIdx.x & 63) == 0) lk.s->tot[ph][lk.w] = t;
+      lk.barrier();
+      return lk.s->tot[ph][0] + lk.s->tot[ph][1];
+    }
+  }
+}
+// one wave per target (K2, the test hook)
 template <int MODE, int S, typename T>
 RL_DEV double wave_sum(const T &term, double L) {
-  if constexpr (MODE == 1)
-    return sum_exact_fast<S>(term, L);
-  else if constexpr (MODE == 2)
-    return sum_exact_fallback<S>(term);
-  else
-    return wave_sum_butterfly(L);
+  WaveLink<1> lk;
+  return wave_sum<MODE, S, 1>(term, L, lk);
 }
 
 template <int S, typename T>

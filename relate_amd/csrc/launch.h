@@ -24,37 +24,42 @@ inline int choose_S(const Layout &lay) {
   return 0;
 }
 
-// the layout of all kernels: all N donors, the target keeps a slot that is pinned to +0.0
-inline Layout make_layout(int N) {
+// the layout of all kernels: all N donors, the target keeps a slot that is pinned to +0.0;
+// cut into 64*waves balanced runs (waves = 1 except for K1 at N > 5120, see paint_waves)
+inline Layout make_layout(int N, int waves = 1) {
   Layout l;
   l.N = N;
   l.P = N;
-  l.q = N / 64;
-  l.rem = N % 64;
+  l.q = N / (64 * waves);
+  l.rem = N % (64 * waves);
   return l;
 }
-hipError_t launch_lane_masks(const uint32_t *bits, int row_words, int L, const Layout &lay, int S,
+// K1 gives a target to a workgroup of two waves once one wave would need more than 80
+// registers per lane (two waves per SIMD need the kernel to stay within 256 VGPRs)
+inline int paint_waves(int N) { return N > 80 * 64 ? 2 : 1; }
+#define RL_FOR_EACH_S_2WAVES(X) X(48, 16) X(64, 16) X(80, 16)
+hipError_t launch_lane_masks(const uint32_t *bits, int row_words, int L, const Layout &lay, int S, int waves,
                              unsigned long long *masks, hipStream_t stream);
 
 // kernel summation modes (template parameter MODE of the kernels)
 //   0 = lanes (RL_SUM_LANES), 1 = exact, parallel (RL_SUM_EXACT), 2 = exact, literal serial (RL_SUM_EXACT_SERIAL)
 template <int MODE>
-hipError_t launch_paint_mode(const PaintParams &p, int S, int backward, hipStream_t stream);
+hipError_t launch_paint_mode(const PaintParams &p, int S, int waves, int backward, hipStream_t stream);
 template <int MODE>
 hipError_t launch_repaint_mode(const RepaintParams &p, int S, int nblocks, int *counter, hipStream_t stream);
-template <> hipError_t launch_paint_mode<0>(const PaintParams &, int, int, hipStream_t);
-template <> hipError_t launch_paint_mode<1>(const PaintParams &, int, int, hipStream_t);
-template <> hipError_t launch_paint_mode<2>(const PaintParams &, int, int, hipStream_t);
+template <> hipError_t launch_paint_mode<0>(const PaintParams &, int, int, int, hipStream_t);
+template <> hipError_t launch_paint_mode<1>(const PaintParams &, int, int, int, hipStream_t);
+template <> hipError_t launch_paint_mode<2>(const PaintParams &, int, int, int, hipStream_t);
 template <> hipError_t launch_repaint_mode<0>(const RepaintParams &, int, int, int *, hipStream_t);
 template <> hipError_t launch_repaint_mode<1>(const RepaintParams &, int, int, int *, hipStream_t);
 template <> hipError_t launch_repaint_mode<2>(const RepaintParams &, int, int, int *, hipStream_t);
 
 inline int kernel_mode(int sum_mode) { return sum_mode == 0 ? 1 : (sum_mode == 1 ? 0 : 2); }
-inline hipError_t launch_paint(const PaintParams &p, int S, int backward, hipStream_t stream) {
+inline hipError_t launch_paint(const PaintParams &p, int S, int waves, int backward, hipStream_t stream) {
   switch (kernel_mode(p.sum_mode)) {
-    case 0: return launch_paint_mode<0>(p, S, backward, stream);
-    case 1: return launch_paint_mode<1>(p, S, backward, stream);
-    default: return launch_paint_mode<2>(p, S, backward, stream);
+    case 0: return launch_paint_mode<0>(p, S, waves, backward, stream);
+    case 1: return launch_paint_mode<1>(p, S, waves, backward, stream);
+    default: return launch_paint_mode<2>(p, S, waves, backward, stream);
   }
 }
 inline hipError_t launch_repaint(const RepaintParams &p, int S, int nblocks, int *counter, hipStream_t stream) {

@@ -165,25 +165,30 @@ RL_DEV void for_each_chunk2_tail(MaskRow rowa, MaskRow rowb, MaskRow vrow, C fir
   }
 }
 
-// One target's view of the layout over all N donors.
+// One target's view of the layout over all N donors.  The donors are cut
+// into 64*WAVES balanced runs ("virtual lanes"); wave w of the target's
+// workgroup holds virtual lanes 64w .. 64w+63 (WAVES = 1 everywhere except in
+// the stepping-stone kernel for N > 5120).
 template <int S>
 struct PaintLane {
   int lane, start, len, k;
   int q;         // registers 0..q-1 are valid in every lane
-  u64 rem_mask;  // lanes in which register q is valid
+  u64 rem_mask;  // lanes of this wave in which register q is valid
   int jk;        // donor k itself sits in register jk ...
-  u64 kbit;      // ... of this lane (mask): it is pinned to +0.0
-  RL_DEV void init(const Layout &lay, int k_) {
+  u64 kbit;      // ... of this lane of this wave (0: another wave holds it): pinned to +0.0
+  RL_DEV void init(const Layout &lay, int k_, int wave = 0) {
     lane = threadIdx.x & 63;
+    const int vl = wave * 64 + lane;  // virtual lane
     k = k_;
     q = lay.q;
-    start = lane * lay.q + (lane < lay.rem ? lane : lay.rem);
-    len = lay.q + (lane < lay.rem ? 1 : 0);
-    rem_mask = lay.rem ? (~0ull >> (64 - lay.rem)) : 0ull;
+    start = vl * lay.q + (vl < lay.rem ? vl : lay.rem);
+    len = lay.q + (vl < lay.rem ? 1 : 0);
+    const int rem_here = lay.rem - wave * 64;  // virtual lanes of this wave that hold one more
+    rem_mask = rem_here >= 64 ? ~0ull : (rem_here > 0 ? (~0ull >> (64 - rem_here)) : 0ull);
     const int big = lay.rem * (lay.q + 1);
     const int lk = k < big ? k / (lay.q + 1) : lay.rem + (k - big) / (lay.q > 0 ? lay.q : 1);
     jk = k - (lk * lay.q + (lk < lay.rem ? lk : lay.rem));
-    kbit = 1ull << lk;
+    kbit = (lk >> 6) == wave ? 1ull << (lk & 63) : 0ull;
   }
   RL_DEV u64 valid(int j) const { return j < q ? ~0ull : (j == q ? rem_mask : 0ull); }
 };
@@ -208,18 +213,19 @@ RL_DEV double in_vgpr(double v) {
 }
 // site word of the plan (bit 31: the target is derived there) -> the row of
 // mismatch masks the target sees: the site's row, or the all-zero row L
-RL_DEV MaskRow site_row(const u64 *masks, int S, int L, int sv) {
+// (the panel holds WAVES consecutive rows of S words per site, one per wave of the target's workgroup)
+RL_DEV MaskRow site_row(const u64 *masks, int S, int L, int sv, int waves = 1, int wave = 0) {
   sv = __builtin_amdgcn_readfirstlane(sv);
   const int r = sv < 0 ? (sv & 0x7fffffff) : L;
-  return (MaskRow)(masks + (size_t)r * S);
+  return (MaskRow)(masks + ((size_t)r * waves + wave) * S);
 }
 // Pull the row of a site that the NEXT step will read into L2 (one dword per
 // 16 bytes; the value is kept alive until then, which also parks the wait
 // for it a whole step later).  Scalar loads that miss L2 cost ~800 cycles per
 // chunk of masks; from L2 the other wave on the SIMD covers them.
-RL_DEV uint32_t touch_row(const u64 *masks, int S, int sv, int lane) {
+RL_DEV uint32_t touch_row(const u64 *masks, int S, int sv, int lane, int waves = 1, int wave = 0) {
   sv = __builtin_amdgcn_readfirstlane(sv);
-  const uint32_t *row = (const uint32_t *)(masks + (size_t)(sv & 0x7fffffff) * S);
+  const uint32_t *row = (const uint32_t *)(masks + ((size_t)(sv & 0x7fffffff) * waves + wave) * S);
   const int o = lane * 4, last = S * 2 - 1;
   return row[o < last ? o : last];
 }

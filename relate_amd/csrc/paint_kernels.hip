@@ -53,10 +53,11 @@ RL_DEV void emit_stone(const PaintLane<S> &pl, const double (&v)[S], float *__re
 
 typedef const __attribute__((address_space(4))) PaintParams *ColdParams;
 
-template <int S, int TAIL, int MODE>
-RL_DEV void paint_forward(const PaintParams &p, int k, float *stage) {
+template <int S, int TAIL, int MODE, int WAVES>
+RL_DEV void paint_forward(const PaintParams &p, int k, float *stage, WaveLink<WAVES> &lk) {
+  const int wv = lk.w;  // this wave of the target's workgroup (wave-uniform)
   PaintLane<S> pl;
-  pl.init(p.lay, k);
+  pl.init(p.lay, k, wv);
   const PaintConsts &c = p.c;
   const int64_t off = p.plan_off[k];
   const int D = (int)(p.plan_off[k + 1] - off);
@@ -68,7 +69,7 @@ RL_DEV void paint_forward(const PaintParams &p, int k, float *stage) {
   double a[S];
 
   // ---- SNP 0 (fast_painting.cpp:207-253)
-  for_each_chunk<S, 8>(site_row(p.masks, S, p.L, st[0]), [&](int j0, const u64x8 &m) {
+  for_each_chunk<S, 8>(site_row(p.masks, S, p.L, st[0], WAVES, wv), [&](int j0, const u64x8 &m) {
 #pragma unroll
     for (int jj = 0; jj < 8; jj++) {
       double v = c.init0;
@@ -78,7 +79,7 @@ RL_DEV void paint_forward(const PaintParams &p, int k, float *stage) {
     }
   });
   set_slot<S>(a, pl.jk, pl.kbit, 0.0);
-  double ssum = wave_sum<MODE, S>(RegTerm<S>{a, 0.0, 0.0, p.stats}, local_sum<S>(RegTerm<S>{a}));
+  double ssum = wave_sum<MODE, S, WAVES>(RegTerm<S>{a, 0.0, 0.0, p.stats}, local_sum<S>(RegTerm<S>{a}), lk);
   double ls = 0.0;
   int wa = 0;
   // stone wa of the target: written when the visited index reaches stone_ia[k][wa] (:354-374)
@@ -90,7 +91,7 @@ RL_DEV void paint_forward(const PaintParams &p, int k, float *stage) {
     const ColdParams cp = cold_params<PaintParams>();
     const size_t N = cp->lay.N, row = (size_t)wa * cp->nloc + (k - cp->k0);
     emit_stone<S>(pl, a, cp->alpha + row * N, 0.0f, stage);
-    if (pl.lane == 0) cp->ls_alpha[row] = (float)ls;
+    if (pl.lane == 0 && wv == 0) cp->ls_alpha[row] = (float)ls;
     wa++;
   };
   int next_stone = stone_index(0);
@@ -108,7 +109,7 @@ RL_DEV void paint_forward(const PaintParams &p, int k, float *stage) {
   const double K1 = in_vgpr(c.K1);
   constexpr int CH = S % 16 == 0 ? 16 : 8;  // registers per chunk of masks
   typedef typename MaskChunk<CH>::type Chunk;
-  MaskRow row = site_row(p.masks, S, p.L, s1);
+  MaskRow row = site_row(p.masks, S, p.L, s1, WAVES, wv);
   Chunk first = load_masks<CH>(row, 0);
   unsigned long long seg1 = 0, seg2 = 0, seg3 = 0, seg4 = 0, seg5 = 0;
   (void)seg1; (void)seg2; (void)seg3; (void)seg4; (void)seg5;
@@ -116,7 +117,7 @@ RL_DEV void paint_forward(const PaintParams &p, int k, float *stage) {
     RL_TICK(0);
     retire_touch(touched);
     RL_TICK(1);
-    if (i + 1 < D) touched = touch_row(p.masks, S, s2, pl.lane);
+    if (i + 1 < D) touched = touch_row(p.masks, S, s2, pl.lane, WAVES, wv);
     s1 = s2;
     if (i + 2 < D) s2 = st[i + 2];
     // requested here, used after the sum: the chunk loop's waits cover the latency
@@ -143,9 +144,9 @@ RL_DEV void paint_forward(const PaintParams &p, int k, float *stage) {
       }
     });
     RL_TICK(3);
-    row = site_row(p.masks, S, p.L, s1);
+    row = site_row(p.masks, S, p.L, s1, WAVES, wv);
     first = load_masks<CH>(row, 0);
-    ssum = wave_sum<MODE, S>(RegTerm<S>{a, 0.0, 0.0, p.stats}, lsum);
+    ssum = wave_sum<MODE, S, WAVES>(RegTerm<S>{a, 0.0, 0.0, p.stats}, lsum, lk);
     RL_TICK(4);
     ls += nx_i;  // :281-282
     cfac = ssum;
@@ -165,7 +166,7 @@ RL_DEV void paint_forward(const PaintParams &p, int k, float *stage) {
   }
   retire_touch(touched);
 #ifdef RL_STATS
-  if (MODE == 0 && p.stats && pl.lane == 0) {  // wait for prefetch | loads + slot | chunk loop | sum | rescale test
+  if (MODE == 0 && p.stats && pl.lane == 0 && wv == 0) {  // wait for prefetch | loads + slot | chunk loop | sum | rescale test
     atomicAdd(&p.stats[0], (unsigned long long)(D - 1));
     atomicAdd(&p.stats[1], seg1); atomicAdd(&p.stats[2], seg2); atomicAdd(&p.stats[3], seg3);
     atomicAdd(&p.stats[4], seg4); atomicAdd(&p.stats[5], seg5);
@@ -173,10 +174,11 @@ RL_DEV void paint_forward(const PaintParams &p, int k, float *stage) {
 #endif
 }
 
-template <int S, int TAIL, int MODE>
-RL_DEV void paint_backward(const PaintParams &p, int k, float *stage) {
+template <int S, int TAIL, int MODE, int WAVES>
+RL_DEV void paint_backward(const PaintParams &p, int k, float *stage, WaveLink<WAVES> &lk) {
+  const int wv = lk.w;
   PaintLane<S> pl;
-  pl.init(p.lay, k);
+  pl.init(p.lay, k, wv);
   const PaintConsts &c = p.c;
   const int64_t off = p.plan_off[k];
   const int D = (int)(p.plan_off[k + 1] - off);
@@ -205,7 +207,7 @@ RL_DEV void paint_backward(const PaintParams &p, int k, float *stage) {
     const ColdParams cp = cold_params<PaintParams>();
     const size_t N = cp->lay.N, row = (size_t)we * cp->nloc + (k - cp->k0);
     emit_stone<S>(pl, b, cp->beta + row * N, self_value, stage);
-    if (pl.lane == 0) cp->ls_beta[row] = (float)ls;
+    if (pl.lane == 0 && wv == 0) cp->ls_beta[row] = (float)ls;
     we--;
   };
   int next_stone = stone_index(we);
@@ -219,13 +221,13 @@ RL_DEV void paint_backward(const PaintParams &p, int k, float *stage) {
   // and s1 (site j); the row of s2 (site j-1) goes to L2 during the step
   int s0 = st[D - 1], s1 = D > 1 ? st[D - 2] : 0, s2 = D > 2 ? st[D - 3] : 0;
   uint32_t touched = 0;
-  MaskRow rown = site_row(p.masks, S, p.L, s0);  // the later site's mismatches drive the update (:481-488)
-  MaskRow rowh = site_row(p.masks, S, p.L, s1);
+  MaskRow rown = site_row(p.masks, S, p.L, s0, WAVES, wv);  // the later site's mismatches drive the update (:481-488)
+  MaskRow rowh = site_row(p.masks, S, p.L, s1, WAVES, wv);
   u64x4 firstn = load_masks<4>(rown, 0), firsth = load_masks<4>(rowh, 0);
   const double K1 = in_vgpr(c.K1), theta = in_vgpr(c.theta), ntheta = in_vgpr(c.ntheta);
   for (int j = D - 2; j >= 0; j--) {
     retire_touch(touched);
-    if (j > 0) touched = touch_row(p.masks, S, s2, pl.lane);
+    if (j > 0) touched = touch_row(p.masks, S, s2, pl.lane, WAVES, wv);
     s0 = s1;
     s1 = s2;
     if (j > 1) s2 = st[j - 2];
@@ -234,7 +236,7 @@ RL_DEV void paint_backward(const PaintParams &p, int k, float *stage) {
     const double bt = cfac / theta - b1; // :475
     set_slot<S>(b, pl.jk, pl.kbit, -b1);   // donor k: (-b1) + b1 = +0.0 (never a mismatch with itself)
     double lsum = 0.0;
-    MaskRow vrow = (MaskRow)(p.masks + (size_t)(p.L + 1) * S);
+    MaskRow vrow = (MaskRow)(p.masks + ((size_t)(p.L + 1) * WAVES + wv) * S);
     asm volatile("" : "+s"(vrow));
     for_each_chunk2_tail<S, 4, TAIL>(rown, rowh, vrow, firstn, firsth,
                                      [&](int j0, const u64x4 &mn, const u64x4 &mh, const u64x4 &va) {
@@ -253,12 +255,12 @@ RL_DEV void paint_backward(const PaintParams &p, int k, float *stage) {
     });
     const MaskTerm<S> term{rowh, b, theta, ntheta, p.stats ? p.stats + 8 : nullptr};
     rown = rowh;
-    rowh = site_row(p.masks, S, p.L, s1);
+    rowh = site_row(p.masks, S, p.L, s1, WAVES, wv);
     if (MODE == 0) {  // lanes: the sum reads no masks, request the next step's first chunks across it
       firstn = load_masks<4>(rown, 0);
       firsth = load_masks<4>(rowh, 0);
     }
-    bsum = wave_sum<MODE, S>(term, lsum);  // :495-503
+    bsum = wave_sum<MODE, S, WAVES>(term, lsum, lk);  // :495-503
     if (MODE != 0) {
       firstn = load_masks<4>(rown, 0);
       firsth = load_masks<4>(rowh, 0);
@@ -280,35 +282,52 @@ RL_DEV void paint_backward(const PaintParams &p, int k, float *stage) {
   retire_touch(touched);
 }
 
-// S <= 80: hold the kernel to 256 registers so that two waves share a SIMD
-template <int S, int TAIL, int MODE, bool BACKWARD>
-__global__ void __launch_bounds__(64, (S <= 80 ? 2 : 1)) paint_kernel(const PaintParams p) {
-  __shared__ float stage[16 * 64];
+// S <= 80: hold the kernel to 256 registers so that two waves share a SIMD.
+// WAVES = 2: a workgroup of two waves paints one target (N > 5120).
+template <int S, int TAIL, int MODE, int WAVES, bool BACKWARD>
+__global__ void __launch_bounds__(64 * WAVES, (S <= 80 ? 2 : 1)) paint_kernel(const PaintParams p) {
+  __shared__ float stage[WAVES][16 * 64];
+  __shared__ WaveLinkStorage link;
+  WaveLink<WAVES> lk;
+  lk.s = &link;
+  lk.w = WAVES > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
   const int k = p.order[blockIdx.x];
   if (BACKWARD)
-    paint_backward<S, TAIL, MODE>(p, k, stage);
+    paint_backward<S, TAIL, MODE, WAVES>(p, k, stage[lk.w], lk);
   else
-    paint_forward<S, TAIL, MODE>(p, k, stage);
+    paint_forward<S, TAIL, MODE, WAVES>(p, k, stage[lk.w], lk);
 }
 
-template <int S, int TAIL>
+template <int S, int TAIL, int WAVES>
 static hipError_t launch_paint_t(const PaintParams &p, int backward, hipStream_t stream) {
-  const dim3 grid(p.nloc), block(64);
+  const dim3 grid(p.nloc), block(64 * WAVES);
   if (backward)
-    hipLaunchKernelGGL((paint_kernel<S, TAIL, RL_MODE, true>), grid, block, 0, stream, p);
+    hipLaunchKernelGGL((paint_kernel<S, TAIL, RL_MODE, WAVES, true>), grid, block, 0, stream, p);
   else
-    hipLaunchKernelGGL((paint_kernel<S, TAIL, RL_MODE, false>), grid, block, 0, stream, p);
+    hipLaunchKernelGGL((paint_kernel<S, TAIL, RL_MODE, WAVES, false>), grid, block, 0, stream, p);
   return hipGetLastError();
 }
 
 template <>
-hipError_t launch_paint_mode<RL_MODE>(const PaintParams &p, int S, int backward, hipStream_t stream) {
-  switch (S) {
+hipError_t launch_paint_mode<RL_MODE>(const PaintParams &p, int S, int waves, int backward, hipStream_t stream) {
+  if (waves == 1) {
+    switch (S) {
 #define RL_CASE(s, t) \
   case s:             \
-    return launch_paint_t<s, t>(p, backward, stream);
-    RL_FOR_EACH_S(RL_CASE)
+    return launch_paint_t<s, t, 1>(p, backward, stream);
+      RL_FOR_EACH_S(RL_CASE)
 #undef RL_CASE
+    }
+  } else if (waves == 2) {
+#ifndef RL_ONLY_S
+    switch (S) {
+#define RL_CASE(s, t) \
+  case s:             \
+    return launch_paint_t<s, t, 2>(p, backward, stream);
+      RL_FOR_EACH_S_2WAVES(RL_CASE)
+#undef RL_CASE
+    }
+#endif
   }
   return hipErrorInvalidValue;
 }

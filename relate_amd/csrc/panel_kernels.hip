@@ -2,21 +2,23 @@
 // kernel (paint_device.h "lane-mask panel"): masks[s][j] bit l = the donor lane
 // l holds in register j (layout over all N donors) is ancestral at site s, 0
 // past the end of a lane's run; row L is all zero; row L+1 holds the validity
-// masks (bit l: register j lies inside lane l's run).  One wavefront per row,
-// once per chunk.
+// masks (bit l: register j lies inside lane l's run).  With `waves` = 2 (K1 at
+// N > 5120) a site has two consecutive rows, one per wave of the painting
+// workgroup (virtual lanes 0..63 / 64..127).  One workgroup per site, once per chunk.
 #include "paint_device.h"
 #include "launch.h"
 
 namespace rl {
 
-__global__ void __launch_bounds__(64) lane_mask_kernel(const uint32_t *__restrict__ bits, int row_words, int L, Layout lay,
-                                                       int S, unsigned long long *__restrict__ masks) {
+__global__ void __launch_bounds__(128) lane_mask_kernel(const uint32_t *__restrict__ bits, int row_words, int L, Layout lay,
+                                                        int S, int waves, unsigned long long *__restrict__ masks) {
   const int s = blockIdx.x;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;  // one wave per wave of the painting workgroup
+  const int vl = threadIdx.x;                                   // virtual lane
   const uint32_t *__restrict__ row = bits + (size_t)s * row_words;
-  const int start = lane * lay.q + (lane < lay.rem ? lane : lay.rem);
-  const int len = lay.q + (lane < lay.rem ? 1 : 0);
-  unsigned long long *__restrict__ out = masks + (size_t)s * S;
+  const int start = vl * lay.q + (vl < lay.rem ? vl : lay.rem);
+  const int len = lay.q + (vl < lay.rem ? 1 : 0);
+  unsigned long long *__restrict__ out = masks + ((size_t)s * waves + wave) * S;
   for (int j0 = 0; j0 < S; j0 += 64) {
     unsigned long long mine = 0;
     const int jn = S - j0 < 64 ? S - j0 : 64;
@@ -30,9 +32,10 @@ __global__ void __launch_bounds__(64) lane_mask_kernel(const uint32_t *__restric
   }
 }
 
-hipError_t launch_lane_masks(const uint32_t *bits, int row_words, int L, const Layout &lay, int S,
+hipError_t launch_lane_masks(const uint32_t *bits, int row_words, int L, const Layout &lay, int S, int waves,
                              unsigned long long *masks, hipStream_t stream) {
-  hipLaunchKernelGGL(lane_mask_kernel, dim3(L + 2), dim3(64), 0, stream, bits, row_words, L, lay, S, masks);
+  hipLaunchKernelGGL(lane_mask_kernel, dim3(L + 2), dim3(64 * waves), 0, stream, bits, row_words, L, lay, S, waves,
+                     masks);
   return hipGetLastError();
 }
 

@@ -34,7 +34,7 @@ def check(ch, modes=("exact", "lanes")):
     for mode in modes:
         ctx = api.Context()
         ctx.set_chunk(ch.seq, ch.r, ch.rpos, ch.wb)
-        ctx.paint(api.RL_SUM_EXACT if mode == "exact" else api.RL_SUM_LANES)
+        ctx.paint({"exact": api.RL_SUM_EXACT, "lanes": api.RL_SUM_LANES, "serial": api.RL_SUM_EXACT_SERIAL}[mode])
         st = [ctx.stones(w) for w in range(ch.W)]
         for k in range(ch.N) if ch.N <= 12 else sorted(set([0, 1, ch.N // 2, ch.N - 2, ch.N - 1])):
             bb, be, al, bt, la, lb = oracle_stones(ch, k, mode == "lanes")
@@ -43,6 +43,18 @@ def check(ch, modes=("exact", "lanes")):
                 assert bits_equal(st[w]["ls_alpha"][k], la[w]) and bits_equal(st[w]["ls_beta"][k], lb[w]), (mode, k, w)
                 assert bits_equal(st[w]["alpha"][k], al[w]) and bits_equal(st[w]["beta"][k], bt[w]), (mode, k, w)
         ctx.close()
+
+
+@pytest.mark.parametrize("N", [5121, 7000, 10240])
+def test_two_wavefronts_per_target(N):
+    """N > 5120: a workgroup of two wavefronts paints one target (128 virtual lanes); the sums run over both"""
+    ch = random_chunk(N, 90, 0.15, seed=N, wb=[0, 40, 90], special="flat_targets")
+    check(ch, modes=("exact", "lanes", "serial"))
+
+
+def test_two_wavefronts_long_run_with_rescales():
+    ch = random_chunk(6000, 700, 0.12, seed=77, wb=[0, 150, 400, 700])
+    check(ch)
 
 
 @pytest.mark.parametrize("N", [2, 3, 5, 9])
