@@ -8,12 +8,35 @@
 // steers which branches redraw random numbers, and the draw order is part of
 // the result.
 #pragma once
+#include <sys/mman.h>
+
 #include <cstdint>
+#include <cstdlib>
+#include <new>
 #include <limits>
 #include <random>
 #include <vector>
 
 namespace rl {
+
+// std::vector allocator for the N x N matrices of the tree builder: 2 MiB-aligned
+// and advised to use transparent huge pages.  MinMatch::coalesce walks down
+// matrix columns (one element per row): with 4 KiB pages every step is a TLB
+// miss on top of the cache miss.
+template <typename T>
+struct HugePageAllocator {
+  typedef T value_type;
+  HugePageAllocator() = default;
+  template <typename U>
+  HugePageAllocator(const HugePageAllocator<U> &) {}
+  T *allocate(size_t n);
+  void deallocate(T *p, size_t) { free(p); }
+  template <typename U>
+  bool operator==(const HugePageAllocator<U> &) const { return true; }
+  template <typename U>
+  bool operator!=(const HugePageAllocator<U> &) const { return false; }
+};
+typedef std::vector<float, HugePageAllocator<float>> MatrixBuf;
 
 struct HostTree {
   int N = 0;
@@ -32,6 +55,21 @@ struct HostTree {
     snp_end.assign(T, 0);
   }
 };
+
+template <typename T>
+T *HugePageAllocator<T>::allocate(size_t n) {
+  const size_t bytes = n * sizeof(T), huge = (size_t)2 << 20;
+  void *p = nullptr;
+  if (bytes >= 2 * huge) {
+    const size_t rounded = (bytes + huge - 1) & ~(huge - 1);
+    p = aligned_alloc(huge, rounded);
+    if (p) (void)madvise(p, rounded, MADV_HUGEPAGE);
+  } else {
+    p = malloc(bytes ? bytes : 1);
+  }
+  if (!p) throw std::bad_alloc();
+  return static_cast<T *>(p);
+}
 
 class MinMatch {
  public:
@@ -53,7 +91,7 @@ class MinMatch {
   std::vector<Cand> mc, mc_sym;
   Cand best, best_sym;
   std::vector<float> min_values, min_values_sym, min_values_CF;
-  std::vector<float> sym_d, d_CF;
+  MatrixBuf sym_d, d_CF;
   float sym_dist = 0.f, dist_random = 0.f;
 
   float *D = nullptr;         // current asymmetric matrix

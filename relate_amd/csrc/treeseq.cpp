@@ -285,7 +285,7 @@ static int force_map_mutation(rl_treeseq &ts, HostTree &t, SnpInfo &si, bool for
 // ancestor; the repeated float additions of `val` are replayed through a table
 // (acc[c] = val added c times, left to right), so every entry is bit-identical
 // to the reference's accumulation.
-static void clade_prior(const HostTree &t, float val, std::vector<float> &dist) {
+static void clade_prior(const HostTree &t, float val, MatrixBuf &dist) {
   const int N = t.N, T = 2 * N - 1;
   dist.assign((size_t)N * N, 0.0f);
   std::vector<int> depth(T, 0);  // internal nodes on the path node..root, inclusive of node if internal
@@ -372,7 +372,7 @@ int rl_treeseq_build(rl_treeseq *ts, int start, int end, rl_matrix_fn matrix, rl
         }
   };
   MinMatch tb(N, ts->theta);
-  std::vector<float> d((size_t)N * N), dist;
+  MatrixBuf d((size_t)N * N), dist;
   float min_value = 0.f, min_value_alt = 0.f;
   int rc;
 
