@@ -56,7 +56,7 @@ RL_DEV int dpp_i32(int v) {
 }
 enum { DPP_ROW_SHR = 0x110, DPP_WAVE_SHR1 = 0x138, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143 };
 
-// inclusive scans over the 64 lanes (zeros shifted in)
+// inclusive scan over the 64 lanes (zeros shifted in)
 RL_DEV double wave_scan_f64(double v) {
   v += dpp_f64<DPP_ROW_SHR + 1>(v);
   v += dpp_f64<DPP_ROW_SHR + 2>(v);
@@ -66,16 +66,6 @@ RL_DEV double wave_scan_f64(double v) {
   v += dpp_f64<DPP_ROW_BCAST31, 0xc>(v);
   return v;
 }
-RL_DEV int wave_scan_i32(int v) {
-  v += dpp_i32<DPP_ROW_SHR + 1>(v);
-  v += dpp_i32<DPP_ROW_SHR + 2>(v);
-  v += dpp_i32<DPP_ROW_SHR + 4>(v);
-  v += dpp_i32<DPP_ROW_SHR + 8>(v);
-  v += dpp_i32<DPP_ROW_BCAST15, 0xa>(v);
-  v += dpp_i32<DPP_ROW_BCAST31, 0xc>(v);
-  return v;
-}
-
 RL_DEV int hi32(double v) { return (int)(__double_as_longlong(v) >> 32); }
 RL_DEV int expo_field(double v) { return (hi32(v) >> 20) & 0x7ff; }  // v >= 0
 RL_DEV double rd_lane_f64(double v, int lane) {

@@ -122,28 +122,11 @@ RL_DEV void for_each_chunk_from(MaskRow row, C first, F &&f) {
     cur = nxt;
   }
 }
-// The same with chunk 0 already requested by the caller (`first`), and with
-// the chunks of `vrow` -- per-register validity masks, the lanes whose run
-// reaches that register -- alongside for the chunks that touch the last TAIL
-// registers: f(j0, chunk, validity chunk).
-template <int S, int CH, int TAIL, typename C, typename F>
-RL_DEV void for_each_chunk_tail(MaskRow row, MaskRow vrow, C first, F &&f) {
-  static_assert(S % CH == 0, "S must be a multiple of the chunk");
-  C cur = first, va = first;
-  if (CH > S - TAIL) va = load_masks<CH>(vrow, 0);
-#pragma unroll
-  for (int c = 0; c < S / CH; c++) {
-    C nxt = cur, nva = va;
-    if (c + 1 < S / CH) {
-      asm volatile("" : "+s"(row), "+s"(vrow) : "s"(cur[0]));
-      nxt = load_masks<CH>(row, c + 1);
-      if ((c + 2) * CH > S - TAIL) nva = load_masks<CH>(vrow, c + 1);
-    }
-    f(c * CH, cur, va);
-    cur = nxt;
-    va = nva;
-  }
-}
+// Two rows at once (the backward update needs the masks of the later site and
+// of this one), chunk 0 of each already requested by the caller, and with the
+// chunks of `vrow` -- per-register validity masks, the lanes whose run reaches
+// that register -- alongside for the chunks that touch the last TAIL
+// registers: f(j0, chunk a, chunk b, validity chunk).
 template <int S, int CH, int TAIL, typename C, typename F>
 RL_DEV void for_each_chunk2_tail(MaskRow rowa, MaskRow rowb, MaskRow vrow, C firsta, C firstb, F &&f) {
   static_assert(S % CH == 0, "S must be a multiple of the chunk");
@@ -260,22 +243,6 @@ RL_DEV void tail_add(double &v, int len, int j, double k) {
                : "+v"(v)
                : "v"(len), "i"(j), "v"(k)
                : "vcc");
-}
-// v[i] += k in the lanes of m[i]
-template <typename M>
-RL_DEV void masked_add8(double (&v)[8], const M &m, double k) {
-  asm volatile(
-      "s_mov_b64 exec, %8\n\tv_add_f64 %0, %0, %16\n\t"
-      "s_mov_b64 exec, %9\n\tv_add_f64 %1, %1, %16\n\t"
-      "s_mov_b64 exec, %10\n\tv_add_f64 %2, %2, %16\n\t"
-      "s_mov_b64 exec, %11\n\tv_add_f64 %3, %3, %16\n\t"
-      "s_mov_b64 exec, %12\n\tv_add_f64 %4, %4, %16\n\t"
-      "s_mov_b64 exec, %13\n\tv_add_f64 %5, %5, %16\n\t"
-      "s_mov_b64 exec, %14\n\tv_add_f64 %6, %6, %16\n\t"
-      "s_mov_b64 exec, %15\n\tv_add_f64 %7, %7, %16\n\t"
-      "s_mov_b64 exec, -1"
-      : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
-      : "s"(m[0]), "s"(m[1]), "s"(m[2]), "s"(m[3]), "s"(m[4]), "s"(m[5]), "s"(m[6]), "s"(m[7]), "v"(k));
 }
 // x[i] = (lane in m[i] ? th : nth) * b[i]   (fast_painting.cpp:495-503)
 template <typename M>
