@@ -132,9 +132,8 @@ int ro_plan_target(const ro_data *d, const int *wb, int W, int k, int *site,
  * all N donors (the target's own term is +0.0), in donor order, are cut into
  * nl contiguous runs (the first N%nl runs hold N/nl+1 donors, the rest N/nl);
  * each run is summed left to right from 0.0, then an xor-butterfly (masks
- * 1..nl/2) combines the partial sums.  nl = 64 lanes, except in the
- * stepping-stone kernel for N > 5120, which gives a target two wavefronts
- * (nl = 128; relate_amd/csrc/launch.h paint_waves). */
+ * 1..nl/2) combines the partial sums.  nl = 64 lanes; for N > 5120 a target
+ * gets two wavefronts (nl = 128; relate_amd/csrc/launch.h target_waves). */
 static double sum_lanes(const double *t, int N, int k, int nl) {
   const int q = N / nl, rem = N % nl;
   double lane[128];
@@ -596,7 +595,7 @@ int ro_repaint_section(const ro_data *d, const float *alpha_begin,
   double *a = alpha;
   for (int n = 0; n < N; n++) a[n] = alpha_begin[n];
   a[k] = 0.0;
-  double S = sum_alpha(a, N, k, order, 64);
+  double S = sum_alpha(a, N, k, order, paint_lanes(N));
   double cfac = trans_factor(c, r_prob[0]) * S;
   double prev_logscale = logscales[0];
   for (int i = 1; i < D; i++) {
@@ -613,7 +612,7 @@ int ro_repaint_section(const ro_data *d, const float *alpha_begin,
       a[n] = v;
     }
     a[k] = 0.0;
-    S = sum_alpha(a, N, k, order, 64);
+    S = sum_alpha(a, N, k, order, paint_lanes(N));
     cfac = S;
     if (cfac < c->lower || cfac > c->upper) { /* :865-877 */
       const double tmp = cfac;
@@ -631,7 +630,7 @@ int ro_repaint_section(const ro_data *d, const float *alpha_begin,
   b[k] = 0.0;
   {
     const char *row = seq + (size_t)last_snp * N;
-    double B0 = sum_beta(b, row, k, N, c, order, scratch, 64);
+    double B0 = sum_beta(b, row, k, N, c, order, scratch, paint_lanes(N));
     a = alpha + (size_t)(D - 1) * N;
     float *t = topology + (size_t)(D - 1) * N;
     for (int n = 0; n < N; n++) t[n] = (float)(a[n] * b[n]); /* :930 */
@@ -653,7 +652,7 @@ int ro_repaint_section(const ro_data *d, const float *alpha_begin,
     }
     b[k] = 0.0;
     const char *row = seq + (size_t)site[j] * N;
-    double B = sum_beta(b, row, k, N, c, order, scratch, 64);
+    double B = sum_beta(b, row, k, N, c, order, scratch, paint_lanes(N));
     cfac = B;
     a = alpha + (size_t)j * N;
     float *t = topology + (size_t)j * N;

@@ -86,10 +86,9 @@ struct rl_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
   int N = 0, L = 0, W = 0;
   int k0 = 0, nloc = 0;  // targets of this context (rl_set_target_range), default all
-  rl::Layout lay{};  // all N donors in 64 balanced runs
+  rl::Layout lay{};  // all N donors in 64*waves balanced runs
   int S = 0;         // register tile (doubles per lane) = words per row of the lane-mask panel
-  rl::Layout paint_lay{};  // K1: the same, or 128 runs for a two-wave workgroup per target (N > 5120)
-  int paint_S = 0, paint_waves = 1;
+  int waves = 1;     // wavefronts per target: 2 for N > 5120 (launch.h target_waves)
   double theta = 0.001, rho = 1.0;
   int row_words = 0;
   std::vector<uint32_t> bits;  // host copy of the panel
@@ -97,7 +96,7 @@ struct rl_ctx {
   std::vector<int> wb;
   rl::Plan plan;
   rl::PaintConsts consts{};
-  rl::DevBuf d_bits, d_masks, d_paint_masks, d_off, d_sites, d_cf, d_nxt, d_ia, d_ie, d_binit, d_order;
+  rl::DevBuf d_bits, d_masks, d_off, d_sites, d_cf, d_nxt, d_ia, d_ie, d_binit, d_order;
   rl::DevBuf d_alpha, d_beta, d_lsa, d_lsb, d_stats;
   bool have_chunk = false, plan_on_device = false, painted = false;
   int paint_mode = -1;

@@ -219,17 +219,10 @@ int upload_plan(rl_ctx *ctx) {
   Plan &pl = ctx->plan;
   int rc;
   if ((rc = ctx->d_bits.upload(ctx->bits))) return rc;
-  // lane-mask form of the panel (K2 and, with one wave per target, K1)
-  if ((rc = ctx->d_masks.alloc(((size_t)ctx->L + 2) * ctx->S * sizeof(unsigned long long)))) return rc;
-  RL_HIP(launch_lane_masks(ctx->d_bits.as<uint32_t>(), ctx->row_words, ctx->L, ctx->lay, ctx->S, 1,
+  // lane-mask form of the panel: `waves` rows of S words per site
+  if ((rc = ctx->d_masks.alloc(((size_t)ctx->L + 2) * ctx->waves * ctx->S * sizeof(unsigned long long)))) return rc;
+  RL_HIP(launch_lane_masks(ctx->d_bits.as<uint32_t>(), ctx->row_words, ctx->L, ctx->lay, ctx->S, ctx->waves,
                            ctx->d_masks.as<unsigned long long>(), nullptr));
-  if (ctx->paint_waves > 1) {  // K1's own panel: two rows per site, for the two waves of a target's workgroup
-    if ((rc = ctx->d_paint_masks.alloc(((size_t)ctx->L + 2) * ctx->paint_waves * ctx->paint_S *
-                                       sizeof(unsigned long long))))
-      return rc;
-    RL_HIP(launch_lane_masks(ctx->d_bits.as<uint32_t>(), ctx->row_words, ctx->L, ctx->paint_lay, ctx->paint_S,
-                             ctx->paint_waves, ctx->d_paint_masks.as<unsigned long long>(), nullptr));
-  }
   RL_HIP(hipDeviceSynchronize());
   if ((rc = ctx->d_off.upload(pl.off))) return rc;
   if ((rc = ctx->d_sites.upload(pl.sites))) return rc;
@@ -433,17 +426,15 @@ static int set_common(rl_ctx *ctx, int N, int L, const double *r, const double *
       set_error("window boundaries must be increasing");
       return RL_EINVAL;
     }
-  Layout lay = make_layout(N);
+  // a workgroup of two waves per target once one wave would need more than 80 registers per lane
+  const int waves = target_waves(N);
+  Layout lay = make_layout(N, waves);
   int S = choose_S(lay);
-  // K1: a workgroup of two waves per target once one wave would need more than 80 registers per lane
-  const int pwaves = paint_waves(N);
-  const Layout play = make_layout(N, pwaves);
-  const int pS = choose_S(play);
   if (S == 0) {
-    set_error("N=%d exceeds the largest compiled register tile (N <= %d)", N, 160 * 64);
+    set_error("N=%d exceeds the largest compiled register tile (N <= %d)", N, 2 * 80 * 64);
     return RL_EINVAL;
   }
-  ctx->N = N; ctx->L = L; ctx->W = W; ctx->lay = lay; ctx->S = S; ctx->paint_lay = play; ctx->paint_S = pS; ctx->paint_waves = pwaves;
+  ctx->N = N; ctx->L = L; ctx->W = W; ctx->lay = lay; ctx->S = S; ctx->waves = waves;
   ctx->k0 = 0; ctx->nloc = N;  // all targets until rl_set_target_range
   ctx->r.assign(r, r + L);
   ctx->rpos.assign(rpos, rpos + L + 1);
@@ -644,14 +635,14 @@ int rl_paint(rl_ctx *ctx, int sum_mode, float *kernel_ms) {
   if ((rc = ctx->d_lsb.alloc(W * nloc * sizeof(float)))) return rc;
 
   PaintParams p;
-  p.lay = ctx->paint_lay;
+  p.lay = ctx->lay;
   p.c = ctx->consts;
   p.L = ctx->L;
   p.W = ctx->W;
   p.k0 = ctx->k0;
   p.nloc = ctx->nloc;
-  p.S = ctx->paint_S;
-  p.masks = (ctx->paint_waves > 1 ? ctx->d_paint_masks : ctx->d_masks).as<unsigned long long>();
+  p.S = ctx->S;
+  p.masks = ctx->d_masks.as<unsigned long long>();
   p.plan_off = ctx->d_off.as<int64_t>();
   p.sites = ctx->d_sites.as<int32_t>();
   p.cf = ctx->d_cf.as<double>();
@@ -674,9 +665,9 @@ int rl_paint(rl_ctx *ctx, int sum_mode, float *kernel_ms) {
 
   // backward then forward on one stream, each bracketed by HIP events
   RL_HIP(hipEventRecord(ctx->ev0, ctx->s0));
-  RL_HIP(launch_paint(p, ctx->paint_S, ctx->paint_waves, 1, ctx->s0));
+  RL_HIP(launch_paint(p, ctx->S, ctx->waves, 1, ctx->s0));
   RL_HIP(hipEventRecord(ctx->ev1, ctx->s0));
-  RL_HIP(launch_paint(p, ctx->paint_S, ctx->paint_waves, 0, ctx->s0));
+  RL_HIP(launch_paint(p, ctx->S, ctx->waves, 0, ctx->s0));
   RL_HIP(hipEventRecord(ctx->ev2, ctx->s0));
   RL_HIP(hipEventSynchronize(ctx->ev2));
   RL_HIP(hipEventElapsedTime(&ctx->ms_bwd, ctx->ev0, ctx->ev1));

@@ -25,7 +25,7 @@ inline int choose_S(const Layout &lay) {
 }
 
 // the layout of all kernels: all N donors, the target keeps a slot that is pinned to +0.0;
-// cut into 64*waves balanced runs (waves = 1 except for K1 at N > 5120, see paint_waves)
+// cut into 64*waves balanced runs (target_waves)
 inline Layout make_layout(int N, int waves = 1) {
   Layout l;
   l.N = N;
@@ -34,9 +34,9 @@ inline Layout make_layout(int N, int waves = 1) {
   l.rem = N % (64 * waves);
   return l;
 }
-// K1 gives a target to a workgroup of two waves once one wave would need more than 80
-// registers per lane (two waves per SIMD need the kernel to stay within 256 VGPRs)
-inline int paint_waves(int N) { return N > 80 * 64 ? 2 : 1; }
+// K1 and K2 give a target to a workgroup of two waves once one wave would need more than 80
+// registers per lane (two waves per SIMD need the kernels to stay within 256 VGPRs)
+inline int target_waves(int N) { return N > 80 * 64 ? 2 : 1; }
 #define RL_FOR_EACH_S_2WAVES(X) X(48, 16) X(64, 16) X(80, 16)
 hipError_t launch_lane_masks(const uint32_t *bits, int row_words, int L, const Layout &lay, int S, int waves,
                              unsigned long long *masks, hipStream_t stream);
@@ -46,13 +46,13 @@ hipError_t launch_lane_masks(const uint32_t *bits, int row_words, int L, const L
 template <int MODE>
 hipError_t launch_paint_mode(const PaintParams &p, int S, int waves, int backward, hipStream_t stream);
 template <int MODE>
-hipError_t launch_repaint_mode(const RepaintParams &p, int S, int nblocks, int *counter, hipStream_t stream);
+hipError_t launch_repaint_mode(const RepaintParams &p, int S, int waves, int nblocks, int *counter, hipStream_t stream);
 template <> hipError_t launch_paint_mode<0>(const PaintParams &, int, int, int, hipStream_t);
 template <> hipError_t launch_paint_mode<1>(const PaintParams &, int, int, int, hipStream_t);
 template <> hipError_t launch_paint_mode<2>(const PaintParams &, int, int, int, hipStream_t);
-template <> hipError_t launch_repaint_mode<0>(const RepaintParams &, int, int, int *, hipStream_t);
-template <> hipError_t launch_repaint_mode<1>(const RepaintParams &, int, int, int *, hipStream_t);
-template <> hipError_t launch_repaint_mode<2>(const RepaintParams &, int, int, int *, hipStream_t);
+template <> hipError_t launch_repaint_mode<0>(const RepaintParams &, int, int, int, int *, hipStream_t);
+template <> hipError_t launch_repaint_mode<1>(const RepaintParams &, int, int, int, int *, hipStream_t);
+template <> hipError_t launch_repaint_mode<2>(const RepaintParams &, int, int, int, int *, hipStream_t);
 
 inline int kernel_mode(int sum_mode) { return sum_mode == 0 ? 1 : (sum_mode == 1 ? 0 : 2); }
 inline hipError_t launch_paint(const PaintParams &p, int S, int waves, int backward, hipStream_t stream) {
@@ -62,13 +62,14 @@ inline hipError_t launch_paint(const PaintParams &p, int S, int waves, int backw
     default: return launch_paint_mode<2>(p, S, waves, backward, stream);
   }
 }
-inline hipError_t launch_repaint(const RepaintParams &p, int S, int nblocks, int *counter, hipStream_t stream) {
+inline hipError_t launch_repaint(const RepaintParams &p, int S, int waves, int nblocks, int *counter,
+                                 hipStream_t stream) {
   switch (kernel_mode(p.sum_mode)) {
-    case 0: return launch_repaint_mode<0>(p, S, nblocks, counter, stream);
-    case 1: return launch_repaint_mode<1>(p, S, nblocks, counter, stream);
-    default: return launch_repaint_mode<2>(p, S, nblocks, counter, stream);
+    case 0: return launch_repaint_mode<0>(p, S, waves, nblocks, counter, stream);
+    case 1: return launch_repaint_mode<1>(p, S, waves, nblocks, counter, stream);
+    default: return launch_repaint_mode<2>(p, S, waves, nblocks, counter, stream);
   }
 }
-hipError_t launch_matrix(const MatrixParams &p, const Layout &lay, int S, hipStream_t stream);
+hipError_t launch_matrix(const MatrixParams &p, const Layout &lay, int S, int waves, hipStream_t stream);
 
 }  // namespace rl

@@ -13,7 +13,7 @@ namespace rl {
 
 // register-major index of donor j in a posterior row (layout over all N donors;
 // the target's own entry holds 0 = alpha[n]*beta[n])
-RL_DEV int phys_index(const Layout &lay, int j) {
+RL_DEV int phys_index(const Layout &lay, int S, int j) {
   const int p = j;
   const int big = lay.rem * (lay.q + 1);
   int l, i;
@@ -25,16 +25,16 @@ RL_DEV int phys_index(const Layout &lay, int j) {
     l = lay.rem + p2 / lay.q;  // q > 0 here because p2 >= 0 implies lanes of length q exist
     i = p2 - (l - lay.rem) * lay.q;
   }
-  return i * 64 + l;
+  return ((l >> 6) * S + i) * 64 + (l & 63);  // [wave][register][lane], l = virtual lane
 }
 
-__global__ void __launch_bounds__(256) matrix_kernel(const MatrixParams p, const Layout lay, int S) {
+__global__ void __launch_bounds__(256) matrix_kernel(const MatrixParams p, const Layout lay, int S, int waves) {
   extern __shared__ float vals[];  // N floats
   __shared__ float red[256];
   const int t = blockIdx.x;   // row of this context
   const int n = p.k0 + t;     // its target
   const int N = p.N;
-  const int64_t stride = (int64_t)S * 64;
+  const int64_t stride = (int64_t)S * 64 * waves;
   const int64_t r0 = p.top_off[t] + p.v_snp_prev[t];
   const float *__restrict__ tp = p.topology + r0 * stride;
   const float *__restrict__ tn = tp + stride;
@@ -49,10 +49,10 @@ __global__ void __launch_bounds__(256) matrix_kernel(const MatrixParams p, const
   for (int j = threadIdx.x; j < N; j += blockDim.x) {
     float v;
     if (direct) {
-      const float x = tp[phys_index(lay, j)];
+      const float x = tp[phys_index(lay, S, j)];
       v = (fast_log_dev(x) + ls_prev) * scale;  // :128
     } else {
-      const int idx = phys_index(lay, j);
+      const int idx = phys_index(lay, S, j);
       const float xp = tp[idx], xn = tn[idx];
       if (ls_prev <= ls_next) {  // :172-178
         const float x = (float)(wl * xp * e_pn + wr * xn);
@@ -79,8 +79,8 @@ __global__ void __launch_bounds__(256) matrix_kernel(const MatrixParams p, const
   for (int j = threadIdx.x; j < N; j += blockDim.x) out[j] = (j == n) ? 0.0f : vals[j] - mn;  // :190-192
 }
 
-hipError_t launch_matrix(const MatrixParams &p, const Layout &lay, int S, hipStream_t stream) {
-  hipLaunchKernelGGL(matrix_kernel, dim3(p.nloc), dim3(256), (size_t)p.N * sizeof(float), stream, p, lay, S);
+hipError_t launch_matrix(const MatrixParams &p, const Layout &lay, int S, int waves, hipStream_t stream) {
+  hipLaunchKernelGGL(matrix_kernel, dim3(p.nloc), dim3(256), (size_t)p.N * sizeof(float), stream, p, lay, S, waves);
   return hipGetLastError();
 }
 

@@ -39,10 +39,12 @@ RL_DEV void load_stone(const PaintLane<S> &pl, const float *__restrict__ in, dou
   }
 }
 
-template <int S, int TAIL, int MODE>
-RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ scratch, float *stage) {
+template <int S, int TAIL, int MODE, int WAVES>
+RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ scratch, float *stage,
+                           WaveLink<WAVES> &lk) {
+  const int wv = lk.w;  // this wave of the target's workgroup (wave-uniform)
   PaintLane<S> pl;
-  pl.init(p.lay, n);
+  pl.init(p.lay, n, wv);
   const PaintConsts &c = p.c;
   const int t = n - p.k0;  // index into the per-target arrays of this context
   const int ib = p.ib[t], ie = p.ie[t];
@@ -52,7 +54,10 @@ RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ s
   const double *__restrict__ cfp = p.cf + off;
   const double *__restrict__ nx = p.nxt + off;
   const double cf_last = p.cf_last[t], nxt_last = p.nxt_last[t];
-  constexpr int ROW = (S + 1) * 64;  // doubles per scratch row (+64: per-lane logscale copy)
+  constexpr int WROW = (S + 1) * 64;    // doubles per wave and scratch row (+64: per-lane logscale copy)
+  constexpr int ROW = WROW * WAVES;     // a scratch row: [wave][register][lane]
+  constexpr int TROW = S * 64 * WAVES;  // a posterior row, same order
+  scratch += (size_t)wv * WROW;
   constexpr int CH = S % 16 == 0 ? 16 : 8;  // registers per chunk of masks (forward)
   typedef typename MaskChunk<CH>::type Chunk;
   const double K1 = in_vgpr(c.K1);
@@ -65,7 +70,7 @@ RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ s
     load_stone<S>(pl, cp->alpha_begin + (size_t)t * cp->lay.N, a, stage);
   }
   set_slot<S>(a, pl.jk, pl.kbit, 0.0);  // alpha[n] = 0 for the target itself (:781)
-  double ssum = wave_sum<MODE, S>(RegTerm<S>{a}, local_sum<S>(RegTerm<S>{a}));
+  double ssum = wave_sum<MODE, S, WAVES>(RegTerm<S>{a}, local_sum<S>(RegTerm<S>{a}), lk);
   float lsf = p.ls_alpha[t];
   double prev_ls = (double)lsf;
   {
@@ -78,11 +83,11 @@ RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ s
   {
     int s1 = D > 1 ? st[1] : 0, s2 = D > 2 ? st[2] : 0;  // row pipeline as in paint_forward
     uint32_t touched = 0;
-    MaskRow row = site_row(p.masks, S, p.L, s1);
+    MaskRow row = site_row(p.masks, S, p.L, s1, WAVES, wv);
     Chunk first = load_masks<CH>(row, 0);
     for (int i = 1; i < D; i++) {
       retire_touch(touched);
-      if (i + 1 < D) touched = touch_row(p.masks, S, s2, pl.lane);
+      if (i + 1 < D) touched = touch_row(p.masks, S, s2, pl.lane, WAVES, wv);
       s1 = s2;
       if (i + 2 < D) s2 = st[i + 2];
       const double nx_i = nx[i - 1], cf_i = (i == D - 1 ? cf_last : cfp[i]);
@@ -106,9 +111,9 @@ RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ s
           lsum += v[jj];
         }
       });
-      row = site_row(p.masks, S, p.L, s1);
+      row = site_row(p.masks, S, p.L, s1, WAVES, wv);
       first = load_masks<CH>(row, 0);
-      ssum = wave_sum<MODE, S>(RegTerm<S>{a}, lsum);
+      ssum = wave_sum<MODE, S, WAVES>(RegTerm<S>{a}, lsum, lk);
       prev_ls += nx_i;
       lsf = (float)prev_ls;  // :806-807
       cfac = ssum;
@@ -131,7 +136,7 @@ RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ s
 
   // ---------------- backward (:887-1073)
   const int64_t trow0 = p.top_off[t];
-  float *__restrict__ top = p.topology + trow0 * (int64_t)(S * 64);
+  float *__restrict__ top = p.topology + trow0 * (int64_t)TROW + (size_t)wv * (S * 64);
   float *__restrict__ lsout = p.logscales + trow0;
   const double theta = in_vgpr(c.theta), ntheta = in_vgpr(c.ntheta);
   double b[S];
@@ -145,27 +150,27 @@ RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ s
     // do not fit the register file).  beta[n] of the stone is 1 at the last SNP of the chunk and 0
     // elsewhere: either way alpha[n] = 0 makes the target's own product 0
     const double *__restrict__ arow = scratch + (int64_t)(D - 1) * ROW;
-    float *trow = top + (int64_t)(D - 1) * (S * 64);
+    float *trow = top + (int64_t)(D - 1) * TROW;
 #pragma unroll
     for (int i = 0; i < S; i++) trow[i * 64 + pl.lane] = (float)(arow[i * 64 + pl.lane] * b[i]);
-    if (pl.lane == 0) lsout[D - 1] = lsf;
+    if (pl.lane == 0 && wv == 0) lsout[D - 1] = lsf;
   }
   set_slot<S>(b, pl.jk, pl.kbit, 0.0);  // from here on the target's own slot is +0.0
   int s0 = st[D - 1], s1 = D > 1 ? st[D - 2] : 0, s2 = D > 2 ? st[D - 3] : 0;
-  MaskRow rown = site_row(p.masks, S, p.L, s0);
+  MaskRow rown = site_row(p.masks, S, p.L, s0, WAVES, wv);
   double bsum;
   {
     const MaskTerm<S> term{rown, b, theta, ntheta};
-    bsum = wave_sum<MODE, S>(term, local_sum<S>(term));
+    bsum = wave_sum<MODE, S, WAVES>(term, local_sum<S>(term), lk);
   }
   cfac = cf_last * bsum;
   prev_ls = (double)p.ls_beta[t];  // :951
-  MaskRow rowh = site_row(p.masks, S, p.L, s1);
+  MaskRow rowh = site_row(p.masks, S, p.L, s1, WAVES, wv);
   u64x4 firstn = load_masks<4>(rown, 0), firsth = load_masks<4>(rowh, 0);
   uint32_t touched = 0;
   for (int j = D - 2; j >= 0; j--) {
     retire_touch(touched);
-    if (j > 0) touched = touch_row(p.masks, S, s2, pl.lane);
+    if (j > 0) touched = touch_row(p.masks, S, s2, pl.lane, WAVES, wv);
     s0 = s1;
     s1 = s2;
     if (j > 1) s2 = st[j - 2];
@@ -176,7 +181,7 @@ RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ s
     const double bt = cfac / theta - b1;
     set_slot<S>(b, pl.jk, pl.kbit, -b1);
     double lsum = 0.0;
-    MaskRow vrow = (MaskRow)(p.masks + (size_t)(p.L + 1) * S);
+    MaskRow vrow = (MaskRow)(p.masks + ((size_t)(p.L + 1) * WAVES + wv) * S);
     asm volatile("" : "+s"(vrow));
     for_each_chunk2_tail<S, 4, TAIL>(rown, rowh, vrow, firstn, firsth,
                                      [&](int j0, const u64x4 &mn, const u64x4 &mh, const u64x4 &va) {
@@ -195,7 +200,7 @@ RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ s
     });
     const MaskTerm<S> term{rowh, b, theta, ntheta};
     rown = rowh;
-    rowh = site_row(p.masks, S, p.L, s1);
+    rowh = site_row(p.masks, S, p.L, s1, WAVES, wv);
     // the first chunks of this site's alpha row: requested across the sum
     constexpr int PC = 8;  // registers per product chunk
     double ac[PC], an[PC];
@@ -205,7 +210,7 @@ RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ s
       firstn = load_masks<4>(rown, 0);
       firsth = load_masks<4>(rowh, 0);
     }
-    bsum = wave_sum<MODE, S>(term, lsum);
+    bsum = wave_sum<MODE, S, WAVES>(term, lsum, lk);
     if (MODE != 0) {
       firstn = load_masks<4>(rown, 0);
       firsth = load_masks<4>(rowh, 0);
@@ -214,7 +219,7 @@ RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ s
     lsf = (float)(als + prev_ls);  // :962-963
     cfac = bsum;
     // topology = float(alpha * beta) before the rescale of this step (:1039 vs :1047)
-    float *__restrict__ trow = top + (int64_t)j * (S * 64);
+    float *__restrict__ trow = top + (int64_t)j * TROW;
 #pragma unroll
     for (int c0 = 0; c0 < S / PC; c0++) {
       if (c0 + 1 < S / PC) {
@@ -235,15 +240,19 @@ RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ s
       cfac = 1.0;
     }
     cfac *= cf_j;
-    if (pl.lane == 0) lsout[j] = lsf;
+    if (pl.lane == 0 && wv == 0) lsout[j] = lsf;
   }
   retire_touch(touched);
 }
 
-template <int S, int TAIL, int MODE>
-__global__ void __launch_bounds__(64, (S <= 80 ? 2 : 1)) repaint_kernel(const RepaintParams p, int *counter) {
-  __shared__ float stage[16 * 64];
+template <int S, int TAIL, int MODE, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES, (S <= 80 ? 2 : 1)) repaint_kernel(const RepaintParams p, int *counter) {
+  __shared__ float stage[WAVES][16 * 64];
+  __shared__ WaveLinkStorage link;
   __shared__ int s_t;
+  WaveLink<WAVES> lk;
+  lk.s = &link;
+  lk.w = WAVES > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
   double *scratch = p.scratch + (int64_t)blockIdx.x * p.scratch_stride;
   for (;;) {
     if (threadIdx.x == 0) s_t = atomicAdd(counter, 1);
@@ -251,19 +260,33 @@ __global__ void __launch_bounds__(64, (S <= 80 ? 2 : 1)) repaint_kernel(const Re
     const int t = s_t;
     __syncthreads();
     if (t >= p.nloc) break;
-    repaint_target<S, TAIL, MODE>(p, p.order[t], scratch, stage);
+    repaint_target<S, TAIL, MODE, WAVES>(p, p.order[t], scratch, stage[lk.w], lk);
   }
 }
 
 template <>
-hipError_t launch_repaint_mode<RL_MODE>(const RepaintParams &p, int S, int nblocks, int *counter, hipStream_t stream) {
-  switch (S) {
-#define RL_CASE(s, t)                                                                                        \
-  case s:                                                                                                    \
-    hipLaunchKernelGGL((repaint_kernel<s, t, RL_MODE>), dim3(nblocks), dim3(64), 0, stream, p, counter); \
+hipError_t launch_repaint_mode<RL_MODE>(const RepaintParams &p, int S, int waves, int nblocks, int *counter,
+                                        hipStream_t stream) {
+  if (waves == 1) {
+    switch (S) {
+#define RL_CASE(s, t)                                                                                           \
+  case s:                                                                                                       \
+    hipLaunchKernelGGL((repaint_kernel<s, t, RL_MODE, 1>), dim3(nblocks), dim3(64), 0, stream, p, counter); \
     return hipGetLastError();
-    RL_FOR_EACH_S(RL_CASE)
+      RL_FOR_EACH_S(RL_CASE)
 #undef RL_CASE
+    }
+  } else if (waves == 2) {
+#ifndef RL_ONLY_S
+    switch (S) {
+#define RL_CASE(s, t)                                                                                            \
+  case s:                                                                                                        \
+    hipLaunchKernelGGL((repaint_kernel<s, t, RL_MODE, 2>), dim3(nblocks), dim3(128), 0, stream, p, counter); \
+    return hipGetLastError();
+      RL_FOR_EACH_S_2WAVES(RL_CASE)
+#undef RL_CASE
+    }
+#endif
   }
   return hipErrorInvalidValue;
 }

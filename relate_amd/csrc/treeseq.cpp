@@ -589,7 +589,7 @@ int rl_stage_build_topology(const char *out_dir, int chunk_index, int first_sect
   {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-      const double per_window = 1.3 * (double)rl_total_sites(ctx) / std::max(1, W) * 4.0 * ctx->S * 64 * 2.0 + 4.0 * ctx->N * ctx->N;
+      const double per_window = 1.3 * (double)rl_total_sites(ctx) / std::max(1, W) * 4.0 * ctx->S * 64 * ctx->waves * 2.0 + 4.0 * ctx->N * ctx->N;
       const int fit = (int)std::max(1.0, 0.8 * (double)free_b / std::max(per_window, 1.0));
       nthreads = std::min(nthreads, fit);
     }

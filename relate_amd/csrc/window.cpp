@@ -67,7 +67,7 @@ rl_window *rl_window_open(rl_ctx *ctx, int w, const char *paint_file, int first_
     return nullptr;
   }
   if (upload_plan(ctx)) return nullptr;
-  const int N = ctx->N, L = ctx->L, W = ctx->W, S = ctx->S;
+  const int N = ctx->N, L = ctx->L, W = ctx->W, S = ctx->S, waves = ctx->waves;
   const int k0 = ctx->k0, nloc = ctx->nloc;  // this context's targets; t = n - k0 indexes the per-target arrays
   const Plan &pl = ctx->plan;
 
@@ -166,7 +166,7 @@ rl_window *rl_window_open(rl_ctx *ctx, int w, const char *paint_file, int first_
 
   DevBuf d_ab, d_be, d_la, d_lb, d_ib, d_ie, d_cfl, d_nxl, d_order, d_scratch, d_counter;
   const int nblocks = std::min(nloc, 2048);
-  const int64_t scratch_stride = (int64_t)maxD * (S + 1) * 64;
+  const int64_t scratch_stride = (int64_t)maxD * (S + 1) * 64 * waves;
   int rc = 0;
   rc = rc ? rc : d_ab.upload(ab);
   rc = rc ? rc : d_be.upload(be);
@@ -178,7 +178,7 @@ rl_window *rl_window_open(rl_ctx *ctx, int w, const char *paint_file, int first_
   rc = rc ? rc : d_nxl.upload(nxt_last);
   rc = rc ? rc : d_order.upload(order);
   rc = rc ? rc : win->d_top_off.upload(win->top_off);
-  rc = rc ? rc : win->d_top.alloc((size_t)rows * S * 64 * sizeof(float));
+  rc = rc ? rc : win->d_top.alloc((size_t)rows * S * 64 * waves * sizeof(float));
   rc = rc ? rc : win->d_ls.alloc((size_t)rows * sizeof(float));
   rc = rc ? rc : d_scratch.alloc((size_t)nblocks * scratch_stride * sizeof(double));
   rc = rc ? rc : d_counter.alloc(sizeof(int));
@@ -217,7 +217,7 @@ rl_window *rl_window_open(rl_ctx *ctx, int w, const char *paint_file, int first_
 
   bool ok = hipMemsetAsync(d_counter.p, 0, sizeof(int), ctx->s0) == hipSuccess;
   ok = ok && hipEventRecord(ctx->ev0, ctx->s0) == hipSuccess;
-  hipError_t le = ok ? launch_repaint(p, S, nblocks, d_counter.as<int>(), ctx->s0) : hipErrorUnknown;
+  hipError_t le = ok ? launch_repaint(p, S, waves, nblocks, d_counter.as<int>(), ctx->s0) : hipErrorUnknown;
   ok = ok && le == hipSuccess;
   ok = ok && hipEventRecord(ctx->ev2, ctx->s0) == hipSuccess;
   hipError_t se = hipEventSynchronize(ctx->ev2);
@@ -277,22 +277,23 @@ int rl_window_get_topology(rl_window *win, int n, float *top, float *logscales) 
   }
   const rl_ctx *ctx = win->ctx;
   RL_HIP(hipSetDevice(ctx->device));
-  const int N = ctx->N, S = ctx->S;
+  const int N = ctx->N, S = ctx->S, waves = ctx->waves;
   const int t = n - win->k0;
   const int D = (int)(win->top_off[t + 1] - win->top_off[t]);
   const Layout &lay = ctx->lay;
   if (logscales) memcpy(logscales, &win->logscales[win->top_off[t]], (size_t)D * sizeof(float));
   if (top) {
-    std::vector<float> phys((size_t)D * S * 64);
-    RL_HIP(hipMemcpy(phys.data(), win->d_top.as<float>() + win->top_off[t] * (int64_t)S * 64,
+    const size_t stride = (size_t)S * 64 * waves;  // one posterior row: [wave][register][lane]
+    std::vector<float> phys((size_t)D * stride);
+    RL_HIP(hipMemcpy(phys.data(), win->d_top.as<float>() + win->top_off[t] * (int64_t)stride,
                      phys.size() * sizeof(float), hipMemcpyDeviceToHost));
     for (int d = 0; d < D; d++) {
-      const float *row = &phys[(size_t)d * S * 64];
+      const float *row = &phys[(size_t)d * stride];
       float *o = top + (size_t)d * N;
       int p = 0;  // donor order = lane runs in order (the target's own entry is 0: alpha[n] = 0, fast_painting.cpp:781)
-      for (int l = 0; l < 64; l++) {
-        const int len = lay.q + (l < lay.rem ? 1 : 0);
-        for (int i = 0; i < len; i++, p++) o[p] = row[i * 64 + l];
+      for (int vl = 0; vl < 64 * waves; vl++) {
+        const int len = lay.q + (vl < lay.rem ? 1 : 0);
+        for (int i = 0; i < len; i++, p++) o[p] = row[((size_t)(vl >> 6) * S + i) * 64 + (vl & 63)];
       }
     }
   }
@@ -376,7 +377,7 @@ static int window_matrix(rl_window *win, int snp, float *d_host, void *d_dev, fl
   p.e_np = win->d_enp.as<float>();
   p.matrix = d_dev ? static_cast<float *>(d_dev) : win->d_matrix.as<float>();
   RL_HIP(hipEventRecord(ctx->ev0, ctx->s0));
-  RL_HIP(launch_matrix(p, ctx->lay, ctx->S, ctx->s0));
+  RL_HIP(launch_matrix(p, ctx->lay, ctx->S, ctx->waves, ctx->s0));
   RL_HIP(hipEventRecord(ctx->ev2, ctx->s0));
   if (d_host)
     RL_HIP(hipMemcpyAsync(d_host, p.matrix, (size_t)nloc * N * sizeof(float), hipMemcpyDeviceToHost, ctx->s0));

@@ -20,9 +20,9 @@ def u32(a):
     return np.ascontiguousarray(a).view(np.uint32)
 
 
-def run_case(tmp_path, N, L, budget, seed, theta=0.001, rho=1.0, windows=None, via_gpu_paint=False):
+def run_case(tmp_path, N, L, budget, seed, theta=0.001, rho=1.0, windows=None, via_gpu_paint=False, chunk=None):
     o = rlutil.oracle()
-    ch = rlutil.synth_chunk(N, L, seed=seed, budget=budget)
+    ch = chunk if chunk is not None else rlutil.synth_chunk(N, L, seed=seed, budget=budget)
     ctx = api.Context()
     ctx.set_chunk(ch.seq, ch.r, ch.rpos, ch.wb)
     if theta != 0.001 or rho != 1.0:
@@ -89,3 +89,11 @@ def test_window_painting_params(tmp_path):
 def test_gpu_paint_files_feed_window(tmp_path):
     # paint files written by the HIP Paint stage, read back by both sides
     run_case(tmp_path, 96, 1400, 60000, 9, via_gpu_paint=True)
+
+
+def test_two_wavefronts_per_target(tmp_path):
+    """N > 5120: RePaint and the matrix gather run on the 128-virtual-lane layout (two wavefronts per target)"""
+    from test_edge_gpu import random_chunk
+    N = 5300
+    ch = random_chunk(N, 70, 0.15, seed=5, wb=[0, 30, 70])
+    run_case(tmp_path, N, 70, None, 5, chunk=ch, via_gpu_paint=True)
