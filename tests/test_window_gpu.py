@@ -97,3 +97,36 @@ def test_two_wavefronts_per_target(tmp_path):
     N = 5300
     ch = random_chunk(N, 70, 0.15, seed=5, wb=[0, 30, 70])
     run_case(tmp_path, N, 70, None, 5, chunk=ch, via_gpu_paint=True)
+
+
+@pytest.mark.parametrize("N,L,wb", [(130, 400, [0, 150, 400]), (5300, 70, [0, 30, 70])])
+def test_repaint_lanes_order_matches_oracle(tmp_path, N, L, wb):
+    """RL_SUM_LANES in K2: posterior rows bit-identical to the oracle run in the same summation order
+    (64 lane runs + balanced tree; 128 runs for the two-wavefront layout at N > 5120)"""
+    from test_edge_gpu import random_chunk
+    o = rlutil.oracle()
+    ch = random_chunk(N, L, 0.15, seed=N, wb=wb)
+    d = ch.ro()
+    assert o.ro_paint_chunk(C.byref(d), ch.wb.ctypes.data_as(C.c_void_p), ch.W, str(tmp_path).encode(), 4, 0, None,
+                            None) == 0
+    ctx = api.Context()
+    ctx.set_chunk(ch.seq, ch.r, ch.rpos, ch.wb)
+    order = rlutil.RoSumOrder(1, 0, 0)
+    for w in range(ch.W):
+        pf = os.path.join(str(tmp_path), "relate_%d.bin" % w)
+        recs = rlutil.parse_paint_file(pf, N)
+        win = ctx.open_window(w, pf, int(ch.wb[w]), api.RL_SUM_LANES)
+        for n in sorted(set([0, 1, N // 2, N - 1])):
+            r = recs[n]
+            D = win.rows(n)
+            top = np.zeros((D + 1, N), np.float32)
+            ls = np.zeros(D + 1, np.float32)
+            ab, be = np.ascontiguousarray(r["alpha"]), np.ascontiguousarray(r["beta"])
+            assert o.ro_repaint_section(C.byref(d), ab.ctypes.data_as(C.c_void_p), be.ctypes.data_as(C.c_void_p),
+                                        r["bb"], r["be"], C.c_float(r["la"]), C.c_float(r["lb"]), n, C.byref(order),
+                                        top.ctypes.data_as(C.c_void_p), ls.ctypes.data_as(C.c_void_p)) == D
+            gtop, gls = win.topology(n)
+            assert np.array_equal(u32(gls), u32(ls[:D])), (w, n)
+            assert np.array_equal(u32(gtop), u32(top[:D])), (w, n)
+        win.close()
+    ctx.close()
