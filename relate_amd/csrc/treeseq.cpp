@@ -583,7 +583,7 @@ int rl_stage_build_topology(const char *out_dir, int chunk_index, int first_sect
             << std::endl;
   // how many sections may be open at once: bounded by host threads and by the
   // HBM their posterior rows need (sum_n D_n rows of S*64 floats per window)
-  int nthreads = std::max(1, std::min(host_threads() / 2, 16));
+  int nthreads = std::max(1, std::min(host_threads() / 2, 64));
   if (const char *e = getenv("RELATE_AMD_SECTION_THREADS")) nthreads = std::max(1, atoi(e));
   nthreads = std::min(nthreads, last_section - first_section + 1);
   {
