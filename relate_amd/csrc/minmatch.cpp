@@ -9,6 +9,7 @@
 #include "minmatch.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 
@@ -17,10 +18,88 @@
 namespace rl {
 
 static constexpr size_t PREFETCH_AHEAD = 12;  // clusters; see MinMatch::coalesce
+static constexpr int MAX_GATHER = 32;          // columns of updated clusters gathered per merge
 
 static const float INF = std::numeric_limits<float>::infinity();
+static inline double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
-MinMatch::MinMatch(int N_, double theta) : N(N_) {
+// ---- helper threads --------------------------------------------------------
+static std::atomic<int> g_build_threads{1};
+void set_build_threads(int T) { g_build_threads = T < 1 ? 1 : (T > 64 ? 64 : T); }
+// fewer live clusters than this: a merge is too short to be worth a hand-off (RELATE_AMD_BUILD_MIN)
+static int build_min_clusters() {
+  const char *e = getenv("RELATE_AMD_BUILD_MIN");
+  const int v = e ? atoi(e) : 512;
+  return v < 2 ? 2 : v;
+}
+int build_threads() {
+  if (const char *e = getenv("RELATE_AMD_BUILD_THREADS")) {
+    const int v = atoi(e);
+    return v < 1 ? 1 : (v > 64 ? 64 : v);
+  }
+  return g_build_threads.load();
+}
+
+BuildThreads::BuildThreads(int T) : T_(T < 1 ? 1 : T) {
+  for (int t = 1; t < T_; t++) th_.emplace_back([this, t] { worker(t); });
+}
+BuildThreads::~BuildThreads() {
+  stop_ = true;
+  {
+    std::lock_guard<std::mutex> lk(m_);
+    gen_.fetch_add(1);
+  }
+  cv_.notify_all();
+  for (auto &t : th_) t.join();
+}
+void BuildThreads::worker(int t) {
+  uint64_t seen = 0;
+  for (;;) {
+    int spins = 0;
+    while (gen_.load(std::memory_order_acquire) == seen) {  // spin, then sleep
+      if (++spins < 20000) {
+        __builtin_ia32_pause();
+      } else {
+        std::unique_lock<std::mutex> lk(m_);
+        sleepers_.fetch_add(1);
+        cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen; });
+        sleepers_.fetch_sub(1);
+      }
+    }
+    seen = gen_.load(std::memory_order_acquire);
+    if (stop_) return;
+    (*job_)(t, T_);
+    done_.fetch_add(1, std::memory_order_release);
+  }
+}
+void BuildThreads::run(const std::function<void(int, int)> &job) {
+  if (T_ == 1) {
+    job(0, 1);
+    return;
+  }
+  job_ = &job;
+  done_.store(0, std::memory_order_relaxed);
+  if (sleepers_.load() > 0) {
+    std::lock_guard<std::mutex> lk(m_);
+    gen_.fetch_add(1, std::memory_order_release);
+    cv_.notify_all();
+  } else {
+    gen_.fetch_add(1, std::memory_order_release);
+    if (sleepers_.load() > 0) {  // one went to sleep in between
+      std::lock_guard<std::mutex> lk(m_);
+      cv_.notify_all();
+    }
+  }
+  job(0, T_);
+  while (done_.load(std::memory_order_acquire) != T_ - 1) __builtin_ia32_pause();
+}
+
+MinMatch::MinMatch(int N_, double theta) : N(N_), pool(N_ >= 2 * build_min_clusters() ? build_threads() : 1) {
+  kflag.resize(N);
+  upos.resize(MAX_GATHER);
+  min_parallel = (size_t)build_min_clusters();
   // tree_builder.cpp:43-44 (double log narrowed to float members)
   threshold = -0.2 * std::log(theta / (1.0 - theta));
   threshold_CF = -0.001 * std::log(theta / (1.0 - theta));
@@ -57,39 +136,66 @@ void MinMatch::consider(int x, int y) {
 
 // tree_builder.cpp:59-146 (no prior) / :1647-1735 (prior)
 void MinMatch::initialize() {
-  for (int a : cluster_index) {
-    mc[a].dist = INF;
-    mc[a].dist2 = INF;
-    float mv = min_values[a];
-    for (int l : cluster_index)
-      if (mv > d(a, l) && l != a) mv = d(a, l);
-    mv += threshold;
-    min_values[a] = mv;
-  }
-  if (CF) {
-    for (int a : cluster_index) {
-      float mv = min_values_CF[a];  // carried over from the previous build (:2399-2400)
-      for (int l : cluster_index)
-        if (mv > CF[(size_t)a * N + l] && l != a) mv = CF[(size_t)a * N + l];
-      mv += threshold_CF;
-      min_values_CF[a] = mv;
-    }
-  }
   const size_t n = cluster_index.size();
-  for (size_t ia = 0; ia < n; ia++) {
-    const int a = cluster_index[ia];
-    for (size_t ib = ia + 1; ib < n; ib++) {
-      const int b = cluster_index[ib];
-      if (min_values[a] >= d(a, b)) {
-        if (min_values[b] >= d(b, a)) {
-          consider(a, b);
-          if (best.dist > mc[b].dist || (best.dist == mc[b].dist && best.dist2 > mc[b].dist2)) {
-            best.lin1 = a; best.lin2 = b; best.dist = sym_dist; best.dist2 = mc[b].dist2;
-          }
+  const bool par = pool.size() > 1 && n >= min_parallel;
+  // row minima (+ threshold): independent per cluster
+  auto rows = [&](int t, int T) {
+    const size_t lo = n * (size_t)t / T, hi = n * (size_t)(t + 1) / T;
+    for (size_t ia = lo; ia < hi; ia++) {
+      const int a = cluster_index[ia];
+      mc[a].dist = INF;
+      mc[a].dist2 = INF;
+      float mv = min_values[a];
+      for (int l : cluster_index)
+        if (mv > d(a, l) && l != a) mv = d(a, l);
+      mv += threshold;
+      min_values[a] = mv;
+      if (CF) {
+        float mc_ = min_values_CF[a];  // carried over from the previous build (:2399-2400)
+        for (int l : cluster_index)
+          if (mc_ > CF[(size_t)a * N + l] && l != a) mc_ = CF[(size_t)a * N + l];
+        mc_ += threshold_CF;
+        min_values_CF[a] = mc_;
+      }
+    }
+  };
+  if (par)
+    pool.run(rows);
+  else
+    rows(0, 1);
+  // mutually close pairs in (a, b) order.  The first half of the test (a row scan) runs in parallel and
+  // leaves the few survivors per thread in order; the second half and the random draws stay sequential.
+  const int T = par ? pool.size() : 1;
+  if ((int)pairs.size() < T) pairs.resize(T);
+  auto scan = [&](int t, int TT) {
+    // contiguous ranges of a with equal numbers of pairs: a < n(1 - sqrt(1 - t/T))
+    auto bound = [&](int x) { return x >= TT ? n : (size_t)((double)n * (1.0 - std::sqrt(1.0 - (double)x / TT))); };
+    std::vector<std::pair<int, int>> &out = pairs[t];
+    out.clear();
+    for (size_t ia = bound(t); ia < bound(t + 1); ia++) {
+      const int a = cluster_index[ia];
+      const float mva = min_values[a];
+      const float *row = D + (size_t)a * N;
+      for (size_t ib = ia + 1; ib < n; ib++) {
+        const int b = cluster_index[ib];
+        if (mva >= row[b]) out.emplace_back(a, b);
+      }
+    }
+  };
+  if (par)
+    pool.run(scan);
+  else
+    scan(0, 1);
+  for (int t = 0; t < T; t++)
+    for (const auto &pr : pairs[t]) {
+      const int a = pr.first, b = pr.second;
+      if (min_values[b] >= d(b, a)) {
+        consider(a, b);
+        if (best.dist > mc[b].dist || (best.dist == mc[b].dist && best.dist2 > mc[b].dist2)) {
+          best.lin1 = a; best.lin2 = b; best.dist = sym_dist; best.dist2 = mc[b].dist2;
         }
       }
     }
-  }
 }
 
 // tree_builder.cpp:255-293
@@ -119,74 +225,126 @@ void MinMatch::initialize_sym() {
 // tree_builder.cpp:296-598 (no prior) / :1844-2070 (prior)
 void MinMatch::coalesce(int i, int j) {
   const float added = cluster_size[i] + cluster_size[j];
-  float min_value_k, min_value_j = INF;
+  const float csi = cluster_size[i], csj = cluster_size[j];
+  const size_t n = cluster_index.size();
+  const double tp0 = now_s();
+
+  // The reference loop over the clusters k interleaves three things; iteration k reads and writes only
+  // row k, column k and the four entries (i|j, k), (k, i|j) of the matrix, and changes candidate state
+  // (mc[], random draws) of k and of clusters BEFORE k only.  So it splits, with identical results, into
+  //
+  // Phase 1 (parallel over k): the size-weighted update of d(j,k), d(k,j); the re-scan of row k's minimum
+  //   when the old minimum sat on a changed entry (:1875-1890); whether k's candidate pair touches i or j.
+  //   The two column reads walk the matrix with a stride of one row (a new cache line each): requested a few
+  //   clusters ahead.
+  auto phase1 = [&](int t, int T) {
+    const size_t lo = n * (size_t)t / T, hi = n * (size_t)(t + 1) / T;
+    for (size_t ik = lo; ik < hi; ik++) {
+      const int k = cluster_index[ik];
+      if (ik + PREFETCH_AHEAD < hi) {
+        const float *nxt = D + (size_t)cluster_index[ik + PREFETCH_AHEAD] * N;
+        __builtin_prefetch(nxt + j, 1);
+        __builtin_prefetch(nxt + i, 0);
+      }
+      if (k == j || k == i) {
+        kflag[ik] = 0;
+        continue;
+      }
+      const float dkj = d(k, j), dki = d(k, i), dik = d(i, k), djk = d(j, k);
+      if (dik != djk) d(j, k) = (csi * dik + csj * djk) / added;
+      if (dki != dkj) d(k, j) = (csi * dki + csj * dkj) / added;
+      bool min_value_changed = false;
+      if (dkj != dki) {
+        float min_value_k = min_values[k];
+        if (std::fabs(min_value_k - threshold - dkj) < 1e-4 || std::fabs(min_value_k - threshold - dki) < 1e-4) {
+          // row minimum may have moved: rescan, stop early if the old minimum is still there
+          const float min_value_old = min_value_k - threshold;
+          min_value_k = INF;
+          min_value_changed = true;
+          for (int l : cluster_index) {
+            if (l != i && l != k) {
+              if (min_value_k > d(k, l)) {
+                min_value_k = d(k, l);
+                if (min_value_k == min_value_old) break;
+              }
+            }
+          }
+          min_value_k += threshold;
+          min_values[k] = min_value_k;
+        }
+      }
+      const bool touches = mc[k].lin1 == j || mc[k].lin2 == j || mc[k].lin1 == i || mc[k].lin2 == i;
+      const bool moved = dkj != dki || djk != dik || touches;
+      // 1: distances or candidate changed, 2: k's candidates are rebuilt (it joins the "updated" list)
+      kflag[ik] = (unsigned char)((moved ? 1 : 0) | ((moved && (min_value_changed || touches)) ? 2 : 0));
+    }
+  };
+  const bool par = pool.size() > 1 && n >= min_parallel;
+  if (par)
+    pool.run(phase1);
+  else
+    phase1(0, 1);
+
+  // Phase 1b: every later cluster k tests d(k,l) against each updated cluster l -- one more column walk per
+  // updated cluster.  Gather those columns (parallel) so that phase 2 reads them sequentially.
+  int nu = 0;
+  for (size_t ik = 0; ik < n && nu < MAX_GATHER; ik++)
+    if (kflag[ik] & 2) upos[nu++] = (int)ik;
+  if (nu > 0) {
+    if (ucol.size() < (size_t)nu * n) ucol.resize((size_t)nu * n);
+    auto gather = [&](int t, int T) {
+      for (int u = 0; u < nu; u++) {
+        const int l = cluster_index[upos[u]];
+        const size_t first = (size_t)upos[u] + 1;  // only clusters after l look at it
+        const size_t span = n - first;
+        const size_t lo = first + span * (size_t)t / T, hi = first + span * (size_t)(t + 1) / T;
+        float *dst = ucol.data() + (size_t)u * n;
+        for (size_t ik = lo; ik < hi; ik++) {
+          if (ik + PREFETCH_AHEAD < hi) __builtin_prefetch(D + (size_t)cluster_index[ik + PREFETCH_AHEAD] * N + l, 0);
+          dst[ik] = D[(size_t)cluster_index[ik] * N + l];
+        }
+      }
+    };
+    if (par)
+      pool.run(gather);
+    else
+      gather(0, 1);
+  }
+  const double tp1 = now_s();
+  t_phase1 += tp1 - tp0;
+
+  // Phase 2 (in cluster order: it draws the random numbers): candidate bookkeeping
+  float min_value_j = INF;
   int ucs = 0;
   best.dist = INF;
   best.dist2 = INF;
-  const size_t n = cluster_index.size();
   for (size_t ik = 0; ik < n; ik++) {
     const int k = cluster_index[ik];
-    // the two column reads below walk the matrix with a stride of one row (a new cache line and,
-    // without huge pages, a new page each): request them a few clusters ahead
-    if (ik + PREFETCH_AHEAD < n) {
-      const float *nxt = D + (size_t)cluster_index[ik + PREFETCH_AHEAD] * N;
-      __builtin_prefetch(nxt + j, 1);
-      __builtin_prefetch(nxt + i, 0);
-    }
     if (k == j || k == i) continue;
-    const float dkj = d(k, j), dki = d(k, i), dik = d(i, k), djk = d(j, k);
-    min_value_k = min_values[k];
-    if (dik != djk) d(j, k) = (cluster_size[i] * dik + cluster_size[j] * djk) / added;
-    if (dki != dkj) d(k, j) = (cluster_size[i] * dki + cluster_size[j] * dkj) / added;
-
-    bool min_value_changed = false;
-    if (dkj != dki) {
-      if (std::fabs(min_value_k - threshold - dkj) < 1e-4 || std::fabs(min_value_k - threshold - dki) < 1e-4) {
-        // row minimum may have moved: rescan, stop early if the old minimum is still there
-        const float min_value_old = min_value_k - threshold;
-        min_value_k = INF;
-        min_value_changed = true;
-        for (int l : cluster_index) {
-          if (l != i && l != k) {
-            if (min_value_k > d(k, l)) {
-              min_value_k = d(k, l);
-              if (min_value_k == min_value_old) break;
-            }
-          }
-        }
-        min_value_k += threshold;
-        min_values[k] = min_value_k;
-      }
-    }
-    const bool touches = mc[k].lin1 == j || mc[k].lin2 == j || mc[k].lin1 == i || mc[k].lin2 == i;
-    if (dkj != dki || djk != dik || touches) {
-      if (min_value_changed || touches) {
-        updated_cluster[ucs++] = k;
-        mc[k].dist = INF;
-        mc[k].dist2 = INF;
-        for (size_t il = 0; il < ik; il++) {  // clusters before k in iteration order
-          const int l = cluster_index[il];
-          if (d(k, l) <= min_value_k) {
-            const float min_value_l = min_values[l];
-            if (l != j && l != i) {
-              if (d(l, k) <= min_value_l) consider(k, l);
-            }
-          }
-        }
-      } else {
-        for (int u = 0; u < ucs; u++) {
-          const int l = updated_cluster[u];
-          if (d(k, l) <= min_value_k) {
-            if (d(l, k) <= min_values[l]) consider(k, l);
+    const float min_value_k = min_values[k];
+    const unsigned char f = kflag[ik];
+    if (f & 2) {
+      updated_cluster[ucs++] = k;
+      mc[k].dist = INF;
+      mc[k].dist2 = INF;
+      for (size_t il = 0; il < ik; il++) {  // clusters before k in iteration order
+        const int l = cluster_index[il];
+        if (d(k, l) <= min_value_k) {
+          const float min_value_l = min_values[l];
+          if (l != j && l != i) {
+            if (d(l, k) <= min_value_l) consider(k, l);
           }
         }
       }
     } else {
-      if (mc[k].lin1 == i) mc[k].lin1 = j;
-      if (mc[k].lin2 == i) mc[k].lin2 = j;
+      if (!(f & 1)) {
+        if (mc[k].lin1 == i) mc[k].lin1 = j;
+        if (mc[k].lin2 == i) mc[k].lin2 = j;
+      }
       for (int u = 0; u < ucs; u++) {
         const int l = updated_cluster[u];
-        if (d(k, l) <= min_value_k) {
+        const float dkl = u < nu ? ucol[(size_t)u * n + ik] : d(k, l);
+        if (dkl <= min_value_k) {
           if (d(l, k) <= min_values[l]) consider(k, l);
         }
       }
@@ -208,6 +366,7 @@ void MinMatch::coalesce(int i, int j) {
     }
   }
   if (best.dist > mc[j].dist || (best.dist == mc[j].dist && best.dist2 > mc[j].dist2)) best = mc[j];
+  t_phase2 += now_s() - tp1;
 }
 
 // tree_builder.cpp:968-1058
@@ -263,24 +422,39 @@ void MinMatch::coalesce_sym(int i, int j) {
 // merge i into j in the prior matrix and refresh j's row minimum (:2571-2596)
 void MinMatch::coalesce_cf(int i, int j) {
   float *cf = d_CF.data();
-  min_values_CF[j] = INF;
   const float added = cluster_size[i] + cluster_size[j];
+  const float csi = cluster_size[i], csj = cluster_size[j];
   const size_t n = cluster_index.size();
-  for (size_t ik = 0; ik < n; ik++) {
-    const int k = cluster_index[ik];
-    if (ik + PREFETCH_AHEAD < n) {
-      const float *nxt = cf + (size_t)cluster_index[ik + PREFETCH_AHEAD] * N;
-      __builtin_prefetch(nxt + j, 1);
-      __builtin_prefetch(nxt + i, 0);
+  // every cluster's update is independent; the row minimum is a plain minimum (order-free)
+  float part[64];
+  auto job = [&](int t, int T) {
+    const size_t lo = n * (size_t)t / T, hi = n * (size_t)(t + 1) / T;
+    float mv = INF;
+    for (size_t ik = lo; ik < hi; ik++) {
+      const int k = cluster_index[ik];
+      if (ik + PREFETCH_AHEAD < hi) {
+        const float *nxt = cf + (size_t)cluster_index[ik + PREFETCH_AHEAD] * N;
+        __builtin_prefetch(nxt + j, 1);
+        __builtin_prefetch(nxt + i, 0);
+      }
+      if (k == j || k == i) continue;
+      const float dkj = cf[(size_t)k * N + j], dki = cf[(size_t)k * N + i];
+      const float dik = cf[(size_t)i * N + k], djk = cf[(size_t)j * N + k];
+      if (dik != djk) cf[(size_t)j * N + k] = (csi * dik + csj * djk) / added;
+      if (dki != dkj) cf[(size_t)k * N + j] = (csi * dki + csj * dkj) / added;
+      if (mv > cf[(size_t)j * N + k]) mv = cf[(size_t)j * N + k];
     }
-    if (k == j || k == i) continue;
-    const float dkj = cf[(size_t)k * N + j], dki = cf[(size_t)k * N + i];
-    const float dik = cf[(size_t)i * N + k], djk = cf[(size_t)j * N + k];
-    if (dik != djk) cf[(size_t)j * N + k] = (cluster_size[i] * dik + cluster_size[j] * djk) / added;
-    if (dki != dkj) cf[(size_t)k * N + j] = (cluster_size[i] * dki + cluster_size[j] * dkj) / added;
-    if (min_values_CF[j] > cf[(size_t)j * N + k]) min_values_CF[j] = cf[(size_t)j * N + k];
-  }
-  min_values_CF[j] += threshold_CF;
+    part[t] = mv;
+  };
+  const int T = (pool.size() > 1 && n >= min_parallel) ? pool.size() : 1;
+  if (T > 1)
+    pool.run(job);
+  else
+    job(0, 1);
+  float mv = INF;
+  for (int t = 0; t < T; t++)
+    if (mv > part[t]) mv = part[t];
+  min_values_CF[j] = mv + threshold_CF;
 }
 
 // tree_builder.cpp:1061-1303 (no prior), :2358-2644 (prior); sample_ages empty
@@ -307,7 +481,11 @@ void MinMatch::quick_build(float *dmat, const float *prior, HostTree &tree) {
   best.dist2 = INF;
   best_sym.dist = INF;
 
-  initialize();
+  {
+    const double t0 = now_s();
+    initialize();
+    t_init += now_s() - t0;
+  }
 
   bool use_sym = false;
   for (int num_nodes = N; num_nodes < 2 * N - 1; num_nodes++) {
@@ -330,7 +508,11 @@ void MinMatch::quick_build(float *dmat, const float *prior, HostTree &tree) {
     tree.num_events[conv_j] = 0.0f;
     tree.child_left[num_nodes] = conv_i;
     tree.child_right[num_nodes] = conv_j;
-    if (CF) coalesce_cf(i, j);
+    if (CF) {
+      const double t0 = now_s();
+      coalesce_cf(i, j);
+      t_cf += now_s() - t0;
+    }
     coalesce(i, j);
     if (use_sym) coalesce_sym(i, j);
     cluster_size[j] = cluster_size[i] + cluster_size[j];

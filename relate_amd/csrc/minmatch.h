@@ -10,9 +10,15 @@
 #pragma once
 #include <sys/mman.h>
 
+#include <atomic>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdlib>
+#include <functional>
+#include <mutex>
 #include <new>
+#include <thread>
+#include <utility>
 #include <limits>
 #include <random>
 #include <vector>
@@ -71,11 +77,42 @@ T *HugePageAllocator<T>::allocate(size_t n) {
   return static_cast<T *>(p);
 }
 
+// A few helper threads of one tree builder.  The merges of a tree are
+// sequential, but inside a merge the distance updates of the two matrices are
+// independent per cluster and are memory-latency-bound walks down two matrix
+// columns: run(job) has every thread (the caller included) execute job(t, T).
+// Helpers spin briefly between jobs (a merge lasts tens of microseconds) and
+// fall asleep when none comes (distance matrix fetch, prior, mapping).
+class BuildThreads {
+ public:
+  explicit BuildThreads(int T);
+  ~BuildThreads();
+  int size() const { return T_; }
+  void run(const std::function<void(int, int)> &job);
+
+ private:
+  void worker(int t);
+  int T_;
+  std::vector<std::thread> th_;
+  const std::function<void(int, int)> *job_ = nullptr;
+  std::atomic<uint64_t> gen_{0};
+  std::atomic<int> done_{0}, sleepers_{0};
+  std::atomic<bool> stop_{false};
+  std::mutex m_;
+  std::condition_variable cv_;
+};
+// threads per tree builder: RELATE_AMD_BUILD_THREADS, else what the stage driver set (default 1)
+int build_threads();
+void set_build_threads(int T);
+
 class MinMatch {
  public:
   MinMatch(int N, double theta);
   // d: N*N floats, destroyed.  prior: N*N floats or nullptr.
   void quick_build(float *d, const float *prior, HostTree &tree);
+  // wall-clock of the parts, accumulated over the builds (seconds): row minima + pair scan, the parallel and the
+  // ordered half of the merges, the prior's merges
+  double t_init = 0, t_phase1 = 0, t_phase2 = 0, t_cf = 0;
 
  private:
   struct Cand {
@@ -105,6 +142,14 @@ class MinMatch {
   void coalesce(int i, int j);
   void coalesce_sym(int i, int j);
   void coalesce_cf(int i, int j);
+
+  // phase 1 of a merge (parallel) leaves per cluster: 1 = distances or candidate changed, 2 = candidates rebuilt
+  std::vector<unsigned char> kflag;
+  std::vector<int> upos;     // positions (in cluster_index) of the first updated clusters of this merge
+  std::vector<std::vector<std::pair<int, int>>> pairs;  // initialize(): half-tested pairs per thread, in order
+  std::vector<float> ucol;   // their matrix columns, gathered: ucol[u*n + ik] = d(cluster_index[ik], l_u)
+  BuildThreads pool;
+  size_t min_parallel = 512;
 };
 
 }  // namespace rl

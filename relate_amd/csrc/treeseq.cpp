@@ -285,31 +285,52 @@ static int force_map_mutation(rl_treeseq &ts, HostTree &t, SnpInfo &si, bool for
 // ancestor; the repeated float additions of `val` are replayed through a table
 // (acc[c] = val added c times, left to right), so every entry is bit-identical
 // to the reference's accumulation.
+// f(row) for row = 0..N-1 on the tree builder's share of host threads (minmatch.h build_threads)
+template <typename F>
+static void parallel_rows(int N, F f) {
+  const int T = std::min(build_threads(), std::max(1, N / 256));
+  if (T <= 1) {
+    for (int r = 0; r < N; r++) f(r);
+    return;
+  }
+  std::vector<std::thread> th;
+  for (int t = 0; t < T; t++)
+    th.emplace_back([=]() {
+      for (int r = t; r < N; r += T) f(r);
+    });
+  for (auto &x : th) x.join();
+}
+
+// dist[a][b] = val added (#clades of the previous tree that contain a but not b) times, accumulated in
+// float as the reference does (:588-606): the clades containing a but not b are a's internal ancestors
+// strictly below lca(a, b).  Row a is filled ancestor by ancestor: for ancestor v, the leaves below v's other
+// child have their lca with a at v; leaves below a node are a contiguous range of a depth-first leaf order.
 static void clade_prior(const HostTree &t, float val, MatrixBuf &dist) {
   const int N = t.N, T = 2 * N - 1;
-  dist.assign((size_t)N * N, 0.0f);
+  dist.resize((size_t)N * N);
   std::vector<int> depth(T, 0);  // internal nodes on the path node..root, inclusive of node if internal
   for (int v = T - 1; v >= N; v--) depth[v] = (t.parent[v] >= 0 ? depth[t.parent[v]] : 0) + 1;
   std::vector<float> acc((size_t)N + 1, 0.0f);
   for (int c = 1; c <= N; c++) acc[c] = acc[c - 1] + val;
-  // leaves below each node, children before parents (labels increase towards the root)
-  std::vector<std::vector<int>> leaves(T);
-  for (int i = 0; i < N; i++) leaves[i].push_back(i);
-  for (int v = N; v < T; v++) {
-    const std::vector<int> &A = leaves[t.child_left[v]], &B = leaves[t.child_right[v]];
-    const int dv = depth[v];
-    for (int a : A)
-      for (int b : B) {
-        // clades containing a but not b: internal ancestors of a strictly below v
-        dist[(size_t)a * N + b] = acc[depth[t.parent[a]] - dv];
-        dist[(size_t)b * N + a] = acc[depth[t.parent[b]] - dv];
-      }
-    leaves[v].reserve(A.size() + B.size());
-    leaves[v].insert(leaves[v].end(), A.begin(), A.end());
-    leaves[v].insert(leaves[v].end(), B.begin(), B.end());
-    std::vector<int>().swap(leaves[t.child_left[v]]);
-    std::vector<int>().swap(leaves[t.child_right[v]]);
+  // depth-first leaf order; [lo, hi) of every node (labels increase towards the root: T-1 is the root)
+  std::vector<int> size(T, 1), lo(T, 0), order(N);
+  for (int v = N; v < T; v++) size[v] = size[t.child_left[v]] + size[t.child_right[v]];
+  for (int v = T - 1; v >= N; v--) {
+    lo[t.child_left[v]] = lo[v];
+    lo[t.child_right[v]] = lo[v] + size[t.child_left[v]];
   }
+  for (int i = 0; i < N; i++) order[lo[i]] = i;
+  parallel_rows(N, [&](int a) {
+    float *row = &dist[(size_t)a * N];
+    row[a] = 0.0f;
+    const int da = depth[t.parent[a]];
+    int child = a;
+    for (int v = t.parent[a]; v >= 0; child = v, v = t.parent[v]) {
+      const int other = t.child_left[v] == child ? t.child_right[v] : t.child_left[v];
+      const float x = acc[da - depth[v]];
+      for (int p = lo[other]; p < lo[other] + size[other]; p++) row[order[p]] = x;
+    }
+  });
 }
 
 }  // namespace rl
@@ -423,13 +444,14 @@ int rl_treeseq_build(rl_treeseq *ts, int start, int end, rl_matrix_fn matrix, rl
       lap(t_matrix);
       if (consistency) {
         // carrier penalty (:563-581): d[c][*] += val, then d[c][c'] -= val
-        for (int c = 0; c < N; c++)
+        parallel_rows(N, [&](int c) {
           if (ts->member[c]) {
             float *row = &d[(size_t)c * N];
             for (int col = 0; col < N; col++) row[col] += val;
             for (int c2 = 0; c2 < N; c2++)
               if (ts->member[c2]) row[c2] -= val;
           }
+        });
         clade_prior(pt, val, dist);
         lap(t_prior);
         tb.quick_build(d.data(), dist.data(), nt);
@@ -461,8 +483,10 @@ int rl_treeseq_build(rl_treeseq *ts, int start, int end, rl_matrix_fn matrix, rl
   if (timing)
     fprintf(stderr,
             "[tree sequence] SNPs %d..%d: %d trees kept of %d built; distance matrices %.2f s, penalty + clade prior "
-            "%.2f s, MinMatch %.2f s, mutation mapping %.2f s\n",
-            start, end, num_tree, builds + 1, t_matrix, t_prior, t_build, t_map);
+            "%.2f s, MinMatch %.2f s (row minima + pair scan %.2f, merges: parallel part %.2f + ordered part %.2f, "
+            "prior's merges %.2f), mutation mapping %.2f s\n",
+            start, end, num_tree, builds + 1, t_matrix, t_prior, t_build, tb.t_init, tb.t_phase1, tb.t_phase2, tb.t_cf,
+            t_map);
   return RL_OK;
 }
 
@@ -594,6 +618,8 @@ int rl_stage_build_topology(const char *out_dir, int chunk_index, int first_sect
       nthreads = std::min(nthreads, fit);
     }
   }
+  // host threads left over by the sections help inside each tree build (minmatch.h BuildThreads)
+  set_build_threads(std::min(8, std::max(1, host_threads() / std::max(1, nthreads) / 2)));
   std::atomic<int> next(first_section);
   std::atomic<int> first_error(0);
   auto worker = [&]() {

@@ -65,6 +65,16 @@ def test_anc_mut_byte_identical_to_reference(tmp_path, oracle, name):
         assert anc == ref_anc, "section %d .anc differs (%d trees)" % (w, nt)
 
 
+def test_helper_threads_do_not_change_the_trees(tmp_path, oracle, monkeypatch):
+    """a tree builder with helper threads (parallel distance updates inside a merge) writes the same bytes"""
+    monkeypatch.setenv("RELATE_AMD_BUILD_THREADS", "3")
+    monkeypatch.setenv("RELATE_AMD_BUILD_MIN", "4")
+    fx = Fixture("synth70", tmp_path)
+    for w in (0, fx.W // 2, fx.W - 1):
+        anc, mut, nt = build_section(fx, w, tmp_path, oracle)
+        assert mut == fx.z["mut/%d" % w].tobytes() and anc == fx.z["anc/%d" % w].tobytes(), w
+
+
 def test_quickbuild_reference_unit_vectors():
     # include/test/test_treebuilder.cpp:9-139 (theta = 0.025)
     d5 = np.array([[0, 0, 1, 2, 2], [2, 0, 3, 4, 4], [0, 0, 0, 1, 1], [1, 1, 1, 0, 0], [1, 1, 1, 0, 0]], np.float32)
