@@ -17,7 +17,11 @@
 
 namespace rl {
 
-static constexpr size_t PREFETCH_AHEAD = 12;  // clusters; see MinMatch::coalesce
+static const size_t PREFETCH_AHEAD = [] {  // clusters; see MinMatch::coalesce (RELATE_AMD_PREFETCH to experiment)
+  const char *e = getenv("RELATE_AMD_PREFETCH");
+  const int v = e ? atoi(e) : 12;
+  return (size_t)(v < 1 ? 1 : v);
+}();
 static constexpr int MAX_GATHER = 32;          // columns of updated clusters gathered per merge
 
 static const float INF = std::numeric_limits<float>::infinity();
@@ -98,7 +102,13 @@ void BuildThreads::run(const std::function<void(int, int)> &job) {
 
 MinMatch::MinMatch(int N_, double theta) : N(N_), pool(N_ >= 2 * build_min_clusters() ? build_threads() : 1) {
   kflag.resize(N);
+  kmask.resize(N);
   upos.resize(MAX_GATHER);
+  part_cf.resize(64);
+  part_mvj.resize(64);
+  part_best.resize(64);
+  part_pos.resize(64);
+  visit_list.resize(64);
   min_parallel = (size_t)build_min_clusters();
   // tree_builder.cpp:43-44 (double log narrowed to float members)
   threshold = -0.2 * std::log(theta / (1.0 - theta));
@@ -228,27 +238,43 @@ void MinMatch::coalesce(int i, int j) {
   const float csi = cluster_size[i], csj = cluster_size[j];
   const size_t n = cluster_index.size();
   const double tp0 = now_s();
+  float *cf = CF ? d_CF.data() : nullptr;
+  const bool par = pool.size() > 1 && n >= min_parallel;
+  const int T = par ? pool.size() : 1;
 
-  // The reference loop over the clusters k interleaves three things; iteration k reads and writes only
+  // The reference loop over the clusters k interleaves several things; iteration k reads and writes only
   // row k, column k and the four entries (i|j, k), (k, i|j) of the matrix, and changes candidate state
   // (mc[], random draws) of k and of clusters BEFORE k only.  So it splits, with identical results, into
   //
-  // Phase 1 (parallel over k): the size-weighted update of d(j,k), d(k,j); the re-scan of row k's minimum
-  //   when the old minimum sat on a changed entry (:1875-1890); whether k's candidate pair touches i or j.
-  //   The two column reads walk the matrix with a stride of one row (a new cache line each): requested a few
-  //   clusters ahead.
-  auto phase1 = [&](int t, int T) {
-    const size_t lo = n * (size_t)t / T, hi = n * (size_t)(t + 1) / T;
+  // Phase 1 (parallel over k): the size-weighted update of d(j,k), d(k,j) -- and of the prior's matrix
+  //   (coalesce_cf, :2583-2607) --; the re-scan of row k's minimum when the old minimum sat on a changed
+  //   entry (:1875-1890); whether k's candidates have to be rebuilt.  The column reads walk the matrices
+  //   with a stride of one row (a new cache line each): requested a few clusters ahead.
+  auto phase1 = [&](int t, int TT) {
+    const size_t lo = n * (size_t)t / TT, hi = n * (size_t)(t + 1) / TT;
+    float mv_cf = INF;
     for (size_t ik = lo; ik < hi; ik++) {
       const int k = cluster_index[ik];
       if (ik + PREFETCH_AHEAD < hi) {
-        const float *nxt = D + (size_t)cluster_index[ik + PREFETCH_AHEAD] * N;
-        __builtin_prefetch(nxt + j, 1);
-        __builtin_prefetch(nxt + i, 0);
+        const size_t ro = (size_t)cluster_index[ik + PREFETCH_AHEAD] * N;
+        __builtin_prefetch(D + ro + j, 1);
+        __builtin_prefetch(D + ro + i, 0);
+        if (cf) {
+          __builtin_prefetch(cf + ro + j, 1);
+          __builtin_prefetch(cf + ro + i, 0);
+        }
       }
+      kmask[ik] = 0;
       if (k == j || k == i) {
         kflag[ik] = 0;
         continue;
+      }
+      if (cf) {
+        const float ckj = cf[(size_t)k * N + j], cki = cf[(size_t)k * N + i];
+        const float cik = cf[(size_t)i * N + k], cjk = cf[(size_t)j * N + k];
+        if (cik != cjk) cf[(size_t)j * N + k] = (csi * cik + csj * cjk) / added;
+        if (cki != ckj) cf[(size_t)k * N + j] = (csi * cki + csj * ckj) / added;
+        if (mv_cf > cf[(size_t)j * N + k]) mv_cf = cf[(size_t)j * N + k];
       }
       const float dkj = d(k, j), dki = d(k, i), dik = d(i, k), djk = d(j, k);
       if (dik != djk) d(j, k) = (csi * dik + csj * djk) / added;
@@ -274,56 +300,84 @@ void MinMatch::coalesce(int i, int j) {
         }
       }
       const bool touches = mc[k].lin1 == j || mc[k].lin2 == j || mc[k].lin1 == i || mc[k].lin2 == i;
-      const bool moved = dkj != dki || djk != dik || touches;
-      // 1: distances or candidate changed, 2: k's candidates are rebuilt (it joins the "updated" list)
-      kflag[ik] = (unsigned char)((moved ? 1 : 0) | ((moved && (min_value_changed || touches)) ? 2 : 0));
+      // 2: k's candidates are rebuilt (it joins the "updated" list).  (A cluster with unchanged distances
+      // whose candidate does not touch i or j needs nothing: the reference's renaming of i to j there is a no-op.)
+      kflag[ik] = (unsigned char)((min_value_changed || touches) ? 2 : 0);
     }
+    part_cf[t] = mv_cf;
   };
-  const bool par = pool.size() > 1 && n >= min_parallel;
   if (par)
     pool.run(phase1);
   else
     phase1(0, 1);
-
-  // Phase 1b: every later cluster k tests d(k,l) against each updated cluster l -- one more column walk per
-  // updated cluster.  Gather those columns (parallel) so that phase 2 reads them sequentially.
-  int nu = 0;
-  for (size_t ik = 0; ik < n && nu < MAX_GATHER; ik++)
-    if (kflag[ik] & 2) upos[nu++] = (int)ik;
-  if (nu > 0) {
-    if (ucol.size() < (size_t)nu * n) ucol.resize((size_t)nu * n);
-    auto gather = [&](int t, int T) {
-      for (int u = 0; u < nu; u++) {
-        const int l = cluster_index[upos[u]];
-        const size_t first = (size_t)upos[u] + 1;  // only clusters after l look at it
-        const size_t span = n - first;
-        const size_t lo = first + span * (size_t)t / T, hi = first + span * (size_t)(t + 1) / T;
-        float *dst = ucol.data() + (size_t)u * n;
-        for (size_t ik = lo; ik < hi; ik++) {
-          if (ik + PREFETCH_AHEAD < hi) __builtin_prefetch(D + (size_t)cluster_index[ik + PREFETCH_AHEAD] * N + l, 0);
-          dst[ik] = D[(size_t)cluster_index[ik] * N + l];
-        }
-      }
-    };
-    if (par)
-      pool.run(gather);
-    else
-      gather(0, 1);
+  if (cf) {  // the prior's row minimum of the merged cluster: a plain minimum, order-free
+    float mv = INF;
+    for (int t = 0; t < T; t++)
+      if (mv > part_cf[t]) mv = part_cf[t];
+    min_values_CF[j] = mv + threshold_CF;
   }
+
+  // Phase 1b (parallel over k): every later cluster k tests d(k,l) <= min_values[k] against each updated
+  //   cluster l -- one more column walk per updated cluster: the outcomes go into a bit mask per k.  The same
+  //   sweep reduces what the reference loop accumulates over all k: the row minimum of the merged cluster and
+  //   the best candidate among the clusters phase 2 will not visit (first one wins among exact ties, as
+  //   in the sequential loop: partial results are combined in cluster order).
+  int nu = 0, nupd = 0;
+  for (size_t ik = 0; ik < n; ik++)
+    if (kflag[ik] & 2) {
+      if (nu < MAX_GATHER) upos[nu++] = (int)ik;
+      nupd++;
+    }
+  const bool overflow = nupd > nu;  // more updated clusters than mask bits: phase 2 visits every later cluster
+  const size_t overflow_from = overflow ? (size_t)upos[nu - 1] + 1 : n;
+  auto sweep = [&](int t, int TT) {
+    const size_t lo = n * (size_t)t / TT, hi = n * (size_t)(t + 1) / TT;
+    Cand b;
+    size_t bpos = n;
+    float mvj = INF;
+    for (int u = 0; u < nu; u++) {  // column of updated cluster u, clusters after it only
+      const int l = cluster_index[upos[u]];
+      const size_t from = std::max(lo, (size_t)upos[u] + 1);
+      for (size_t ik = from; ik < hi; ik++) {
+        if (ik + PREFETCH_AHEAD < hi) __builtin_prefetch(D + (size_t)cluster_index[ik + PREFETCH_AHEAD] * N + l, 0);
+        const int k = cluster_index[ik];
+        if (D[(size_t)k * N + l] <= min_values[k]) kmask[ik] |= 1u << u;
+      }
+    }
+    const float *rowj = D + (size_t)j * N;
+    std::vector<int> &vis = visit_list[t];
+    vis.clear();
+    for (size_t ik = lo; ik < hi; ik++) {
+      const int k = cluster_index[ik];
+      if (k == j || k == i) continue;
+      if (rowj[k] < mvj) mvj = rowj[k];
+      const bool visited = (kflag[ik] & 2) || kmask[ik] != 0 || ik >= overflow_from;
+      if (visited) {
+        vis.push_back((int)ik);
+      } else if (b.dist > mc[k].dist || (b.dist == mc[k].dist && b.dist2 > mc[k].dist2)) {
+        b = mc[k];
+        bpos = ik;
+      }
+    }
+    part_best[t] = b;
+    part_pos[t] = bpos;
+    part_mvj[t] = mvj;
+  };
+  if (par)
+    pool.run(sweep);
+  else
+    sweep(0, 1);
   const double tp1 = now_s();
   t_phase1 += tp1 - tp0;
 
-  // Phase 2 (in cluster order: it draws the random numbers): candidate bookkeeping
-  float min_value_j = INF;
+  // Phase 2 (in cluster order: it draws the random numbers): the clusters whose candidates change
+  Cand sbest;  // best among the visited clusters, and where
+  size_t spos = n;
   int ucs = 0;
-  best.dist = INF;
-  best.dist2 = INF;
-  for (size_t ik = 0; ik < n; ik++) {
+  auto visit = [&](size_t ik) {
     const int k = cluster_index[ik];
-    if (k == j || k == i) continue;
     const float min_value_k = min_values[k];
-    const unsigned char f = kflag[ik];
-    if (f & 2) {
+    if (kflag[ik] & 2) {
       updated_cluster[ucs++] = k;
       mc[k].dist = INF;
       mc[k].dist2 = INF;
@@ -337,33 +391,64 @@ void MinMatch::coalesce(int i, int j) {
         }
       }
     } else {
-      if (!(f & 1)) {
-        if (mc[k].lin1 == i) mc[k].lin1 = j;
-        if (mc[k].lin2 == i) mc[k].lin2 = j;
-      }
       for (int u = 0; u < ucs; u++) {
         const int l = updated_cluster[u];
-        const float dkl = u < nu ? ucol[(size_t)u * n + ik] : d(k, l);
-        if (dkl <= min_value_k) {
+        const bool first = u < nu ? ((kmask[ik] >> u) & 1u) : (d(k, l) <= min_value_k);
+        if (first) {
           if (d(l, k) <= min_values[l]) consider(k, l);
         }
       }
     }
-    if (best.dist > mc[k].dist || (best.dist == mc[k].dist && best.dist2 > mc[k].dist2)) best = mc[k];
-    if (d(j, k) < min_value_j) min_value_j = d(j, k);
-  }
+    if (sbest.dist > mc[k].dist || (sbest.dist == mc[k].dist && sbest.dist2 > mc[k].dist2)) {
+      sbest = mc[k];
+      spos = ik;
+    }
+  };
+  for (int t = 0; t < T; t++)  // slices are contiguous and in order
+    for (int ik : visit_list[t]) visit((size_t)ik);
+  // the loop's running "best": smallest (dist, dist2), the earliest cluster among exact ties
+  best.dist = INF;
+  best.dist2 = INF;
+  size_t bpos = n;
+  auto take = [&](const Cand &c, size_t pos) {
+    if (pos >= n) return;
+    if (best.dist > c.dist || (best.dist == c.dist && (best.dist2 > c.dist2 || (best.dist2 == c.dist2 && pos < bpos)))) {
+      best = c;
+      bpos = pos;
+    }
+  };
+  for (int t = 0; t < T; t++) take(part_best[t], part_pos[t]);
+  take(sbest, spos);
+  float min_value_j = INF;
+  for (int t = 0; t < T; t++)
+    if (part_mvj[t] < min_value_j) min_value_j = part_mvj[t];
   min_value_j += threshold;
   min_values[j] = min_value_j;
 
-  // candidates with the merged cluster j
+  // candidates with the merged cluster j: the first half of the test is a scan of row j (parallel, survivors
+  // kept in order), the second half and the draws are sequential
   mc[j].dist = INF;
   mc[j].dist2 = INF;
-  for (int k : cluster_index) {
-    if (d(j, k) <= min_value_j) {
-      if (d(k, j) <= min_values[k]) {
-        if (k != i && k != j) consider(k, j);
+  {
+    const float *rowj = D + (size_t)j * N;
+    auto scanj = [&](int t, int TT) {
+      const size_t lo = n * (size_t)t / TT, hi = n * (size_t)(t + 1) / TT;
+      std::vector<int> &vis = visit_list[t];
+      vis.clear();
+      for (size_t ik = lo; ik < hi; ik++) {
+        const int k = cluster_index[ik];
+        if (rowj[k] <= min_value_j) vis.push_back(k);
       }
-    }
+    };
+    if (par)
+      pool.run(scanj);
+    else
+      scanj(0, 1);
+    for (int t = 0; t < T; t++)
+      for (int k : visit_list[t])
+        if (d(k, j) <= min_values[k]) {
+          if (k != i && k != j) consider(k, j);
+        }
   }
   if (best.dist > mc[j].dist || (best.dist == mc[j].dist && best.dist2 > mc[j].dist2)) best = mc[j];
   t_phase2 += now_s() - tp1;
@@ -420,43 +505,6 @@ void MinMatch::coalesce_sym(int i, int j) {
 }
 
 // merge i into j in the prior matrix and refresh j's row minimum (:2571-2596)
-void MinMatch::coalesce_cf(int i, int j) {
-  float *cf = d_CF.data();
-  const float added = cluster_size[i] + cluster_size[j];
-  const float csi = cluster_size[i], csj = cluster_size[j];
-  const size_t n = cluster_index.size();
-  // every cluster's update is independent; the row minimum is a plain minimum (order-free)
-  float part[64];
-  auto job = [&](int t, int T) {
-    const size_t lo = n * (size_t)t / T, hi = n * (size_t)(t + 1) / T;
-    float mv = INF;
-    for (size_t ik = lo; ik < hi; ik++) {
-      const int k = cluster_index[ik];
-      if (ik + PREFETCH_AHEAD < hi) {
-        const float *nxt = cf + (size_t)cluster_index[ik + PREFETCH_AHEAD] * N;
-        __builtin_prefetch(nxt + j, 1);
-        __builtin_prefetch(nxt + i, 0);
-      }
-      if (k == j || k == i) continue;
-      const float dkj = cf[(size_t)k * N + j], dki = cf[(size_t)k * N + i];
-      const float dik = cf[(size_t)i * N + k], djk = cf[(size_t)j * N + k];
-      if (dik != djk) cf[(size_t)j * N + k] = (csi * dik + csj * djk) / added;
-      if (dki != dkj) cf[(size_t)k * N + j] = (csi * dki + csj * dkj) / added;
-      if (mv > cf[(size_t)j * N + k]) mv = cf[(size_t)j * N + k];
-    }
-    part[t] = mv;
-  };
-  const int T = (pool.size() > 1 && n >= min_parallel) ? pool.size() : 1;
-  if (T > 1)
-    pool.run(job);
-  else
-    job(0, 1);
-  float mv = INF;
-  for (int t = 0; t < T; t++)
-    if (mv > part[t]) mv = part[t];
-  min_values_CF[j] = mv + threshold_CF;
-}
-
 // tree_builder.cpp:1061-1303 (no prior), :2358-2644 (prior); sample_ages empty
 void MinMatch::quick_build(float *dmat, const float *prior, HostTree &tree) {
   rng.seed(1);
@@ -508,11 +556,6 @@ void MinMatch::quick_build(float *dmat, const float *prior, HostTree &tree) {
     tree.num_events[conv_j] = 0.0f;
     tree.child_left[num_nodes] = conv_i;
     tree.child_right[num_nodes] = conv_j;
-    if (CF) {
-      const double t0 = now_s();
-      coalesce_cf(i, j);
-      t_cf += now_s() - t0;
-    }
     coalesce(i, j);
     if (use_sym) coalesce_sym(i, j);
     cluster_size[j] = cluster_size[i] + cluster_size[j];

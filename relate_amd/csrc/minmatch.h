@@ -111,8 +111,8 @@ class MinMatch {
   // d: N*N floats, destroyed.  prior: N*N floats or nullptr.
   void quick_build(float *d, const float *prior, HostTree &tree);
   // wall-clock of the parts, accumulated over the builds (seconds): row minima + pair scan, the parallel and the
-  // ordered half of the merges, the prior's merges
-  double t_init = 0, t_phase1 = 0, t_phase2 = 0, t_cf = 0;
+  // ordered half of the merges
+  double t_init = 0, t_phase1 = 0, t_phase2 = 0;
 
  private:
   struct Cand {
@@ -141,13 +141,16 @@ class MinMatch {
   void initialize_sym();
   void coalesce(int i, int j);
   void coalesce_sym(int i, int j);
-  void coalesce_cf(int i, int j);
 
   // phase 1 of a merge (parallel) leaves per cluster: 1 = distances or candidate changed, 2 = candidates rebuilt
   std::vector<unsigned char> kflag;
-  std::vector<int> upos;     // positions (in cluster_index) of the first updated clusters of this merge
+  std::vector<uint32_t> kmask;  // bit u: d(k, l_u) <= min_values[k] for the u-th updated cluster of this merge
+  std::vector<int> upos;        // positions (in cluster_index) of the first updated clusters of this merge
   std::vector<std::vector<std::pair<int, int>>> pairs;  // initialize(): half-tested pairs per thread, in order
-  std::vector<float> ucol;   // their matrix columns, gathered: ucol[u*n + ik] = d(cluster_index[ik], l_u)
+  std::vector<float> part_cf, part_mvj;  // per-thread partial results of a merge
+  std::vector<Cand> part_best;
+  std::vector<size_t> part_pos;
+  std::vector<std::vector<int>> visit_list;  // per thread: positions phase 2 visits / survivors of a row scan
   BuildThreads pool;
   size_t min_parallel = 512;
 };
