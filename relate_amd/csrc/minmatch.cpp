@@ -109,6 +109,7 @@ MinMatch::MinMatch(int N_, double theta) : N(N_), pool(N_ >= 2 * build_min_clust
   part_best.resize(64);
   part_pos.resize(64);
   visit_list.resize(64);
+  cand_j.resize(64);
   min_parallel = (size_t)build_min_clusters();
   // tree_builder.cpp:43-44 (double log narrowed to float members)
   threshold = -0.2 * std::log(theta / (1.0 - theta));
@@ -362,6 +363,15 @@ void MinMatch::coalesce(int i, int j) {
     part_best[t] = b;
     part_pos[t] = bpos;
     part_mvj[t] = mvj;
+    // survivors of the first half of the merged cluster's candidate test, d(j,k) <= min_j + threshold: the
+    // slice's own minimum is an upper bound of min_j, so this is a superset; filtered once min_j is known
+    std::vector<int> &cj = cand_j[t];
+    cj.clear();
+    const float bound = mvj + threshold;
+    for (size_t ik = lo; ik < hi; ik++) {
+      const int k = cluster_index[ik];
+      if (rowj[k] <= bound) cj.push_back(k);
+    }
   };
   if (par)
     pool.run(sweep);
@@ -425,31 +435,16 @@ void MinMatch::coalesce(int i, int j) {
   min_value_j += threshold;
   min_values[j] = min_value_j;
 
-  // candidates with the merged cluster j: the first half of the test is a scan of row j (parallel, survivors
-  // kept in order), the second half and the draws are sequential
+  // candidates with the merged cluster j (first half of the test done in the sweep)
   mc[j].dist = INF;
   mc[j].dist2 = INF;
-  {
-    const float *rowj = D + (size_t)j * N;
-    auto scanj = [&](int t, int TT) {
-      const size_t lo = n * (size_t)t / TT, hi = n * (size_t)(t + 1) / TT;
-      std::vector<int> &vis = visit_list[t];
-      vis.clear();
-      for (size_t ik = lo; ik < hi; ik++) {
-        const int k = cluster_index[ik];
-        if (rowj[k] <= min_value_j) vis.push_back(k);
-      }
-    };
-    if (par)
-      pool.run(scanj);
-    else
-      scanj(0, 1);
-    for (int t = 0; t < T; t++)
-      for (int k : visit_list[t])
+  for (int t = 0; t < T; t++)
+    for (int k : cand_j[t])
+      if (d(j, k) <= min_value_j) {
         if (d(k, j) <= min_values[k]) {
           if (k != i && k != j) consider(k, j);
         }
-  }
+      }
   if (best.dist > mc[j].dist || (best.dist == mc[j].dist && best.dist2 > mc[j].dist2)) best = mc[j];
   t_phase2 += now_s() - tp1;
 }

@@ -150,7 +150,8 @@ class MinMatch {
   std::vector<float> part_cf, part_mvj;  // per-thread partial results of a merge
   std::vector<Cand> part_best;
   std::vector<size_t> part_pos;
-  std::vector<std::vector<int>> visit_list;  // per thread: positions phase 2 visits / survivors of a row scan
+  std::vector<std::vector<int>> visit_list;  // per thread: positions phase 2 visits
+  std::vector<std::vector<int>> cand_j;      // per thread: clusters close to the merged one (superset)
   BuildThreads pool;
   size_t min_parallel = 512;
 };
