@@ -90,3 +90,29 @@ def test_find_equivalent_branches_matches_reference_binary(tmp_path, N, L, budge
         a = open(ours / "out" / "chunk_0" / ("out_%d.anc" % w), "rb").read()
         b = open(tmp_path / "out" / "chunk_0" / ("out_%d.anc" % w), "rb").read()
         assert a == b, "window %d" % w
+
+
+@pytest.mark.parametrize("seed,with_prior,threads", [(1, False, 1), (2, True, 1), (3, True, 4), (4, False, 4), (5, True, 4)])
+def test_quickbuild_random_matrices_match_reference_binary(tmp_path, monkeypatch, seed, with_prior, threads):
+    """MinMatch on unstructured matrices with many exact ties (and through the symmetric fallback), sequential and
+    with helper threads, against MinMatch::QuickBuild of the reference"""
+    import subprocess
+    from relate_amd import api
+    rng = np.random.RandomState(seed)
+    N = 220
+    d = (rng.rand(N, N) * 4 + rng.rand(N)[:, None]).astype(np.float32)
+    d[rng.rand(N, N) < 0.3] = 1.5
+    np.fill_diagonal(d, 0)
+    d.tofile(str(tmp_path / "d.bin"))
+    args = [rlutil.REF_HARNESS, "quickbuild", str(N), str(tmp_path / "d.bin"), str(tmp_path / "p.bin")]
+    prior = None
+    if with_prior:
+        prior = (np.floor(rng.rand(N, N) * 4) * 6.9).astype(np.float32)
+        prior.tofile(str(tmp_path / "prior.bin"))
+        args.append(str(tmp_path / "prior.bin"))
+    subprocess.run(args, check=True)
+    ref = np.fromfile(str(tmp_path / "p.bin"), dtype=np.int32)
+    monkeypatch.setenv("RELATE_AMD_BUILD_THREADS", str(threads))
+    monkeypatch.setenv("RELATE_AMD_BUILD_MIN", "4")
+    got = api.quickbuild(d.copy(), 0.001, prior)
+    assert np.array_equal(got, ref)

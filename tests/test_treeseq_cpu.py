@@ -75,6 +75,27 @@ def test_helper_threads_do_not_change_the_trees(tmp_path, oracle, monkeypatch):
         assert mut == fx.z["mut/%d" % w].tobytes() and anc == fx.z["anc/%d" % w].tobytes(), w
 
 
+@pytest.mark.parametrize("seed,with_prior", [(1, False), (2, True), (3, True)])
+def test_quickbuild_same_tree_with_helper_threads(monkeypatch, seed, with_prior):
+    """unstructured matrices: many clusters rebuild their candidates per merge (more than the 32 mask bits),
+    frequent row-minimum re-scans -- the threaded split of a merge must still give the sequential result"""
+    import numpy as np
+    from relate_amd import api
+    rng = np.random.RandomState(seed)
+    N = 260
+    d = (rng.rand(N, N) * 4 + rng.rand(N)[:, None]).astype(np.float32)
+    d[rng.rand(N, N) < 0.3] = 1.5  # plenty of exact ties
+    np.fill_diagonal(d, 0)
+    prior = (np.floor(rng.rand(N, N) * 4) * 6.9).astype(np.float32) if with_prior else None
+    monkeypatch.setenv("RELATE_AMD_BUILD_THREADS", "1")
+    ref = api.quickbuild(d.copy(), 0.001, None if prior is None else prior.copy())
+    monkeypatch.setenv("RELATE_AMD_BUILD_THREADS", "4")
+    monkeypatch.setenv("RELATE_AMD_BUILD_MIN", "4")
+    got = api.quickbuild(d.copy(), 0.001, None if prior is None else prior.copy())
+    for a, b in zip(ref, got):
+        assert np.array_equal(a, b)
+
+
 def test_quickbuild_reference_unit_vectors():
     # include/test/test_treebuilder.cpp:9-139 (theta = 0.025)
     d5 = np.array([[0, 0, 1, 2, 2], [2, 0, 3, 4, 4], [0, 0, 0, 1, 1], [1, 1, 1, 0, 0], [1, 1, 1, 0, 0]], np.float32)
