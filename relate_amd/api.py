@@ -243,3 +243,13 @@ def stage_build_topology(out_dir, chunk_index, first_section, last_section, pain
     _check(lib().rl_stage_build_topology(out_dir.encode(), chunk_index, first_section, last_section,
                                          1 if painting else 0, th, rho, 1 if no_consistency else 0, fb,
                                          sum_mode, device))
+
+
+def stage_find_equivalent_branches(out_dir, chunk_index=0):
+    _check(lib().rl_stage_find_equivalent_branches(out_dir.encode(), chunk_index))
+
+
+def num_sections(out_dir, chunk_index=0):
+    """number of windows (= BuildTopology sections) of a chunk, from parameters_c<chunk>.bin"""
+    p = np.fromfile(os.path.join(out_dir, "parameters_c%d.bin" % chunk_index), dtype=np.int32, count=3)
+    return int(p[2]) - 1

@@ -59,3 +59,38 @@ def all_gather_rows(rows, N):
         k0, k1 = target_range(r, world, N)
         blocks.append(out[r * maxrows: r * maxrows + (k1 - k0)])
     return torch.cat(blocks, 0)
+
+
+def section_ranges(num_sections, rank, world):
+    """contiguous, balanced [first, last] range of BuildTopology sections for a rank, or None (rl_stage_build_topology
+    takes a range and runs its sections on host threads; sections are independent, RelateParallel.sh:231-257)"""
+    k0, k1 = target_range(rank, world, num_sections)
+    return (k0, k1 - 1) if k1 > k0 else None
+
+
+def run_chunk(out_dir, chunk_index=0, painting=None, device=None, stages=None):
+    """Paint -> BuildTopology -> FindEquivalentBranches of one chunk on all ranks of the job (one process per GPU):
+    rank 0 paints and writes the paint files, every rank builds its share of the sections from them, rank 0
+    runs the (host-only) branch association.  The only synchronisation is a barrier between the stages -- the files
+    are the interface, exactly as between the reference's cluster jobs.  `stages` = object with stage_paint,
+    stage_build_topology, stage_find_equivalent_branches, num_sections (default: relate_amd.api)."""
+    if stages is None:
+        from relate_amd import api as stages
+    live = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank() if live else 0
+    world = dist.get_world_size() if live else 1
+    dev = device if device is not None else (rank if live and dist.get_backend() == "nccl" else 0)
+    if rank == 0:
+        stages.stage_paint(out_dir, chunk_index, painting=painting, device=dev)
+    if live:
+        dist.barrier()
+    rng = section_ranges(stages.num_sections(out_dir, chunk_index), rank, world)
+    if rng is not None:
+        stages.stage_build_topology(out_dir, chunk_index, rng[0], rng[1], painting=painting, device=dev)
+    if live:
+        dist.barrier()
+    if rank == 0:
+        stages.stage_find_equivalent_branches(out_dir, chunk_index)
+    if live:
+        dist.barrier()
+    return rng

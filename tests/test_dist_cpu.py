@@ -104,3 +104,53 @@ def test_target_range_is_a_partition():
             assert rs[0][0] == 0 and rs[-1][1] == N
             assert all(rs[i][1] == rs[i + 1][0] for i in range(world - 1))
             assert max(b - a for a, b in rs) - min(b - a for a, b in rs) <= 1
+
+
+def _chunk_worker(rank, world, port, q, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from relate_amd import dist as rdist
+
+    class Stages:  # records what each rank is asked to do (the real stages need a GPU)
+        calls = []
+
+        def stage_paint(self, out, c, painting=None, device=0):
+            self.calls.append(("paint", c))
+            open(os.path.join(out, "painted"), "w").close()
+
+        def num_sections(self, out, c):
+            return 7
+
+        def stage_build_topology(self, out, c, first, last, painting=None, device=0):
+            assert os.path.exists(os.path.join(out, "painted"))  # only after rank 0's paint stage
+            self.calls.append(("build", first, last))
+            open(os.path.join(out, "built_%d" % dist.get_rank()), "w").close()
+
+        def stage_find_equivalent_branches(self, out, c):
+            assert all(os.path.exists(os.path.join(out, "built_%d" % r)) for r in range(dist.get_world_size()))
+            self.calls.append(("feb", c))
+
+    st = Stages()
+    rng = rdist.run_chunk(out_dir, 0, stages=st)
+    q.put((rank, rng, st.calls))
+    dist.destroy_process_group()
+
+
+def test_chunk_pipeline_shards_sections_three_ranks(tmp_path):
+    """Paint on rank 0, BuildTopology sections split over the ranks, FindEquivalentBranches on rank 0, barriers between"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 3
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_chunk_worker, args=(r, world, port, q, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [(0, 2), (3, 4), (5, 6)]
+    assert res[0][2] == [("paint", 0), ("build", 0, 2), ("feb", 0)]
+    assert res[1][2] == [("build", 3, 4)] and res[2][2] == [("build", 5, 6)]

@@ -47,3 +47,17 @@ def test_cli_rejects_unknown_option_and_other_modes(tmp_path):
     p = subprocess.run([CLI, "--mode", "Paint", "-o", "a/b", "--chunk_index", "0"], cwd=str(tmp_path),
                        stderr=subprocess.PIPE)
     assert p.returncode != 0 and b"working directory" in p.stderr
+
+
+def test_chunk_pipeline_through_python(tmp_path):
+    """relate_amd.dist.run_chunk (one rank): Paint -> BuildTopology -> FindEquivalentBranches, every file as the
+    reference leaves it"""
+    from relate_amd import dist as rdist
+    out = tmp_path / "out"
+    out.mkdir()
+    fx = Fixture("synth70", out)
+    assert rdist.run_chunk(str(out), 0) == (0, fx.W - 1)
+    for w in range(fx.W):
+        assert open(out / "chunk_0" / "paint" / ("relate_%d.bin" % w), "rb").read() == fx.paint_file(w), w
+        assert open(out / "chunk_0" / ("out_%d.mut" % w), "rb").read() == fx.z["mut/%d" % w].tobytes(), w
+        assert open(out / "chunk_0" / ("out_%d.anc" % w), "rb").read() == fx.z["feb_anc/%d" % w].tobytes(), w
