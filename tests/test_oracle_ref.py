@@ -116,3 +116,30 @@ def test_quickbuild_random_matrices_match_reference_binary(tmp_path, monkeypatch
     monkeypatch.setenv("RELATE_AMD_BUILD_MIN", "4")
     got = api.quickbuild(d.copy(), 0.001, prior)
     assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("opts,flags,fb", [(["--no_consistency"], 1, 0), (["--fb", "3000"], 0, 3000),
+                                           (["--fb", "1500", "--no_consistency"], 1, 1500)])
+def test_treeseq_options_match_reference_binary(tmp_path, oracle, opts, flags, fb):
+    """BuildTopology's --no_consistency (no carrier penalty / clade prior) and --fb (force a new tree every fb
+    base pairs) against the reference binary, byte for byte"""
+    import test_treeseq_cpu as T
+
+    ch = rlutil.synth_chunk(90, 1500, seed=17, budget=200000)
+    ch.write(str(tmp_path / "out"))
+    rlutil.run_ref(["--mode", "Paint", "--chunk_index", "0", "-o", "out"], cwd=str(tmp_path))
+    rlutil.run_ref(["--mode", "BuildTopology", "--chunk_index", "0", "--first_section", "0", "--last_section",
+                    str(ch.W - 1), "-o", "out"] + opts, cwd=str(tmp_path))
+
+    class Fx:
+        pass
+    fx = Fx()
+    fx.chunk, fx.W, fx.dir = ch, ch.W, str(tmp_path / "out")
+    fx.write_paint_files = lambda d: os.makedirs(d, exist_ok=True) or [
+        os.replace(str(tmp_path / "out" / "chunk_0" / "paint" / ("relate_%d.bin" % w)),
+                   os.path.join(d, "relate_%d.bin" % w))
+        for w in range(ch.W) if not os.path.exists(os.path.join(d, "relate_%d.bin" % w))]
+    for w in range(ch.W):
+        anc, mut, nt = T.build_section(fx, w, tmp_path, oracle, flags=flags, fb=fb)
+        assert mut == open(tmp_path / "out" / "chunk_0" / ("out_%d.mut" % w), "rb").read(), w
+        assert anc == open(tmp_path / "out" / "chunk_0" / ("out_%d.anc" % w), "rb").read(), (w, nt)

@@ -61,3 +61,22 @@ def test_chunk_pipeline_through_python(tmp_path):
         assert open(out / "chunk_0" / "paint" / ("relate_%d.bin" % w), "rb").read() == fx.paint_file(w), w
         assert open(out / "chunk_0" / ("out_%d.mut" % w), "rb").read() == fx.z["mut/%d" % w].tobytes(), w
         assert open(out / "chunk_0" / ("out_%d.anc" % w), "rb").read() == fx.z["feb_anc/%d" % w].tobytes(), w
+
+
+@pytest.mark.parametrize("tag,opts", [("nc", ["--no_consistency"]), ("fb", ["--fb", "2500"])])
+def test_cli_build_topology_options(tmp_path, tag, opts):
+    """--no_consistency / --fb through the CLI: .anc and .mut as the reference writes them with the same option"""
+    work = tmp_path / "work"
+    (work / "out").mkdir(parents=True)
+    fx = Fixture("synth70", work / "out")
+    fx.write_paint_files(str(work / "out" / "chunk_0" / "paint"))
+    run_cli(["--mode", "BuildTopology", "--chunk_index", "0", "--first_section", "0", "--last_section",
+             str(fx.W - 1), "-o", "out"] + opts, str(work))
+    differs = 0
+    for w in range(fx.W):
+        mut = open(work / "out" / "chunk_0" / ("out_%d.mut" % w), "rb").read()
+        anc = open(work / "out" / "chunk_0" / ("out_%d.anc" % w), "rb").read()
+        assert mut == fx.z["mut_%s/%d" % (tag, w)].tobytes(), w
+        assert anc == fx.z["anc_%s/%d" % (tag, w)].tobytes(), w
+        differs += anc != fx.z["anc/%d" % w].tobytes()
+    assert differs > 0  # the option changed something

@@ -17,7 +17,7 @@ MATRIX_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_float))
 ADVANCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
 
 
-def build_section(fx, w, tmp_path, oracle, flags=0):
+def build_section(fx, w, tmp_path, oracle, flags=0, fb=0):
     lib = api.lib()
     lib.rl_treeseq_create.restype = C.c_void_p
     ch = fx.chunk
@@ -44,7 +44,7 @@ def build_section(fx, w, tmp_path, oracle, flags=0):
                                state.ctypes.data_as(C.c_void_p), C.c_double(ch.theta))
     assert ts
     mcb, acb = MATRIX_FN(matrix), ADVANCE_FN(advance)
-    rc = lib.rl_treeseq_build(C.c_void_p(ts), s0, s1, mcb, acb, None, flags, 0)
+    rc = lib.rl_treeseq_build(C.c_void_p(ts), s0, s1, mcb, acb, None, flags, fb)
     assert rc == 0, lib.rl_last_error()
     anc, mut = str(tmp_path / ("s%d.anc" % w)), str(tmp_path / ("s%d.mut" % w))
     assert lib.rl_treeseq_write(C.c_void_p(ts), anc.encode(), mut.encode()) == 0

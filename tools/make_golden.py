@@ -76,6 +76,13 @@ def collect(work, out, W, painting=None, windows_dump=(1,), with_trees=True):
         run([rlutil.REF_RELATE, "--mode", "FindEquivalentBranches", "--chunk_index", "0", "-o", out], work)
         for w in range(W):
             data["feb_anc/%d" % w] = fbytes(os.path.join(work, out, "chunk_0", "%s_%d.anc" % (out, w)))
+        # BuildTopology's options: --no_consistency, and --fb (a new tree at least every fb base pairs)
+        for tag, opts in (("nc", ["--no_consistency"]), ("fb", ["--fb", "2500"])):
+            run([rlutil.REF_RELATE, "--mode", "BuildTopology", "--chunk_index", "0", "--first_section", "0",
+                 "--last_section", str(W - 1), "-o", out] + pa + opts, work)
+            for w in range(W):
+                data["anc_%s/%d" % (tag, w)] = fbytes(os.path.join(work, out, "chunk_0", "%s_%d.anc" % (out, w)))
+                data["mut_%s/%d" % (tag, w)] = fbytes(os.path.join(work, out, "chunk_0", "%s_%d.mut" % (out, w)))
     return data
 
 
