@@ -17,11 +17,8 @@
 
 namespace rl {
 
-static const size_t PREFETCH_AHEAD = [] {  // clusters; see MinMatch::coalesce (RELATE_AMD_PREFETCH to experiment)
-  const char *e = getenv("RELATE_AMD_PREFETCH");
-  const int v = e ? atoi(e) : 12;
-  return (size_t)(v < 1 ? 1 : v);
-}();
+static constexpr size_t PREFETCH_AHEAD = 12;  // clusters; see MinMatch::coalesce (6..48 measure the same)
+static inline void pf(const void *p) { __builtin_prefetch(p, 0, 3); }
 static constexpr int MAX_GATHER = 32;          // columns of updated clusters gathered per merge
 
 static const float INF = std::numeric_limits<float>::infinity();
@@ -258,11 +255,11 @@ void MinMatch::coalesce(int i, int j) {
       const int k = cluster_index[ik];
       if (ik + PREFETCH_AHEAD < hi) {
         const size_t ro = (size_t)cluster_index[ik + PREFETCH_AHEAD] * N;
-        __builtin_prefetch(D + ro + j, 1);
-        __builtin_prefetch(D + ro + i, 0);
+        pf(D + ro + j);
+        pf(D + ro + i);
         if (cf) {
-          __builtin_prefetch(cf + ro + j, 1);
-          __builtin_prefetch(cf + ro + i, 0);
+          pf(cf + ro + j);
+          pf(cf + ro + i);
         }
       }
       kmask[ik] = 0;
@@ -311,6 +308,7 @@ void MinMatch::coalesce(int i, int j) {
     pool.run(phase1);
   else
     phase1(0, 1);
+  t_phase1a += now_s() - tp0;
   if (cf) {  // the prior's row minimum of the merged cluster: a plain minimum, order-free
     float mv = INF;
     for (int t = 0; t < T; t++)
@@ -340,7 +338,7 @@ void MinMatch::coalesce(int i, int j) {
       const int l = cluster_index[upos[u]];
       const size_t from = std::max(lo, (size_t)upos[u] + 1);
       for (size_t ik = from; ik < hi; ik++) {
-        if (ik + PREFETCH_AHEAD < hi) __builtin_prefetch(D + (size_t)cluster_index[ik + PREFETCH_AHEAD] * N + l, 0);
+        if (ik + PREFETCH_AHEAD < hi) pf(D + (size_t)cluster_index[ik + PREFETCH_AHEAD] * N + l);
         const int k = cluster_index[ik];
         if (D[(size_t)k * N + l] <= min_values[k]) kmask[ik] |= 1u << u;
       }
@@ -379,6 +377,8 @@ void MinMatch::coalesce(int i, int j) {
     sweep(0, 1);
   const double tp1 = now_s();
   t_phase1 += tp1 - tp0;
+  n_updated += nupd;
+  n_merges++;
 
   // Phase 2 (in cluster order: it draws the random numbers): the clusters whose candidates change
   Cand sbest;  // best among the visited clusters, and where
@@ -461,8 +461,8 @@ void MinMatch::coalesce_sym(int i, int j) {
     const int k = cluster_index[ik];
     if (ik + PREFETCH_AHEAD < n) {
       const float *nxt = sym_d.data() + (size_t)cluster_index[ik + PREFETCH_AHEAD] * N;
-      __builtin_prefetch(nxt + j, 1);
-      __builtin_prefetch(nxt + i, 0);
+      pf(nxt + j);
+      pf(nxt + i);
     }
     if (k == j || k == i) continue;
     const float dkj = s(k, j), dki = s(k, i), dik = s(i, k), djk = s(j, k);

@@ -112,7 +112,8 @@ class MinMatch {
   void quick_build(float *d, const float *prior, HostTree &tree);
   // wall-clock of the parts, accumulated over the builds (seconds): row minima + pair scan, the parallel and the
   // ordered half of the merges
-  double t_init = 0, t_phase1 = 0, t_phase2 = 0;
+  double t_init = 0, t_phase1 = 0, t_phase1a = 0, t_phase2 = 0;
+  long long n_updated = 0, n_merges = 0;  // clusters that rebuilt their candidates / merges
 
  private:
   struct Cand {

@@ -483,9 +483,10 @@ int rl_treeseq_build(rl_treeseq *ts, int start, int end, rl_matrix_fn matrix, rl
   if (timing)
     fprintf(stderr,
             "[tree sequence] SNPs %d..%d: %d trees kept of %d built; distance matrices %.2f s, penalty + clade prior "
-            "%.2f s, MinMatch %.2f s (row minima + pair scan %.2f, merges: parallel part %.2f + ordered part %.2f), "
-            "mutation mapping %.2f s\n",
-            start, end, num_tree, builds + 1, t_matrix, t_prior, t_build, tb.t_init, tb.t_phase1, tb.t_phase2, t_map);
+            "%.2f s, MinMatch %.2f s (row minima + pair scan %.2f, merges: parallel part %.2f [updates %.2f] + ordered part %.2f, "
+            "%.2f rebuilt clusters per merge), mutation mapping %.2f s\n",
+            start, end, num_tree, builds + 1, t_matrix, t_prior, t_build, tb.t_init, tb.t_phase1, tb.t_phase1a, tb.t_phase2,
+            (double)tb.n_updated / std::max<long long>(1, tb.n_merges), t_map);
   return RL_OK;
 }
 
