@@ -46,6 +46,10 @@ struct PaintParams {
 };
 
 // RePaintSection over one window, all targets.
+// The forward pass keeps every REPAINT_CHECKPOINT-th alpha row in the scratch strip; the backward pass rebuilds
+// the rows in between from the nearest one (repaint_kernels.hip).  Per step it also keeps 3 doubles (side record).
+constexpr int REPAINT_CHECKPOINT = 4;
+constexpr int REPAINT_SIDE = 3;  // doubles per step: the step's additive constant, its rescaling divisor (0: none), logscale
 struct RepaintParams {
   Layout lay;
   PaintConsts c;
@@ -69,8 +73,10 @@ struct RepaintParams {
   const int64_t *top_off;     // [nloc+1] row offsets into topology/logscales
   float *topology;            // [sum D][S*64] register-major: row[i*64 + lane] = donor start_lane + i
   float *logscales;           // [sum D]
-  double *scratch;            // per-block alpha rows [maxD][S*64]
+  double *scratch;            // per block: checkpoint alpha rows [ceil(maxD/CHECKPOINT)][waves][S*64], then the
+                              // side records [maxD][REPAINT_SIDE]
   int64_t scratch_stride;     // doubles per block
+  int64_t side_offset;        // doubles from the block's strip to its side records
   const int32_t *order;       // [nloc] targets (global index), longest first
   int sum_mode;
 };

@@ -54,10 +54,13 @@ RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ s
   const double *__restrict__ cfp = p.cf + off;
   const double *__restrict__ nx = p.nxt + off;
   const double cf_last = p.cf_last[t], nxt_last = p.nxt_last[t];
-  constexpr int WROW = (S + 1) * 64;    // doubles per wave and scratch row (+64: per-lane logscale copy)
+  constexpr int CK = REPAINT_CHECKPOINT;
+  constexpr int WROW = S * 64;          // doubles per wave and scratch row
   constexpr int ROW = WROW * WAVES;     // a scratch row: [wave][register][lane]
   constexpr int TROW = S * 64 * WAVES;  // a posterior row, same order
+  double *__restrict__ side = scratch + p.side_offset;  // [step][cfac, rescaling divisor or 0, logscale]
   scratch += (size_t)wv * WROW;
+  const bool scribe = pl.lane == 0 && wv == 0;  // writes the side records
   constexpr int CH = S % 16 == 0 ? 16 : 8;  // registers per chunk of masks (forward)
   typedef typename MaskChunk<CH>::type Chunk;
   const double K1 = in_vgpr(c.K1);
@@ -74,10 +77,14 @@ RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ s
   float lsf = p.ls_alpha[t];
   double prev_ls = (double)lsf;
   {
-    double *row = scratch;
+    double *row = scratch;  // row 0 is a checkpoint
 #pragma unroll
     for (int i = 0; i < S; i++) row[i * 64 + pl.lane] = a[i];
-    row[S * 64 + pl.lane] = (double)lsf;
+    if (scribe) {
+      side[0] = 0.0;
+      side[1] = 0.0;
+      side[2] = (double)lsf;
+    }
   }
   double cfac = (D == 1 ? cf_last : cfp[0]) * ssum;
   {
@@ -91,6 +98,8 @@ RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ s
       s1 = s2;
       if (i + 2 < D) s2 = st[i + 2];
       const double nx_i = nx[i - 1], cf_i = (i == D - 1 ? cf_last : cfp[i]);
+      const double cfac_used = cfac;
+      double divisor = 0.0;
       set_slot<S>(a, pl.jk, pl.kbit, -cfac);  // the target's own slot: (-c) + c = +0.0
       double lsum = 0.0;
       for_each_chunk_from<S, CH>(row, first, [&](int j0, const Chunk &m) {
@@ -120,16 +129,23 @@ RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ s
       if (cfac < c.lower || cfac > c.upper) {  // :865-877
 #pragma unroll
         for (int j = 0; j < S; j++) a[j] /= ssum;
+        divisor = ssum;
         const double lg = log(ssum);
         prev_ls += lg;
         lsf = (float)((double)lsf + lg);
         cfac = 1.0;
       }
       cfac *= cf_i;
-      double *srow = scratch + (int64_t)i * ROW;
+      if (i % CK == 0) {  // checkpoint row
+        double *srow = scratch + (int64_t)(i / CK) * ROW;
 #pragma unroll
-      for (int j = 0; j < S; j++) srow[j * 64 + pl.lane] = a[j];
-      srow[S * 64 + pl.lane] = (double)lsf;
+        for (int j = 0; j < S; j++) srow[j * 64 + pl.lane] = a[j];
+      }
+      if (scribe) {  // what the backward pass needs to redo this step from the previous row
+        side[(size_t)i * REPAINT_SIDE + 0] = cfac_used;
+        side[(size_t)i * REPAINT_SIDE + 1] = divisor;
+        side[(size_t)i * REPAINT_SIDE + 2] = (double)lsf;
+      }
     }
     retire_touch(touched);
   }
@@ -145,17 +161,49 @@ RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ s
     const ColdRepaint cp = cold_params<RepaintParams>();
     load_stone<S>(pl, cp->beta_end + (size_t)t * cp->lay.N, b, stage);
   }
-  {
-    // row D-1 (:930), alpha re-read from the scratch strip so that `a` is dead by now (a and b together
-    // do not fit the register file).  beta[n] of the stone is 1 at the last SNP of the chunk and 0
-    // elsewhere: either way alpha[n] = 0 makes the target's own product 0
-    const double *__restrict__ arow = scratch + (int64_t)(D - 1) * ROW;
-    float *trow = top + (int64_t)(D - 1) * TROW;
+  if constexpr (WAVES > 1) __syncthreads();  // the side records of wave 0 are visible to wave 1
+  __threadfence_block();
+  set_slot<S>(b, pl.jk, pl.kbit, 0.0);  // the target's own slot of beta is +0.0 (fast_painting.cpp: b[k] = 0)
+  // topology row j = float(alpha_j * beta_j).  alpha_j is rebuilt chunk by chunk from the nearest checkpoint row
+  // at or before j: up to CK-1 forward steps (the same operations on the same operands: same bits).  Its slots of
+  // the target itself and past a lane's run come out as finite garbage there; beta is +0.0 in both.
+  auto product_row = [&](int j) {
+    const int cp = j - j % CK, r = j - cp;
+    const double *__restrict__ arow = scratch + (int64_t)(cp / CK) * ROW;
+    float *__restrict__ trow = top + (int64_t)j * TROW;
+    MaskRow rows[CK];
+    double cfs[CK], dvs[CK];
 #pragma unroll
-    for (int i = 0; i < S; i++) trow[i * 64 + pl.lane] = (float)(arow[i * 64 + pl.lane] * b[i]);
-    if (pl.lane == 0 && wv == 0) lsout[D - 1] = lsf;
-  }
-  set_slot<S>(b, pl.jk, pl.kbit, 0.0);  // from here on the target's own slot is +0.0
+    for (int q = 1; q < CK; q++) {
+      const int i = cp + q <= j ? cp + q : j;  // (unused beyond r)
+      rows[q] = site_row(p.masks, S, p.L, st[i], WAVES, wv);
+      cfs[q] = side[(size_t)i * REPAINT_SIDE + 0];
+      dvs[q] = side[(size_t)i * REPAINT_SIDE + 1];
+    }
+#pragma unroll
+    for (int c0 = 0; c0 < S / 8; c0++) {
+      double a8[8];
+#pragma unroll
+      for (int jj = 0; jj < 8; jj++) a8[jj] = arow[(c0 * 8 + jj) * 64 + pl.lane];
+#pragma unroll
+      for (int q = 1; q < CK; q++) {
+        if (q <= r) {  // wave-uniform
+          const u64x8 m = load_masks<8>(rows[q], c0);
+#pragma unroll
+          for (int jj = 0; jj < 8; jj++) a8[jj] = a8[jj] + cfs[q];
+          masked_mul8<0>(a8, m, K1);
+          if (dvs[q] != 0.0) {
+#pragma unroll
+            for (int jj = 0; jj < 8; jj++) a8[jj] /= dvs[q];
+          }
+        }
+      }
+#pragma unroll
+      for (int jj = 0; jj < 8; jj++) trow[(c0 * 8 + jj) * 64 + pl.lane] = (float)(a8[jj] * b[c0 * 8 + jj]);
+    }
+  };
+  product_row(D - 1);  // :930
+  if (pl.lane == 0 && wv == 0) lsout[D - 1] = lsf;
   int s0 = st[D - 1], s1 = D > 1 ? st[D - 2] : 0, s2 = D > 2 ? st[D - 3] : 0;
   MaskRow rown = site_row(p.masks, S, p.L, s0, WAVES, wv);
   double bsum;
@@ -175,8 +223,7 @@ RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ s
     s1 = s2;
     if (j > 1) s2 = st[j - 2];
     const double nx_j = (j + 1 == D - 1 ? nxt_last : nx[j + 1]), cf_j = cfp[j];
-    const double *__restrict__ arow = scratch + (int64_t)j * ROW;  // alpha of this site, re-read below
-    const double als = arow[S * 64 + pl.lane];
+    const double als = side[(size_t)j * REPAINT_SIDE + 2];  // the forward logscale of this site
     const double b1 = cfac / ntheta;
     const double bt = cfac / theta - b1;
     set_slot<S>(b, pl.jk, pl.kbit, -b1);
@@ -201,11 +248,6 @@ RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ s
     const MaskTerm<S> term{rowh, b, theta, ntheta};
     rown = rowh;
     rowh = site_row(p.masks, S, p.L, s1, WAVES, wv);
-    // the first chunks of this site's alpha row: requested across the sum
-    constexpr int PC = 8;  // registers per product chunk
-    double ac[PC], an[PC];
-#pragma unroll
-    for (int jj = 0; jj < PC; jj++) ac[jj] = arow[jj * 64 + pl.lane];
     if (MODE == 0) {
       firstn = load_masks<4>(rown, 0);
       firsth = load_masks<4>(rowh, 0);
@@ -218,19 +260,7 @@ RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ s
     prev_ls += nx_j;
     lsf = (float)(als + prev_ls);  // :962-963
     cfac = bsum;
-    // topology = float(alpha * beta) before the rescale of this step (:1039 vs :1047)
-    float *__restrict__ trow = top + (int64_t)j * TROW;
-#pragma unroll
-    for (int c0 = 0; c0 < S / PC; c0++) {
-      if (c0 + 1 < S / PC) {
-#pragma unroll
-        for (int jj = 0; jj < PC; jj++) an[jj] = arow[((c0 + 1) * PC + jj) * 64 + pl.lane];
-      }
-#pragma unroll
-      for (int jj = 0; jj < PC; jj++) trow[(c0 * PC + jj) * 64 + pl.lane] = (float)(ac[jj] * b[c0 * PC + jj]);
-#pragma unroll
-      for (int jj = 0; jj < PC; jj++) ac[jj] = an[jj];
-    }
+    product_row(j);  // topology = float(alpha * beta) before the rescale of this step (:1039 vs :1047)
     if (cfac < c.lower || cfac > c.upper) {  // :1047-1061
 #pragma unroll
       for (int i = 0; i < S; i++) b[i] /= bsum;

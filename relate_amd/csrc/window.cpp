@@ -166,7 +166,8 @@ rl_window *rl_window_open(rl_ctx *ctx, int w, const char *paint_file, int first_
 
   DevBuf d_ab, d_be, d_la, d_lb, d_ib, d_ie, d_cfl, d_nxl, d_order, d_scratch, d_counter;
   const int nblocks = std::min(nloc, 2048);
-  const int64_t scratch_stride = (int64_t)maxD * (S + 1) * 64 * waves;
+  const int64_t side_offset = (int64_t)((maxD + REPAINT_CHECKPOINT - 1) / REPAINT_CHECKPOINT) * S * 64 * waves;
+  const int64_t scratch_stride = side_offset + (int64_t)maxD * REPAINT_SIDE;
   int rc = 0;
   rc = rc ? rc : d_ab.upload(ab);
   rc = rc ? rc : d_be.upload(be);
@@ -212,6 +213,7 @@ rl_window *rl_window_open(rl_ctx *ctx, int w, const char *paint_file, int first_
   p.logscales = win->d_ls.as<float>();
   p.scratch = d_scratch.as<double>();
   p.scratch_stride = scratch_stride;
+  p.side_offset = side_offset;
   p.order = d_order.as<int32_t>();
   p.sum_mode = sum_mode;
 
