@@ -605,21 +605,42 @@ int rl_stage_build_topology(const char *out_dir, int chunk_index, int first_sect
   std::cerr << "---------------------------------------------------------" << std::endl;
   std::cerr << "Estimating topologies of AncesTrees in sections " << first_section << "-" << last_section << "..."
             << std::endl;
-  // how many sections may be open at once: bounded by host threads and by the
-  // HBM their posterior rows need (sum_n D_n rows of S*64 floats per window)
+  // How many sections are open at once is bounded by host threads and by HBM: a window's posterior rows (sum_n D_n
+  // rows of S*64*waves floats) stay resident while its trees are built.  Every open is admitted against the HBM
+  // that is free at that moment (window_bytes below); the estimate here only sizes the thread pools.
+  if (!ctx->plan.valid && build_plan(ctx)) {
+    rl_destroy(ctx);
+    return RL_EINVAL;
+  }
+  const double row_bytes = 4.0 * ctx->S * 64 * ctx->waves;
+  auto window_bytes = [&](int w) {
+    double rows = 0;
+    int maxD = 1;
+    for (int n = ctx->k0; n < ctx->k0 + ctx->nloc; n++) {
+      const int D = ctx->plan.ie[(size_t)n * W + w] - ctx->plan.ia[(size_t)n * W + w] + 1;
+      rows += D;
+      maxD = std::max(maxD, D);
+    }
+    const double scratch = 8.0 * std::min(ctx->nloc, 2048) *
+                           ((double)((maxD + REPAINT_CHECKPOINT - 1) / REPAINT_CHECKPOINT) * ctx->S * 64 * ctx->waves +
+                            (double)maxD * REPAINT_SIDE);
+    return rows * (row_bytes + 4.0) + scratch + 3.0 * 4.0 * ctx->N * ctx->N + 64e6;
+  };
   int nthreads = std::max(1, std::min(host_threads() / 2, 64));
   if (const char *e = getenv("RELATE_AMD_SECTION_THREADS")) nthreads = std::max(1, atoi(e));
   nthreads = std::min(nthreads, last_section - first_section + 1);
+  int concurrent = nthreads;
   {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-      const double per_window = 1.3 * (double)rl_total_sites(ctx) / std::max(1, W) * 4.0 * ctx->S * 64 * ctx->waves * 2.0 + 4.0 * ctx->N * ctx->N;
-      const int fit = (int)std::max(1.0, 0.8 * (double)free_b / std::max(per_window, 1.0));
-      nthreads = std::min(nthreads, fit);
+      const double per_window = window_bytes((first_section + last_section) / 2);
+      concurrent = std::max(1, std::min(nthreads, (int)(0.9 * (double)free_b / std::max(per_window, 1.0))));
+      nthreads = std::min(nthreads, concurrent + 2);  // a couple more wait for room instead of idling a slot
     }
   }
   // host threads left over by the sections help inside each tree build (minmatch.h BuildThreads)
-  set_build_threads(std::min(8, std::max(1, host_threads() / std::max(1, nthreads) / 2)));
+  set_build_threads(std::min(8, std::max(1, host_threads() / std::max(1, concurrent) / 2)));
+  std::atomic<int> open_sections(0);
   std::atomic<int> next(first_section);
   std::atomic<int> first_error(0);
   auto worker = [&]() {
@@ -636,16 +657,28 @@ int rl_stage_build_topology(const char *out_dir, int chunk_index, int first_sect
       int end = (section < W - 1) ? ctx->wb[section + 1] - 1 : L - 1;
       if (end >= L) end = L - 1;
       const std::string pf = od + "/chunk_" + c + "/paint/relate_" + std::to_string(section) + ".bin";
-      rl_window *win;
-      {
-        std::lock_guard<std::mutex> lk(g_gpu_mutex);
-        win = rl_window_open(ctx, section, pf.c_str(), start, sum_mode, nullptr);
+      rl_window *win = nullptr;
+      const double need = window_bytes(section);
+      for (;;) {  // admission: wait until the window fits next to the ones that are open
+        {
+          std::lock_guard<std::mutex> lk(g_gpu_mutex);
+          size_t free_b = 0, total_b = 0;
+          const bool known = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
+          if (!known || (double)free_b >= need || open_sections.load() == 0) {
+            win = rl_window_open(ctx, section, pf.c_str(), start, sum_mode, nullptr);
+            if (win) open_sections++;
+            break;
+          }
+        }
+        if (first_error.load()) break;
+        std::this_thread::sleep_for(std::chrono::milliseconds(50));
       }
-      int r = win ? RL_OK : RL_EIO;
+      int r = win ? RL_OK : (first_error.load() ? first_error.load() : RL_EIO);
       if (!r) r = rl_treeseq_build(ts, start, end, win_matrix, win_advance, win, flags, fb);
       if (win) {
         std::lock_guard<std::mutex> lk(g_gpu_mutex);
         rl_window_close(win);
+        open_sections--;
       }
       if (!r) {
         const std::string b = od + "/chunk_" + c + "/" + base + "_" + std::to_string(section);
