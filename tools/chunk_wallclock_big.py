@@ -52,7 +52,7 @@ with tempfile.TemporaryDirectory() as work:
                             str(min(sections, W) - 1), "-o", "out"], cwd=work, stderr=subprocess.PIPE,
                            env=dict(os.environ, RELATE_AMD_TIMING="1"))
         assert p.returncode == 0, p.stderr.decode()[-400:]
-        out["build_topology_phases"] = [l.strip() for l in p.stderr.decode().split("\n") if l.startswith("[tree sequence]")]
+        out["build_topology_phases"] = [l.strip() for l in p.stderr.decode().split("\n") if "[tree sequence]" in l]
     t2 = time.time()
     out["build_topology_s"] = t2 - t1
     trees = snps = 0
