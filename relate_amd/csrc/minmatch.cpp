@@ -316,8 +316,10 @@ void MinMatch::coalesce(int i, int j) {
     min_values_CF[j] = mv + threshold_CF;
   }
 
-  // Phase 1b (parallel over k): every later cluster k tests d(k,l) <= min_values[k] against each updated
-  //   cluster l -- one more column walk per updated cluster: the outcomes go into a bit mask per k.  The same
+  // Phase 1b (parallel over k): a pair (k, l) of a later cluster k and an updated cluster l is a candidate when
+  //   d(k,l) <= min_values[k] and d(l,k) <= min_values[l].  The reference tests k's half first, one more walk
+  //   down column l per updated cluster; both halves are pure, so l's half -- a scan along row l -- goes first
+  //   here, into a bit mask per k, and phase 2 looks up k's half for the few survivors only.  The same
   //   sweep reduces what the reference loop accumulates over all k: the row minimum of the merged cluster and
   //   the best candidate among the clusters phase 2 will not visit (first one wins among exact ties, as
   //   in the sequential loop: partial results are combined in cluster order).
@@ -334,14 +336,13 @@ void MinMatch::coalesce(int i, int j) {
     Cand b;
     size_t bpos = n;
     float mvj = INF;
-    for (int u = 0; u < nu; u++) {  // column of updated cluster u, clusters after it only
+    for (int u = 0; u < nu; u++) {  // row of updated cluster u, clusters after it only
       const int l = cluster_index[upos[u]];
+      const float *rowl = D + (size_t)l * N;
+      const float mvl = min_values[l];
       const size_t from = std::max(lo, (size_t)upos[u] + 1);
-      for (size_t ik = from; ik < hi; ik++) {
-        if (ik + PREFETCH_AHEAD < hi) pf(D + (size_t)cluster_index[ik + PREFETCH_AHEAD] * N + l);
-        const int k = cluster_index[ik];
-        if (D[(size_t)k * N + l] <= min_values[k]) kmask[ik] |= 1u << u;
-      }
+      for (size_t ik = from; ik < hi; ik++)
+        if (rowl[cluster_index[ik]] <= mvl) kmask[ik] |= 1u << u;
     }
     const float *rowj = D + (size_t)j * N;
     std::vector<int> &vis = visit_list[t];
@@ -403,8 +404,9 @@ void MinMatch::coalesce(int i, int j) {
     } else {
       for (int u = 0; u < ucs; u++) {
         const int l = updated_cluster[u];
-        const bool first = u < nu ? ((kmask[ik] >> u) & 1u) : (d(k, l) <= min_value_k);
-        if (first) {
+        if (u < nu) {  // l's half of the test is in the mask
+          if (((kmask[ik] >> u) & 1u) && d(k, l) <= min_value_k) consider(k, l);
+        } else if (d(k, l) <= min_value_k) {
           if (d(l, k) <= min_values[l]) consider(k, l);
         }
       }

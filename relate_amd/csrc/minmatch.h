@@ -145,7 +145,7 @@ class MinMatch {
 
   // phase 1 of a merge (parallel) leaves per cluster: 1 = distances or candidate changed, 2 = candidates rebuilt
   std::vector<unsigned char> kflag;
-  std::vector<uint32_t> kmask;  // bit u: d(k, l_u) <= min_values[k] for the u-th updated cluster of this merge
+  std::vector<uint32_t> kmask;  // bit u: d(l_u, k) <= min_values[l_u] for the u-th updated cluster of this merge
   std::vector<int> upos;        // positions (in cluster_index) of the first updated clusters of this merge
   std::vector<std::vector<std::pair<int, int>>> pairs;  // initialize(): half-tested pairs per thread, in order
   std::vector<float> part_cf, part_mvj;  // per-thread partial results of a merge
