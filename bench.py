@@ -76,6 +76,27 @@ def cpu_baseline(N, L, bits, r, rpos, wb, seconds_target=15.0):
                        "%.1f s wall" % (count, N, stride, cores, dt))
 
 
+def chunk_wallclock_sample():
+    """The other half of BASELINE.json's metric, "chunk wall-clock, N=5000": a bounded sample through the drop-in
+    CLI, files in -> files out, in a child process (tools/chunk_wallclock_big.py): the Paint stage of an N=5000 x
+    L=20000 chunk and BuildTopology of its first section.  Not part of the timed steps."""
+    import subprocess
+    tool = os.path.join(ROOT, "tools", "chunk_wallclock_big.py")
+    try:
+        p = subprocess.run([sys.executable, tool, "5000", "20000", "20", "1"], stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, timeout=900)
+        d = json.loads(p.stdout.decode().strip().split("\n")[-1])
+        return {"workload": "synthetic N=5000 x L=20000 chunk (%d windows) through Relate --mode Paint (whole chunk) "
+                            "and --mode BuildTopology (section 0), chunk files in, paint/.anc/.mut files out" %
+                            d["windows"],
+                "paint_stage_s": d["paint_stage_s"], "paint_files_GB": d["paint_files_GB"],
+                "build_topology_section_s": d["build_topology_s"], "trees": d["trees"],
+                "snps_in_section": d["snps_in_timed_sections"], "host_threads": d["host_threads"],
+                "build_topology_phases": d.get("build_topology_phases"), "md5": d["md5"]}
+    except Exception as e:  # a sample, never a reason to lose the bench line
+        return {"error": str(e)[:200]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -88,6 +109,8 @@ def main():
     ap.add_argument("--skip-cpu", dest="no_cpu", action="store_true")
     ap.add_argument("--skip-alt", dest="no_alt", action="store_true", help="skip timing the other summation mode")
     ap.add_argument("--skip-k23", dest="skip_k23", action="store_true", help="skip the RePaint / matrix measurement")
+    ap.add_argument("--skip-chunk", dest="skip_chunk", action="store_true",
+                    help="skip the chunk wall-clock sample through the CLI (N=5000 runs on one GPU only)")
     ap.add_argument("--shard", default="chunks", choices=["chunks", "targets"],
                     help="chunks (default, the contract's weak scaling): one chunk per GPU, no collective. "
                          "targets: ONE chunk for all ranks, each paints a range of target haplotypes (strong "
@@ -245,8 +268,13 @@ def main():
         }
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(N, L, bits, r, rpos, wb)
+        if world == 1 and N == 5000 and not args.skip_chunk:
+            ctx.close()
+            ctx = None
+            out["config"]["chunk_wallclock_sample"] = chunk_wallclock_sample()
         print(json.dumps(out), flush=True)
-    ctx.close()
+    if ctx is not None:
+        ctx.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
