@@ -155,6 +155,19 @@ int rl_stage_paint(const char *out_dir, int chunk_index, int use_painting,
  * (anc_builder.cpp:81-101). */
 rl_window *rl_window_open(rl_ctx *ctx, int w, const char *paint_file,
                           int first_snp, int sum_mode, float *kernel_ms);
+/* The same with at most max_rows posterior rows resident (0 = all of them).
+ * The reference's DistanceMeasure keeps the whole window (`topology`,
+ * src/anc_builder.hpp:58, filled at anc_builder.cpp:75-78); a tree at `snp`
+ * reads two rows per target and the tree builder only moves forward
+ * (anc_builder.cpp:487-495), so a bounded window keeps the rows from its
+ * cursors onwards and runs RePaintSection again (same operations, same bits)
+ * when rl_window_matrix is asked for a SNP past them.  N = 5000 keeps 20 GB
+ * per window otherwise, which bounds how many sections one GPU serves.
+ * rl_window_repaints: how many times RePaintSection has run for the window. */
+rl_window *rl_window_open_bounded(rl_ctx *ctx, int w, const char *paint_file,
+                                  int first_snp, int sum_mode,
+                                  long long max_rows, float *kernel_ms);
+int rl_window_repaints(const rl_window *win);
 void rl_window_close(rl_window *win);
 int rl_window_bounds(const rl_window *win, int *start, int *end);
 /* rows D_n of target n's topology and copies of it (tests / debugging):

@@ -41,6 +41,9 @@ def lib():
         L.rl_total_sites.argtypes = [C.c_void_p]
         L.rl_window_open.restype = C.c_void_p
         L.rl_window_open.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_void_p]
+        L.rl_window_open_bounded.restype = C.c_void_p
+        L.rl_window_open_bounded.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_longlong,
+                                             C.c_void_p]
         L.rl_window_close.argtypes = [C.c_void_p]
         L.rl_stage_paint.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int]
         L.rl_stage_build_topology.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
@@ -163,19 +166,20 @@ class Context:
         os.makedirs(paint_dir, exist_ok=True)
         _check(lib().rl_write_paint_files(C.c_void_p(self._h), paint_dir.encode()))
 
-    def open_window(self, w, paint_file=None, first_snp=None, sum_mode=RL_SUM_EXACT):
-        return Window(self, w, paint_file, first_snp, sum_mode)
+    def open_window(self, w, paint_file=None, first_snp=None, sum_mode=RL_SUM_EXACT, max_rows=0):
+        """max_rows > 0: keep at most that many posterior rows resident (rl_window_open_bounded)"""
+        return Window(self, w, paint_file, first_snp, sum_mode, max_rows)
 
 
 class Window:
     """DistanceMeasure for one window (rl_window): topology resident in HBM."""
 
-    def __init__(self, ctx, w, paint_file, first_snp, sum_mode):
+    def __init__(self, ctx, w, paint_file, first_snp, sum_mode, max_rows=0):
         self.ctx = ctx
         ms = C.c_float(0)
         fs = -1 if first_snp is None else int(first_snp)
-        self._h = lib().rl_window_open(C.c_void_p(ctx._h), w, paint_file.encode() if paint_file else None,
-                                       fs, sum_mode, C.byref(ms))
+        self._h = lib().rl_window_open_bounded(C.c_void_p(ctx._h), w, paint_file.encode() if paint_file else None,
+                                               fs, sum_mode, int(max_rows), C.byref(ms))
         if not self._h:
             raise RelateError(lib().rl_last_error().decode())
         self.repaint_ms = ms.value
@@ -193,6 +197,11 @@ class Window:
 
     def rows(self, n):
         return lib().rl_window_rows(C.c_void_p(self._h), n)
+
+    @property
+    def repaints(self):
+        """times RePaintSection has run for this window (> 1 only for a bounded one)"""
+        return lib().rl_window_repaints(C.c_void_p(self._h))
 
     def topology(self, n):
         D, N = self.rows(n), self.ctx.N

@@ -70,8 +70,12 @@ struct RepaintParams {
   const float *beta_end;      // [nloc][N]
   const float *ls_alpha;      // [nloc]
   const float *ls_beta;       // [nloc]
-  const int64_t *top_off;     // [nloc+1] row offsets into topology/logscales
-  float *topology;            // [sum D][S*64] register-major: row[i*64 + lane] = donor start_lane + i
+  const int64_t *top_off;     // [nloc+1] row offsets into logscales (every posterior row of the window)
+  // Posterior rows [row_lo, row_hi) of target t are kept, row j at topology row slab_off[t] + j - row_lo[t]: the
+  // whole window (row_lo = 0, row_hi = D, slab_off = top_off) or the part of it the tree builder is working in.
+  const int64_t *slab_off;    // [nloc]
+  const int32_t *row_lo, *row_hi;  // [nloc]
+  float *topology;            // [kept rows][S*64] register-major: row[i*64 + lane] = donor start_lane + i
   float *logscales;           // [sum D]
   double *scratch;            // per block: checkpoint alpha rows [ceil(maxD/CHECKPOINT)][waves][S*64], then the
                               // side records [maxD][REPAINT_SIDE]
@@ -86,7 +90,8 @@ struct MatrixParams {
   int k0, nloc;  // rows of targets k0 .. k0+nloc-1; per-row arrays and `matrix` are indexed by t = n - k0
   const float *topology;
   const float *logscales;
-  const int64_t *top_off;   // [nloc+1]
+  const int64_t *top_off;   // [nloc+1] row offsets into logscales
+  const int64_t *slab_base;   // [nloc] posterior row j of target t is topology row slab_base[t] + j
   const int32_t *v_snp_prev;  // [nloc]
   const uint8_t *direct;      // [nloc] 1: no interpolation
   const double *wl, *wr;      // [nloc] interpolation weights

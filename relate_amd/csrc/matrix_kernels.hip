@@ -36,7 +36,7 @@ __global__ void __launch_bounds__(256) matrix_kernel(const MatrixParams p, const
   const int N = p.N;
   const int64_t stride = (int64_t)S * 64 * waves;
   const int64_t r0 = p.top_off[t] + p.v_snp_prev[t];
-  const float *__restrict__ tp = p.topology + r0 * stride;
+  const float *__restrict__ tp = p.topology + (p.slab_base[t] + p.v_snp_prev[t]) * stride;
   const float *__restrict__ tn = tp + stride;
   const float ls_prev = p.logscales[r0];
   const bool direct = p.direct[t] != 0;

@@ -151,9 +151,9 @@ RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ s
   }
 
   // ---------------- backward (:887-1073)
-  const int64_t trow0 = p.top_off[t];
-  float *__restrict__ top = p.topology + trow0 * (int64_t)TROW + (size_t)wv * (S * 64);
-  float *__restrict__ lsout = p.logscales + trow0;
+  const int row_lo = p.row_lo[t], row_hi = p.row_hi[t];  // posterior rows that are kept
+  float *__restrict__ top = p.topology + p.slab_off[t] * (int64_t)TROW + (size_t)wv * (S * 64);
+  float *__restrict__ lsout = p.logscales + p.top_off[t];
   const double theta = in_vgpr(c.theta), ntheta = in_vgpr(c.ntheta);
   double b[S];
   lsf = lsf + p.ls_beta[t];  // float += float (:895)
@@ -168,9 +168,10 @@ RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ s
   // at or before j: up to CK-1 forward steps (the same operations on the same operands: same bits).  Its slots of
   // the target itself and past a lane's run come out as finite garbage there; beta is +0.0 in both.
   auto product_row = [&](int j) {
+    if (j < row_lo || j >= row_hi) return;  // (uniform over the workgroup)
     const int cp = j - j % CK, r = j - cp;
     const double *__restrict__ arow = scratch + (int64_t)(cp / CK) * ROW;
-    float *__restrict__ trow = top + (int64_t)j * TROW;
+    float *__restrict__ trow = top + (int64_t)(j - row_lo) * TROW;
     MaskRow rows[CK];
     double cfs[CK], dvs[CK];
 #pragma unroll

@@ -643,33 +643,55 @@ int rl_stage_build_topology(const char *out_dir, int chunk_index, int first_sect
   std::cerr << "Estimating topologies of AncesTrees in sections " << first_section << "-" << last_section << "..."
             << std::endl;
   // How many sections are open at once is bounded by host threads and by HBM: a window's posterior rows (sum_n D_n
-  // rows of S*64*waves floats) stay resident while its trees are built.  Every open is admitted against the HBM
-  // that is free at that moment (window_bytes below); the estimate here only sizes the thread pools.
+  // rows of S*64*waves floats, 20 GB at N = 5000) stay resident while its trees are built.  When the sections the
+  // host could work on do not fit, every window keeps a part of its rows and repaints as its builder moves on
+  // (rl_window_open_bounded; RELATE_AMD_WINDOW_ROWS sets the rows per window by hand).  Every open is admitted
+  // against the HBM that is free at that moment (window_bytes below); the estimate here sizes the thread pools.
   if (!ctx->plan.valid && build_plan(ctx)) {
     rl_destroy(ctx);
     return RL_EINVAL;
   }
   const double row_bytes = 4.0 * ctx->S * 64 * ctx->waves;
-  auto window_bytes = [&](int w) {
-    double rows = 0;
-    int maxD = 1;
+  long long cap_rows = 0;  // posterior rows a window keeps resident; 0: all
+  double max_rows = 0;
+  int maxD = 1;
+  std::vector<double> rows_of(W, 0.0);
+  for (int w = first_section; w <= last_section; w++) {
     for (int n = ctx->k0; n < ctx->k0 + ctx->nloc; n++) {
       const int D = ctx->plan.ie[(size_t)n * W + w] - ctx->plan.ia[(size_t)n * W + w] + 1;
-      rows += D;
+      rows_of[w] += D;
       maxD = std::max(maxD, D);
     }
-    const double scratch = 8.0 * std::min(ctx->nloc, 2048) *
-                           ((double)((maxD + REPAINT_CHECKPOINT - 1) / REPAINT_CHECKPOINT) * ctx->S * 64 * ctx->waves +
-                            (double)maxD * REPAINT_SIDE);
-    return rows * (row_bytes + 4.0) + scratch + 3.0 * 4.0 * ctx->N * ctx->N + 64e6;
+    max_rows = std::max(max_rows, rows_of[w]);
+  }
+  // stones + matrix + cursors next to the rows; RePaint's strips are one buffer of the context (reserved below)
+  const double fixed_bytes = 3.0 * 4.0 * ctx->N * ctx->nloc + 4.0 * max_rows + 64e6;
+  auto window_bytes = [&](int w) {
+    const double kept = cap_rows > 0 ? std::min(rows_of[w], (double)cap_rows) : rows_of[w];
+    return kept * row_bytes + fixed_bytes;
   };
   int nthreads = std::max(1, std::min(host_threads() / 2, 64));
   if (const char *e = getenv("RELATE_AMD_SECTION_THREADS")) nthreads = std::max(1, atoi(e));
   nthreads = std::min(nthreads, last_section - first_section + 1);
   int concurrent = nthreads;
   {
+    const size_t strips = (size_t)8 * std::min(ctx->nloc, 2048) *
+                          ((size_t)((maxD + REPAINT_CHECKPOINT - 1) / REPAINT_CHECKPOINT) * ctx->S * 64 * ctx->waves +
+                           (size_t)maxD * REPAINT_SIDE);
+    if (ctx->d_k2_scratch.alloc(strips)) {
+      rl_destroy(ctx);
+      return RL_ENOMEM;
+    }
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+    const bool known = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
+    if (const char *e = getenv("RELATE_AMD_WINDOW_ROWS")) {
+      cap_rows = std::max(0LL, atoll(e));
+    } else if (known) {
+      const double budget = 0.85 * (double)free_b / nthreads - fixed_bytes;
+      if (max_rows * row_bytes > budget)  // not below a sixteenth of a window: RePaint runs again for every part
+        cap_rows = (long long)std::max({budget / row_bytes, max_rows / 16.0, 3.0 * ctx->nloc + 64.0});
+    }
+    if (known) {
       const double per_window = window_bytes((first_section + last_section) / 2);
       concurrent = std::max(1, std::min(nthreads, (int)(0.9 * (double)free_b / std::max(per_window, 1.0))));
       nthreads = std::min(nthreads, concurrent + 2);  // a couple more wait for room instead of idling a slot
@@ -716,7 +738,7 @@ int rl_stage_build_topology(const char *out_dir, int chunk_index, int first_sect
           size_t free_b = 0, total_b = 0;
           const bool known = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
           if (!known || (double)free_b >= need || open_sections.load() == 0) {
-            win = rl_window_open(ctx, section, pf.c_str(), start, sum_mode, nullptr);
+            win = rl_window_open_bounded(ctx, section, pf.c_str(), start, sum_mode, cap_rows, nullptr);
             if (win) open_sections++;
             break;
           }

@@ -25,11 +25,137 @@ struct rl_window {
   std::vector<double> v_rpos_prev, v_rpos_next;
   DevBuf d_top, d_ls, d_top_off, d_matrix;
   DevBuf d_vsp, d_direct, d_wl, d_wr, d_epn, d_enp;
+  // What RePaint needs to run again (a bounded window keeps part of its posterior rows and recomputes as the
+  // tree builder moves on): the decoded stones, the plan slices, the last-interval coefficients.
+  DevBuf d_ab, d_be, d_la, d_lb, d_ib, d_ie, d_cfl, d_nxl, d_order;
+  DevBuf d_slab_off, d_row_lo, d_row_hi, d_slab_base;
+  std::vector<int64_t> slab_off, slab_base;  // [nloc]
+  std::vector<int32_t> row_lo, row_hi;       // [nloc] resident posterior rows [lo, hi) of each target
+  int64_t cap_rows = 0;                      // rows d_top holds; >= all rows: the whole window is resident
+  int maxD = 0, sum_mode = 0, repaints = 0;
+  bool have_logscales = false;
 };
 
 static inline bool derived(const rl_ctx *ctx, int snp, int n) {
   return (ctx->bits[(size_t)snp * ctx->row_words + (n >> 5)] >> (n & 31)) & 1u;
 }
+
+// RePaintSection for all targets of the window, keeping the posterior rows [row_lo, row_hi) (already uploaded).
+static int repaint_rows(rl_window *win, float *kernel_ms) {
+  rl_ctx *ctx = win->ctx;
+  const int N = ctx->N, S = ctx->S, waves = ctx->waves, nloc = win->nloc;
+  const int nblocks = std::min(nloc, 2048);
+  const int64_t side_offset = (int64_t)((win->maxD + REPAINT_CHECKPOINT - 1) / REPAINT_CHECKPOINT) * S * 64 * waves;
+  const int64_t scratch_stride = side_offset + (int64_t)win->maxD * REPAINT_SIDE;
+  // the strips of the forward rows are scratch of the launch: one buffer per context, launches are serialised
+  int rc = ctx->d_k2_scratch.alloc((size_t)nblocks * scratch_stride * sizeof(double));
+  rc = rc ? rc : ctx->d_k2_counter.alloc(sizeof(int));
+  if (rc) return rc;
+  RepaintParams p;
+  p.lay = ctx->lay;
+  p.c = ctx->consts;
+  p.L = ctx->L;
+  p.k0 = win->k0;
+  p.nloc = nloc;
+  p.masks = ctx->d_masks.as<unsigned long long>();
+  p.plan_off = ctx->d_off.as<int64_t>();
+  p.sites = ctx->d_sites.as<int32_t>();
+  p.cf = ctx->d_cf.as<double>();
+  p.nxt = ctx->d_nxt.as<double>();
+  p.ib = win->d_ib.as<int32_t>();
+  p.ie = win->d_ie.as<int32_t>();
+  p.cf_last = win->d_cfl.as<double>();
+  p.nxt_last = win->d_nxl.as<double>();
+  p.alpha_begin = win->d_ab.as<float>();
+  p.beta_end = win->d_be.as<float>();
+  p.ls_alpha = win->d_la.as<float>();
+  p.ls_beta = win->d_lb.as<float>();
+  p.top_off = win->d_top_off.as<int64_t>();
+  p.slab_off = win->d_slab_off.as<int64_t>();
+  p.row_lo = win->d_row_lo.as<int32_t>();
+  p.row_hi = win->d_row_hi.as<int32_t>();
+  p.topology = win->d_top.as<float>();
+  p.logscales = win->d_ls.as<float>();
+  p.scratch = ctx->d_k2_scratch.as<double>();
+  p.scratch_stride = scratch_stride;
+  p.side_offset = side_offset;
+  p.order = win->d_order.as<int32_t>();
+  p.sum_mode = win->sum_mode;
+  (void)N;
+  bool ok = hipMemsetAsync(ctx->d_k2_counter.p, 0, sizeof(int), ctx->s0) == hipSuccess;
+  ok = ok && hipEventRecord(ctx->ev0, ctx->s0) == hipSuccess;
+  hipError_t le = ok ? launch_repaint(p, S, waves, nblocks, ctx->d_k2_counter.as<int>(), ctx->s0) : hipErrorUnknown;
+  ok = ok && le == hipSuccess;
+  ok = ok && hipEventRecord(ctx->ev2, ctx->s0) == hipSuccess;
+  hipError_t se = hipEventSynchronize(ctx->ev2);
+  ok = ok && se == hipSuccess;
+  if (!ok) {
+    set_error("repaint launch failed: %s / %s", hipGetErrorString(le), hipGetErrorString(se));
+    return RL_EHIP;
+  }
+  if (kernel_ms) (void)hipEventElapsedTime(kernel_ms, ctx->ev0, ctx->ev2);
+  win->repaints++;
+  if (!win->have_logscales) {  // (every launch writes all of them, with the same values)
+    const int64_t rows = win->top_off[nloc];
+    win->logscales.resize((size_t)rows);
+    if (hipMemcpy(win->logscales.data(), win->d_ls.p, (size_t)rows * sizeof(float), hipMemcpyDeviceToHost) !=
+        hipSuccess) {
+      set_error("copy of logscales failed");
+      return RL_EHIP;
+    }
+    win->have_logscales = true;
+  }
+  return RL_OK;
+}
+
+// Choose the resident rows from the cursors at `snp` onwards and recompute them.  A tree at SNP s reads rows
+// v_snp_prev and v_snp_prev + 1 of every target, and v_snp_prev grows by one at each of the target's derived
+// sites: the rows from the cursor to two past the derived sites in [snp, last] cover all trees up to `last`,
+// which is taken as far as the capacity allows.
+static int place_rows(rl_window *win, int snp, float *kernel_ms) {
+  rl_ctx *ctx = win->ctx;
+  const int nloc = win->nloc, k0 = win->k0, L = ctx->L;
+  const int64_t all_rows = win->top_off[nloc];
+  if (win->cap_rows >= all_rows) {
+    for (int t = 0; t < nloc; t++) {
+      win->row_lo[t] = 0;
+      win->row_hi[t] = (int32_t)(win->top_off[t + 1] - win->top_off[t]);
+    }
+  } else {
+    std::vector<int32_t> extra(nloc, 0);
+    int64_t used = 2 * (int64_t)nloc;
+    const int last_wanted = std::min(L - 1, win->end + 1);
+    for (int s0 = std::max(snp, 0); s0 <= last_wanted; s0++) {
+      int64_t pop = 0;
+      for (int t = 0; t < nloc; t++) pop += derived(ctx, s0, k0 + t);
+      if (used + pop > win->cap_rows && s0 > snp) break;
+      used += pop;
+      for (int t = 0; t < nloc; t++) extra[t] += derived(ctx, s0, k0 + t);
+    }
+    for (int t = 0; t < nloc; t++) {
+      const int D = (int)(win->top_off[t + 1] - win->top_off[t]);
+      win->row_lo[t] = std::min(std::max(win->v_snp_prev[t], 0), D);
+      win->row_hi[t] = (int32_t)std::min<int64_t>(D, (int64_t)win->row_lo[t] + extra[t] + 2);
+    }
+  }
+  int64_t at = 0;
+  for (int t = 0; t < nloc; t++) {
+    win->slab_off[t] = at;
+    win->slab_base[t] = at - win->row_lo[t];
+    at += win->row_hi[t] - win->row_lo[t];
+  }
+  if (at > std::max(win->cap_rows, (int64_t)1) && win->cap_rows < all_rows) {
+    set_error("window %d: %lld posterior rows do not fit the %lld allowed", win->w, (long long)at,
+              (long long)win->cap_rows);
+    return RL_ENOMEM;
+  }
+  int rc = win->d_slab_off.upload(win->slab_off);
+  rc = rc ? rc : win->d_slab_base.upload(win->slab_base);
+  rc = rc ? rc : win->d_row_lo.upload(win->row_lo);
+  rc = rc ? rc : win->d_row_hi.upload(win->row_hi);
+  return rc ? rc : repaint_rows(win, kernel_ms);
+}
+
 
 static int read_file(const char *fn, std::vector<unsigned char> &buf) {
   FILE *fp = fopen(fn, "rb");
@@ -54,6 +180,11 @@ extern "C" {
 
 rl_window *rl_window_open(rl_ctx *ctx, int w, const char *paint_file, int first_snp, int sum_mode,
                           float *kernel_ms) {
+  return rl_window_open_bounded(ctx, w, paint_file, first_snp, sum_mode, 0, kernel_ms);
+}
+
+rl_window *rl_window_open_bounded(rl_ctx *ctx, int w, const char *paint_file, int first_snp, int sum_mode,
+                                  long long max_rows, float *kernel_ms) {
   if (!ctx || !ctx->have_chunk || w < 0 || w >= ctx->W) {
     set_error("rl_window_open: bad arguments");
     return nullptr;
@@ -67,7 +198,7 @@ rl_window *rl_window_open(rl_ctx *ctx, int w, const char *paint_file, int first_
     return nullptr;
   }
   if (upload_plan(ctx)) return nullptr;
-  const int N = ctx->N, L = ctx->L, W = ctx->W, S = ctx->S, waves = ctx->waves;
+  const int N = ctx->N, W = ctx->W, S = ctx->S, waves = ctx->waves;
   const int k0 = ctx->k0, nloc = ctx->nloc;  // this context's targets; t = n - k0 indexes the per-target arrays
   const Plan &pl = ctx->plan;
 
@@ -164,76 +295,28 @@ rl_window *rl_window_open(rl_ctx *ctx, int w, const char *paint_file, int first_
     return (ie[a - k0] - ib[a - k0]) > (ie[b - k0] - ib[b - k0]);
   });
 
-  DevBuf d_ab, d_be, d_la, d_lb, d_ib, d_ie, d_cfl, d_nxl, d_order, d_scratch, d_counter;
-  const int nblocks = std::min(nloc, 2048);
-  const int64_t side_offset = (int64_t)((maxD + REPAINT_CHECKPOINT - 1) / REPAINT_CHECKPOINT) * S * 64 * waves;
-  const int64_t scratch_stride = side_offset + (int64_t)maxD * REPAINT_SIDE;
+  win->maxD = maxD;
+  win->sum_mode = sum_mode;
+  win->cap_rows = (max_rows > 0 && max_rows < rows) ? std::max<int64_t>(max_rows, 3 * (int64_t)nloc + 64) : rows;
+  win->slab_off.assign(nloc, 0);
+  win->slab_base.assign(nloc, 0);
+  win->row_lo.assign(nloc, 0);
+  win->row_hi.assign(nloc, 0);
   int rc = 0;
-  rc = rc ? rc : d_ab.upload(ab);
-  rc = rc ? rc : d_be.upload(be);
-  rc = rc ? rc : d_la.upload(la);
-  rc = rc ? rc : d_lb.upload(lb);
-  rc = rc ? rc : d_ib.upload(ib);
-  rc = rc ? rc : d_ie.upload(ie);
-  rc = rc ? rc : d_cfl.upload(cf_last);
-  rc = rc ? rc : d_nxl.upload(nxt_last);
-  rc = rc ? rc : d_order.upload(order);
+  rc = rc ? rc : win->d_ab.upload(ab);
+  rc = rc ? rc : win->d_be.upload(be);
+  rc = rc ? rc : win->d_la.upload(la);
+  rc = rc ? rc : win->d_lb.upload(lb);
+  rc = rc ? rc : win->d_ib.upload(ib);
+  rc = rc ? rc : win->d_ie.upload(ie);
+  rc = rc ? rc : win->d_cfl.upload(cf_last);
+  rc = rc ? rc : win->d_nxl.upload(nxt_last);
+  rc = rc ? rc : win->d_order.upload(order);
   rc = rc ? rc : win->d_top_off.upload(win->top_off);
-  rc = rc ? rc : win->d_top.alloc((size_t)rows * S * 64 * waves * sizeof(float));
+  rc = rc ? rc : win->d_top.alloc((size_t)std::min(rows, win->cap_rows) * S * 64 * waves * sizeof(float));
   rc = rc ? rc : win->d_ls.alloc((size_t)rows * sizeof(float));
-  rc = rc ? rc : d_scratch.alloc((size_t)nblocks * scratch_stride * sizeof(double));
-  rc = rc ? rc : d_counter.alloc(sizeof(int));
   rc = rc ? rc : win->d_matrix.alloc((size_t)nloc * N * sizeof(float));
   if (rc) {
-    delete win;
-    return nullptr;
-  }
-
-  RepaintParams p;
-  p.lay = ctx->lay;
-  p.c = ctx->consts;
-  p.L = L;
-  p.k0 = k0;
-  p.nloc = nloc;
-  p.masks = ctx->d_masks.as<unsigned long long>();
-  p.plan_off = ctx->d_off.as<int64_t>();
-  p.sites = ctx->d_sites.as<int32_t>();
-  p.cf = ctx->d_cf.as<double>();
-  p.nxt = ctx->d_nxt.as<double>();
-  p.ib = d_ib.as<int32_t>();
-  p.ie = d_ie.as<int32_t>();
-  p.cf_last = d_cfl.as<double>();
-  p.nxt_last = d_nxl.as<double>();
-  p.alpha_begin = d_ab.as<float>();
-  p.beta_end = d_be.as<float>();
-  p.ls_alpha = d_la.as<float>();
-  p.ls_beta = d_lb.as<float>();
-  p.top_off = win->d_top_off.as<int64_t>();
-  p.topology = win->d_top.as<float>();
-  p.logscales = win->d_ls.as<float>();
-  p.scratch = d_scratch.as<double>();
-  p.scratch_stride = scratch_stride;
-  p.side_offset = side_offset;
-  p.order = d_order.as<int32_t>();
-  p.sum_mode = sum_mode;
-
-  bool ok = hipMemsetAsync(d_counter.p, 0, sizeof(int), ctx->s0) == hipSuccess;
-  ok = ok && hipEventRecord(ctx->ev0, ctx->s0) == hipSuccess;
-  hipError_t le = ok ? launch_repaint(p, S, waves, nblocks, d_counter.as<int>(), ctx->s0) : hipErrorUnknown;
-  ok = ok && le == hipSuccess;
-  ok = ok && hipEventRecord(ctx->ev2, ctx->s0) == hipSuccess;
-  hipError_t se = hipEventSynchronize(ctx->ev2);
-  ok = ok && se == hipSuccess;
-  if (!ok) {
-    set_error("repaint launch failed: %s / %s", hipGetErrorString(le), hipGetErrorString(se));
-    delete win;
-    return nullptr;
-  }
-  if (kernel_ms) (void)hipEventElapsedTime(kernel_ms, ctx->ev0, ctx->ev2);
-  win->logscales.resize((size_t)rows);
-  if (hipMemcpy(win->logscales.data(), win->d_ls.p, (size_t)rows * sizeof(float), hipMemcpyDeviceToHost) !=
-      hipSuccess) {
-    set_error("copy of logscales failed");
     delete win;
     return nullptr;
   }
@@ -254,10 +337,16 @@ rl_window *rl_window_open(rl_ctx *ctx, int w, const char *paint_file, int first_
     win->v_rpos_prev[t] = ctx->rpos[s];
     win->v_rpos_next[t] = win->v_rpos_prev[t];
   }
+  if (place_rows(win, snp, kernel_ms)) {  // RePaintSection (anc_builder.cpp:75-78)
+    delete win;
+    return nullptr;
+  }
   return win;
 }
 
 void rl_window_close(rl_window *win) { delete win; }
+
+int rl_window_repaints(const rl_window *win) { return win ? win->repaints : RL_EINVAL; }
 
 int rl_window_bounds(const rl_window *win, int *start, int *end) {
   if (!win) return RL_EINVAL;
@@ -283,11 +372,16 @@ int rl_window_get_topology(rl_window *win, int n, float *top, float *logscales) 
   const int t = n - win->k0;
   const int D = (int)(win->top_off[t + 1] - win->top_off[t]);
   const Layout &lay = ctx->lay;
+  if (top && (win->row_lo[t] != 0 || win->row_hi[t] != D)) {
+    set_error("rl_window_get_topology: the window is bounded, rows %d..%d of %d of target %d are resident",
+              win->row_lo[t], win->row_hi[t] - 1, D, n);
+    return RL_ESTATE;
+  }
   if (logscales) memcpy(logscales, &win->logscales[win->top_off[t]], (size_t)D * sizeof(float));
   if (top) {
     const size_t stride = (size_t)S * 64 * waves;  // one posterior row: [wave][register][lane]
     std::vector<float> phys((size_t)D * stride);
-    RL_HIP(hipMemcpy(phys.data(), win->d_top.as<float>() + win->top_off[t] * (int64_t)stride,
+    RL_HIP(hipMemcpy(phys.data(), win->d_top.as<float>() + win->slab_off[t] * (int64_t)stride,
                      phys.size() * sizeof(float), hipMemcpyDeviceToHost));
     for (int d = 0; d < D; d++) {
       const float *row = &phys[(size_t)d * stride];
@@ -356,6 +450,16 @@ static int window_matrix(rl_window *win, int snp, float *d_host, void *d_dev, fl
     epn[t] = expf(lsp - lsn);  // float expf of a float difference (:167-168), glibc
     enp[t] = expf(lsn - lsp);
   }
+  // a bounded window: are the rows this tree reads resident?  If not, move on to the part starting here.
+  bool covered = true;
+  for (int t = 0; t < nloc && covered; t++) {
+    const int p = win->v_snp_prev[t];
+    covered = p >= win->row_lo[t] && p + (direct[t] ? 0 : 1) < win->row_hi[t];
+  }
+  if (!covered) {
+    const int prc = place_rows(win, snp, nullptr);
+    if (prc) return prc;
+  }
   int rc = 0;
   rc = rc ? rc : win->d_vsp.upload(win->v_snp_prev);
   rc = rc ? rc : win->d_direct.upload(direct);
@@ -371,6 +475,7 @@ static int window_matrix(rl_window *win, int snp, float *d_host, void *d_dev, fl
   p.topology = win->d_top.as<float>();
   p.logscales = win->d_ls.as<float>();
   p.top_off = win->d_top_off.as<int64_t>();
+  p.slab_base = win->d_slab_base.as<int64_t>();
   p.v_snp_prev = win->d_vsp.as<int32_t>();
   p.direct = win->d_direct.as<uint8_t>();
   p.wl = win->d_wl.as<double>();

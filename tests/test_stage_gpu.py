@@ -80,3 +80,19 @@ def test_cli_build_topology_options(tmp_path, tag, opts):
         assert anc == fx.z["anc_%s/%d" % (tag, w)].tobytes(), w
         differs += anc != fx.z["anc/%d" % w].tobytes()
     assert differs > 0  # the option changed something
+
+
+def test_cli_build_topology_bounded_windows(tmp_path):
+    """windows that keep a fraction of their posterior rows resident (as the stage does by itself when the open
+    sections would not fit in HBM): the same .anc / .mut bytes"""
+    work = tmp_path / "work"
+    (work / "out").mkdir(parents=True)
+    fx = Fixture("synth70", work / "out")
+    fx.write_paint_files(str(work / "out" / "chunk_0" / "paint"))
+    p = subprocess.run([CLI, "--mode", "BuildTopology", "--chunk_index", "0", "--first_section", "0",
+                        "--last_section", str(fx.W - 1), "-o", "out"], cwd=str(work), stderr=subprocess.PIPE,
+                       env=dict(os.environ, RELATE_AMD_WINDOW_ROWS="300"))
+    assert p.returncode == 0, p.stderr.decode()
+    for w in range(fx.W):
+        assert open(work / "out" / "chunk_0" / ("out_%d.mut" % w), "rb").read() == fx.z["mut/%d" % w].tobytes(), w
+        assert open(work / "out" / "chunk_0" / ("out_%d.anc" % w), "rb").read() == fx.z["anc/%d" % w].tobytes(), w

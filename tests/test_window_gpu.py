@@ -130,3 +130,56 @@ def test_repaint_lanes_order_matches_oracle(tmp_path, N, L, wb):
             assert np.array_equal(u32(gtop), u32(top[:D])), (w, n)
         win.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("N,L,budget,seed,cap", [(96, 1400, 60000, 9, 0.08), (200, 1500, 400000, 7, 0.3),
+                                                 (64, 1500, 30000, 1, 0.0)])
+def test_bounded_window_same_matrices(tmp_path, N, L, budget, seed, cap):
+    """rl_window_open_bounded: a window that keeps part of its posterior rows resident and repaints as the tree
+    builder moves on gives, SNP by SNP, the matrices of the window that keeps everything (and of the oracle)"""
+    o = rlutil.oracle()
+    ch = rlutil.synth_chunk(N, L, seed=seed, budget=budget)
+    ctx = api.Context()
+    ctx.set_chunk(ch.seq, ch.r, ch.rpos, ch.wb)
+    ctx.paint(api.RL_SUM_EXACT)
+    ctx.write_paint_files(str(tmp_path))
+    d = ch.ro()
+    M = np.zeros((N, N), np.float32)
+    for w in sorted(set([0, ch.W - 1])):
+        pf = os.path.join(str(tmp_path), "relate_%d.bin" % w)
+        s0, s1 = int(ch.wb[w]), int(ch.wb[w + 1]) - 1
+        full = ctx.open_window(w, pf, s0, api.RL_SUM_EXACT)
+        rows = sum(full.rows(n) for n in range(N))
+        part = ctx.open_window(w, pf, s0, api.RL_SUM_EXACT, max_rows=max(1, int(cap * rows)))
+        ow = o.ro_window_open(C.byref(d), pf.encode(), s0, 4)
+        with pytest.raises(api.RelateError):
+            part.topology(int(np.argmax([full.rows(n) for n in range(N)])))  # not all of its rows are there
+        step = max(1, (s1 - s0) // 40)
+        for s in range(s0, s1 + 1):
+            if s > s0:
+                full.advance(s)
+                part.advance(s)
+                o.ro_window_advance(C.c_void_p(ow), s)
+            if (s - s0) % step == 0 or s == s1:
+                A, B = full.matrix(s), part.matrix(s)
+                o.ro_window_matrix(C.c_void_p(ow), s, M.ctypes.data_as(C.c_void_p))
+                assert np.array_equal(u32(A), u32(B)), (w, s)
+                assert np.array_equal(u32(A), u32(M)), (w, s)
+        assert full.repaints == 1
+        assert part.repaints >= 2, part.repaints  # it did move through the window in parts
+        part.close()
+        full.close()
+        o.ro_window_free(C.c_void_p(ow))
+    ctx.close()
+
+
+def test_bounded_window_with_room_for_everything(tmp_path):
+    ch = rlutil.synth_chunk(64, 900, seed=4, budget=30000)
+    ctx = api.Context()
+    ctx.set_chunk(ch.seq, ch.r, ch.rpos, ch.wb)
+    ctx.paint(api.RL_SUM_EXACT)
+    win = ctx.open_window(0, None, int(ch.wb[0]), api.RL_SUM_EXACT, max_rows=10 ** 9)
+    top, ls = win.topology(3)  # all rows resident: readable
+    assert top.shape[0] == win.rows(3) and win.repaints == 1
+    win.close()
+    ctx.close()
