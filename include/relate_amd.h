@@ -198,6 +198,22 @@ int rl_window_matrix_rows_device(rl_window *win, int snp, void *d_rows, float *k
  * the children of the N-1 internal nodes N..2N-2. */
 int rl_quickbuild(int N, double theta, float *d, const float *d_prior,
                   int *parent, int *child_left, int *child_right);
+/* The same as an object, the way AncesTreeBuilder::BuildTopology uses one
+ * MinMatch for all trees of a section (src/anc_builder.cpp:436, :447, :608):
+ * the builder keeps what MinMatch keeps from one QuickBuild to the next
+ * (min_values_CF, the stale candidate indices -- they steer the random
+ * draws).  device >= 0: trees are built on that GPU, one workgroup per tree
+ * with the matrices in HBM (src/tree_builder.cpp restated in
+ * relate_amd/csrc/minmatch_gpu.hip); a tree that needs the symmetric
+ * fallback (tree_builder.cpp:255-293, :968-1058) is built by the host code
+ * with the same state.  device < 0: the host builder.  d is destroyed.
+ * rl_builder_last_on_gpu: 1 if the last tree was built on the GPU. */
+typedef struct rl_builder rl_builder;
+rl_builder *rl_builder_create(int N, double theta, int device);
+int rl_builder_build(rl_builder *b, float *d, const float *d_prior,
+                     int *parent, int *child_left, int *child_right);
+int rl_builder_last_on_gpu(const rl_builder *b);
+void rl_builder_destroy(rl_builder *b);
 
 /* Tree-sequence loop of one section, AncesTreeBuilder::BuildTopology
  * (src/anc_builder.cpp:398-656): first tree from the distance matrix at
@@ -219,6 +235,9 @@ rl_treeseq *rl_treeseq_create(int N, int L, const uint32_t *bits, int row_words,
                               const double *rpos, const int *bp_pos,
                               const int *state, double theta);
 void rl_treeseq_destroy(rl_treeseq *ts);
+/* device >= 0: rl_treeseq_build builds its trees on that GPU (see rl_builder_create),
+ * < 0 (default): on the host. */
+int rl_treeseq_set_build_device(rl_treeseq *ts, int device);
 int rl_treeseq_build(rl_treeseq *ts, int start, int end, rl_matrix_fn matrix,
                      rl_advance_fn advance, void *user, int flags, int fb);
 int rl_treeseq_num_trees(const rl_treeseq *ts);

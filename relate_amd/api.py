@@ -241,6 +241,45 @@ def quickbuild(d, theta=0.001, prior=None):
     return parent
 
 
+class Builder:
+    """One MinMatch for a sequence of trees (rl_builder): device=None builds on the host, an int on that GPU."""
+
+    def __init__(self, N, theta=0.001, device=None):
+        L = lib()
+        L.rl_builder_create.restype = C.c_void_p
+        L.rl_builder_create.argtypes = [C.c_int, C.c_double, C.c_int]
+        L.rl_builder_build.argtypes = [C.c_void_p] * 6
+        L.rl_builder_last_on_gpu.argtypes = [C.c_void_p]
+        L.rl_builder_destroy.argtypes = [C.c_void_p]
+        self.N = N
+        self._h = L.rl_builder_create(N, theta, -1 if device is None else int(device))
+        if not self._h:
+            raise RelateError(L.rl_last_error().decode())
+
+    def build(self, d, prior=None):
+        """-> (parent[2N-1], child_left[N-1], child_right[N-1])"""
+        N = self.N
+        d = np.array(d, dtype=np.float32, order="C")
+        pr = None if prior is None else np.ascontiguousarray(prior, dtype=np.float32)
+        parent = np.empty(2 * N - 1, np.int32)
+        cl = np.empty(N - 1, np.int32)
+        cr = np.empty(N - 1, np.int32)
+        _check(lib().rl_builder_build(C.c_void_p(self._h), _p(d), _p(pr), _p(parent), _p(cl), _p(cr)))
+        return parent, cl, cr
+
+    @property
+    def last_on_gpu(self):
+        return lib().rl_builder_last_on_gpu(C.c_void_p(self._h)) == 1
+
+    def close(self):
+        if self._h:
+            lib().rl_builder_destroy(C.c_void_p(self._h))
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
 def stage_paint(out_dir, chunk_index=0, painting=None, sum_mode=RL_SUM_EXACT, device=0):
     th, rho = painting if painting else (0.001, 1.0)
     _check(lib().rl_stage_paint(out_dir.encode(), chunk_index, 1 if painting else 0, th, rho, sum_mode, device))

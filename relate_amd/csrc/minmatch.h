@@ -106,6 +106,8 @@ int build_threads();
 void set_build_threads(int T);
 
 class MinMatch {
+  friend class DeviceMinMatch;
+
  public:
   MinMatch(int N, double theta);
   // d: N*N floats, destroyed.  prior: N*N floats or nullptr.
@@ -155,6 +157,22 @@ class MinMatch {
   std::vector<std::vector<int>> cand_j;      // per thread: clusters close to the merged one (superset)
   BuildThreads pool;
   size_t min_parallel = 512;
+};
+
+// The same builder on the GPU (minmatch_gpu.hip): one workgroup per tree, matrices in HBM.  build() takes the
+// state a MinMatch carries from tree to tree from `tb` and puts it back, so the two can alternate: it returns
+// 0 when the tree is built, > 0 when this tree needs the host (symmetric fallback; tb untouched), < 0 on error.
+class DeviceMinMatch {
+ public:
+  DeviceMinMatch(int N, int device);
+  ~DeviceMinMatch();
+  DeviceMinMatch(const DeviceMinMatch &) = delete;
+  DeviceMinMatch &operator=(const DeviceMinMatch &) = delete;
+  int build(MinMatch &tb, const float *d, const float *prior, HostTree &tree);
+
+ private:
+  struct Impl;
+  Impl *impl;
 };
 
 }  // namespace rl

@@ -22,6 +22,7 @@
 #include <cstring>
 #include <iomanip>
 #include <iostream>
+#include <memory>
 #include <mutex>
 #include <sstream>
 #include <thread>
@@ -62,6 +63,8 @@ struct rl_treeseq {
   int start = 0, end = 0;
   std::vector<char> member;  // carriers of the current SNP
   int num_carriers = 0;
+  int build_device = -1;  // >= 0: trees are built on that GPU (minmatch_gpu.hip), the host builder as fallback
+  long long gpu_trees = 0, host_trees = 0;
 
   bool derived(int snp, int n) const { return (bits[(size_t)snp * row_words + (n >> 5)] >> (n & 31)) & 1u; }
 };
@@ -394,13 +397,28 @@ int rl_treeseq_build(rl_treeseq *ts, int start, int end, rl_matrix_fn matrix, rl
         }
   };
   MinMatch tb(N, ts->theta);
+  std::unique_ptr<DeviceMinMatch> dev;
+  if (ts->build_device >= 0) dev.reset(new DeviceMinMatch(N, ts->build_device));
+  int build_rc = 0;
+  auto build_tree = [&](float *dm, const float *prior, HostTree &t) {
+    if (dev) {
+      const int st = dev->build(tb, dm, prior, t);
+      if (st == 0) {
+        ts->gpu_trees++;
+        return;
+      }
+      if (st < 0) build_rc = RL_EHIP;
+    }
+    ts->host_trees++;
+    tb.quick_build(dm, prior, t);
+  };
   MatrixBuf d((size_t)N * N), dist;
   float min_value = 0.f, min_value_alt = 0.f;
   int rc;
 
   ts->trees.emplace_back();
   if ((rc = matrix(user, start, d.data()))) return rc;
-  tb.quick_build(d.data(), nullptr, ts->trees.back());  // :447, no prior for the first tree
+  build_tree(d.data(), nullptr, ts->trees.back());  // :447, no prior for the first tree
   ts->trees.back().pos = start;
   std::fill(ts->trees.back().snp_begin.begin(), ts->trees.back().snp_begin.end(), start);
   set_carriers(start);
@@ -455,10 +473,11 @@ int rl_treeseq_build(rl_treeseq *ts, int start, int end, rl_matrix_fn matrix, rl
         });
         clade_prior(pt, val, dist);
         lap(t_prior);
-        tb.quick_build(d.data(), dist.data(), nt);
+        build_tree(d.data(), dist.data(), nt);
       } else {
-        tb.quick_build(d.data(), nullptr, nt);
+        build_tree(d.data(), nullptr, nt);
       }
+      if (build_rc) return build_rc;
       lap(t_build);
       nt.pos = snp;
       const int is_mapping_alt = map_mutation(*ts, nt, si, min_value_alt, use);
@@ -485,9 +504,15 @@ int rl_treeseq_build(rl_treeseq *ts, int start, int end, rl_matrix_fn matrix, rl
     fprintf(stderr,
             "[tree sequence] SNPs %d..%d: %d trees kept of %d built; distance matrices %.2f s, penalty + clade prior "
             "%.2f s, MinMatch %.2f s (row minima + pair scan %.2f, merges: parallel part %.2f [updates %.2f] + ordered part %.2f, "
-            "%.2f rebuilt clusters per merge), mutation mapping %.2f s\n",
+            "%.2f rebuilt clusters per merge; %lld trees on the GPU, %lld on the host), mutation mapping %.2f s\n",
             start, end, num_tree, builds + 1, t_matrix, t_prior, t_build, tb.t_init, tb.t_phase1, tb.t_phase1a, tb.t_phase2,
-            (double)tb.n_updated / std::max<long long>(1, tb.n_merges), t_map);
+            (double)tb.n_updated / std::max<long long>(1, tb.n_merges), ts->gpu_trees, ts->host_trees, t_map);
+  return RL_OK;
+}
+
+int rl_treeseq_set_build_device(rl_treeseq *ts, int device) {
+  if (!ts) return RL_EINVAL;
+  ts->build_device = device;
   return RL_OK;
 }
 
@@ -702,6 +727,8 @@ int rl_stage_build_topology(const char *out_dir, int chunk_index, int first_sect
   // core stalls every merge, so they get a quarter of the physical cores at most: measured on 2 x 64 cores with 8
   // sections open, 4 helpers each finished in 109 s, 8 in 177 s, none in 165 s.
   set_build_threads(std::min(8, std::max(1, host_threads() / (8 * std::max(1, concurrent)))));
+  // RELATE_AMD_GPU_BUILD=1: the trees themselves are built on the GPU too (minmatch_gpu.hip)
+  const bool gpu_build = getenv("RELATE_AMD_GPU_BUILD") && atoi(getenv("RELATE_AMD_GPU_BUILD")) != 0;
   std::atomic<int> open_sections(0);
   std::atomic<int> next(first_section);
   std::atomic<int> first_error(0);
@@ -723,6 +750,7 @@ int rl_stage_build_topology(const char *out_dir, int chunk_index, int first_sect
       if (pinned) sched_setaffinity(0, sizeof(before), &before);
       return;
     }
+    if (gpu_build) rl_treeseq_set_build_device(ts, device);
     for (;;) {
       const int section = next.fetch_add(1);
       if (section > last_section || first_error.load()) break;

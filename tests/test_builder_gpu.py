@@ -1,0 +1,82 @@
+"""The tree builder on the GPU (relate_amd/csrc/minmatch_gpu.hip) against the host builder -- which is the one
+checked against the reference binary (tests/test_oracle_ref.py) and the golden tree sequences: the same parent
+and child arrays, tree after tree, with the state MinMatch carries between builds."""
+import numpy as np
+import pytest
+
+from relate_amd import api
+
+pytestmark = pytest.mark.gpu
+
+
+def tied_matrix(rng, N, ties=0.3):
+    d = (rng.rand(N, N) * 4 + rng.rand(N)[:, None]).astype(np.float32)
+    d[rng.rand(N, N) < ties] = 1.5  # plenty of exact ties: the random draws decide
+    np.fill_diagonal(d, 0)
+    return d
+
+
+def coalescent_matrix(rng, N):
+    """distances shaped like the path's: near-ultrametric from a random binary tree plus asymmetric noise"""
+    order = rng.permutation(N)
+    h = np.zeros((N, N), np.float32)
+    groups = [[int(x)] for x in order]
+    t = 0.0
+    while len(groups) > 1:
+        t += rng.exponential(1.0 / (len(groups) * (len(groups) - 1) / 2))
+        a, b = sorted(rng.choice(len(groups), 2, replace=False))
+        for x in groups[a]:
+            for y in groups[b]:
+                h[x, y] = h[y, x] = t
+        groups[a] = groups[a] + groups[b]
+        del groups[b]
+    d = (h * 20 + rng.rand(N, N) * 0.05).astype(np.float32)
+    d -= d.min(axis=1, keepdims=True)
+    np.fill_diagonal(d, 0)
+    return d
+
+
+def run_sequence(N, mats, theta=0.001):
+    host, dev = api.Builder(N, theta), api.Builder(N, theta, device=0)
+    on_gpu = 0
+    for t, (d, prior) in enumerate(mats):
+        ref = host.build(d, prior)
+        got = dev.build(d, prior)
+        on_gpu += dev.last_on_gpu
+        for name, a, b in zip(("parent", "child_left", "child_right"), ref, got):
+            assert np.array_equal(a, b), (t, name, int(np.argmax(a != b)))
+    host.close()
+    dev.close()
+    return on_gpu
+
+
+@pytest.mark.parametrize("N,seed", [(5, 1), (64, 2), (130, 3), (260, 4), (1100, 5)])
+def test_tied_matrices_with_and_without_prior(N, seed):
+    rng = np.random.RandomState(seed)
+    mats = [(tied_matrix(rng, N), None)]
+    for _ in range(3):
+        mats.append((tied_matrix(rng, N), (np.floor(rng.rand(N, N) * 4) * 6.9).astype(np.float32)))
+    mats.append((tied_matrix(rng, N, 0.0), None))
+    run_sequence(N, mats)
+
+
+@pytest.mark.parametrize("N,seed", [(90, 7), (400, 8), (1500, 9)])
+def test_coalescent_matrices(N, seed):
+    rng = np.random.RandomState(seed)
+    mats = [(coalescent_matrix(rng, N), None)]
+    for _ in range(2):
+        prior = (np.floor(rng.rand(N, N) * 3) * 6.9).astype(np.float32)
+        mats.append((coalescent_matrix(rng, N), prior))
+    assert run_sequence(N, mats) >= 1  # (not every tree fell back to the host)
+
+
+def test_reference_unit_vectors_on_gpu():
+    # include/test/test_treebuilder.cpp:9-139 (theta = 0.025)
+    d5 = np.array([[0, 0, 1, 2, 2], [2, 0, 3, 4, 4], [0, 0, 0, 1, 1], [1, 1, 1, 0, 0], [1, 1, 1, 0, 0]], np.float32)
+    b = api.Builder(5, 0.025, device=0)
+    assert list(b.build(d5)[0][:8]) == [6, 6, 7, 5, 5, 8, 7, 8]
+    b.close()
+    d4 = np.array([[0, 1, 2, 2], [3, 0, 1, 1], [0, 1, 0, 1], [1, 1, 0, 0]], np.float32)
+    b = api.Builder(4, 0.025, device=0)
+    assert list(b.build(d4)[0][:6]) == [6, 5, 4, 4, 5, 6]
+    b.close()

@@ -96,3 +96,23 @@ def test_cli_build_topology_bounded_windows(tmp_path):
     for w in range(fx.W):
         assert open(work / "out" / "chunk_0" / ("out_%d.mut" % w), "rb").read() == fx.z["mut/%d" % w].tobytes(), w
         assert open(work / "out" / "chunk_0" / ("out_%d.anc" % w), "rb").read() == fx.z["anc/%d" % w].tobytes(), w
+
+
+@pytest.mark.parametrize("name", ["synth24", "synth70", "example8"])
+def test_cli_build_topology_trees_built_on_the_gpu(tmp_path, name):
+    """RELATE_AMD_GPU_BUILD=1: MinMatch itself on the GPU (one workgroup per tree), host builder as the fallback
+    for trees that need the symmetric matrix -- the same .anc / .mut bytes as the reference"""
+    work = tmp_path / "work"
+    (work / "out").mkdir(parents=True)
+    fx = Fixture(name, work / "out")
+    fx.write_paint_files(str(work / "out" / "chunk_0" / "paint"))
+    p = subprocess.run([CLI, "--mode", "BuildTopology", "--chunk_index", "0", "--first_section", "0",
+                        "--last_section", str(fx.W - 1), "-o", "out"], cwd=str(work), stderr=subprocess.PIPE,
+                       env=dict(os.environ, RELATE_AMD_GPU_BUILD="1", RELATE_AMD_TIMING="1"))
+    assert p.returncode == 0, p.stderr.decode()
+    on_gpu = sum(int(l.split(" trees on the GPU")[0].split()[-1]) for l in p.stderr.decode().split("\n")
+                 if " trees on the GPU" in l)
+    assert on_gpu > 0
+    for w in range(fx.W):
+        assert open(work / "out" / "chunk_0" / ("out_%d.mut" % w), "rb").read() == fx.z["mut/%d" % w].tobytes(), w
+        assert open(work / "out" / "chunk_0" / ("out_%d.anc" % w), "rb").read() == fx.z["anc/%d" % w].tobytes(), w

@@ -53,6 +53,16 @@ with tempfile.TemporaryDirectory() as work:
                            env=dict(os.environ, RELATE_AMD_TIMING="1"))
         assert p.returncode == 0, p.stderr.decode()[-400:]
         out["build_topology_phases"] = [l.strip() for l in p.stderr.decode().split("\n") if "[tree sequence]" in l]
+        import re
+        acc, ntr = {}, 0
+        for l in p.stderr.decode().split("\n"):
+            if "[gpu tree builder]" in l and "us:" in l:
+                ntr += 1
+                for m in re.finditer(r"([a-z_+ ]+?) (\d+)(?= |$)", l.split("us:")[1]):
+                    acc[m.group(1).strip()] = acc.get(m.group(1).strip(), 0) + int(m.group(2))
+        if ntr:
+            out["gpu_builder_ms_per_tree"] = {k: round(v / ntr / 1000.0, 2) for k, v in acc.items()}
+            out["gpu_builder_trees_timed"] = ntr
     t2 = time.time()
     out["build_topology_s"] = t2 - t1
     trees = snps = 0
