@@ -40,6 +40,9 @@ struct MMParams {
   float threshold, threshold_CF;
   float *D;   // [N*N] destroyed
   float *CF;  // [N*N] destroyed, or nullptr
+  float *SYM;  // [N*N] room for the symmetric matrix
+  float *min_values_sym, *mcs_dist;
+  int *mcs_lin1, *mcs_lin2;
   float *min_values, *min_values_CF;
   float *mc_dist, *mc_dist2;
   int *mc_lin1, *mc_lin2;
@@ -99,7 +102,8 @@ struct Best {
 
 struct Shared {
   Rng rng;
-  Best best;
+  Best best, best_sym;
+  int use_sym;
   int n, i, j, ipos;
   int wave_i[MM_WAVES];
   float wave_f[MM_WAVES];
@@ -244,6 +248,7 @@ __device__ inline void block_scan2(int v1, int v2, int &e1, int &e2, int &t1, in
 
 #define DD(a, b) p.D[(size_t)(a) * N + (b)]
 #define CC(a, b) p.CF[(size_t)(a) * N + (b)]
+#define SS(a, b) p.SYM[(size_t)(a) * N + (b)]
 
 // One feasible pair (thread 0): symmetric distance, one draw, both clusters' best candidate
 // (tree_builder.cpp:1699-1716); minmatch.cpp: consider().
@@ -309,6 +314,8 @@ __global__ void __launch_bounds__(MM_BLOCK) minmatch_kernel(const MMParams *__re
     sh.best.dist2 = INF;
     sh.best.lin1 = -1;
     sh.best.lin2 = -1;
+    sh.best_sym = sh.best;
+    sh.use_sym = 0;
     sh.n = N;
   }
   __syncthreads();
@@ -377,12 +384,67 @@ __global__ void __launch_bounds__(MM_BLOCK) minmatch_kernel(const MMParams *__re
   LAP(1);
   // ---- the merges
   for (int num_nodes = N; num_nodes < 2 * N - 1; num_nodes++) {
-    if (sh.best.dist == INF) {  // no mutually closest pair: the symmetric fallback is the host's
-      if (tid == 0) *p.status = 1;
-      return;
-    }
-    const int i = sh.best.lin1, j = sh.best.lin2;
     const int n = sh.n;
+    if (sh.best.dist == INF && !sh.use_sym) {
+      // no mutually closest pair: from here on the symmetric matrix picks the pair when there is none
+      // (initialize_sym, tree_builder.cpp:255-293): s(a,l) = d(a,l) + d(l,a) over the live clusters, row minima
+      // with the first cluster that reaches them, the smallest of those (first row, first cluster)
+      if (!p.SYM) {  // (the caller gave no room for it)
+        if (tid == 0) *p.status = 1;
+        return;
+      }
+      float bs = INF;
+      int bs_pos = n;
+      for (int ia = wave; ia < n; ia += MM_WAVES) {
+        const int a = ci[ia];
+        float mv = INF;
+        int mp = n;
+        for (int il = lane; il < n; il += 64) {
+          const int l = ci[il];
+          if (l == a) continue;
+          const float v = DD(a, l) + DD(l, a);
+          SS(a, l) = v;
+          if (v < mv) {  // (ascending per lane: the first one stays)
+            mv = v;
+            mp = il;
+          }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const float ov = __shfl_xor(mv, o, 64);
+          const int op = __shfl_xor(mp, o, 64);
+          if (ov < mv || (ov == mv && op < mp)) {
+            mv = ov;
+            mp = op;
+          }
+        }
+        if (lane == 0) {
+          p.min_values_sym[a] = mv;
+          p.mcs_dist[a] = mv;
+          if (mv < INF) {
+            p.mcs_lin1[a] = a;
+            p.mcs_lin2[a] = ci[mp];
+          }
+          if (mv < bs) {  // (rows ascending per wave)
+            bs = mv;
+            bs_pos = ia;
+          }
+        }
+      }
+      float bs2 = 0.0f;
+      block_lex_min(bs, bs2, bs_pos, sh.wave_f, sh.wave_f2, sh.wave_i);
+      if (tid == 0) {
+        sh.use_sym = 1;
+        sh.best_sym.dist = bs;
+        if (bs_pos < n && bs < INF) {
+          sh.best_sym.lin1 = p.mcs_lin1[ci[bs_pos]];
+          sh.best_sym.lin2 = p.mcs_lin2[ci[bs_pos]];
+        }
+      }
+      __syncthreads();
+    }
+    const bool by_sym = sh.best.dist == INF;
+    const int i = by_sym ? sh.best_sym.lin1 : sh.best.lin1, j = by_sym ? sh.best_sym.lin2 : sh.best.lin2;
     const float csi = p.cluster_size[i], csj = p.cluster_size[j];
     const float added = csi + csj;
     if (tid == 0) {
@@ -672,6 +734,103 @@ __global__ void __launch_bounds__(MM_BLOCK) minmatch_kernel(const MMParams *__re
       p.cluster_size[j] = csi + csj;
       p.convert_index[j] = num_nodes;
     }
+    // -- the same merge in the symmetric matrix once it is in use (coalesce_sym, tree_builder.cpp:968-1058)
+    if (sh.use_sym) {
+      if (tid == 0) sh.count = 0;  // (thread 0 is past its ordered part; the others wait at the barrier below)
+      __syncthreads();
+      for (int ik = tid; ik < n; ik += MM_BLOCK) {
+        const int k = ci[ik];
+        if (k == j || k == i) continue;
+        const float dkj = SS(k, j), dki = SS(k, i), dik = SS(i, k), djk = SS(j, k);
+        const float mvk = p.min_values_sym[k];
+        if (dik != djk) SS(j, k) = (csi * dik + csj * djk) / added;
+        if (dki != dkj) SS(k, j) = (csi * dki + csj * dkj) / added;
+        if (dkj != dki) {
+          if ((double)fabsf(mvk - dkj) < 1e-6 || (double)fabsf(mvk - dki) < 1e-6)
+            p.upd_pos[atomicAdd(&sh.count, 1)] = ik;  // (scratch use: rows to rescan)
+        } else {
+          if (p.mcs_lin1[k] == i) p.mcs_lin1[k] = j;
+          if (p.mcs_lin2[k] == i) p.mcs_lin2[k] = j;
+        }
+      }
+      __syncthreads();
+      const int nres_s = sh.count;
+      for (int r = 0; r < nres_s; r++) {
+        const int k = ci[p.upd_pos[r]];
+        const float old = p.min_values_sym[k];
+        const float *row = p.SYM + (size_t)k * N;
+        float fm = INF, fm2 = 0.0f;
+        int fpos = n, pos_old = n, pos_less = n;
+        for (int il = tid; il < n; il += MM_BLOCK) {
+          const int l = ci[il];
+          if (l != i && l != k) {
+            const float v = row[l];
+            if (v < fm) {
+              fm = v;
+              fpos = il;
+            }
+            if (v == old) pos_old = min(pos_old, il);
+            if (v < old) pos_less = min(pos_less, il);
+          }
+        }
+        float dummy = 0.0f;
+        block_min3(dummy, pos_old, pos_less, sh.wave_f, sh.wave_i, sh.wave_i2);
+        block_lex_min(fm, fm2, fpos, sh.wave_f, sh.wave_f2, sh.wave_i3);
+        if (tid == 0) {
+          const bool stops = pos_old < n && pos_old < pos_less;
+          const float v = stops ? old : fm;
+          const int at = stops ? pos_old : fpos;
+          p.min_values_sym[k] = v;
+          p.mcs_dist[k] = v;
+          if (v < INF) {
+            p.mcs_lin1[k] = k;
+            p.mcs_lin2[k] = ci[at];
+          }
+        }
+      }
+      __syncthreads();
+      float b1 = INF, b2 = 0.0f, mj = INF, mj2 = 0.0f;
+      int bp = n, mjp = n;
+      const float *srowj = p.SYM + (size_t)j * N;
+      for (int ik = tid; ik < n; ik += MM_BLOCK) {
+        const int k = ci[ik];
+        if (k == j || k == i) continue;
+        const float dk = p.mcs_dist[k];
+        if (dk < b1) {
+          b1 = dk;
+          bp = ik;
+        }
+        const float sj = srowj[k];
+        if (sj < mj) {
+          mj = sj;
+          mjp = ik;
+        }
+      }
+      block_lex_min(b1, b2, bp, sh.wave_f, sh.wave_f2, sh.wave_i);
+      block_lex_min(mj, mj2, mjp, sh.wave_f, sh.wave_f2, sh.wave_i3);
+      if (tid == 0) {
+        Best b = sh.best_sym;
+        b.dist = INF;
+        if (bp < n && b1 < INF) {
+          const int k = ci[bp];
+          b.dist = b1;
+          b.lin1 = p.mcs_lin1[k];
+          b.lin2 = p.mcs_lin2[k];
+        }
+        p.min_values_sym[j] = mj;
+        p.mcs_dist[j] = mj;  // (INF when nothing is left)
+        if (mjp < n && mj < INF) {
+          p.mcs_lin1[j] = ci[mjp];
+          p.mcs_lin2[j] = j;
+        }
+        if (b.dist > mj) {
+          b.dist = mj;
+          b.lin1 = p.mcs_lin1[j];
+          b.lin2 = p.mcs_lin2[j];
+        }
+        sh.best_sym = b;
+      }
+    }
     LAP(9);
     // -- the merged-away cluster leaves the list (copied to the other buffer, one position up behind it)
     {
@@ -795,7 +954,7 @@ class BuildDispatcher {
 struct DeviceMinMatch::Impl {
   int N = 0, device = 0;
   hipStream_t stream = nullptr;
-  DevBuf d_D, d_CF, d_f, d_i, d_feas, d_rowlist, d_status, d_flags;
+  DevBuf d_D, d_CF, d_SYM, d_f, d_i, d_feas, d_rowlist, d_status, d_flags;
   long long feas_cap = 0;
 };
 
@@ -820,8 +979,9 @@ int DeviceMinMatch::build(MinMatch &tb, const float *d, const float *prior, Host
   m.feas_cap = (long long)8 * N;
   int rc = m.d_D.alloc(NN * 4);
   rc = rc ? rc : (prior ? m.d_CF.alloc(NN * 4) : 0);
-  rc = rc ? rc : m.d_f.alloc((size_t)5 * N * 4);                        // min_values, min_values_CF, mc_dist, mc_dist2, cluster_size
-  rc = rc ? rc : m.d_i.alloc(((size_t)9 * N + (size_t)5 * N + 8) * 4);  // ints, see below
+  rc = rc ? rc : m.d_SYM.alloc(NN * 4);
+  rc = rc ? rc : m.d_f.alloc((size_t)7 * N * 4);  // min_values, min_values_CF, mc_dist, mc_dist2, cluster_size, + 2 sym
+  rc = rc ? rc : m.d_i.alloc(((size_t)9 * N + (size_t)7 * N + 8) * 4);  // ints, see below
   rc = rc ? rc : m.d_feas.alloc((size_t)m.feas_cap * 4);
   rc = rc ? rc : m.d_rowlist.alloc((size_t)MM_WAVES * N * 4);
   rc = rc ? rc : m.d_status.alloc(16 + 12 * 8);
@@ -839,6 +999,9 @@ int DeviceMinMatch::build(MinMatch &tb, const float *d, const float *prior, Host
   p.mc_dist = f + 2 * (size_t)N;
   p.mc_dist2 = f + 3 * (size_t)N;
   p.cluster_size = f + 4 * (size_t)N;
+  p.min_values_sym = f + 5 * (size_t)N;
+  p.mcs_dist = f + 6 * (size_t)N;
+  p.SYM = m.d_SYM.as<float>();
   int *q = m.d_i.as<int>();
   p.mc_lin1 = q;
   p.mc_lin2 = q + N;
@@ -853,6 +1016,8 @@ int DeviceMinMatch::build(MinMatch &tb, const float *d, const float *prior, Host
   p.child_left = q + 11 * (size_t)N + 4;    // [N-1]
   p.child_right = q + 12 * (size_t)N + 4;   // [N-1]
   p.cluster_index2 = q + 13 * (size_t)N + 4;
+  p.mcs_lin1 = q + 14 * (size_t)N + 4;
+  p.mcs_lin2 = q + 15 * (size_t)N + 4;
   p.kflag = m.d_flags.as<unsigned char>();
   p.feas = m.d_feas.as<int>();
   p.feas_cap = m.feas_cap;

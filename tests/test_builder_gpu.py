@@ -43,6 +43,7 @@ def run_sequence(N, mats, theta=0.001):
         ref = host.build(d, prior)
         got = dev.build(d, prior)
         on_gpu += dev.last_on_gpu
+        assert dev.last_on_gpu  # (the symmetric fallback included)
         for name, a, b in zip(("parent", "child_left", "child_right"), ref, got):
             assert np.array_equal(a, b), (t, name, int(np.argmax(a != b)))
     host.close()
@@ -80,3 +81,16 @@ def test_reference_unit_vectors_on_gpu():
     b = api.Builder(4, 0.025, device=0)
     assert list(b.build(d4)[0][:6]) == [6, 5, 4, 4, 5, 6]
     b.close()
+
+
+@pytest.mark.parametrize("N,seed", [(7, 1), (100, 2), (700, 3)])
+def test_no_mutually_closest_pair_symmetric_fallback(N, seed):
+    """circulant distances: every row's minimum points at a cluster whose own minimum points elsewhere, so the
+    pairs come from the symmetric matrix (tree_builder.cpp:255-293, :968-1058) from the first merge on"""
+    rng = np.random.RandomState(seed)
+    idx = np.arange(N)
+    circ = (((idx[None, :] - idx[:, None]) % N) * 10.0).astype(np.float32)
+    mats = [(circ, None), (circ + rng.rand(N, N).astype(np.float32), None),
+            (circ + np.floor(rng.rand(N, N) * 3).astype(np.float32), (np.floor(rng.rand(N, N) * 3) * 6.9).astype(np.float32)),
+            (tied_matrix(rng, N), None)]
+    run_sequence(N, mats)

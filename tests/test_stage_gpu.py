@@ -112,7 +112,9 @@ def test_cli_build_topology_trees_built_on_the_gpu(tmp_path, name):
     assert p.returncode == 0, p.stderr.decode()
     on_gpu = sum(int(l.split(" trees on the GPU")[0].split()[-1]) for l in p.stderr.decode().split("\n")
                  if " trees on the GPU" in l)
-    assert on_gpu > 0
+    on_host = sum(int(l.split(" on the host")[0].split()[-1]) for l in p.stderr.decode().split("\n")
+                  if " on the host" in l)
+    assert on_gpu > 0 and on_host == 0
     for w in range(fx.W):
         assert open(work / "out" / "chunk_0" / ("out_%d.mut" % w), "rb").read() == fx.z["mut/%d" % w].tobytes(), w
         assert open(work / "out" / "chunk_0" / ("out_%d.anc" % w), "rb").read() == fx.z["anc/%d" % w].tobytes(), w
