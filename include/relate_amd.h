@@ -238,6 +238,12 @@ void rl_treeseq_destroy(rl_treeseq *ts);
 /* device >= 0: rl_treeseq_build builds its trees on that GPU (see rl_builder_create),
  * < 0 (default): on the host. */
 int rl_treeseq_set_build_device(rl_treeseq *ts, int device);
+/* With a build device: where the distance matrix of `snp` comes from when it
+ * is to stay on the device (N*N floats at d_dev, e.g. through
+ * rl_window_matrix_rows_device); carrier penalty, clade prior and the build
+ * then run there too and no matrix crosses PCIe. */
+typedef int (*rl_matrix_dev_fn)(void *user, int snp, void *d_dev);
+int rl_treeseq_set_device_matrix(rl_treeseq *ts, rl_matrix_dev_fn matrix_dev);
 int rl_treeseq_build(rl_treeseq *ts, int start, int end, rl_matrix_fn matrix,
                      rl_advance_fn advance, void *user, int flags, int fb);
 int rl_treeseq_num_trees(const rl_treeseq *ts);

@@ -169,8 +169,16 @@ class DeviceMinMatch {
   DeviceMinMatch(const DeviceMinMatch &) = delete;
   DeviceMinMatch &operator=(const DeviceMinMatch &) = delete;
   int build(MinMatch &tb, const float *d, const float *prior, HostTree &tree);
+  // The same without the matrices crossing PCIe: the caller has the distance matrix written into
+  // device_matrix() (K3, rl_window_matrix_rows_device), the carrier penalty and the clade prior of the previous
+  // tree are applied on the device (anc_builder.cpp:563-606), build_resident builds from what is there.
+  float *device_matrix();
+  int apply_penalty(const char *member, float val);
+  int apply_prior(const HostTree &previous, float val);
+  int build_resident(MinMatch &tb, bool with_prior, HostTree &tree);
 
  private:
+  int build_impl(MinMatch &tb, const float *d, const float *prior, bool resident, bool with_prior, HostTree &tree);
   struct Impl;
   Impl *impl;
 };

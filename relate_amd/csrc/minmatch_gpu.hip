@@ -853,6 +853,41 @@ __global__ void __launch_bounds__(MM_BLOCK) minmatch_kernel(const MMParams *__re
   }
 }
 
+// Carrier penalty of AncesTreeBuilder::BuildTopology (anc_builder.cpp:563-581) on the device: every entry of a
+// carrier's row gets + val, and - val again where the column is a carrier too (the same two operations in
+// the same order per entry as the host loop).
+__global__ void penalty_kernel(float *__restrict__ D, int N, const unsigned char *__restrict__ member, float val) {
+  const int c = blockIdx.x;
+  if (!member[c]) return;
+  float *row = D + (size_t)c * N;
+  for (int col = threadIdx.x; col < N; col += blockDim.x) {
+    float x = row[col] + val;
+    if (member[col]) x -= val;
+    row[col] = x;
+  }
+}
+
+// Clade prior from the previous tree (treeseq.cpp: clade_prior; anc_builder.cpp:583-606): row a holds, for
+// every other leaf b, acc[depth(parent(a)) - depth(mrca(a,b))]; the leaves under the sibling of every ancestor
+// step are a contiguous range of the depth-first leaf order.
+__global__ void prior_kernel(float *__restrict__ CF, int N, const int *__restrict__ parent,
+                             const int *__restrict__ child_left, const int *__restrict__ child_right,
+                             const int *__restrict__ depth, const int *__restrict__ lo,
+                             const int *__restrict__ size, const int *__restrict__ order,
+                             const float *__restrict__ acc) {
+  const int a = blockIdx.x;
+  float *row = CF + (size_t)a * N;
+  if (threadIdx.x == 0) row[a] = 0.0f;
+  const int da = depth[parent[a]];
+  int child = a;
+  for (int v = parent[a]; v >= 0; child = v, v = parent[v]) {
+    const int other = child_left[v] == child ? child_right[v] : child_left[v];
+    const float x = acc[da - depth[v]];
+    const int b = lo[other], e = b + size[other];
+    for (int q = b + threadIdx.x; q < e; q += blockDim.x) row[order[q]] = x;
+  }
+}
+
 }  // namespace
 
 // ---- host side
@@ -954,7 +989,7 @@ class BuildDispatcher {
 struct DeviceMinMatch::Impl {
   int N = 0, device = 0;
   hipStream_t stream = nullptr;
-  DevBuf d_D, d_CF, d_SYM, d_f, d_i, d_feas, d_rowlist, d_status, d_flags;
+  DevBuf d_D, d_CF, d_SYM, d_f, d_i, d_feas, d_rowlist, d_status, d_flags, d_member, d_tab, d_acc;
   long long feas_cap = 0;
 };
 
@@ -969,12 +1004,82 @@ DeviceMinMatch::~DeviceMinMatch() {
   delete impl;
 }
 
+float *DeviceMinMatch::device_matrix() {
+  Impl &m = *impl;
+  if (hipSetDevice(m.device) != hipSuccess) return nullptr;
+  if (m.d_D.alloc((size_t)m.N * m.N * 4)) return nullptr;
+  return m.d_D.as<float>();
+}
+
+int DeviceMinMatch::apply_penalty(const char *member, float val) {
+  Impl &m = *impl;
+  const int N = m.N;
+  RL_HIP(hipSetDevice(m.device));
+  if (!m.stream) RL_HIP(hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking));
+  if (m.d_member.alloc((size_t)N)) return -1;
+  RL_HIP(hipMemcpyAsync(m.d_member.p, member, (size_t)N, hipMemcpyHostToDevice, m.stream));
+  hipLaunchKernelGGL(penalty_kernel, dim3(N), dim3(256), 0, m.stream, m.d_D.as<float>(), N,
+                     m.d_member.as<unsigned char>(), val);
+  RL_HIP(hipGetLastError());
+  return 0;
+}
+
+int DeviceMinMatch::apply_prior(const HostTree &t, float val) {
+  Impl &m = *impl;
+  const int N = m.N, T = 2 * N - 1;
+  RL_HIP(hipSetDevice(m.device));
+  if (!m.stream) RL_HIP(hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking));
+  // the same tables as the host's clade_prior (treeseq.cpp)
+  std::vector<int> tab((size_t)6 * T + N);
+  int *parent = tab.data(), *cl = parent + T, *cr = cl + T, *depth = cr + T, *lo = depth + T, *size = lo + T,
+      *order = size + T;
+  for (int v = 0; v < T; v++) {
+    parent[v] = t.parent[v];
+    cl[v] = t.child_left[v];
+    cr[v] = t.child_right[v];
+    depth[v] = 0;
+    lo[v] = 0;
+    size[v] = 1;
+  }
+  for (int v = T - 1; v >= N; v--) depth[v] = (parent[v] >= 0 ? depth[parent[v]] : 0) + 1;
+  for (int v = N; v < T; v++) size[v] = size[cl[v]] + size[cr[v]];
+  for (int v = T - 1; v >= N; v--) {
+    lo[cl[v]] = lo[v];
+    lo[cr[v]] = lo[v] + size[cl[v]];
+  }
+  for (int i = 0; i < N; i++) order[lo[i]] = i;
+  std::vector<float> acc((size_t)N + 1, 0.0f);
+  for (int c = 1; c <= N; c++) acc[c] = acc[c - 1] + val;
+  int rc = m.d_tab.alloc(tab.size() * 4);
+  rc = rc ? rc : m.d_acc.alloc(acc.size() * 4);
+  rc = rc ? rc : m.d_CF.alloc((size_t)N * N * 4);
+  if (rc) return -1;
+  RL_HIP(hipMemcpyAsync(m.d_tab.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, m.stream));
+  RL_HIP(hipMemcpyAsync(m.d_acc.p, acc.data(), acc.size() * 4, hipMemcpyHostToDevice, m.stream));
+  const int *q = m.d_tab.as<int>();
+  hipLaunchKernelGGL(prior_kernel, dim3(N), dim3(256), 0, m.stream, m.d_CF.as<float>(), N, q, q + T, q + 2 * (size_t)T,
+                     q + 3 * (size_t)T, q + 4 * (size_t)T, q + 5 * (size_t)T, q + 6 * (size_t)T, m.d_acc.as<float>());
+  RL_HIP(hipGetLastError());
+  RL_HIP(hipStreamSynchronize(m.stream));  // (tab and acc are locals)
+  return 0;
+}
+
+int DeviceMinMatch::build_resident(MinMatch &tb, bool with_prior, HostTree &tree) {
+  return build_impl(tb, nullptr, nullptr, true, with_prior, tree);
+}
+
 int DeviceMinMatch::build(MinMatch &tb, const float *d, const float *prior, HostTree &tree) {
+  return build_impl(tb, d, prior, false, prior != nullptr, tree);
+}
+
+int DeviceMinMatch::build_impl(MinMatch &tb, const float *d, const float *prior_host, bool resident, bool with_prior,
+                               HostTree &tree) {
   Impl &m = *impl;
   const int N = m.N;
   if (N < 2 || N > 32768) return 1;
   RL_HIP(hipSetDevice(m.device));
   if (!m.stream) RL_HIP(hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking));
+  const bool prior = with_prior;
   const size_t NN = (size_t)N * N;
   m.feas_cap = (long long)8 * N;
   int rc = m.d_D.alloc(NN * 4);
@@ -1034,8 +1139,10 @@ int DeviceMinMatch::build(MinMatch &tb, const float *d, const float *prior, Host
   }
   RL_HIP(hipMemcpyAsync(p.mc_lin1, lin.data(), (size_t)2 * N * 4, hipMemcpyHostToDevice, m.stream));
   RL_HIP(hipMemcpyAsync(p.min_values_CF, tb.min_values_CF.data(), (size_t)N * 4, hipMemcpyHostToDevice, m.stream));
-  RL_HIP(hipMemcpyAsync(p.D, d, NN * 4, hipMemcpyHostToDevice, m.stream));
-  if (prior) RL_HIP(hipMemcpyAsync(p.CF, prior, NN * 4, hipMemcpyHostToDevice, m.stream));
+  if (!resident) {
+    RL_HIP(hipMemcpyAsync(p.D, d, NN * 4, hipMemcpyHostToDevice, m.stream));
+    if (prior) RL_HIP(hipMemcpyAsync(p.CF, prior_host, NN * 4, hipMemcpyHostToDevice, m.stream));
+  }
   const int minus1 = -1;
   RL_HIP(hipMemcpyAsync(p.status, &minus1, 4, hipMemcpyHostToDevice, m.stream));
   RL_HIP(hipStreamSynchronize(m.stream));  // inputs in place

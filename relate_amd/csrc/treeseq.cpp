@@ -64,6 +64,7 @@ struct rl_treeseq {
   std::vector<char> member;  // carriers of the current SNP
   int num_carriers = 0;
   int build_device = -1;  // >= 0: trees are built on that GPU (minmatch_gpu.hip), the host builder as fallback
+  rl_matrix_dev_fn matrix_dev = nullptr;  // with it the distance matrices never leave the device
   long long gpu_trees = 0, host_trees = 0;
 
   bool derived(int snp, int n) const { return (bits[(size_t)snp * row_words + (n >> 5)] >> (n & 31)) & 1u; }
@@ -416,9 +417,18 @@ int rl_treeseq_build(rl_treeseq *ts, int start, int end, rl_matrix_fn matrix, rl
   float min_value = 0.f, min_value_alt = 0.f;
   int rc;
 
+  const bool resident = dev && ts->matrix_dev;
   ts->trees.emplace_back();
-  if ((rc = matrix(user, start, d.data()))) return rc;
-  build_tree(d.data(), nullptr, ts->trees.back());  // :447, no prior for the first tree
+  if (resident) {
+    float *dd = dev->device_matrix();
+    if (!dd) return RL_ENOMEM;
+    if ((rc = ts->matrix_dev(user, start, dd))) return rc;
+    if (dev->build_resident(tb, false, ts->trees.back())) return RL_EHIP;
+    ts->gpu_trees++;
+  } else {
+    if ((rc = matrix(user, start, d.data()))) return rc;
+    build_tree(d.data(), nullptr, ts->trees.back());  // :447, no prior for the first tree
+  }
   ts->trees.back().pos = start;
   std::fill(ts->trees.back().snp_begin.begin(), ts->trees.back().snp_begin.end(), start);
   set_carriers(start);
@@ -459,9 +469,23 @@ int rl_treeseq_build(rl_treeseq *ts, int start, int end, rl_matrix_fn matrix, rl
       HostTree &pt = ts->trees[ts->trees.size() - 2];
       t_mark = now();
       builds++;
-      if ((rc = matrix(user, snp, d.data()))) return rc;
-      lap(t_matrix);
-      if (consistency) {
+      if (resident) {  // matrix, carrier penalty, clade prior and the build itself on the device
+        float *dd = dev->device_matrix();
+        if ((rc = ts->matrix_dev(user, snp, dd))) return rc;
+        lap(t_matrix);
+        int st = 0;
+        if (consistency) {
+          st = dev->apply_penalty(ts->member.data(), val);
+          st = st ? st : dev->apply_prior(pt, val);
+          lap(t_prior);
+        }
+        st = st ? st : dev->build_resident(tb, consistency, nt);
+        if (st) return RL_EHIP;
+        ts->gpu_trees++;
+      } else if ((rc = matrix(user, snp, d.data()))) {
+        return rc;
+      } else if (consistency) {
+        lap(t_matrix);
         // carrier penalty (:563-581): d[c][*] += val, then d[c][c'] -= val
         parallel_rows(N, [&](int c) {
           if (ts->member[c]) {
@@ -513,6 +537,12 @@ int rl_treeseq_build(rl_treeseq *ts, int start, int end, rl_matrix_fn matrix, rl
 int rl_treeseq_set_build_device(rl_treeseq *ts, int device) {
   if (!ts) return RL_EINVAL;
   ts->build_device = device;
+  return RL_OK;
+}
+
+int rl_treeseq_set_device_matrix(rl_treeseq *ts, rl_matrix_dev_fn matrix_dev) {
+  if (!ts) return RL_EINVAL;
+  ts->matrix_dev = matrix_dev;
   return RL_OK;
 }
 
@@ -589,6 +619,10 @@ std::mutex g_gpu_mutex;
 static int win_matrix(void *user, int snp, float *d) {
   std::lock_guard<std::mutex> lk(g_gpu_mutex);
   return rl_window_matrix((rl_window *)user, snp, d, nullptr);
+}
+static int win_matrix_dev(void *user, int snp, void *d_dev) {
+  std::lock_guard<std::mutex> lk(g_gpu_mutex);
+  return rl_window_matrix_rows_device((rl_window *)user, snp, d_dev, nullptr);
 }
 static int win_advance(void *user, int snp) { return rl_window_advance((rl_window *)user, snp); }
 
@@ -750,7 +784,10 @@ int rl_stage_build_topology(const char *out_dir, int chunk_index, int first_sect
       if (pinned) sched_setaffinity(0, sizeof(before), &before);
       return;
     }
-    if (gpu_build) rl_treeseq_set_build_device(ts, device);
+    if (gpu_build) {
+      rl_treeseq_set_build_device(ts, device);
+      if (ctx->nloc == ctx->N) rl_treeseq_set_device_matrix(ts, win_matrix_dev);
+    }
     for (;;) {
       const int section = next.fetch_add(1);
       if (section > last_section || first_error.load()) break;
