@@ -11,9 +11,10 @@
 //     on all 1024 threads; the random draws -- one per feasible pair, in the reference's order -- and the
 //     candidate bookkeeping run on thread 0 over lists the parallel parts leave in order;
 //   * std::mt19937 (seed 1 per build) and libstdc++'s generate_canonical<double, 53> are restated below.
-// A build that needs the symmetric fallback (no mutually closest pair left, :255-293 / :968-1058) stops with
-// status 1 and the caller builds that tree on the host: the state both builders carry from tree to tree
-// (min_values_CF and the stale candidate indices, minmatch.h) is copied in before and out after every build.
+// The symmetric fallback (no mutually closest pair left, :255-293 / :968-1058) is here too: "the first cluster in
+// scan order that reaches the minimum" is a lexicographic (value, position) reduction.  The state both builders
+// carry from tree to tree (min_values_CF and the stale candidate indices, minmatch.h) is copied in before and
+// out after every build, so host and device builders can alternate on a section.
 #include <hip/hip_runtime.h>
 
 #include <chrono>
