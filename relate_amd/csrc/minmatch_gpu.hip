@@ -281,7 +281,7 @@ __device__ inline void consider(const MMParams &p, Shared &sh, int x, int y) {
 }
 
 // one workgroup per tree: workgroup b builds the tree of params[b]
-__global__ void __launch_bounds__(MM_BLOCK) minmatch_kernel(const MMParams *__restrict__ params) {
+__global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *__restrict__ params) {
   const MMParams p = params[blockIdx.x];
   __shared__ Shared sh;
   const int N = p.N;

@@ -48,7 +48,11 @@ with tempfile.TemporaryDirectory() as work:
                                 for f in os.listdir(os.path.join(d, "chunk_0", "paint"))) / 1e9
     t1 = time.time()
     if sections > 0:
-        p = subprocess.run([exe, "--mode", "BuildTopology", "--chunk_index", "0", "--first_section", "0", "--last_section",
+        pre = []
+        if os.environ.get("CHUNK_ROCPROF"):  # kernel trace of the BuildTopology process (the program itself after --)
+            pre = ["rocprofv3", "--kernel-trace", "--stats", "-d", os.path.abspath(os.environ["CHUNK_ROCPROF"]), "-o", "bt",
+                   "--"]
+        p = subprocess.run(pre + [exe, "--mode", "BuildTopology", "--chunk_index", "0", "--first_section", "0", "--last_section",
                             str(min(sections, W) - 1), "-o", "out"], cwd=work, stderr=subprocess.PIPE,
                            env=dict(os.environ, RELATE_AMD_TIMING="1"))
         assert p.returncode == 0, p.stderr.decode()[-400:]
