@@ -399,7 +399,7 @@ int rl_treeseq_build(rl_treeseq *ts, int start, int end, rl_matrix_fn matrix, rl
   };
   MinMatch tb(N, ts->theta);
   std::unique_ptr<DeviceMinMatch> dev;
-  if (ts->build_device >= 0) dev.reset(new DeviceMinMatch(N, ts->build_device));
+  if (ts->build_device >= 0 && N <= 32768) dev.reset(new DeviceMinMatch(N, ts->build_device));  // (its position masks)
   int build_rc = 0;
   auto build_tree = [&](float *dm, const float *prior, HostTree &t) {
     if (dev) {

@@ -118,3 +118,34 @@ def test_cli_build_topology_trees_built_on_the_gpu(tmp_path, name):
     for w in range(fx.W):
         assert open(work / "out" / "chunk_0" / ("out_%d.mut" % w), "rb").read() == fx.z["mut/%d" % w].tobytes(), w
         assert open(work / "out" / "chunk_0" / ("out_%d.anc" % w), "rb").read() == fx.z["anc/%d" % w].tobytes(), w
+
+
+def test_cli_gpu_build_with_bounded_windows(tmp_path):
+    """both together: windows that repaint in parts feed the device-resident tree builder"""
+    work = tmp_path / "work"
+    (work / "out").mkdir(parents=True)
+    fx = Fixture("synth70", work / "out")
+    fx.write_paint_files(str(work / "out" / "chunk_0" / "paint"))
+    p = subprocess.run([CLI, "--mode", "BuildTopology", "--chunk_index", "0", "--first_section", "0",
+                        "--last_section", str(fx.W - 1), "-o", "out"], cwd=str(work), stderr=subprocess.PIPE,
+                       env=dict(os.environ, RELATE_AMD_GPU_BUILD="1", RELATE_AMD_WINDOW_ROWS="300"))
+    assert p.returncode == 0, p.stderr.decode()
+    for w in range(fx.W):
+        assert open(work / "out" / "chunk_0" / ("out_%d.mut" % w), "rb").read() == fx.z["mut/%d" % w].tobytes(), w
+        assert open(work / "out" / "chunk_0" / ("out_%d.anc" % w), "rb").read() == fx.z["anc/%d" % w].tobytes(), w
+
+
+@pytest.mark.parametrize("tag,opts", [("nc", ["--no_consistency"]), ("fb", ["--fb", "2500"])])
+def test_cli_gpu_build_options(tmp_path, tag, opts):
+    """--no_consistency (no penalty, no prior) and --fb with the trees built on the GPU"""
+    work = tmp_path / "work"
+    (work / "out").mkdir(parents=True)
+    fx = Fixture("synth70", work / "out")
+    fx.write_paint_files(str(work / "out" / "chunk_0" / "paint"))
+    p = subprocess.run([CLI, "--mode", "BuildTopology", "--chunk_index", "0", "--first_section", "0",
+                        "--last_section", str(fx.W - 1), "-o", "out"] + opts, cwd=str(work), stderr=subprocess.PIPE,
+                       env=dict(os.environ, RELATE_AMD_GPU_BUILD="1"))
+    assert p.returncode == 0, p.stderr.decode()
+    for w in range(fx.W):
+        assert open(work / "out" / "chunk_0" / ("out_%d.mut" % w), "rb").read() == fx.z["mut_%s/%d" % (tag, w)].tobytes(), w
+        assert open(work / "out" / "chunk_0" / ("out_%d.anc" % w), "rb").read() == fx.z["anc_%s/%d" % (tag, w)].tobytes(), w
