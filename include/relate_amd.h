@@ -214,6 +214,10 @@ int rl_builder_build(rl_builder *b, float *d, const float *d_prior,
                      int *parent, int *child_left, int *child_right);
 int rl_builder_last_on_gpu(const rl_builder *b);
 void rl_builder_destroy(rl_builder *b);
+/* Test hook (host only): the device builder's restatement of std::mt19937 +
+ * libstdc++'s uniform_real_distribution<double> against the library itself,
+ * n draws from `seed`; returns how many differ. */
+int rl_debug_rng_mismatches(unsigned seed, int n);
 
 /* Tree-sequence loop of one section, AncesTreeBuilder::BuildTopology
  * (src/anc_builder.cpp:398-656): first tree from the distance matrix at

@@ -22,6 +22,7 @@
 #include <condition_variable>
 #include <cstdint>
 #include <mutex>
+#include <random>
 #include <thread>
 #include <vector>
 
@@ -65,12 +66,12 @@ struct Rng {  // std::mt19937
   int idx;
 };
 
-__device__ inline void rng_seed(Rng &r, uint32_t seed) {
+__host__ __device__ inline void rng_seed(Rng &r, uint32_t seed) {
   r.mt[0] = seed;
   for (int i = 1; i < 624; i++) r.mt[i] = 1812433253u * (r.mt[i - 1] ^ (r.mt[i - 1] >> 30)) + (uint32_t)i;
   r.idx = 624;
 }
-__device__ inline uint32_t rng_next(Rng &r) {
+__host__ __device__ inline uint32_t rng_next(Rng &r) {
   if (r.idx >= 624) {
     for (int i = 0; i < 624; i++) {
       const uint32_t y = (r.mt[i] & 0x80000000u) | (r.mt[(i + 1) % 624] & 0x7fffffffu);
@@ -87,7 +88,7 @@ __device__ inline uint32_t rng_next(Rng &r) {
 }
 // std::uniform_real_distribution<double>(0,1)(rng) of libstdc++: generate_canonical<double, 53> = two draws,
 // sum = g1 + g2 * 2^32 in double, / 2^64, a result of 1 replaced by nextafter(1, 0)
-__device__ inline double rng_unif(Rng &r) {
+__host__ __device__ inline double rng_unif(Rng &r) {
   const double g1 = (double)rng_next(r);
   const double g2 = (double)rng_next(r);
   const double sum = g1 + g2 * 4294967296.0;
@@ -896,6 +897,17 @@ __global__ void prior_kernel(float *__restrict__ CF, int N, const int *__restric
 
 }  // namespace
 
+// The restated generator against the library's, on the host: how many of n draws differ (0 expected).
+int rng_restatement_mismatches(unsigned seed, int n) {
+  Rng r;
+  rng_seed(r, seed);
+  std::mt19937 ref(seed);
+  std::uniform_real_distribution<double> unif(0.0, 1.0);
+  int bad = 0;
+  for (int i = 0; i < n; i++) bad += rng_unif(r) != unif(ref);
+  return bad;
+}
+
 // ---- host side
 // Trees of different sections are built at the same time, but a process has a handful of hardware queues (4 by
 // default): 40 builders with a stream and a one-workgroup launch each run 4 at a time.  So builders hand their
@@ -1240,5 +1252,7 @@ int rl_builder_build(rl_builder *b, float *d, const float *d_prior, int *parent,
 }
 
 int rl_builder_last_on_gpu(const rl_builder *b) { return b ? b->last_on_gpu : RL_EINVAL; }
+
+int rl_debug_rng_mismatches(unsigned seed, int n) { return rl::rng_restatement_mismatches(seed, n); }
 
 }  // extern "C"

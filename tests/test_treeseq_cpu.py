@@ -105,3 +105,11 @@ def test_quickbuild_reference_unit_vectors():
     # an all-zero matrix must still give a valid binary tree (test_treebuilder.cpp:22-29)
     p = api.quickbuild(np.zeros((5, 5), np.float32), theta=0.025)
     assert p[-1] == -1 and sorted(np.bincount(p[:-1])[5:]) == [2, 2, 2, 2]
+
+
+@pytest.mark.parametrize("seed", [1, 2, 5489, 4294967295])
+def test_device_builder_rng_restatement_matches_the_library(seed):
+    """minmatch_gpu.hip restates std::mt19937 and libstdc++'s generate_canonical<double, 53> for the device; the
+    same functions compiled for the host against the library, draw by draw (200 regenerations of the state)"""
+    from relate_amd import api
+    assert api.lib().rl_debug_rng_mismatches(seed, 125000) == 0
