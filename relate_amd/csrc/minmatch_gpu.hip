@@ -106,15 +106,13 @@ struct Shared {
   Rng rng;
   Best best, best_sym;
   int use_sym;
-  int n, i, j, ipos;
+  int n, ipos;
   int wave_i[MM_WAVES];
   float wave_f[MM_WAVES];
   int wave_i2[MM_WAVES];
   int wave_i3[MM_WAVES];
   float wave_f2[MM_WAVES];
   int count;
-  int nupd;
-  float mv_cf, mvj;
   int rowcount[MM_WAVES];
   float sym_dist;
 };
