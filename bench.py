@@ -266,7 +266,7 @@ def main():
                                        "frac": (13 if args.mode == "exact" else 6) * N * sites / (bwd_ms * 1e-3) / 1e12
                                        / FP64_PEAK_TINSTR}},
         }
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:  # (the CPU baseline is a one-GPU-run item: rank 0 at N=1 only)
             out["cpu_baseline"] = cpu_baseline(N, L, bits, r, rpos, wb)
         if world == 1 and N == 5000 and not args.skip_chunk:
             ctx.close()
