@@ -13,6 +13,7 @@
 //       (cursors advanced the way AncesTreeBuilder::BuildTopology does)
 //       dump: int N; per matrix: int snp; float d[N*N]
 //   ref_harness quickbuild <N> <d.bin> <parents.out> [<prior.bin>]
+//   ref_harness quickbuild_seq <N> <parents.out> (<d.bin> <prior.bin|->)...
 //       MinMatch::QuickBuild on a raw N*N float matrix (with optional prior)
 //       output: int parent[2N-1]
 //   ref_harness treeseq  <outdir> <chunk> <window> <dump.bin>
@@ -70,6 +71,41 @@ static void apply_painting(Data &data) {
 int main(int argc, char **argv) {
   if (argc < 2) return 2;
   std::string mode = argv[1];
+
+  if (mode == "quickbuild_seq") {
+    // ref_harness quickbuild_seq <N> <parents.out> (<d.bin> <prior.bin|->)...
+    // ONE MinMatch for the whole sequence, as AncesTreeBuilder::BuildTopology keeps one per section
+    // (anc_builder.cpp:436): what it carries from build to build is part of the result.
+    int N = atoi(argv[2]);
+    Data data(N, 1);
+    MinMatch tb(data);
+    std::vector<double> ages;
+    FILE *fo = fopen(argv[3], "wb");
+    if (!fo) return 1;
+    for (int a = 4; a + 1 < argc; a += 2) {
+      CollapsedMatrix<float> d, prior;
+      d.resize(N, N);
+      FILE *fp = fopen(argv[a], "rb");
+      if (!fp || fread(&d[0][0], 4, (size_t)N * N, fp) != (size_t)N * N) return 1;
+      fclose(fp);
+      Tree tree;
+      if (std::string(argv[a + 1]) != "-") {
+        prior.resize(N, N);
+        fp = fopen(argv[a + 1], "rb");
+        if (!fp || fread(&prior[0][0], 4, (size_t)N * N, fp) != (size_t)N * N) return 1;
+        fclose(fp);
+        tb.QuickBuild(d, tree, ages, prior);
+      } else {
+        tb.QuickBuild(d, tree, ages);
+      }
+      for (int i = 0; i < 2 * N - 1; i++) {
+        int p = tree.nodes[i].parent ? (*tree.nodes[i].parent).label : -1;
+        fwrite(&p, 4, 1, fo);
+      }
+    }
+    fclose(fo);
+    return 0;
+  }
 
   if (mode == "quickbuild") {
     int N = atoi(argv[2]);

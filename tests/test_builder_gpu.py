@@ -55,8 +55,8 @@ def run_sequence(N, mats, theta=0.001):
 def test_tied_matrices_with_and_without_prior(N, seed):
     rng = np.random.RandomState(seed)
     mats = [(tied_matrix(rng, N), None)]
-    for _ in range(3):
-        mats.append((tied_matrix(rng, N), (np.floor(rng.rand(N, N) * 4) * 6.9).astype(np.float32)))
+    for t in range(3):  # row minima of the prior rise from tree to tree: the minima carried over stay below them
+        mats.append((tied_matrix(rng, N), ((np.floor(rng.rand(N, N) * 4) + t) * 6.9).astype(np.float32)))
     mats.append((tied_matrix(rng, N, 0.0), None))
     run_sequence(N, mats)
 

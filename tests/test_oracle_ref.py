@@ -143,3 +143,40 @@ def test_treeseq_options_match_reference_binary(tmp_path, oracle, opts, flags, f
         anc, mut, nt = T.build_section(fx, w, tmp_path, oracle, flags=flags, fb=fb)
         assert mut == open(tmp_path / "out" / "chunk_0" / ("out_%d.mut" % w), "rb").read(), w
         assert anc == open(tmp_path / "out" / "chunk_0" / ("out_%d.anc" % w), "rb").read(), (w, nt)
+
+
+@pytest.mark.parametrize("seed,N", [(11, 60), (12, 220)])
+def test_builder_sequences_match_one_reference_minmatch(tmp_path, seed, N):
+    """rl_builder (host): a sequence of trees from ONE builder against a sequence from ONE MinMatch of the
+    reference -- what MinMatch carries from build to build (min_values_CF, stale candidate indices) included.
+    The GPU builder is held to the host builder on such sequences (tests/test_builder_gpu.py)."""
+    import subprocess
+    from relate_amd import api
+    rng = np.random.RandomState(seed)
+    mats = []
+    for t in range(5):
+        d = (rng.rand(N, N) * 4 + rng.rand(N)[:, None]).astype(np.float32)
+        d[rng.rand(N, N) < 0.3] = 1.5
+        np.fill_diagonal(d, 0)
+        # priors whose row minima rise from tree to tree: the minima a builder carries over stay below them
+        prior = None if t in (0, 3) else ((np.floor(rng.rand(N, N) * 4) + (t >= 2)) * 6.9).astype(np.float32)
+        mats.append((d, prior))
+    args = [rlutil.REF_HARNESS, "quickbuild_seq", str(N), str(tmp_path / "p.bin")]
+    for t, (d, prior) in enumerate(mats):
+        d.tofile(str(tmp_path / ("d%d.bin" % t)))
+        args.append(str(tmp_path / ("d%d.bin" % t)))
+        if prior is None:
+            args.append("-")
+        else:
+            prior.tofile(str(tmp_path / ("c%d.bin" % t)))
+            args.append(str(tmp_path / ("c%d.bin" % t)))
+    subprocess.run(args, check=True)
+    ref = np.fromfile(str(tmp_path / "p.bin"), dtype=np.int32).reshape(len(mats), 2 * N - 1)
+    b = api.Builder(N)
+    fresh_differs = 0
+    for t, (d, prior) in enumerate(mats):
+        got = b.build(d, prior)[0]
+        assert np.array_equal(got, ref[t]), t
+        fresh_differs += not np.array_equal(api.quickbuild(d, 0.001, prior), ref[t])
+    b.close()
+    assert fresh_differs > 0  # (the carried state matters: a fresh builder per tree gives other trees)
