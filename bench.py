@@ -2,8 +2,9 @@
 """bench.py -- Paint (stepping-stone Li-Stephens forward/backward) throughput.
 
 One "step" = one pass of the Paint hot path over one synthetic chunk already
-resident in HBM: the backward kernel + the forward kernel for all N targets
-(replacing the loop of pipeline/Paint.cpp:81-87 in the reference).
+resident in HBM: the backward and the forward pass for all N targets, one
+launch of 2N workgroups (replacing the loop of pipeline/Paint.cpp:81-87 in the
+reference).
 
     python bench.py [--gpus N --steps K --warmup W] [--haplotypes 5000 --snps 500000]
 
@@ -52,28 +53,35 @@ def make_chunk(N, L, seed, memory_gb):
     return bits, r, rpos, wbuf[:W + 1].copy()
 
 
-def cpu_baseline(N, L, bits, r, rpos, wb, seconds_target=15.0):
+def cpu_baseline(N, L, bits, r, rpos, wb, seconds_target=12.0):
     """the oracle (plain-C port of the reference's PaintSteppingStones) timed on
-    the host cores on a bounded sample of targets of the SAME chunk"""
+    the host cores on a bounded sample of targets of the SAME chunk: on all cores
+    (targets split over threads) and on ONE thread (the reference is
+    single-threaded; SURVEY.md 8d asks for both)"""
     import rlutil
     o = rlutil.oracle()
-    cores = min(os.cpu_count() or 1, 64)
     seq = np.unpackbits(bits.view(np.uint8), axis=1, bitorder="little")[:, :N]
     seq = np.ascontiguousarray(seq + ord("0"), dtype=np.uint8)
     d = rlutil.RoData(N, L, seq.ctypes.data, r.ctypes.data, rpos.ctypes.data, 0.001)
     # ~3.1e8 updates/s/core measured on the reference (BASELINE.md); one target
     # costs 2*N*D_k ~ 2*N*0.11*L updates
     per_target = 2.0 * N * 0.12 * L / 3.0e8
-    per_thread = max(1, int(seconds_target / max(per_target, 1e-3)))
-    count = min(N, cores * per_thread)
-    stride = max(1, N // count)
-    t0 = time.time()
-    sites = o.ro_paint_sample(C.byref(d), wb.ctypes.data_as(C.c_void_p), len(wb) - 1, 0, stride, count, cores)
-    dt = time.time() - t0
-    assert sites > 0
-    return dict(value=2.0 * N * sites / dt, unit="updates/s", cores=cores, kind="port",
-                sample="%d of %d targets (every %d-th) of the same chunk, oracle ro_paint_sample on %d threads, "
-                       "%.1f s wall" % (count, N, stride, cores, dt))
+
+    def sample(cores, seconds):
+        per_thread = max(1, int(seconds / max(per_target, 1e-3)))
+        count = min(N, cores * per_thread)
+        stride = max(1, N // count)
+        t0 = time.time()
+        sites = o.ro_paint_sample(C.byref(d), wb.ctypes.data_as(C.c_void_p), len(wb) - 1, 0, stride, count, cores)
+        dt = time.time() - t0
+        assert sites > 0
+        return dict(value=2.0 * N * sites / dt, unit="updates/s", cores=cores, kind="port",
+                    sample="%d of %d targets (every %d-th) of the same chunk, oracle ro_paint_sample on %d "
+                           "thread%s, %.1f s wall" % (count, N, stride, cores, "s" if cores > 1 else "", dt))
+
+    out = sample(min(os.cpu_count() or 1, 64), seconds_target)
+    out["single_thread"] = sample(1, seconds_target)
+    return out
 
 
 def chunk_wallclock_sample():
@@ -150,31 +158,40 @@ def main():
         torch.cuda.synchronize()
 
     def timed(m, steps, warmup):
+        """-> wall seconds of `steps` Paints, mean duration of the launch in ms (HIP events on the launch's
+        stream, taken inside rl_paint)"""
         for _ in range(warmup):
             ctx.paint(m)
         barrier()
         t0 = time.time()
-        fwd = bwd = 0.0
+        kern = 0.0
         for _ in range(steps):
-            ctx.paint(m)  # returns after both kernels completed (HIP events)
-            f, b = ctx.paint_times()
-            fwd += f
-            bwd += b
+            kern += ctx.paint(m)  # returns after the launch completed (HIP events)
         barrier()
-        return time.time() - t0, fwd / steps, bwd / steps
+        return time.time() - t0, kern / steps
 
-    dt, fwd_ms, bwd_ms = timed(mode, args.steps, args.warmup)
+    def split_times(m):
+        """one launch per direction: (forward ms, backward ms) -- what each pass costs when it has the chip alone"""
+        ctx.set_paint_split(True)
+        ctx.paint(m)
+        f, b = ctx.paint_times()
+        ctx.set_paint_split(False)
+        return f, b
+
+    dt, kernel_ms = timed(mode, args.steps, args.warmup)
     from relate_amd import dist as rdist
     total_updates, dt = rdist.job_stats(updates, dt)  # sum of units, max of seconds over ranks
+    fwd_ms, bwd_ms = split_times(mode) if rank == 0 else (0.0, 0.0)
 
     alt = None
     if not args.no_alt:
         other = api.RL_SUM_LANES if mode == api.RL_SUM_EXACT else api.RL_SUM_EXACT
-        adt, af, ab = timed(other, max(1, args.steps), 1 if other == api.RL_SUM_LANES else 0)
+        adt, ak = timed(other, max(1, args.steps), 1 if other == api.RL_SUM_LANES else 0)
+        af, ab = split_times(other) if rank == 0 else (0.0, 0.0)
         alt = dict(mode="lanes" if other == api.RL_SUM_LANES else "exact",
                    value=updates * max(1, args.steps) / adt, ms_per_step=1e3 * adt / max(1, args.steps),
-                   fwd_kernel_ms=af, bwd_kernel_ms=ab,
-                   bwd_roofline_frac=(N * sites / 8.0) / (ab * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                   kernel_ms=ak, fwd_alone_ms=af, bwd_alone_ms=ab,
+                   roofline_frac=(2.0 * N * sites / 8.0) / (ak * 1e-3) / 1e9 / HBM_PEAK_GBS)
 
     # secondary kernels of the path on the same chunk (reported under config, not timed steps):
     # K2 RePaintSection of one window for all targets, K3 one N x N distance matrix
@@ -193,37 +210,56 @@ def main():
                   "all_gather_ms": 1e3 * (time.time() - t0), "matrix_shape": list(full.shape)}
         win.close()
     extra = None
+    roofline_k2 = None
     if rank == 0 and not args.skip_k23 and not by_target:
         try:
             w = (len(wb) - 1) // 2
             ctx.open_window(w, None, int(wb[w]), mode).close()   # first launch loads the kernel's code object
             win = ctx.open_window(w, None, int(wb[w]), mode)     # stones resident after the last paint
             win.matrix(int(wb[w]))
-            rows = sum(win.rows(n) for n in range(0, N, 50)) * 50.0   # sampled row count
+            rows = float(sum(win.rows(n) for n in range(N)))      # (target, visited site) pairs of the window
+            W = len(wb) - 1
+            # K2's algorithmic bytes per (target, visited site, donor): 4 B of posterior written + 2 bits of
+            # panel read (forward and backward pass), SURVEY.md 8d
+            k2_bytes = rows * N * 4.25
+            k2_gbs = k2_bytes / (win.repaint_ms * 1e-3) / 1e9
+            roofline_k2 = {"bound": "hbm", "kernel": "repaint_kernel (one window, all targets)",
+                           "achieved": k2_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k2_gbs / HBM_PEAK_GBS,
+                           "traffic": None, "window": w, "target_site_rows": rows, "ms": win.repaint_ms}
             extra = {"window": w,
                      "k2_repaint_ms": win.repaint_ms,
                      "k2_topology_write_GBps": rows * N * 4.0 / (win.repaint_ms * 1e-3) / 1e9,
                      "k3_matrix_ms": win.matrix_ms,
-                     "k3_GBps": 12.0 * N * N / (win.matrix_ms * 1e-3) / 1e9}
+                     "k3_GBps": 12.0 * N * N / (win.matrix_ms * 1e-3) / 1e9,
+                     # GPU time of one chunk of this shape: K1 once, K2 once per window (more with bounded
+                     # windows), K3 once per tree built
+                     "gpu_time_per_chunk": {"k1_paint_s": kernel_ms * 1e-3, "k2_all_windows_s": W * win.repaint_ms * 1e-3,
+                                            "k3_per_tree_ms": win.matrix_ms, "windows": W}}
             win.close()
         except Exception as e:  # never let the secondary measurement break the bench line
             extra = {"error": str(e)[:200]}
 
     if rank == 0:
         ms_per_step = 1e3 * dt / args.steps
-        # dominant kernel: the backward launch.  Algorithmic bytes = 1 bit per
-        # directional update: N * sum_k D_k / 8 per launch.
-        alg_bytes = N * sites / 8.0
-        achieved = alg_bytes / (bwd_ms * 1e-3) / 1e9
-        # HBM bytes of that launch from the PMC passes (FETCH_SIZE + WRITE_SIZE, collected by
-        # tools/gpu_profile_r01.sh in separate rocprofv3 runs, summary committed under profiles/)
-        traffic = None
+        # dominant kernel: paint_kernel, both directions of every target in one launch.  Algorithmic bytes =
+        # 1 bit per directional update: 2 * N * sum_k D_k / 8 per launch.
+        alg_bytes = 2.0 * N * sites / 8.0
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        # HBM bytes per launch: PMC passes (FETCH_SIZE + WRITE_SIZE) are separate rocprofv3 runs
+        # (tools/gpu_profile_r02.sh); the committed summary is read here, NOT measured in this run
+        traffic, traffic_from = None, None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_c3.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_c3.json")))
             if pmc["N"] == N and pmc["L"] == L and not by_target:
-                traffic = pmc["kernels"][args.mode + "_bwd"]["hbm_bytes_per_launch"]
+                traffic = pmc["kernels"][args.mode]["hbm_bytes_per_launch"]
+                traffic_from = "profiles/r02_pmc_c3.json"
         except Exception:
             pass
+        # SURVEY.md 8d caveat H5: at 1 bit per update the FP64 vector pipe, not HBM, is the resource that binds.
+        # USEFUL f64 instructions per pair of directional updates (one donor at one visited site, both passes):
+        # 3 forward (add, masked mul, add into the sum) + 6 backward (masked add, add, masked mul, two for the
+        # weighted term, add into the sum) = 9; whatever else the exact order costs is overhead, not counted.
+        useful = 9.0 * N * sites / (kernel_ms * 1e-3) / 1e12
         out = {
             "metric": "haplotype-pair*SNP updates/sec (Paint)",
             "value": total_updates * args.steps / dt,
@@ -246,26 +282,24 @@ def main():
                 "sum_k_D_k": int(sites),
                 "updates_per_step_per_gpu": updates,
                 "nominal_updates_per_s_2NNL": 2.0 * N * N * L * world / (dt / args.steps),
-                "fwd_kernel_ms": fwd_ms,
-                "bwd_kernel_ms": bwd_ms,
+                "kernel_ms": kernel_ms,
+                "fwd_alone_ms": fwd_ms,
+                "bwd_alone_ms": bwd_ms,
                 "other_mode": alt,
                 "repaint_and_matrix": extra,
                 "shard": args.shard,
                 "target_shard_matrix": gather,
             },
-            "roofline": {"bound": "hbm", "kernel": "paint_kernel<backward>", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic,
-                         # SURVEY.md 8d caveat H5: at 1 bit per update the FP64 vector pipe, not HBM, is the
-                         # resource that binds.  Algorithmic f64 instructions per directional update of the
-                         # backward kernel: 6 (update + weighted lane sum), + 7 for the exact sum.
-                         "fp64_valu": {"instr_per_update": 13 if args.mode == "exact" else 6,
-                                       "achieved_Tinstr_per_s": (13 if args.mode == "exact" else 6) * N * sites
-                                       / (bwd_ms * 1e-3) / 1e12,
+            "roofline": {"bound": "fp64_valu", "kernel": "paint_kernel (forward + backward, one launch)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_static_from": traffic_from,
+                         "fp64_valu": {"useful_instr_per_update_pair": 9,
+                                       "achieved_Tinstr_per_s": useful,
                                        "peak_Tinstr_per_s": FP64_PEAK_TINSTR,
-                                       "frac": (13 if args.mode == "exact" else 6) * N * sites / (bwd_ms * 1e-3) / 1e12
-                                       / FP64_PEAK_TINSTR}},
+                                       "frac": useful / FP64_PEAK_TINSTR}},
         }
+        if roofline_k2 is not None:
+            out["roofline_k2"] = roofline_k2
         if not args.no_cpu and world == 1:  # (the CPU baseline is a one-GPU-run item: rank 0 at N=1 only)
             out["cpu_baseline"] = cpu_baseline(N, L, bits, r, rpos, wb)
         if world == 1 and N == 5000 and not args.skip_chunk:

@@ -112,9 +112,17 @@ int rl_prepare(rl_ctx *ctx);
  * stones (alpha, beta, logscales at window boundaries) left in HBM.
  * kernel_ms (optional) receives the GPU time of the kernels (HIP events). */
 int rl_paint(rl_ctx *ctx, int sum_mode, float *kernel_ms);
+/* rl_paint normally paints both directions in ONE launch (2 workgroups per
+ * target: the passes are independent in this stage, fast_painting.cpp:207-378
+ * vs :380-586).  split != 0: one launch per direction (backward, then forward),
+ * which is what rl_paint_times reports on. */
+int rl_set_paint_split(rl_ctx *ctx, int split);
 /* HIP-event durations of the last rl_paint's two launches (forward kernel,
- * backward kernel), in milliseconds. */
+ * backward kernel), in milliseconds; both 0 unless rl_set_paint_split(ctx, 1). */
 int rl_paint_times(const rl_ctx *ctx, float *fwd_ms, float *bwd_ms);
+/* Register tile of the loaded chunk: S doubles per lane, `waves` wavefronts
+ * per target (relate_amd/csrc/launch.h) -- which kernel instantiation runs. */
+int rl_register_tile(const rl_ctx *ctx, int *S, int *waves);
 
 /* Test hook: `batch` arrays of n doubles each are summed, one wavefront per
  * array, with the summation machinery of the painting kernels (sum_mode as

@@ -143,6 +143,22 @@ class Context:
         _check(lib().rl_paint(C.c_void_p(self._h), sum_mode, C.byref(ms)))
         return ms.value
 
+    def set_paint_split(self, split):
+        """one launch per direction (so that paint_times() has something to report) instead of one for both"""
+        _check(lib().rl_set_paint_split(C.c_void_p(self._h), int(bool(split))))
+
+    @property
+    def tile(self):
+        s, w = C.c_int(), C.c_int()
+        _check(lib().rl_register_tile(C.c_void_p(self._h), C.byref(s), C.byref(w)))
+        return s.value
+
+    @property
+    def waves(self):
+        s, w = C.c_int(), C.c_int()
+        _check(lib().rl_register_tile(C.c_void_p(self._h), C.byref(s), C.byref(w)))
+        return w.value
+
     def paint_times(self):
         """-> (forward kernel ms, backward kernel ms) of the last paint()"""
         f, b = C.c_float(0), C.c_float(0)

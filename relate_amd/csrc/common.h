@@ -101,7 +101,8 @@ struct rl_ctx {
   rl::DevBuf d_k2_scratch, d_k2_counter;  // RePaint's per-launch strips, shared by the context's windows (window.cpp)
   bool have_chunk = false, plan_on_device = false, painted = false;
   int paint_mode = -1;
-  float ms_fwd = 0.f, ms_bwd = 0.f;
+  float ms_fwd = 0.f, ms_bwd = 0.f, ms_paint = 0.f;
+  bool paint_split = false;  // rl_set_paint_split: one launch per direction instead of one for both
 };
 
 namespace rl {

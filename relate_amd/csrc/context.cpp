@@ -430,7 +430,7 @@ static int set_common(rl_ctx *ctx, int N, int L, const double *r, const double *
   const int waves = target_waves(N);
   Layout lay = make_layout(N, waves);
   int S = choose_S(lay);
-  if (S == 0) {
+  if (S == 0 || waves > 2) {
     set_error("N=%d exceeds the largest compiled register tile (N <= %d)", N, 2 * 80 * 64);
     return RL_EINVAL;
   }
@@ -663,16 +663,27 @@ int rl_paint(rl_ctx *ctx, int sum_mode, float *kernel_ms) {
     p.stats = ctx->d_stats.as<unsigned long long>();
   }
 
-  // backward then forward on one stream, each bracketed by HIP events
-  RL_HIP(hipEventRecord(ctx->ev0, ctx->s0));
-  RL_HIP(launch_paint(p, ctx->S, ctx->waves, 1, ctx->s0));
-  RL_HIP(hipEventRecord(ctx->ev1, ctx->s0));
-  RL_HIP(launch_paint(p, ctx->S, ctx->waves, 0, ctx->s0));
-  RL_HIP(hipEventRecord(ctx->ev2, ctx->s0));
-  RL_HIP(hipEventSynchronize(ctx->ev2));
-  RL_HIP(hipEventElapsedTime(&ctx->ms_bwd, ctx->ev0, ctx->ev1));
-  RL_HIP(hipEventElapsedTime(&ctx->ms_fwd, ctx->ev1, ctx->ev2));
-  if (kernel_ms) *kernel_ms = ctx->ms_bwd + ctx->ms_fwd;
+  if (ctx->paint_split) {
+    // one direction per launch, backward then forward on one stream, each bracketed by HIP events
+    RL_HIP(hipEventRecord(ctx->ev0, ctx->s0));
+    RL_HIP(launch_paint(p, ctx->S, ctx->waves, 1, ctx->s0));
+    RL_HIP(hipEventRecord(ctx->ev1, ctx->s0));
+    RL_HIP(launch_paint(p, ctx->S, ctx->waves, 0, ctx->s0));
+    RL_HIP(hipEventRecord(ctx->ev2, ctx->s0));
+    RL_HIP(hipEventSynchronize(ctx->ev2));
+    RL_HIP(hipEventElapsedTime(&ctx->ms_bwd, ctx->ev0, ctx->ev1));
+    RL_HIP(hipEventElapsedTime(&ctx->ms_fwd, ctx->ev1, ctx->ev2));
+    ctx->ms_paint = ctx->ms_bwd + ctx->ms_fwd;
+  } else {
+    // both directions in one launch of 2 * nloc workgroups (paint_kernels.hip)
+    RL_HIP(hipEventRecord(ctx->ev0, ctx->s0));
+    RL_HIP(launch_paint(p, ctx->S, ctx->waves, 2, ctx->s0));
+    RL_HIP(hipEventRecord(ctx->ev2, ctx->s0));
+    RL_HIP(hipEventSynchronize(ctx->ev2));
+    RL_HIP(hipEventElapsedTime(&ctx->ms_paint, ctx->ev0, ctx->ev2));
+    ctx->ms_bwd = ctx->ms_fwd = 0.f;
+  }
+  if (kernel_ms) *kernel_ms = ctx->ms_paint;
   ctx->painted = true;
   ctx->paint_mode = sum_mode;
   return RL_OK;
@@ -681,6 +692,25 @@ int rl_paint(rl_ctx *ctx, int sum_mode, float *kernel_ms) {
 int rl_debug_stats(rl_ctx *ctx, unsigned long long *out16) {
   if (!ctx || !ctx->d_stats.p || !out16) return RL_ESTATE;
   RL_HIP(hipMemcpy(out16, ctx->d_stats.p, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return RL_OK;
+}
+
+int rl_set_paint_split(rl_ctx *ctx, int split) {
+  if (!ctx) {
+    set_error("rl_set_paint_split: no context");
+    return RL_EINVAL;
+  }
+  ctx->paint_split = split != 0;
+  return RL_OK;
+}
+
+int rl_register_tile(const rl_ctx *ctx, int *S, int *waves) {
+  if (!ctx || !ctx->have_chunk) {
+    set_error("no chunk loaded");
+    return RL_ESTATE;
+  }
+  if (S) *S = ctx->S;
+  if (waves) *waves = ctx->waves;
   return RL_OK;
 }
 

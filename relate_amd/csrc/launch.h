@@ -12,13 +12,13 @@ namespace rl {
 #define RL_FOR_EACH_S(X) X(RL_ONLY_S, 16)
 #else
 #define RL_FOR_EACH_S(X) \
-  X(8, 8) X(16, 8) X(32, 16) X(48, 16) X(64, 16) X(80, 16) X(96, 16) X(128, 32) X(160, 32)
+  X(8, 8) X(16, 8) X(32, 16) X(48, 16) X(64, 16) X(80, 16)
 #endif
 
 // smallest instantiated S with S >= q + (rem > 0); 0 if N is too large
 inline int choose_S(const Layout &lay) {
   const int need = lay.q + (lay.rem > 0 ? 1 : 0);
-  static const int sizes[] = {8, 16, 32, 48, 64, 80, 96, 128, 160};
+  static const int sizes[] = {8, 16, 32, 48, 64, 80};
   for (int s : sizes)
     if (s >= need) return s;
   return 0;
@@ -43,8 +43,9 @@ hipError_t launch_lane_masks(const uint32_t *bits, int row_words, int L, const L
 
 // kernel summation modes (template parameter MODE of the kernels)
 //   0 = lanes (RL_SUM_LANES), 1 = exact, parallel (RL_SUM_EXACT), 2 = exact, literal serial (RL_SUM_EXACT_SERIAL)
+// dir: 0 forward pass, 1 backward pass, 2 both in one launch of 2 * nloc workgroups
 template <int MODE>
-hipError_t launch_paint_mode(const PaintParams &p, int S, int waves, int backward, hipStream_t stream);
+hipError_t launch_paint_mode(const PaintParams &p, int S, int waves, int dir, hipStream_t stream);
 template <int MODE>
 hipError_t launch_repaint_mode(const RepaintParams &p, int S, int waves, int nblocks, int *counter, hipStream_t stream);
 template <> hipError_t launch_paint_mode<0>(const PaintParams &, int, int, int, hipStream_t);
@@ -55,11 +56,11 @@ template <> hipError_t launch_repaint_mode<1>(const RepaintParams &, int, int, i
 template <> hipError_t launch_repaint_mode<2>(const RepaintParams &, int, int, int, int *, hipStream_t);
 
 inline int kernel_mode(int sum_mode) { return sum_mode == 0 ? 1 : (sum_mode == 1 ? 0 : 2); }
-inline hipError_t launch_paint(const PaintParams &p, int S, int waves, int backward, hipStream_t stream) {
+inline hipError_t launch_paint(const PaintParams &p, int S, int waves, int dir, hipStream_t stream) {
   switch (kernel_mode(p.sum_mode)) {
-    case 0: return launch_paint_mode<0>(p, S, waves, backward, stream);
-    case 1: return launch_paint_mode<1>(p, S, waves, backward, stream);
-    default: return launch_paint_mode<2>(p, S, waves, backward, stream);
+    case 0: return launch_paint_mode<0>(p, S, waves, dir, stream);
+    case 1: return launch_paint_mode<1>(p, S, waves, dir, stream);
+    default: return launch_paint_mode<2>(p, S, waves, dir, stream);
   }
 }
 inline hipError_t launch_repaint(const RepaintParams &p, int S, int waves, int nblocks, int *counter,

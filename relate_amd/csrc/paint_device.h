@@ -341,12 +341,11 @@ RL_DEV void pin_registers(double (&a)[S]) {
 #define RL_SLOT8(B) RL_SLOT(B) RL_SLOT(B + 1) RL_SLOT(B + 2) RL_SLOT(B + 3) RL_SLOT(B + 4) RL_SLOT(B + 5) RL_SLOT(B + 6) RL_SLOT(B + 7)
 template <int S>
 RL_DEV void set_slot(double (&a)[S], int j, u64 bit, double v) {
-  static_assert(S <= 160, "extend the case list");
+  static_assert(S <= 80, "extend the case list");
   pin_registers<S>(a);
   switch (j) {
     RL_SLOT8(0) RL_SLOT8(8) RL_SLOT8(16) RL_SLOT8(24) RL_SLOT8(32) RL_SLOT8(40) RL_SLOT8(48) RL_SLOT8(56)
-    RL_SLOT8(64) RL_SLOT8(72) RL_SLOT8(80) RL_SLOT8(88) RL_SLOT8(96) RL_SLOT8(104) RL_SLOT8(112) RL_SLOT8(120)
-    RL_SLOT8(128) RL_SLOT8(136) RL_SLOT8(144) RL_SLOT8(152)
+    RL_SLOT8(64) RL_SLOT8(72)
     default: break;
   }
   pin_registers<S>(a);

@@ -1,8 +1,11 @@
 // paint_kernels.hip -- K1: stepping-stone painting of all targets.
 //
 // Replaces FastPainting::PaintSteppingStones (fast_painting.cpp:18-618).
-// Two launches of N wavefronts each (forward, backward: independent in this
-// stage); block b paints target order[b] (longest target first).
+// The two directions are independent in this stage: by default ONE launch of
+// 2N workgroups paints both (block 2i the backward pass of target order[i],
+// block 2i+1 its forward pass; longest target first), so that the last round
+// of workgroups of one direction does not leave the chip half empty while the
+// other direction waits.  DIR = 0 / 1 launch one direction alone (profiling).
 #include "paint_device.h"
 #include "exact_sum.h"
 #include "launch.h"
@@ -284,37 +287,45 @@ RL_DEV void paint_backward(const PaintParams &p, int k, float *stage, WaveLink<W
 
 // S <= 80: hold the kernel to 256 registers so that two waves share a SIMD.
 // WAVES = 2: a workgroup of two waves paints one target (N > 5120).
-template <int S, int TAIL, int MODE, int WAVES, bool BACKWARD>
-__global__ void __launch_bounds__(64 * WAVES, (S <= 80 ? 2 : 1)) paint_kernel(const PaintParams p) {
+template <int S, int TAIL, int MODE, int WAVES, int DIR>
+__global__ void __launch_bounds__(64 * WAVES, 2) paint_kernel(const PaintParams p) {
   __shared__ float stage[WAVES][16 * 64];
   __shared__ WaveLinkStorage link;
   WaveLink<WAVES> lk;
   lk.s = &link;
   lk.w = WAVES > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
-  const int k = p.order[blockIdx.x];
-  if (BACKWARD)
+  int b = blockIdx.x;
+  bool backward = DIR == 1;
+  if (DIR == 2) {
+    backward = !(b & 1);
+    b >>= 1;
+  }
+  const int k = p.order[b];
+  if (backward)
     paint_backward<S, TAIL, MODE, WAVES>(p, k, stage[lk.w], lk);
   else
     paint_forward<S, TAIL, MODE, WAVES>(p, k, stage[lk.w], lk);
 }
 
 template <int S, int TAIL, int WAVES>
-static hipError_t launch_paint_t(const PaintParams &p, int backward, hipStream_t stream) {
-  const dim3 grid(p.nloc), block(64 * WAVES);
-  if (backward)
-    hipLaunchKernelGGL((paint_kernel<S, TAIL, RL_MODE, WAVES, true>), grid, block, 0, stream, p);
+static hipError_t launch_paint_t(const PaintParams &p, int dir, hipStream_t stream) {
+  const dim3 grid(dir == 2 ? 2 * p.nloc : p.nloc), block(64 * WAVES);
+  if (dir == 2)
+    hipLaunchKernelGGL((paint_kernel<S, TAIL, RL_MODE, WAVES, 2>), grid, block, 0, stream, p);
+  else if (dir == 1)
+    hipLaunchKernelGGL((paint_kernel<S, TAIL, RL_MODE, WAVES, 1>), grid, block, 0, stream, p);
   else
-    hipLaunchKernelGGL((paint_kernel<S, TAIL, RL_MODE, WAVES, false>), grid, block, 0, stream, p);
+    hipLaunchKernelGGL((paint_kernel<S, TAIL, RL_MODE, WAVES, 0>), grid, block, 0, stream, p);
   return hipGetLastError();
 }
 
 template <>
-hipError_t launch_paint_mode<RL_MODE>(const PaintParams &p, int S, int waves, int backward, hipStream_t stream) {
+hipError_t launch_paint_mode<RL_MODE>(const PaintParams &p, int S, int waves, int dir, hipStream_t stream) {
   if (waves == 1) {
     switch (S) {
 #define RL_CASE(s, t) \
   case s:             \
-    return launch_paint_t<s, t, 1>(p, backward, stream);
+    return launch_paint_t<s, t, 1>(p, dir, stream);
       RL_FOR_EACH_S(RL_CASE)
 #undef RL_CASE
     }
@@ -323,7 +334,7 @@ hipError_t launch_paint_mode<RL_MODE>(const PaintParams &p, int S, int waves, in
     switch (S) {
 #define RL_CASE(s, t) \
   case s:             \
-    return launch_paint_t<s, t, 2>(p, backward, stream);
+    return launch_paint_t<s, t, 2>(p, dir, stream);
       RL_FOR_EACH_S_2WAVES(RL_CASE)
 #undef RL_CASE
     }

@@ -52,6 +52,19 @@ def test_two_wavefronts_per_target(N):
     check(ch, modes=("exact", "lanes", "serial"))
 
 
+@pytest.mark.parametrize("N,S", [(2100, 48), (3500, 64), (5000, 80), (5120, 80)])
+def test_single_wave_large_tiles(N, S):
+    """N = 2049..5120: one wavefront per target with the S = 48/64/80 register tiles -- N = 5000 is the tile of
+    the headline configuration (BASELINE.json config #3); K1 in all three sum orders against the oracle
+    (fast_painting.cpp:18-618)"""
+    ch = random_chunk(N, 420, 0.13, seed=N, wb=[0, 130, 300, 420], special="flat_targets")
+    ctx = api.Context()
+    ctx.set_chunk(ch.seq, ch.r, ch.rpos, ch.wb)
+    assert (ctx.tile, ctx.waves) == (S, 1)
+    ctx.close()
+    check(ch, modes=("exact", "lanes", "serial"))
+
+
 def test_two_wavefronts_long_run_with_rescales():
     ch = random_chunk(6000, 700, 0.12, seed=77, wb=[0, 150, 400, 700])
     check(ch)
@@ -89,6 +102,9 @@ def test_bad_arguments_are_reported():
     ch = random_chunk(8, 30, 0.3, 7)
     with pytest.raises(api.RelateError):
         ctx.set_chunk(ch.seq, ch.r, ch.rpos, np.array([0, 10, 10, 30], np.int32))   # empty window
+    with pytest.raises(api.RelateError, match="exceeds the largest"):
+        big = random_chunk(10241, 4, 0.3, 7)                                         # N > 2 * 80 * 64
+        ctx.set_chunk(big.seq, big.r, big.rpos, big.wb)
     with pytest.raises(api.RelateError):
         ctx.paint()                                                                  # nothing loaded
     ctx.set_chunk(ch.seq, ch.r, ch.rpos, ch.wb)

@@ -99,7 +99,17 @@ def test_two_wavefronts_per_target(tmp_path):
     run_case(tmp_path, N, 70, None, 5, chunk=ch, via_gpu_paint=True)
 
 
-@pytest.mark.parametrize("N,L,wb", [(130, 400, [0, 150, 400]), (5300, 70, [0, 30, 70])])
+@pytest.mark.parametrize("N", [2100, 3500, 5000])
+def test_single_wave_large_tiles(tmp_path, N):
+    """K2 / K3 at the S = 48/64/80 register tiles (N = 5000: the headline configuration's): posterior rows,
+    logscales and distance matrices of all three windows against the oracle, paint files by the oracle"""
+    from test_edge_gpu import random_chunk
+    ch = random_chunk(N, 330, 0.13, seed=N + 1, wb=[0, 100, 230, 330])
+    run_case(tmp_path, N, 330, None, N, chunk=ch, windows=[0, 1, 2])
+
+
+@pytest.mark.parametrize("N,L,wb", [(130, 400, [0, 150, 400]), (3500, 90, [0, 40, 90]), (5000, 90, [0, 40, 90]),
+                                    (5300, 70, [0, 30, 70])])
 def test_repaint_lanes_order_matches_oracle(tmp_path, N, L, wb):
     """RL_SUM_LANES in K2: posterior rows bit-identical to the oracle run in the same summation order
     (64 lane runs + balanced tree; 128 runs for the two-wavefront layout at N > 5120)"""
