@@ -154,8 +154,12 @@ static double sum_lanes(const double *t, int N, int k, int nl) {
 }
 static inline int paint_lanes(int N) { return N > 80 * 64 ? 128 : 64; }
 
+static ro_sum_probe_fn g_probe = NULL;
+void ro_set_sum_probe(ro_sum_probe_fn fn) { g_probe = fn; }
+
 static inline double sum_alpha(const double *a, int N, int k, const ro_sum_order *o, int nl) {
-  if (o == NULL || o->mode == RO_SUM_SERIAL) {
+  if (o != NULL && o->mode == RO_SUM_PROBE && g_probe) g_probe(a, N, 0);
+  if (o == NULL || o->mode != RO_SUM_LANES) {
     double s = 0.0;
     for (int n = 0; n < N; n++) s += a[n]; /* :300-303 */
     return s;
@@ -168,7 +172,12 @@ static inline double sum_beta(const double *b, const char *row, int k,
                               int N, const paint_consts *c,
                               const ro_sum_order *o, double *scratch, int nl) {
   const char seq_k = row[k];
-  if (o == NULL || o->mode == RO_SUM_SERIAL) {
+  if (o != NULL && o->mode == RO_SUM_PROBE && g_probe) {
+    for (int n = 0; n < N; n++)
+      scratch[n] = (seq_k > row[n]) ? c->theta * b[n] : c->ntheta * b[n];
+    g_probe(scratch, N, 1);
+  }
+  if (o == NULL || o->mode != RO_SUM_LANES) {
     double s = 0.0;
     for (int n = 0; n < N; n++) {
       if (seq_k > row[n])

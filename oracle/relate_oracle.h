@@ -43,7 +43,12 @@ typedef struct {
  *                   summed left to right, then an xor-butterfly over the 64
  *                   partial sums (masks 1,2,4,8,16,32).  Used to check those
  *                   kernels bit for bit; it is NOT the reference order. */
-enum { RO_SUM_SERIAL = 0, RO_SUM_LANES = 1 };
+enum { RO_SUM_SERIAL = 0, RO_SUM_LANES = 1, RO_SUM_PROBE = 2 };
+/* RO_SUM_PROBE (experiments, tools/exact_sum_stats.py): the serial order, and
+ * every normalising sum's term vector is shown to ro_sum_probe first
+ * (dir 0: forward, alpha; 1: backward, e(n)*beta).  Not thread-safe. */
+typedef void (*ro_sum_probe_fn)(const double *terms, int N, int dir);
+void ro_set_sum_probe(ro_sum_probe_fn fn);
 
 typedef struct {
   int mode;   /* RO_SUM_* */

@@ -145,7 +145,7 @@ class Context:
 
     def set_paint_split(self, split):
         """one launch per direction (so that paint_times() has something to report) instead of one for both"""
-        _check(lib().rl_set_paint_split(C.c_void_p(self._h), int(bool(split))))
+        _check(lib().rl_set_paint_split(C.c_void_p(self._h), int(split)))
 
     @property
     def tile(self):

@@ -102,7 +102,7 @@ struct rl_ctx {
   bool have_chunk = false, plan_on_device = false, painted = false;
   int paint_mode = -1;
   float ms_fwd = 0.f, ms_bwd = 0.f, ms_paint = 0.f;
-  bool paint_split = false;  // rl_set_paint_split: one launch per direction instead of one for both
+  int paint_split = 0;  // rl_set_paint_split: one launch per direction instead of one for both
 };
 
 namespace rl {

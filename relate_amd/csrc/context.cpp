@@ -656,6 +656,8 @@ int rl_paint(rl_ctx *ctx, int sum_mode, float *kernel_ms) {
   p.ls_alpha = ctx->d_lsa.as<float>();
   p.ls_beta = ctx->d_lsb.as<float>();
   p.sum_mode = sum_mode;
+  p.merge_order = 0;
+  if (const char *e = getenv("RELATE_AMD_PAINT_ORDER")) p.merge_order = atoi(e);  // experiments
   p.stats = nullptr;
   if (getenv("RELATE_AMD_STATS")) {  // experiment builds (-DRL_STATS): 16 counters, see tools/exp_stats.py
     if ((rc = ctx->d_stats.alloc(16 * sizeof(unsigned long long)))) return rc;
@@ -663,7 +665,19 @@ int rl_paint(rl_ctx *ctx, int sum_mode, float *kernel_ms) {
     p.stats = ctx->d_stats.as<unsigned long long>();
   }
 
-  if (ctx->paint_split) {
+  if (ctx->paint_split == 2) {
+    // experiment: the two directions as two launches on two streams
+    RL_HIP(hipEventRecord(ctx->ev0, ctx->s0));
+    RL_HIP(hipStreamWaitEvent(ctx->s1, ctx->ev0, 0));
+    RL_HIP(launch_paint(p, ctx->S, ctx->waves, 1, ctx->s0));
+    RL_HIP(launch_paint(p, ctx->S, ctx->waves, 0, ctx->s1));
+    RL_HIP(hipEventRecord(ctx->ev1, ctx->s1));
+    RL_HIP(hipStreamWaitEvent(ctx->s0, ctx->ev1, 0));
+    RL_HIP(hipEventRecord(ctx->ev2, ctx->s0));
+    RL_HIP(hipEventSynchronize(ctx->ev2));
+    RL_HIP(hipEventElapsedTime(&ctx->ms_paint, ctx->ev0, ctx->ev2));
+    ctx->ms_bwd = ctx->ms_fwd = 0.f;
+  } else if (ctx->paint_split) {
     // one direction per launch, backward then forward on one stream, each bracketed by HIP events
     RL_HIP(hipEventRecord(ctx->ev0, ctx->s0));
     RL_HIP(launch_paint(p, ctx->S, ctx->waves, 1, ctx->s0));
@@ -700,7 +714,7 @@ int rl_set_paint_split(rl_ctx *ctx, int split) {
     set_error("rl_set_paint_split: no context");
     return RL_EINVAL;
   }
-  ctx->paint_split = split != 0;
+  ctx->paint_split = split;
   return RL_OK;
 }
 

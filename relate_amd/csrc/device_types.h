@@ -42,6 +42,7 @@ struct PaintParams {
   float *alpha, *beta;      // [W][nloc][N] stepping stones, donor order
   float *ls_alpha, *ls_beta;  // [W][nloc]
   int sum_mode;             // RL_SUM_EXACT / RL_SUM_LANES / RL_SUM_EXACT_SERIAL
+  int merge_order;          // one launch for both directions: 0 = backward blocks first, then forward; 1 = interleaved
   unsigned long long *stats;  // 16 event counters (experiment builds with -DRL_STATS), else null
 };
 

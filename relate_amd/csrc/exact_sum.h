@@ -209,7 +209,12 @@ RL_DEV double sum_exact_fast(const T &term, double L, WaveLink<WAVES> &lk) {
     }
   }
   const long long pb = __double_as_longlong(P);
-  const bool zero_entry = pb == 0;            // nothing but zeros before this lane: entry exactly 0
+  // Lanes whose entry value is known exactly need no bracket: nothing but zeros before the lane (entry
+  // +0.0; lane 0 always), and lane 1 of the first wave, whose entry is lane 0's local sum -- a serial sum
+  // from +0.0, i.e. the true prefix.  Their four runs start AT the entry, so the run is the true one whatever
+  // it crosses (lane 1 is where two-binade jumps are most frequent), and the lane's map is the constant
+  // exit offset.
+  const bool zero_entry = pb == 0 || ((threadIdx.x & 63) == 1 && lk.w == 0);
 
   const unsigned long long tk1 = RL_CLK();
   // ---- B. four runs from r_h = h (mod 4 ulp), r_0 / r_3 bracketing the true entry
@@ -219,7 +224,7 @@ RL_DEV double sum_exact_fast(const T &term, double L, WaveLink<WAVES> &lk) {
   double c1 = __longlong_as_double(base + 1);
   double c2 = __longlong_as_double(base + 2);
   double c3 = __longlong_as_double(base + 3 + G4);
-  if (zero_entry) { c0 = 0.0; c1 = 0.0; c2 = 0.0; c3 = 0.0; }
+  if (zero_entry) { c0 = P; c1 = P; c2 = P; c3 = P; }
   const double r0 = c0, r3 = c3;
   const int e_in = expo_field(r0);
   const bool entry_ok = zero_entry || (e_in == expo_field(r3) && e_in > 64);
@@ -265,6 +270,9 @@ RL_DEV double sum_exact_fast(const T &term, double L, WaveLink<WAVES> &lk) {
   // (|A_h| < 2^15) and entry offsets B_h = (r_h - P)/ulp_in of their starts:
   int A0 = 0, A1 = 0, A2 = 0, A3 = 0;
   if (constant) A0 = (int)((c0 - Q) * inv_u_out);
+  // exact entry: the exit is c0 itself; offset 0 wherever the approximate prefix Q is that same sum (lane 0,
+  // all-zero prefixes), a few ulp for lane 1
+  if (zero_entry && __double_as_longlong(c0) != __double_as_longlong(Q)) A0 = (int)((c0 - Q) * inv_u_out);
   if (!invalid && !jump && !zero_entry) {
     A0 = (int)((c0 - Q) * inv_u_out);
     A1 = (int)((c1 - Q) * inv_u_out);
@@ -274,7 +282,7 @@ RL_DEV double sum_exact_fast(const T &term, double L, WaveLink<WAVES> &lk) {
   const int B0 = -p0 - G4, B1 = 1 - p0, B2 = 2 - p0, B3 = 3 - p0 + G4;
   // Is the lane's map delta -> A_h + ((delta - B_h) >> sh), h = (p0 + delta) & 3,
   // of the tie-free form ((delta + K) >> sh) + C ?   (K in {0,1} when sh = 1)
-  int mK = 0, mC = 0;
+  int mK = 0, mC = zero_entry ? A0 : 0;  // exact entry: delta is 0 on entry (nothing but exact lanes before), A0 on exit
   bool affine = zero_entry;
   if (!invalid && !jump && !zero_entry) {
     if (sh == 0) {

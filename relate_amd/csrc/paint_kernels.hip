@@ -297,8 +297,13 @@ __global__ void __launch_bounds__(64 * WAVES, 2) paint_kernel(const PaintParams 
   int b = blockIdx.x;
   bool backward = DIR == 1;
   if (DIR == 2) {
-    backward = !(b & 1);
-    b >>= 1;
+    if (p.merge_order == 1) {
+      backward = !(b & 1);
+      b >>= 1;
+    } else {
+      backward = b < p.nloc;
+      if (!backward) b -= p.nloc;
+    }
   }
   const int k = p.order[b];
   if (backward)

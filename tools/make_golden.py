@@ -125,9 +125,67 @@ def example_fixture(nsnps=3000):
     print("example8 N", p[0], "L", p[1], "W", W, "%.1f KB" % (os.path.getsize(os.path.join(GOLD, "example8.npz")) / 1e3))
 
 
+def n5000_fixture(N=5000, L=1200, mem=10.0):
+    """The headline tile (BASELINE.json config #3's N = 5000, one wavefront of S = 80 registers per target) against
+    the reference binary: a short chunk (3 windows), Paint of the whole chunk and BuildTopology of section 0.
+    The inputs are regenerated from the seed by the test (their md5s are kept); of the outputs the fixture
+    keeps the md5 of every file, the head of window 0's paint file and the parent arrays of the section's trees
+    (md5 per tree, the first and the last two in full)."""
+    import ctypes as C
+    import hashlib
+    from relate_amd import api
+    lib = api.lib()
+    seq = np.zeros((L, N), dtype=np.uint8)
+    bp = np.zeros(L, dtype=np.int32)
+    r = np.zeros(L); rpos = np.zeros(L + 1)
+    assert lib.rl_synth_panel(N, L, C.c_uint64(1), 100, 1, seq.ctypes.data_as(C.c_void_p), None, 0,
+                              bp.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p),
+                              rpos.ctypes.data_as(C.c_void_p)) == 0
+    budget = mem * 1e9 / 4.0 - (2.0 * N * N + 3.0 * N)
+    wb = np.zeros(L + 2, dtype=np.int32)
+    W = lib.rl_synth_windows(N, L, seq.ctypes.data_as(C.c_void_p), C.c_double(budget), wb.ctypes.data_as(C.c_void_p), 499)
+    assert W >= 2, W
+    md5 = lambda b: np.frombuffer(hashlib.md5(b).digest(), dtype=np.uint8)
+    data = {"meta": np.array([N, L, W, 1], dtype=np.int64), "mem": np.array([mem]), "wb": wb[:W + 1].copy()}
+    with tempfile.TemporaryDirectory() as work:
+        d = os.path.join(work, "out")
+        os.makedirs(d)
+        lib.rl_write_chunk_files.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int]
+        assert lib.rl_write_chunk_files(d.encode(), 0, N, L, seq.ctypes.data_as(C.c_void_p),
+                                        bp.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p),
+                                        rpos.ctypes.data_as(C.c_void_p), wb.ctypes.data_as(C.c_void_p), W) == 0
+        for f in ["parameters_c0.bin", "chunk_0.hap", "chunk_0.r", "chunk_0.rpos", "chunk_0.bp", "chunk_0.dist",
+                  "chunk_0.state"]:
+            data["in_md5/" + f] = md5(open(os.path.join(d, f), "rb").read())
+        run([rlutil.REF_RELATE, "--mode", "Paint", "--chunk_index", "0", "-o", "out"], work)
+        for w in range(W):
+            b = open(os.path.join(d, "chunk_0", "paint", "relate_%d.bin" % w), "rb").read()
+            data["md5/paint/relate_%d.bin" % w] = md5(b)
+            if w == 0:
+                data["head/paint/relate_0.bin"] = np.frombuffer(b[:1 << 16], dtype=np.uint8)
+        run([rlutil.REF_RELATE, "--mode", "BuildTopology", "--chunk_index", "0", "--first_section", "0",
+             "--last_section", "0", "-o", "out"], work)
+        anc = open(os.path.join(d, "chunk_0", "out_0.anc"), "rb").read()
+        mut = open(os.path.join(d, "chunk_0", "out_0.mut"), "rb").read()
+        data["md5/out_0.anc"] = md5(anc)
+        data["md5/out_0.mut"] = md5(mut)
+        data["mut/0"] = np.frombuffer(mut, dtype=np.uint8)
+        _, trees = rlutil.parse_anc(os.path.join(d, "chunk_0", "out_0.anc"))
+        data["tree_pos"] = np.array([t[0] for t in trees], dtype=np.int32)
+        data["tree_parent_md5"] = np.stack([md5(t[1].astype("<i4").tobytes()) for t in trees])
+        for i in sorted(set([0, len(trees) - 2, len(trees) - 1])):
+            data["tree_parent/%d" % i] = trees[i][1].astype(np.int32)
+    np.savez_compressed(os.path.join(GOLD, "n5000.npz"), **data)
+    print("n5000 N", N, "L", L, "W", W, "trees", len(trees),
+          "%.1f KB" % (os.path.getsize(os.path.join(GOLD, "n5000.npz")) / 1e3))
+
+
 if __name__ == "__main__":
     assert rlutil.have_ref(), "run `make -C oracle ref` first (needs /root/reference)"
     os.makedirs(GOLD, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "n5000":  # ~15 minutes of the single-threaded reference
+        n5000_fixture()
+        sys.exit(0)
     synth_fixture("synth24", 24, 900, seed=21, budget=4000)
     synth_fixture("synth24_paint", 24, 900, seed=21, budget=4000, painting="0.025,2", with_trees=False)
     synth_fixture("synth70", 70, 700, seed=5, budget=40000, windows_dump=(0, 2))
