@@ -24,6 +24,7 @@
 #include <mutex>
 #include <random>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -35,29 +36,31 @@ namespace {
 
 constexpr int MM_BLOCK = 1024;
 constexpr int MM_WAVES = MM_BLOCK / 64;
-constexpr int MM_GATHER = 32;  // updated clusters whose half of the candidate test is kept as mask bits
+constexpr int MM_ROWS = 4;        // rows of rebuilt clusters scanned per pass of a merge
+constexpr int MM_UPD_MAX = 1024;  // rebuilt clusters of one merge (list in LDS); more: the host builds the tree
+constexpr int MM_PAIRS_LDS = 768; // feasible pairs of one merge kept in LDS; more go through global scratch
+constexpr int MM_MAXN = 10240;    // one thread holds up to 10 clusters of a merge in registers
 
 struct MMParams {
   int N;
+  int lds_state;  // the per-cluster state lives in LDS for the build (it fits: N <= ~5200)
   float threshold, threshold_CF;
   float *D;   // [N*N] destroyed
   float *CF;  // [N*N] destroyed, or nullptr
   float *SYM;  // [N*N] room for the symmetric matrix
   float *min_values_sym, *mcs_dist;
   int *mcs_lin1, *mcs_lin2;
-  float *min_values, *min_values_CF;
+  float *min_values, *min_values_CF;  // min_values_CF, mc_lin1, mc_lin2: carried from tree to tree (in and out)
   float *mc_dist, *mc_dist2;
   int *mc_lin1, *mc_lin2;
-  int *cluster_index, *cluster_index2, *convert_index;
-  float *cluster_size;
+  int *cluster_index, *cluster_size, *convert_index;
   unsigned char *kflag;
-  unsigned *kmask;
-  int *visit_list, *cand_j, *upd_pos;  // [N] each
-  int *feas, *feas_off;                // [N*?] feasible partners of the rebuilt clusters, [N+1] offsets
-  int *rowlist;                        // [MM_WAVES][N] pair-scan survivors per wave
+  int *upd_pos;         // [N] scratch of the symmetric path
+  unsigned *pair_g;     // [6 * pair_cap] feasible pairs of a merge beyond MM_PAIRS_LDS: key, x<<16|y, sym; unsorted, sorted
+  int *rowlist;         // [MM_WAVES][N] pair-scan survivors per wave
   int *parent, *child_left, *child_right;
   int *status;
-  long long feas_cap;
+  long long pair_cap;
   long long *timers;  // optional: 100 MHz ticks per phase (RELATE_AMD_TIMING)
 };
 
@@ -103,18 +106,41 @@ struct Best {
 };
 
 struct Shared {
+  long long tacc[12], tmark;
   Rng rng;
   Best best, best_sym;
   int use_sym;
   int n, ipos;
+  int count;
+  int nupd, npairs;
   int wave_i[MM_WAVES];
   float wave_f[MM_WAVES];
   int wave_i2[MM_WAVES];
   int wave_i3[MM_WAVES];
   float wave_f2[MM_WAVES];
-  int count;
+  float lex_d[MM_WAVES], lex_d2[MM_WAVES];
+  int lex_p[MM_WAVES];
   int rowcount[MM_WAVES];
   float sym_dist;
+  float red_f[MM_ROWS][MM_WAVES];
+  int red_a[MM_ROWS][MM_WAVES], red_b[MM_ROWS][MM_WAVES];
+  unsigned upd[MM_UPD_MAX];  // rebuilt clusters of the merge: position | rescan << 16, any order
+  // feasible pairs of the merge, [0]: as found, [1]: in the reference's order
+  unsigned pk[2][MM_PAIRS_LDS];   // key: position of the later cluster << 16 | position of the earlier one
+  unsigned pxy[2][MM_PAIRS_LDS];  // later cluster << 16 | earlier cluster
+  float psym[2][MM_PAIRS_LDS];    // symmetric distance of the pair (0 if the prior makes it a certain pair)
+};
+
+// The per-cluster state of a build: in LDS when it fits (25 bytes per cluster; indices as shorts), else in the
+// global arrays of MMParams.
+template <bool LDS>
+struct State {
+  typedef typename std::conditional<LDS, short, int>::type idx_t;
+  float *mv, *mvcf, *mcd, *mcd2;   // min_values, min_values_CF, candidate (dist, dist2)
+  idx_t *lin1, *lin2;              // candidate pair (stale indices are part of the carried state)
+  idx_t *ci;                       // the live clusters in order
+  idx_t *csz;                      // cluster sizes (floats in the reference: exact integers)
+  unsigned char *flag;             // rebuilt in this merge
 };
 
 __device__ inline float wave_min_f(float v) {
@@ -127,37 +153,42 @@ __device__ inline int wave_min_i(int v) {
   for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
   return v;
 }
-__device__ inline float block_min_f(float v, float *buf) {
-  v = wave_min_f(v);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) buf[threadIdx.x >> 6] = v;
-  __syncthreads();
-  float r = buf[0];
-#pragma unroll
-  for (int w = 1; w < MM_WAVES; w++) r = fminf(r, buf[w]);
-  return r;
+// lexicographic minimum of (d1, d2, pos)
+__device__ inline bool lex_less(float a1, float a2, int ap, float b1, float b2, int bp) {
+  return a1 < b1 || (a1 == b1 && (a2 < b2 || (a2 == b2 && ap < bp)));
 }
-// exclusive prefix of v over the threads in order; *total = sum
-__device__ inline int block_scan(int v, int *total, int *buf) {
-  int x = v;
+__device__ inline void wave_lex_min(float &d1, float &d2, int &pos) {
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int y = __shfl_up(x, o, 64);
-    if ((int)(threadIdx.x & 63) >= o) x += y;
+  for (int o = 32; o > 0; o >>= 1) {
+    const float o1 = __shfl_xor(d1, o, 64), o2 = __shfl_xor(d2, o, 64);
+    const int op = __shfl_xor(pos, o, 64);
+    if (lex_less(o1, o2, op, d1, d2, pos)) {
+      d1 = o1;
+      d2 = o2;
+      pos = op;
+    }
+  }
+}
+__device__ inline void block_lex_min(float &d1, float &d2, int &pos, float *b1, float *b2, int *bp) {
+  wave_lex_min(d1, d2, pos);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+    b1[threadIdx.x >> 6] = d1;
+    b2[threadIdx.x >> 6] = d2;
+    bp[threadIdx.x >> 6] = pos;
   }
   __syncthreads();
-  if ((threadIdx.x & 63) == 63) buf[threadIdx.x >> 6] = x;
-  __syncthreads();
-  int base = 0, tot = 0;
+  d1 = b1[0];
+  d2 = b2[0];
+  pos = bp[0];
 #pragma unroll
-  for (int w = 0; w < MM_WAVES; w++) {
-    if (w < (int)(threadIdx.x >> 6)) base += buf[w];
-    tot += buf[w];
-  }
-  *total = tot;
-  return base + x - v;
+  for (int w = 1; w < MM_WAVES; w++)
+    if (lex_less(b1[w], b2[w], bp[w], d1, d2, pos)) {
+      d1 = b1[w];
+      d2 = b2[w];
+      pos = bp[w];
+    }
 }
-
 // three independent minima with one exchange
 __device__ inline void block_min3(float &f, int &a, int &b, float *bf, int *ba, int *bb) {
   f = wave_min_f(f);
@@ -180,132 +211,127 @@ __device__ inline void block_min3(float &f, int &a, int &b, float *bf, int *ba, 
     b = min(b, bb[w]);
   }
 }
-// lexicographic minimum of (d1, d2, pos)
-__device__ inline bool lex_less(float a1, float a2, int ap, float b1, float b2, int bp) {
-  return a1 < b1 || (a1 == b1 && (a2 < b2 || (a2 == b2 && ap < bp)));
-}
-__device__ inline void block_lex_min(float &d1, float &d2, int &pos, float *b1, float *b2, int *bp) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float o1 = __shfl_xor(d1, o, 64), o2 = __shfl_xor(d2, o, 64);
-    const int op = __shfl_xor(pos, o, 64);
-    if (lex_less(o1, o2, op, d1, d2, pos)) {
-      d1 = o1;
-      d2 = o2;
-      pos = op;
-    }
-  }
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) {
-    b1[threadIdx.x >> 6] = d1;
-    b2[threadIdx.x >> 6] = d2;
-    bp[threadIdx.x >> 6] = pos;
-  }
-  __syncthreads();
-  d1 = b1[0];
-  d2 = b2[0];
-  pos = bp[0];
-#pragma unroll
-  for (int w = 1; w < MM_WAVES; w++)
-    if (lex_less(b1[w], b2[w], bp[w], d1, d2, pos)) {
-      d1 = b1[w];
-      d2 = b2[w];
-      pos = bp[w];
-    }
-}
-// two exclusive prefixes with one exchange
-__device__ inline void block_scan2(int v1, int v2, int &e1, int &e2, int &t1, int &t2, int *buf1, int *buf2) {
-  int x1 = v1, x2 = v2;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int y1 = __shfl_up(x1, o, 64), y2 = __shfl_up(x2, o, 64);
-    if ((int)(threadIdx.x & 63) >= o) {
-      x1 += y1;
-      x2 += y2;
-    }
-  }
-  __syncthreads();
-  if ((threadIdx.x & 63) == 63) {
-    buf1[threadIdx.x >> 6] = x1;
-    buf2[threadIdx.x >> 6] = x2;
-  }
-  __syncthreads();
-  int base1 = 0, base2 = 0;
-  t1 = 0;
-  t2 = 0;
-#pragma unroll
-  for (int w = 0; w < MM_WAVES; w++) {
-    if (w < (int)(threadIdx.x >> 6)) {
-      base1 += buf1[w];
-      base2 += buf2[w];
-    }
-    t1 += buf1[w];
-    t2 += buf2[w];
-  }
-  e1 = base1 + x1 - v1;
-  e2 = base2 + x2 - v2;
-}
 
-#define DD(a, b) p.D[(size_t)(a) * N + (b)]
-#define CC(a, b) p.CF[(size_t)(a) * N + (b)]
-#define SS(a, b) p.SYM[(size_t)(a) * N + (b)]
+// (32-bit element offsets from a scalar base -- N <= 10240: one address register per load instead of two)
+#define DD(a, b) p.D[(unsigned)(a) * (unsigned)N + (unsigned)(b)]
+#define CC(a, b) p.CF[(unsigned)(a) * (unsigned)N + (unsigned)(b)]
+#define SS(a, b) p.SYM[(unsigned)(a) * (unsigned)N + (unsigned)(b)]
 
-// One feasible pair (thread 0): symmetric distance, one draw, both clusters' best candidate
-// (tree_builder.cpp:1699-1716); minmatch.cpp: consider().
-__device__ inline void consider(const MMParams &p, Shared &sh, int x, int y) {
+// Symmetric distance of a feasible pair (tree_builder.cpp:1699-1702): 0 when the pair is also mutually closest
+// under the prior.
+template <bool LDS>
+__device__ inline float pair_sym(const MMParams &p, const State<LDS> &st, int x, int y) {
   const int N = p.N;
-  float sym;
   if (p.CF) {
-    const bool both = (CC(x, y) <= p.min_values_CF[x]) && (CC(y, x) <= p.min_values_CF[y]);
-    sym = both ? 0.0f : DD(y, x) + DD(x, y);
-  } else {
-    sym = DD(y, x) + DD(x, y);
+    const bool both = (CC(x, y) <= st.mvcf[x]) && (CC(y, x) <= st.mvcf[y]);
+    return both ? 0.0f : DD(y, x) + DD(x, y);
   }
-  sh.sym_dist = sym;
+  return DD(y, x) + DD(x, y);
+}
+// One feasible pair in the reference's order (one lane): one draw, both clusters' best candidate (:1704-1716).
+template <bool LDS>
+__device__ inline void apply_pair(const State<LDS> &st, Shared &sh, int x, int y, float sym) {
+  typedef typename State<LDS>::idx_t idx_t;
   const float rnd = (float)rng_unif(sh.rng);
-  const float ad = p.mc_dist[x], ad2 = p.mc_dist2[x];
+  const float ad = st.mcd[x], ad2 = st.mcd2[x];
   if (ad > sym || (ad == sym && ad2 > rnd)) {
-    p.mc_lin1[x] = x;
-    p.mc_lin2[x] = y;
-    p.mc_dist[x] = sym;
-    p.mc_dist2[x] = rnd;
+    st.lin1[x] = (idx_t)x;
+    st.lin2[x] = (idx_t)y;
+    st.mcd[x] = sym;
+    st.mcd2[x] = rnd;
   }
-  const float bd = p.mc_dist[y], bd2 = p.mc_dist2[y];
+  const float bd = st.mcd[y], bd2 = st.mcd2[y];
   if (bd > sym || (bd == sym && bd2 > rnd)) {
-    p.mc_lin1[y] = x;
-    p.mc_lin2[y] = y;
-    p.mc_dist[y] = sym;
-    p.mc_dist2[y] = rnd;
+    st.lin1[y] = (idx_t)x;
+    st.lin2[y] = (idx_t)y;
+    st.mcd[y] = sym;
+    st.mcd2[y] = rnd;
   }
 }
 
-// one workgroup per tree: workgroup b builds the tree of params[b]
+// One workgroup per tree: workgroup b builds the tree of params[b].
+//
+// A merge (i into j) on the workgroup, thread t holding the clusters at positions t, t + 1024, ... of the live list:
+//   A. every thread: the four entries (k,j), (k,i), (i,k), (j,k) of both matrices for its clusters k (all loads
+//      issued at once), the size-weighted updates written back and KEPT in registers; which clusters rebuild their
+//      candidates (row minimum on a changed entry, or candidate touching i or j: appended to a list in LDS, their
+//      candidates reset); partial minima of the merged cluster's row (both matrices) and the best candidate among
+//      the clusters that keep theirs, (dist, dist2, position)-lexicographic -- one exchange for all of it;
+//   B. the rows of the rebuilt clusters, MM_ROWS at a time, an element per thread and position: first the
+//      row-minimum rescans (the reference's scan with early exit = "the old minimum if it occurs before any smaller
+//      entry, else the row's minimum": three reductions, finished by one wave per row), then, on the values still
+//      in registers, the row half of the candidate test of every pair the rebuilt cluster is part of; the few
+//      survivors fetch the column half (and the prior's entries) themselves and append the feasible pairs,
+//      keyed by (position of the later cluster, position of the earlier one), to a list in LDS;
+//   C. the merged cluster's own pairs from the registers of A, keyed behind all others;
+//   D. the pairs sorted by key (rank = number of smaller keys) -- the order in which the reference meets them --
+//      and ONE lane draws the random numbers and updates the candidates in that order, then settles the running
+//      best: per cluster the candidate it holds at its turn of the reference's loop, smallest (dist, dist2),
+//      earliest position among exact ties;
+//   E. the merged-away cluster leaves the list.
+// Three dependent memory round trips and eight workgroup barriers per merge; everything else is LDS.
+template <bool LDS, int MAXQ>
 __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *__restrict__ params) {
+  typedef typename State<LDS>::idx_t idx_t;
   const MMParams p = params[blockIdx.x];
+  if ((p.lds_state != 0) != LDS) return;  // (the launch carries trees of one kind)
   __shared__ Shared sh;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
   const int N = p.N;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float INF = INFINITY;
   const float threshold = p.threshold, threshold_CF = p.threshold_CF;
-  int *ci = p.cluster_index, *ci_next = p.cluster_index2;  // the live clusters in order; the list is rewritten per merge
-  long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  long long tmark = wall_clock64();
-  const long long tstart = tmark, cstart = clock64();
+  State<LDS> st;
+  if constexpr (LDS) {
+    float *f = reinterpret_cast<float *>(dyn);
+    st.mv = f;
+    st.mvcf = f + N;
+    st.mcd = f + 2 * (size_t)N;
+    st.mcd2 = f + 3 * (size_t)N;
+    short *s = reinterpret_cast<short *>(f + 4 * (size_t)N);
+    st.lin1 = s;
+    st.lin2 = s + N;
+    st.ci = s + 2 * (size_t)N;
+    st.csz = s + 3 * (size_t)N;
+    st.flag = reinterpret_cast<unsigned char *>(s + 4 * (size_t)N);
+  } else {
+    st.mv = p.min_values;
+    st.mvcf = p.min_values_CF;
+    st.mcd = p.mc_dist;
+    st.mcd2 = p.mc_dist2;
+    st.lin1 = p.mc_lin1;
+    st.lin2 = p.mc_lin2;
+    st.ci = p.cluster_index;
+    st.csz = p.cluster_size;
+    st.flag = p.kflag;
+  }
+  // (timing: thread 0 only, accumulators in LDS -- twelve 64-bit counters per thread would cost the kernel its registers)
+  if (tid == 0) {
+    for (int x = 0; x < 12; x++) sh.tacc[x] = 0;
+    sh.tmark = wall_clock64();
+  }
+  const long long tstart = wall_clock64(), cstart = clock64();
 #define LAP(x)                           \
-  {                                      \
+  if (p.timers && tid == 0) {            \
     const long long tn = wall_clock64(); \
-    tacc[x] += tn - tmark;               \
-    tmark = tn;                          \
+    sh.tacc[x] += tn - sh.tmark;         \
+    sh.tmark = tn;                       \
   }
 
   // ---- QuickBuild set-up (:1061-1100)
   for (int c = tid; c < N; c += MM_BLOCK) {
-    ci[c] = c;
+    st.ci[c] = (idx_t)c;
     p.convert_index[c] = c;
-    p.cluster_size[c] = 1.0f;
-    p.min_values[c] = INF;
-    p.mc_dist[c] = INF;
-    p.mc_dist2[c] = INF;
+    st.csz[c] = (idx_t)1;
+    st.mv[c] = INF;
+    st.mcd[c] = INF;
+    st.mcd2[c] = INF;
+    st.flag[c] = 0;
+    if constexpr (LDS) {  // the state carried from tree to tree comes in
+      st.lin1[c] = (idx_t)p.mc_lin1[c];
+      st.lin2[c] = (idx_t)p.mc_lin2[c];
+      st.mvcf[c] = p.min_values_CF[c];
+    }
   }
   for (int c = tid; c < 2 * N - 1; c += MM_BLOCK) p.parent[c] = -1;
   if (tid == 0) {
@@ -317,6 +343,8 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
     sh.best_sym = sh.best;
     sh.use_sym = 0;
     sh.n = N;
+    sh.nupd = 0;
+    sh.npairs = 0;
   }
   __syncthreads();
 
@@ -336,11 +364,11 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
         if (l != a) mc_ = fminf(mc_, crow[l]);
       mc_ = wave_min_f(mc_);
       if (lane == 0) {
-        const float old = p.min_values_CF[a];  // carried over from the previous build (:2399-2400)
-        p.min_values_CF[a] = (old > mc_ ? mc_ : old) + threshold_CF;
+        const float old = st.mvcf[a];  // carried over from the previous build (:2399-2400)
+        st.mvcf[a] = (old > mc_ ? mc_ : old) + threshold_CF;
       }
     }
-    if (lane == 0) p.min_values[a] = mv + threshold;
+    if (lane == 0) st.mv[a] = mv + threshold;
   }
   __syncthreads();
   LAP(0);
@@ -349,13 +377,13 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
     const int a = base + wave;
     int cnt = 0;
     if (a < N) {
-      const float mva = p.min_values[a];
+      const float mva = st.mv[a];
       const float *row = p.D + (size_t)a * N;
       int *out = p.rowlist + (size_t)wave * N;
       for (int b0 = a + 1; b0 < N; b0 += 64) {
         const int b = b0 + lane;
         bool hit = false;
-        if (b < N && mva >= row[b]) hit = p.min_values[b] >= DD(b, a);
+        if (b < N && mva >= row[b]) hit = st.mv[b] >= DD(b, a);
         const unsigned long long m = __ballot(hit);
         if (hit) out[cnt + __popcll(m & ((1ull << lane) - 1ull))] = b;
         cnt += __popcll(m);
@@ -369,12 +397,13 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
         const int *lst = p.rowlist + (size_t)w * N;
         for (int e = 0; e < sh.rowcount[w]; e++) {
           const int b = lst[e];
-          consider(p, sh, aa, b);
-          const float md = p.mc_dist[b], md2 = p.mc_dist2[b];
+          const float sym = pair_sym<LDS>(p, st, aa, b);
+          apply_pair<LDS>(st, sh, aa, b, sym);
+          const float md = st.mcd[b], md2 = st.mcd2[b];
           if (sh.best.dist > md || (sh.best.dist == md && sh.best.dist2 > md2)) {
             sh.best.lin1 = aa;
             sh.best.lin2 = b;
-            sh.best.dist = sh.sym_dist;
+            sh.best.dist = sym;
             sh.best.dist2 = md2;
           }
         }
@@ -382,8 +411,8 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
     }
     __syncthreads();
   }
-
   LAP(1);
+
   // ---- the merges
   for (int num_nodes = N; num_nodes < 2 * N - 1; num_nodes++) {
     const int n = sh.n;
@@ -398,11 +427,11 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
       float bs = INF;
       int bs_pos = n;
       for (int ia = wave; ia < n; ia += MM_WAVES) {
-        const int a = ci[ia];
+        const int a = st.ci[ia];
         float mv = INF;
         int mp = n;
         for (int il = lane; il < n; il += 64) {
-          const int l = ci[il];
+          const int l = st.ci[il];
           if (l == a) continue;
           const float v = DD(a, l) + DD(l, a);
           SS(a, l) = v;
@@ -425,7 +454,7 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
           p.mcs_dist[a] = mv;
           if (mv < INF) {
             p.mcs_lin1[a] = a;
-            p.mcs_lin2[a] = ci[mp];
+            p.mcs_lin2[a] = st.ci[mp];
           }
           if (mv < bs) {  // (rows ascending per wave)
             bs = mv;
@@ -439,15 +468,15 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
         sh.use_sym = 1;
         sh.best_sym.dist = bs;
         if (bs_pos < n && bs < INF) {
-          sh.best_sym.lin1 = p.mcs_lin1[ci[bs_pos]];
-          sh.best_sym.lin2 = p.mcs_lin2[ci[bs_pos]];
+          sh.best_sym.lin1 = p.mcs_lin1[st.ci[bs_pos]];
+          sh.best_sym.lin2 = p.mcs_lin2[st.ci[bs_pos]];
         }
       }
       __syncthreads();
     }
     const bool by_sym = sh.best.dist == INF;
     const int i = by_sym ? sh.best_sym.lin1 : sh.best.lin1, j = by_sym ? sh.best_sym.lin2 : sh.best.lin2;
-    const float csi = p.cluster_size[i], csj = p.cluster_size[j];
+    const float csi = (float)st.csz[i], csj = (float)st.csz[j];
     const float added = csi + csj;
     if (tid == 0) {
       const int conv_i = p.convert_index[i], conv_j = p.convert_index[j];
@@ -455,252 +484,359 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
       p.parent[conv_j] = num_nodes;
       p.child_left[num_nodes - N] = conv_i;
       p.child_right[num_nodes - N] = conv_j;
-      sh.count = 0;
     }
-    __syncthreads();
 
-    // -- phase 1: distance updates of both matrices, which rows rescan their minimum, which clusters rebuild
-    float mv_cf = INF;
-    // (four clusters per thread at a time, every load of the four issued before the first store: the loads walk
-    //  down matrix columns, a new line each, and would otherwise wait for each other behind the stores)
-    for (int base = tid; base < n; base += 4 * MM_BLOCK) {
-      int kk[4];
-      float c4[4][4], d4[4][4], mvk4[4];
-      int l14[4], l24[4];
+    // -- A: this thread's clusters
+    int a_k[MAXQ];
+    float a_njk[MAXQ], a_nkj[MAXQ], a_cjk[MAXQ], a_ckj[MAXQ];  // d(j,k), d(k,j), cf(j,k), cf(k,j) after the merge
+    float mv_cf = INF, mvj = INF, bd = INF, bd2 = INF;
+    int bpos = n;
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int ik = base + q * MM_BLOCK;
-        kk[q] = ik < n ? ci[ik] : -1;
-      }
+    for (int q = 0; q < MAXQ; q++) {
+      const int ik = q * MM_BLOCK + tid;
+      a_k[q] = ik < n ? (int)st.ci[ik] : -1;
+      a_njk[q] = a_nkj[q] = a_cjk[q] = a_ckj[q] = INF;
+    }
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int k = kk[q];
+    for (int q0 = 0; q0 < MAXQ; q0 += 5) {
+      if (q0 * MM_BLOCK >= n) break;
+      float d4[5][4], c4[5][4];
+#pragma unroll
+      for (int qq = 0; qq < 5; qq++) {  // (every load of the five issued before the first store)
+        const int k = a_k[q0 + qq];
         if (k < 0 || k == j || k == i) continue;
         if (p.CF) {
-          c4[q][0] = CC(k, j);
-          c4[q][1] = CC(k, i);
-          c4[q][2] = CC(i, k);
-          c4[q][3] = CC(j, k);
+          c4[qq][0] = CC(k, j);
+          c4[qq][1] = CC(k, i);
+          c4[qq][2] = CC(i, k);
+          c4[qq][3] = CC(j, k);
         }
-        d4[q][0] = DD(k, j);
-        d4[q][1] = DD(k, i);
-        d4[q][2] = DD(i, k);
-        d4[q][3] = DD(j, k);
-        mvk4[q] = p.min_values[k];
-        l14[q] = p.mc_lin1[k];
-        l24[q] = p.mc_lin2[k];
+        d4[qq][0] = DD(k, j);
+        d4[qq][1] = DD(k, i);
+        d4[qq][2] = DD(i, k);
+        d4[qq][3] = DD(j, k);
       }
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int ik = base + q * MM_BLOCK;
-        const int k = kk[q];
+      for (int qq = 0; qq < 5; qq++) {
+        const int q = q0 + qq;
+        const int ik = q * MM_BLOCK + tid;
+        const int k = a_k[q];
         if (k < 0) continue;
-        p.kmask[ik] = 0;
         if (k == j || k == i) {
-          p.kflag[ik] = 0;
           if (k == i) sh.ipos = ik;
           continue;
         }
         if (p.CF) {
-          const float ckj = c4[q][0], cki = c4[q][1], cik = c4[q][2], cjk = c4[q][3];
-          float njk = cjk;
+          const float ckj = c4[qq][0], cki = c4[qq][1], cik = c4[qq][2], cjk = c4[qq][3];
+          float ncjk = cjk, nckj = ckj;
           if (cik != cjk) {
-            njk = (csi * cik + csj * cjk) / added;
-            CC(j, k) = njk;
+            ncjk = (csi * cik + csj * cjk) / added;
+            CC(j, k) = ncjk;
           }
-          if (cki != ckj) CC(k, j) = (csi * cki + csj * ckj) / added;
-          if (mv_cf > njk) mv_cf = njk;
+          if (cki != ckj) {
+            nckj = (csi * cki + csj * ckj) / added;
+            CC(k, j) = nckj;
+          }
+          if (mv_cf > ncjk) mv_cf = ncjk;
+          a_cjk[q] = ncjk;
+          a_ckj[q] = nckj;
         }
-        const float dkj = d4[q][0], dki = d4[q][1], dik = d4[q][2], djk = d4[q][3];
-        if (dik != djk) DD(j, k) = (csi * dik + csj * djk) / added;
-        if (dki != dkj) DD(k, j) = (csi * dki + csj * dkj) / added;
+        const float dkj = d4[qq][0], dki = d4[qq][1], dik = d4[qq][2], djk = d4[qq][3];
+        float njk = djk, nkj = dkj;
+        if (dik != djk) {
+          njk = (csi * dik + csj * djk) / added;
+          DD(j, k) = njk;
+        }
+        if (dki != dkj) {
+          nkj = (csi * dki + csj * dkj) / added;
+          DD(k, j) = nkj;
+        }
+        if (njk < mvj) mvj = njk;
+        a_njk[q] = njk;
+        a_nkj[q] = nkj;
         bool rescan = false;
         if (dkj != dki) {
-          const float mvk = mvk4[q];
+          const float mvk = st.mv[k];
           rescan = (double)fabsf(mvk - threshold - dkj) < 1e-4 || (double)fabsf(mvk - threshold - dki) < 1e-4;
         }
-        const int l1 = l14[q], l2 = l24[q];
+        const int l1 = st.lin1[k], l2 = st.lin2[k];
         const bool touches = l1 == j || l2 == j || l1 == i || l2 == i;
-        p.kflag[ik] = (unsigned char)(((rescan || touches) ? 2 : 0) | (rescan ? 4 : 0));
-        if (rescan) p.visit_list[atomicAdd(&sh.count, 1)] = ik;  // (scratch use: rows to rescan, any order)
+        if (rescan || touches) {  // k rebuilds its candidates (:1893-1911)
+          st.flag[k] = 1;
+          st.mcd[k] = INF;
+          st.mcd2[k] = INF;
+          const int slot = atomicAdd(&sh.nupd, 1);
+          if (slot < MM_UPD_MAX) sh.upd[slot] = (unsigned)ik | (rescan ? 0x10000u : 0u);
+        } else {  // k keeps its candidate: what the reference's running best sees at k's turn
+          const float d1 = st.mcd[k], d2 = st.mcd2[k];
+          if (bd > d1 || (bd == d1 && bd2 > d2)) {  // (ascending positions per thread: the first one wins)
+            bd = d1;
+            bd2 = d2;
+            bpos = ik;
+          }
+        }
       }
     }
-    if (p.CF) {
-      const float m = block_min_f(mv_cf, sh.wave_f);
-      if (tid == 0) p.min_values_CF[j] = m + threshold_CF;
+    mvj = wave_min_f(mvj);
+    mv_cf = wave_min_f(mv_cf);
+    wave_lex_min(bd, bd2, bpos);
+    if (lane == 0) {
+      sh.wave_f[wave] = mvj;
+      sh.wave_f2[wave] = mv_cf;
+      sh.lex_d[wave] = bd;
+      sh.lex_d2[wave] = bd2;
+      sh.lex_p[wave] = bpos;
     }
     __syncthreads();
     LAP(2);
-    // row-minimum rescans (:1875-1890).  The reference scans row k in order and stops when the running minimum
-    // equals the old one: the result is the old minimum if it occurs before any smaller entry, else the row's.
-    const int nres = sh.count;
-    for (int r = 0; r < nres; r++) {
-      const int k = ci[p.visit_list[r]];
-      const float old = p.min_values[k] - threshold;
-      const float *row = p.D + (size_t)k * N;
-      float fm = INF;
-      int pos_old = n, pos_less = n;
-#pragma unroll 4
-      for (int il = tid; il < n; il += MM_BLOCK) {
-        const int l = ci[il];
-        if (l != i && l != k) {
-          const float v = row[l];
-          fm = fminf(fm, v);
-          if (v == old) pos_old = min(pos_old, il);
-          if (v < old) pos_less = min(pos_less, il);
-        }
-      }
-      block_min3(fm, pos_old, pos_less, sh.wave_f, sh.wave_i, sh.wave_i2);
-      if (tid == 0) p.min_values[k] = ((pos_old < n && pos_old < pos_less) ? old : fm) + threshold;
+    float min_value_j = sh.wave_f[0], mvcf_j = sh.wave_f2[0];
+#pragma unroll
+    for (int w = 1; w < MM_WAVES; w++) {
+      min_value_j = fminf(min_value_j, sh.wave_f[w]);
+      mvcf_j = fminf(mvcf_j, sh.wave_f2[w]);
     }
-    __syncthreads();
-    LAP(3);
-
-    // -- phase 1b: the rebuilt clusters in order; per later cluster, which of the first 32 it is a candidate of
-    const int per = (n + MM_BLOCK - 1) / MM_BLOCK;
-    const int lo = min(n, tid * per), hi = min(n, lo + per);
-    int total;
-    {
-      int c = 0;
-      for (int ik = lo; ik < hi; ik++) c += (p.kflag[ik] & 2) ? 1 : 0;
-      int at = block_scan(c, &total, sh.wave_i);
-      for (int ik = lo; ik < hi; ik++)
-        if (p.kflag[ik] & 2) p.upd_pos[at++] = ik;
-    }
-    const int nupd = total;
-    const int nu = min(nupd, MM_GATHER);
-    __syncthreads();
-    LAP(4);
-    const int overflow_from = nupd > nu ? p.upd_pos[nu - 1] + 1 : n;
-    const float *rowj = p.D + (size_t)j * N;
-    float mvj = INF;
-#pragma unroll 2
-    for (int ik = tid; ik < n; ik += MM_BLOCK) {
-      const int k = ci[ik];
-      unsigned m = 0;
-      for (int u = 0; u < nu; u++) {
-        const int up = p.upd_pos[u];
-        if (ik > up) {
-          const int l = ci[up];
-          if (DD(l, k) <= p.min_values[l]) m |= 1u << u;
-        }
-      }
-      p.kmask[ik] = m;
-      if (k != j && k != i) mvj = fminf(mvj, rowj[k]);
-    }
-    mvj = block_min_f(mvj, sh.wave_f);
-    const float min_value_j = mvj + threshold;
-    LAP(5);
-    // best candidate among the clusters the ordered part does not visit: smallest (dist, dist2), earliest
-    // cluster among exact ties
-    float bd = INF, bd2 = INF;
-    int bpos = n;
-#pragma unroll 4
-    for (int ik = tid; ik < n; ik += MM_BLOCK) {
-      const int k = ci[ik];
-      if (k == j || k == i) continue;
-      const bool visited = (p.kflag[ik] & 2) || p.kmask[ik] != 0 || ik >= overflow_from;
-      if (!visited) {
-        const float d1 = p.mc_dist[k], d2 = p.mc_dist2[k];
-        if (bd > d1 || (bd == d1 && bd2 > d2)) {  // (ascending positions per thread: the first one wins)
-          bd = d1;
-          bd2 = d2;
-          bpos = ik;
-        }
-      }
-    }
-    block_lex_min(bd, bd2, bpos, sh.wave_f, sh.wave_f2, sh.wave_i);  // (dist, dist2, position) over the workgroup
-    LAP(6);
-    // lists in cluster order: the clusters the ordered part visits, the candidates of the merged cluster
-    int nvisit, ncand;
-    {
-      unsigned vbits = 0, cbits = 0;  // per <= 32 positions per thread
-      for (int ik = lo; ik < hi; ik++) {
-        const int k = ci[ik];
-        if (k == j || k == i) continue;
-        if ((p.kflag[ik] & 2) || p.kmask[ik] != 0 || ik >= overflow_from) vbits |= 1u << (ik - lo);
-        if (rowj[k] <= min_value_j && DD(k, j) <= p.min_values[k]) cbits |= 1u << (ik - lo);
-      }
-      int at, atc;
-      block_scan2(__popc(vbits), __popc(cbits), at, atc, nvisit, ncand, sh.wave_i, sh.wave_i2);
-      for (int ik = lo; ik < hi; ik++) {
-        if (vbits & (1u << (ik - lo))) p.visit_list[at++] = ik;
-        if (cbits & (1u << (ik - lo))) p.cand_j[atc++] = ci[ik];
-      }
-    }
-    LAP(7);
-    // feasible partners of every rebuilt cluster k: the clusters l before it with d(k,l) <= min_k and
-    // d(l,k) <= min_l, in order (:1893-1911)
-    int feas_total = 0;
-    bool feas_overflow = false;
-    for (int u = 0; u < nupd; u++) {
-      const int up = p.upd_pos[u];
-      const int k = ci[up];
-      const float mvk = p.min_values[k];
-      const float *rowk = p.D + (size_t)k * N;
-      const int perk = (up + MM_BLOCK - 1) / MM_BLOCK;
-      const int l0 = min(up, tid * perk), l1 = min(up, l0 + perk);
-      unsigned bits = 0;  // perk <= 32 for N <= 32768
-      for (int il = l0; il < l1; il++) {
-        const int l = ci[il];
-        if (rowk[l] <= mvk && l != j && l != i && DD(l, k) <= p.min_values[l]) bits |= 1u << (il - l0);
-      }
-      int tot;
-      int at = feas_total + block_scan(__popc(bits), &tot, sh.wave_i3);
-      if (feas_total + tot > p.feas_cap) {
-        feas_overflow = true;
-        break;
-      }
-      for (int il = l0; il < l1; il++)
-        if (bits & (1u << (il - l0))) p.feas[at++] = ci[il];
-      if (tid == 0) p.feas_off[u] = feas_total;
-      feas_total += tot;
-    }
-    if (feas_overflow) {
+    min_value_j += threshold;
+    mvcf_j += threshold_CF;
+    const int nupd = sh.nupd;
+    if (nupd > MM_UPD_MAX) {  // (degenerate matrices: this tree is the host's)
       if (tid == 0) *p.status = 2;
       return;
     }
-    if (tid == 0) p.feas_off[nupd] = feas_total;
-    __syncthreads();
-    LAP(8);
 
-    // -- phase 2 (thread 0, in cluster order: it draws the random numbers)
+    // -- B: rows of the rebuilt clusters.  First the row-minimum rescans (:1875-1890) ...
+    float v[MM_ROWS][MAXQ];
+    const bool single = nupd <= MM_ROWS;  // one pass: the rows stay in registers for the candidate tests
+    for (int u0 = 0; u0 < nupd; u0 += MM_ROWS) {
+      bool anyres = false;
+      int ups[MM_ROWS], kus[MM_ROWS];
+      bool res[MM_ROWS];
+#pragma unroll
+      for (int r = 0; r < MM_ROWS; r++) {
+        const unsigned e = u0 + r < nupd ? sh.upd[u0 + r] : 0u;
+        ups[r] = (int)(e & 0xffffu);
+        res[r] = u0 + r < nupd && (e >> 16) != 0;
+        kus[r] = u0 + r < nupd ? (int)st.ci[ups[r]] : -1;
+        anyres |= res[r];
+        if (kus[r] >= 0 && (single || res[r])) {
+#pragma unroll
+          for (int q = 0; q < MAXQ; q++) v[r][q] = a_k[q] >= 0 ? DD(kus[r], a_k[q]) : INF;
+        }
+      }
+      if (!anyres) continue;
+#pragma unroll
+      for (int r = 0; r < MM_ROWS; r++) {
+        if (!res[r]) continue;
+        const int k = kus[r];
+        const float old = st.mv[k] - threshold;
+        float fm = INF;
+        int pos_old = n, pos_less = n;
+#pragma unroll
+        for (int q = 0; q < MAXQ; q++) {
+          const int l = a_k[q];
+          if (l < 0 || l == i || l == k) continue;
+          const float x = v[r][q];
+          fm = fminf(fm, x);
+          if (x == old) pos_old = min(pos_old, q * MM_BLOCK + tid);
+          if (x < old) pos_less = min(pos_less, q * MM_BLOCK + tid);
+        }
+        fm = wave_min_f(fm);
+        pos_old = wave_min_i(pos_old);
+        pos_less = wave_min_i(pos_less);
+        if (lane == 0) {
+          sh.red_f[r][wave] = fm;
+          sh.red_a[r][wave] = pos_old;
+          sh.red_b[r][wave] = pos_less;
+        }
+      }
+      __syncthreads();
+      bool mine = false;  // one wave finishes one row
+      int myk = -1;
+#pragma unroll
+      for (int r = 0; r < MM_ROWS; r++)
+        if (wave == r) {
+          mine = res[r];
+          myk = kus[r];
+        }
+      if (mine) {
+        float fm = lane < MM_WAVES ? sh.red_f[wave][lane] : INF;
+        int pos_old = lane < MM_WAVES ? sh.red_a[wave][lane] : n;
+        int pos_less = lane < MM_WAVES ? sh.red_b[wave][lane] : n;
+        fm = wave_min_f(fm);
+        pos_old = wave_min_i(pos_old);
+        pos_less = wave_min_i(pos_less);
+        if (lane == 0) {
+          const int k = myk;
+          const float old = st.mv[k] - threshold;
+          st.mv[k] = ((pos_old < n && pos_old < pos_less) ? old : fm) + threshold;
+        }
+      }
+      __syncthreads();
+    }
+    LAP(3);
+    // ... then the candidate tests of every pair a rebuilt cluster is part of (:1893-1911 for the clusters before
+    // it, :1913-2018 for the ones behind): the row half on the values at hand, the column half fetched by the few
+    // survivors
+    auto append_pair = [&](unsigned key, int x, int y, float sym) {
+      const int slot = atomicAdd(&sh.npairs, 1);
+      if (slot < MM_PAIRS_LDS) {
+        sh.pk[0][slot] = key;
+        sh.pxy[0][slot] = ((unsigned)x << 16) | (unsigned)y;
+        sh.psym[0][slot] = sym;
+      } else if (slot - MM_PAIRS_LDS < p.pair_cap) {
+        unsigned *g = p.pair_g + (size_t)(slot - MM_PAIRS_LDS) * 3;
+        g[0] = key;
+        g[1] = ((unsigned)x << 16) | (unsigned)y;
+        g[2] = __float_as_uint(sym);
+      }
+    };
+    for (int u0 = 0; u0 < nupd; u0 += MM_ROWS) {
+      unsigned long long surv = 0;  // bit r * MAXQ + q: the row half holds for (row r, this thread's cluster q)
+#pragma unroll
+      for (int r = 0; r < MM_ROWS; r++) {
+        if (u0 + r >= nupd) continue;
+        const int up = (int)(sh.upd[u0 + r] & 0xffffu);
+        const int ku = st.ci[up];
+        if (!single) {
+#pragma unroll
+          for (int q = 0; q < MAXQ; q++) v[r][q] = a_k[q] >= 0 ? DD(ku, a_k[q]) : INF;
+        }
+        const float mvk = st.mv[ku];
+#pragma unroll
+        for (int q = 0; q < MAXQ; q++) {
+          const int l = a_k[q];
+          const bool ok = l >= 0 && l != i && l != j && l != ku && v[r][q] <= mvk;
+          surv |= ok ? 1ull << (r * MAXQ + q) : 0ull;
+        }
+      }
+      while (surv) {  // (few)
+        const int bit = __ffsll((long long)surv) - 1;
+        surv &= surv - 1;
+        const int r = bit / MAXQ, q = bit - r * MAXQ;
+        const int il = q * MM_BLOCK + tid, l = st.ci[il];
+        const int up = (int)(sh.upd[u0 + r] & 0xffffu), ku = st.ci[up];
+        int x, y;
+        unsigned key;
+        if (il < up) {  // the rebuilt cluster meets the clusters before it
+          x = ku;
+          y = l;
+          key = ((unsigned)up << 16) | (unsigned)il;
+        } else {  // a later cluster meets the rebuilt ones before it (a rebuilt one: from its own row)
+          if (st.flag[l]) continue;
+          x = l;
+          y = ku;
+          key = ((unsigned)il << 16) | (unsigned)up;
+        }
+        const float dlk = DD(l, ku);
+        if (!(dlk <= st.mv[l])) continue;
+        float sym = dlk + DD(ku, l);
+        if (p.CF && CC(x, y) <= st.mvcf[x] && CC(y, x) <= st.mvcf[y]) sym = 0.0f;
+        append_pair(key, x, y, sym);
+      }
+    }
+    // -- C: candidates with the merged cluster j, behind all others (:2033-2064)
+    {
+      unsigned cand = 0;
+#pragma unroll
+      for (int q = 0; q < MAXQ; q++) {
+        const int k = a_k[q];
+        const bool ok = k >= 0 && k != i && k != j && a_njk[q] <= min_value_j && a_nkj[q] <= st.mv[k];
+        cand |= ok ? 1u << q : 0u;
+      }
+#pragma unroll
+      for (int q = 0; q < MAXQ; q++) {
+        if (!(cand & (1u << q))) continue;
+        const int k = a_k[q];
+        float sym = a_njk[q] + a_nkj[q];
+        if (p.CF && a_ckj[q] <= st.mvcf[k] && a_cjk[q] <= mvcf_j) sym = 0.0f;
+        append_pair(0x80000000u | (unsigned)(q * MM_BLOCK + tid), k, j, sym);
+      }
+    }
+    __syncthreads();
+    LAP(4);
+    // -- D: the pairs in the reference's order
+    const int m = sh.npairs;
+    if (m - MM_PAIRS_LDS > p.pair_cap) {
+      if (tid == 0) *p.status = 2;
+      return;
+    }
+    auto pair_at = [&](int side, int e, unsigned &key, unsigned &xy, float &sym) {
+      if (e < MM_PAIRS_LDS) {
+        key = sh.pk[side][e];
+        xy = sh.pxy[side][e];
+        sym = sh.psym[side][e];
+      } else {
+        const unsigned *g = p.pair_g + ((size_t)side * p.pair_cap + (size_t)(e - MM_PAIRS_LDS)) * 3;
+        key = g[0];
+        xy = g[1];
+        sym = __uint_as_float(g[2]);
+      }
+    };
+    const int side = m > 1 ? 1 : 0;
+    if (m > 1) {
+      for (int e = tid; e < m; e += MM_BLOCK) {
+        unsigned key, xy;
+        float sym;
+        pair_at(0, e, key, xy, sym);
+        int rank = 0;
+        const int ml = min(m, MM_PAIRS_LDS);
+        for (int f = 0; f < ml; f++) rank += sh.pk[0][f] < key ? 1 : 0;
+        for (int f = MM_PAIRS_LDS; f < m; f++) rank += p.pair_g[(size_t)(f - MM_PAIRS_LDS) * 3] < key ? 1 : 0;
+        if (rank < MM_PAIRS_LDS) {
+          sh.pk[1][rank] = key;
+          sh.pxy[1][rank] = xy;
+          sh.psym[1][rank] = sym;
+        } else {
+          unsigned *g = p.pair_g + ((size_t)p.pair_cap + (size_t)(rank - MM_PAIRS_LDS)) * 3;
+          g[0] = key;
+          g[1] = xy;
+          g[2] = __float_as_uint(sym);
+        }
+      }
+      __syncthreads();
+    }
+    LAP(5);
     if (tid == 0) {
-      // (the unvisited best is a copy taken before the visits: they may still change that cluster's candidate)
-      const int bl1 = bpos < n ? p.mc_lin1[ci[bpos]] : -1;
-      const int bl2 = bpos < n ? p.mc_lin2[ci[bpos]] : -1;
+      // the best among the clusters that keep their candidate (a copy taken before the draws: they may still
+      // change such a cluster's candidate, behind its turn)
+      float ud = sh.lex_d[0], ud2 = sh.lex_d2[0];
+      int upos = sh.lex_p[0];
+      for (int w = 1; w < MM_WAVES; w++)
+        if (lex_less(sh.lex_d[w], sh.lex_d2[w], sh.lex_p[w], ud, ud2, upos)) {
+          ud = sh.lex_d[w];
+          ud2 = sh.lex_d2[w];
+          upos = sh.lex_p[w];
+        }
+      const int bl1 = upos < n ? (int)st.lin1[st.ci[upos]] : -1;
+      const int bl2 = upos < n ? (int)st.lin2[st.ci[upos]] : -1;
+      // the clusters whose candidates change, at their turn: after their own pairs
       float sd = INF, sd2 = INF;
       int sl1 = -1, sl2 = -1, spos = n;
-      int ucs = 0;
-      for (int v = 0; v < nvisit; v++) {
-        const int ik = p.visit_list[v];
-        const int k = ci[ik];
-        const float mvk = p.min_values[k];
-        if (p.kflag[ik] & 2) {
-          const int u = ucs++;
-          p.mc_dist[k] = INF;
-          p.mc_dist2[k] = INF;
-          for (int e = p.feas_off[u]; e < p.feas_off[u + 1]; e++) consider(p, sh, k, p.feas[e]);
-        } else {
-          const unsigned m = p.kmask[ik];
-          for (int u = 0; u < ucs; u++) {
-            const int l = ci[p.upd_pos[u]];
-            if (u < nu) {
-              if (((m >> u) & 1u) && DD(k, l) <= mvk) consider(p, sh, k, l);
-            } else if (DD(k, l) <= mvk) {
-              if (DD(l, k) <= p.min_values[l]) consider(p, sh, k, l);
-            }
-          }
-        }
-        const float d1 = p.mc_dist[k], d2 = p.mc_dist2[k];
+      int cur = -1, curk = -1;
+      auto settle = [&]() {
+        const float d1 = st.mcd[curk], d2 = st.mcd2[curk];
         if (sd > d1 || (sd == d1 && sd2 > d2)) {
           sd = d1;
           sd2 = d2;
-          sl1 = p.mc_lin1[k];
-          sl2 = p.mc_lin2[k];
-          spos = ik;
+          sl1 = st.lin1[curk];
+          sl2 = st.lin2[curk];
+          spos = cur;
         }
+      };
+      int e = 0;
+      for (; e < m; e++) {
+        unsigned key, xy;
+        float sym;
+        pair_at(side, e, key, xy, sym);
+        if (key & 0x80000000u) break;
+        const int pos = (int)(key >> 16), x = (int)(xy >> 16), y = (int)(xy & 0xffffu);
+        if (pos != cur) {
+          if (cur >= 0) settle();
+          cur = pos;
+          curk = x;
+        }
+        apply_pair<LDS>(st, sh, x, y, sym);
       }
+      if (cur >= 0) settle();
       // the loop's running "best": smallest (dist, dist2), the earliest cluster among exact ties
       Best b;
       b.dist = INF;
@@ -708,12 +844,12 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
       b.lin1 = sh.best.lin1;
       b.lin2 = sh.best.lin2;
       int pos = n;
-      if (bpos < n) {
-        b.dist = bd;
-        b.dist2 = bd2;
+      if (upos < n) {
+        b.dist = ud;
+        b.dist2 = ud2;
         b.lin1 = bl1;
         b.lin2 = bl2;
-        pos = bpos;
+        pos = upos;
       }
       if (spos < n) {
         if (b.dist > sd || (b.dist == sd && (b.dist2 > sd2 || (b.dist2 == sd2 && spos < pos)))) {
@@ -724,27 +860,36 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
           pos = spos;
         }
       }
-      p.min_values[j] = min_value_j;
-      p.mc_dist[j] = INF;
-      p.mc_dist2[j] = INF;
-      for (int e = 0; e < ncand; e++) consider(p, sh, p.cand_j[e], j);
-      const float jd = p.mc_dist[j], jd2 = p.mc_dist2[j];
+      st.mv[j] = min_value_j;
+      if (p.CF) st.mvcf[j] = mvcf_j;
+      st.mcd[j] = INF;
+      st.mcd2[j] = INF;
+      for (; e < m; e++) {
+        unsigned key, xy;
+        float sym;
+        pair_at(side, e, key, xy, sym);
+        apply_pair<LDS>(st, sh, (int)(xy >> 16), j, sym);
+      }
+      const float jd = st.mcd[j], jd2 = st.mcd2[j];
       if (b.dist > jd || (b.dist == jd && b.dist2 > jd2)) {
         b.dist = jd;
         b.dist2 = jd2;
-        b.lin1 = p.mc_lin1[j];
-        b.lin2 = p.mc_lin2[j];
+        b.lin1 = st.lin1[j];
+        b.lin2 = st.lin2[j];
       }
       sh.best = b;
-      p.cluster_size[j] = csi + csj;
+      st.csz[j] = (idx_t)((int)st.csz[i] + (int)st.csz[j]);
       p.convert_index[j] = num_nodes;
+      sh.nupd = 0;
+      sh.npairs = 0;
     }
+    LAP(6);
     // -- the same merge in the symmetric matrix once it is in use (coalesce_sym, tree_builder.cpp:968-1058)
     if (sh.use_sym) {
       if (tid == 0) sh.count = 0;  // (thread 0 is past its ordered part; the others wait at the barrier below)
       __syncthreads();
       for (int ik = tid; ik < n; ik += MM_BLOCK) {
-        const int k = ci[ik];
+        const int k = st.ci[ik];
         if (k == j || k == i) continue;
         const float dkj = SS(k, j), dki = SS(k, i), dik = SS(i, k), djk = SS(j, k);
         const float mvk = p.min_values_sym[k];
@@ -752,7 +897,7 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
         if (dki != dkj) SS(k, j) = (csi * dki + csj * dkj) / added;
         if (dkj != dki) {
           if ((double)fabsf(mvk - dkj) < 1e-6 || (double)fabsf(mvk - dki) < 1e-6)
-            p.upd_pos[atomicAdd(&sh.count, 1)] = ik;  // (scratch use: rows to rescan)
+            p.upd_pos[atomicAdd(&sh.count, 1)] = ik;  // rows to rescan
         } else {
           if (p.mcs_lin1[k] == i) p.mcs_lin1[k] = j;
           if (p.mcs_lin2[k] == i) p.mcs_lin2[k] = j;
@@ -761,21 +906,21 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
       __syncthreads();
       const int nres_s = sh.count;
       for (int r = 0; r < nres_s; r++) {
-        const int k = ci[p.upd_pos[r]];
+        const int k = st.ci[p.upd_pos[r]];
         const float old = p.min_values_sym[k];
         const float *row = p.SYM + (size_t)k * N;
         float fm = INF, fm2 = 0.0f;
         int fpos = n, pos_old = n, pos_less = n;
         for (int il = tid; il < n; il += MM_BLOCK) {
-          const int l = ci[il];
+          const int l = st.ci[il];
           if (l != i && l != k) {
-            const float v = row[l];
-            if (v < fm) {
-              fm = v;
+            const float x = row[l];
+            if (x < fm) {
+              fm = x;
               fpos = il;
             }
-            if (v == old) pos_old = min(pos_old, il);
-            if (v < old) pos_less = min(pos_less, il);
+            if (x == old) pos_old = min(pos_old, il);
+            if (x < old) pos_less = min(pos_less, il);
           }
         }
         float dummy = 0.0f;
@@ -783,13 +928,13 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
         block_lex_min(fm, fm2, fpos, sh.wave_f, sh.wave_f2, sh.wave_i3);
         if (tid == 0) {
           const bool stops = pos_old < n && pos_old < pos_less;
-          const float v = stops ? old : fm;
+          const float x = stops ? old : fm;
           const int at = stops ? pos_old : fpos;
-          p.min_values_sym[k] = v;
-          p.mcs_dist[k] = v;
-          if (v < INF) {
+          p.min_values_sym[k] = x;
+          p.mcs_dist[k] = x;
+          if (x < INF) {
             p.mcs_lin1[k] = k;
-            p.mcs_lin2[k] = ci[at];
+            p.mcs_lin2[k] = st.ci[at];
           }
         }
       }
@@ -798,7 +943,7 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
       int bp = n, mjp = n;
       const float *srowj = p.SYM + (size_t)j * N;
       for (int ik = tid; ik < n; ik += MM_BLOCK) {
-        const int k = ci[ik];
+        const int k = st.ci[ik];
         if (k == j || k == i) continue;
         const float dk = p.mcs_dist[k];
         if (dk < b1) {
@@ -817,7 +962,7 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
         Best b = sh.best_sym;
         b.dist = INF;
         if (bp < n && b1 < INF) {
-          const int k = ci[bp];
+          const int k = st.ci[bp];
           b.dist = b1;
           b.lin1 = p.mcs_lin1[k];
           b.lin2 = p.mcs_lin2[k];
@@ -825,7 +970,7 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
         p.min_values_sym[j] = mj;
         p.mcs_dist[j] = mj;  // (INF when nothing is left)
         if (mjp < n && mj < INF) {
-          p.mcs_lin1[j] = ci[mjp];
+          p.mcs_lin1[j] = st.ci[mjp];
           p.mcs_lin2[j] = j;
         }
         if (b.dist > mj) {
@@ -836,24 +981,39 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
         sh.best_sym = b;
       }
     }
-    LAP(9);
-    // -- the merged-away cluster leaves the list (copied to the other buffer, one position up behind it)
+    __syncthreads();
+    LAP(7);
+    // -- E: the merged-away cluster leaves the list; the rebuilt marks are taken back
     {
       const int ipos = sh.ipos;
-      for (int ik = tid; ik < n - 1; ik += MM_BLOCK) ci_next[ik] = ci[ik >= ipos ? ik + 1 : ik];
-      int *t = ci;
-      ci = ci_next;
-      ci_next = t;
+      int nxt[MAXQ];
+#pragma unroll
+      for (int q = 0; q < MAXQ; q++) {
+        const int ik = q * MM_BLOCK + tid;
+        nxt[q] = (ik >= ipos && ik + 1 < n) ? (int)st.ci[ik + 1] : -1;
+      }
+      for (int u = tid; u < nupd; u += MM_BLOCK) st.flag[st.ci[sh.upd[u] & 0xffffu]] = 0;
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < MAXQ; q++)
+        if (nxt[q] >= 0) st.ci[q * MM_BLOCK + tid] = (idx_t)nxt[q];
     }
     if (tid == 0) sh.n = n - 1;
     __syncthreads();
-    LAP(10);
+    LAP(8);
+  }
+  if constexpr (LDS) {  // the carried state goes out
+    for (int c = tid; c < N; c += MM_BLOCK) {
+      p.mc_lin1[c] = (int)st.lin1[c];
+      p.mc_lin2[c] = (int)st.lin2[c];
+      p.min_values_CF[c] = st.mvcf[c];
+    }
   }
   if (tid == 0) {
     *p.status = 0;
     if (p.timers) {
-      tacc[11] = (clock64() - cstart) * 100 / (wall_clock64() - tstart + 1);  // shader clock, MHz
-      for (int x = 0; x < 12; x++) p.timers[x] = tacc[x];
+      sh.tacc[11] = (clock64() - cstart) * 100 / (wall_clock64() - tstart + 1);  // shader clock, MHz
+      for (int x = 0; x < 12; x++) p.timers[x] = sh.tacc[x];
     }
   }
 }
@@ -907,6 +1067,19 @@ int rng_restatement_mismatches(unsigned seed, int n) {
 }
 
 // ---- host side
+// dynamic LDS of a build whose per-cluster state lives there: 4 floats, 4 shorts and a flag per cluster
+static size_t lds_state_bytes(int N) { return (((size_t)25 * N) + 255) & ~(size_t)255; }
+// ... and whether it fits next to the kernel's static LDS (160 KB per workgroup on gfx950)
+static bool lds_state_fits(int N) {
+  static size_t fixed = 0;
+  if (!fixed) {
+    hipFuncAttributes a;
+    if (hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&minmatch_kernel<true, 5>)) != hipSuccess) return false;
+    fixed = a.sharedSizeBytes;
+  }
+  return N <= 5 * MM_BLOCK && fixed + lds_state_bytes(N) <= (size_t)160 * 1024;
+}
+
 // Trees of different sections are built at the same time, but a process has a handful of hardware queues (4 by
 // default): 40 builders with a stream and a one-workgroup launch each run 4 at a time.  So builders hand their
 // request to a dispatcher of the device, which puts all that are waiting into one launch -- a workgroup each --
@@ -947,6 +1120,12 @@ class BuildDispatcher {
     (void)hipSetDevice(device_);
     hipStream_t stream = nullptr;
     (void)hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+    {  // the per-cluster state of a build in LDS: more than the default 64 KB of dynamic LDS
+      hipFuncAttributes a;
+      if (hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&minmatch_kernel<true, 5>)) == hipSuccess)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&minmatch_kernel<true, 5>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)a.sharedSizeBytes);
+    }
     DevBuf d_params;
     std::vector<Request *> batch;
     std::vector<MMParams> params;
@@ -975,9 +1154,25 @@ class BuildDispatcher {
         rc = RL_EHIP;
       if (!rc) {
         const auto t0 = std::chrono::steady_clock::now();
-        hipLaunchKernelGGL(minmatch_kernel, dim3((unsigned)batch.size()), dim3(MM_BLOCK), 0, stream,
-                           d_params.as<MMParams>());
-        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) rc = RL_EHIP;
+        // the trees whose per-cluster state fits in LDS and the larger ones: one launch per kind, each kernel
+        // leaves the other kind's workgroups at once
+        size_t dyn = 0;
+        bool any_lds = false, any_glob = false;
+        for (const MMParams &q : params) {
+          if (q.lds_state) {
+            any_lds = true;
+            dyn = std::max(dyn, lds_state_bytes(q.N));
+          } else {
+            any_glob = true;
+          }
+        }
+        if (any_lds)
+          hipLaunchKernelGGL((minmatch_kernel<true, 5>), dim3((unsigned)batch.size()), dim3(MM_BLOCK), dyn, stream,
+                             d_params.as<MMParams>());
+        if (any_glob && !rc)
+          hipLaunchKernelGGL((minmatch_kernel<false, 10>), dim3((unsigned)batch.size()), dim3(MM_BLOCK), 0, stream,
+                             d_params.as<MMParams>());
+        if (rc || hipGetLastError() != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) rc = RL_EHIP;
         if (getenv("RELATE_AMD_TIMING"))
           fprintf(stderr, "[tree builder launch] %zu trees, %.1f ms\n", batch.size(),
                   1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
@@ -1006,7 +1201,7 @@ struct DeviceMinMatch::Impl {
   int N = 0, device = 0;
   hipStream_t stream = nullptr;
   DevBuf d_D, d_CF, d_SYM, d_f, d_i, d_feas, d_rowlist, d_status, d_flags, d_member, d_tab, d_acc;
-  long long feas_cap = 0;
+  long long builds = 0;
 };
 
 DeviceMinMatch::DeviceMinMatch(int N, int device) : impl(new Impl()) {
@@ -1092,24 +1287,29 @@ int DeviceMinMatch::build_impl(MinMatch &tb, const float *d, const float *prior_
                                HostTree &tree) {
   Impl &m = *impl;
   const int N = m.N;
-  if (N < 2 || N > 32768) return 1;
+  if (N < 2 || N > MM_MAXN) return 1;  // (the painting kernels stop at N = 10240 too)
+  if (resident) {  // tests: every k-th resident build is handed to the host, as a tree with too many tied candidates is
+    static const int every = getenv("RELATE_AMD_BUILDER_HANDOVER_EVERY") ? atoi(getenv("RELATE_AMD_BUILDER_HANDOVER_EVERY")) : 0;
+    if (every > 0 && ++m.builds % every == 0) return 2;
+  }
   RL_HIP(hipSetDevice(m.device));
   if (!m.stream) RL_HIP(hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking));
   const bool prior = with_prior;
   const size_t NN = (size_t)N * N;
-  m.feas_cap = (long long)8 * N;
+  const long long pair_cap = (long long)8 * N;
   int rc = m.d_D.alloc(NN * 4);
   rc = rc ? rc : (prior ? m.d_CF.alloc(NN * 4) : 0);
   rc = rc ? rc : m.d_SYM.alloc(NN * 4);
-  rc = rc ? rc : m.d_f.alloc((size_t)7 * N * 4);  // min_values, min_values_CF, mc_dist, mc_dist2, cluster_size, + 2 sym
-  rc = rc ? rc : m.d_i.alloc(((size_t)9 * N + (size_t)7 * N + 8) * 4);  // ints, see below
-  rc = rc ? rc : m.d_feas.alloc((size_t)m.feas_cap * 4);
+  rc = rc ? rc : m.d_f.alloc((size_t)6 * N * 4);  // min_values, min_values_CF, mc_dist, mc_dist2, + 2 of the symmetric path
+  rc = rc ? rc : m.d_i.alloc(((size_t)12 * N + 8) * 4);  // ints, see below
+  rc = rc ? rc : m.d_feas.alloc((size_t)pair_cap * 6 * 4);
   rc = rc ? rc : m.d_rowlist.alloc((size_t)MM_WAVES * N * 4);
   rc = rc ? rc : m.d_status.alloc(16 + 12 * 8);
   rc = rc ? rc : m.d_flags.alloc((size_t)N);
   if (rc) return -1;
   MMParams p;
   p.N = N;
+  p.lds_state = lds_state_fits(N) ? 1 : 0;
   p.threshold = tb.threshold;
   p.threshold_CF = tb.threshold_CF;
   p.D = m.d_D.as<float>();
@@ -1119,29 +1319,24 @@ int DeviceMinMatch::build_impl(MinMatch &tb, const float *d, const float *prior_
   p.min_values_CF = f + N;
   p.mc_dist = f + 2 * (size_t)N;
   p.mc_dist2 = f + 3 * (size_t)N;
-  p.cluster_size = f + 4 * (size_t)N;
-  p.min_values_sym = f + 5 * (size_t)N;
-  p.mcs_dist = f + 6 * (size_t)N;
+  p.min_values_sym = f + 4 * (size_t)N;
+  p.mcs_dist = f + 5 * (size_t)N;
   p.SYM = m.d_SYM.as<float>();
   int *q = m.d_i.as<int>();
   p.mc_lin1 = q;
   p.mc_lin2 = q + N;
   p.cluster_index = q + 2 * (size_t)N;
-  p.convert_index = q + 3 * (size_t)N;
-  p.kmask = reinterpret_cast<unsigned *>(q + 4 * (size_t)N);
-  p.visit_list = q + 5 * (size_t)N;
-  p.cand_j = q + 6 * (size_t)N;
-  p.upd_pos = q + 7 * (size_t)N;
-  p.feas_off = q + 8 * (size_t)N;  // [N+1]
-  p.parent = q + 9 * (size_t)N + 4;         // [2N-1]
-  p.child_left = q + 11 * (size_t)N + 4;    // [N-1]
-  p.child_right = q + 12 * (size_t)N + 4;   // [N-1]
-  p.cluster_index2 = q + 13 * (size_t)N + 4;
-  p.mcs_lin1 = q + 14 * (size_t)N + 4;
-  p.mcs_lin2 = q + 15 * (size_t)N + 4;
+  p.cluster_size = q + 3 * (size_t)N;
+  p.convert_index = q + 4 * (size_t)N;
+  p.upd_pos = q + 5 * (size_t)N;
+  p.mcs_lin1 = q + 6 * (size_t)N;
+  p.mcs_lin2 = q + 7 * (size_t)N;
+  p.parent = q + 8 * (size_t)N;            // [2N-1]
+  p.child_left = q + 10 * (size_t)N;       // [N-1]
+  p.child_right = q + 11 * (size_t)N;      // [N-1]
   p.kflag = m.d_flags.as<unsigned char>();
-  p.feas = m.d_feas.as<int>();
-  p.feas_cap = m.feas_cap;
+  p.pair_g = m.d_feas.as<unsigned>();
+  p.pair_cap = pair_cap;
   p.rowlist = m.d_rowlist.as<int>();
   p.status = m.d_status.as<int>();
   const bool timing = getenv("RELATE_AMD_TIMING") != nullptr;
@@ -1178,13 +1373,13 @@ int DeviceMinMatch::build_impl(MinMatch &tb, const float *d, const float *prior_
     long long tk[12];
     RL_HIP(hipMemcpy(tk, p.timers, sizeof(tk), hipMemcpyDeviceToHost));
     fprintf(stderr, "[gpu tree builder] N=%d, us:", N);
-    static const char *names[12] = {"row minima", "pair scan", "updates", "rescans", "rebuilt list", "masks+min_j",
-                                    "unvisited best", "lists", "partners", "ordered", "erase", ""};
-    for (int x = 0; x < 11; x++) fprintf(stderr, " %s %.0f", names[x], tk[x] / 100.0);
+    static const char *names[12] = {"row minima", "pair scan", "updates", "rescans", "pair tests", "pair order",
+                                    "ordered", "symmetric", "erase", "", "", ""};
+    for (int x = 0; x < 9; x++) fprintf(stderr, " %s %.0f", names[x], tk[x] / 100.0);
     fprintf(stderr, " shader_MHz %lld\n", tk[11]);
   }
   // out: the tree and the carried state
-  std::vector<int> tr((size_t)4 * N);
+  std::vector<int> tr((size_t)4 * N);  // parent [2N), child_left [N), child_right [N) lie back to back
   RL_HIP(hipMemcpyAsync(tr.data(), p.parent, ((size_t)4 * N - 1) * 4, hipMemcpyDeviceToHost, m.stream));
   RL_HIP(hipMemcpyAsync(lin.data(), p.mc_lin1, (size_t)2 * N * 4, hipMemcpyDeviceToHost, m.stream));
   RL_HIP(hipMemcpyAsync(tb.min_values_CF.data(), p.min_values_CF, (size_t)N * 4, hipMemcpyDeviceToHost, m.stream));

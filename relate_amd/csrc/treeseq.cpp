@@ -399,7 +399,7 @@ int rl_treeseq_build(rl_treeseq *ts, int start, int end, rl_matrix_fn matrix, rl
   };
   MinMatch tb(N, ts->theta);
   std::unique_ptr<DeviceMinMatch> dev;
-  if (ts->build_device >= 0 && N <= 32768) dev.reset(new DeviceMinMatch(N, ts->build_device));  // (its position masks)
+  if (ts->build_device >= 0 && N <= 10240) dev.reset(new DeviceMinMatch(N, ts->build_device));  // (its registers per thread)
   int build_rc = 0;
   auto build_tree = [&](float *dm, const float *prior, HostTree &t) {
     if (dev) {
@@ -423,8 +423,15 @@ int rl_treeseq_build(rl_treeseq *ts, int start, int end, rl_matrix_fn matrix, rl
     float *dd = dev->device_matrix();
     if (!dd) return RL_ENOMEM;
     if ((rc = ts->matrix_dev(user, start, dd))) return rc;
-    if (dev->build_resident(tb, false, ts->trees.back())) return RL_EHIP;
-    ts->gpu_trees++;
+    const int st = dev->build_resident(tb, false, ts->trees.back());
+    if (st < 0) return RL_EHIP;
+    if (st > 0) {  // this tree is the host's (tb untouched): the matrix again, to the host
+      if ((rc = matrix(user, start, d.data()))) return rc;
+      ts->host_trees++;
+      tb.quick_build(d.data(), nullptr, ts->trees.back());
+    } else {
+      ts->gpu_trees++;
+    }
   } else {
     if ((rc = matrix(user, start, d.data()))) return rc;
     build_tree(d.data(), nullptr, ts->trees.back());  // :447, no prior for the first tree
@@ -480,8 +487,31 @@ int rl_treeseq_build(rl_treeseq *ts, int start, int end, rl_matrix_fn matrix, rl
           lap(t_prior);
         }
         st = st ? st : dev->build_resident(tb, consistency, nt);
-        if (st) return RL_EHIP;
-        ts->gpu_trees++;
+        if (st < 0) {
+          set_error("tree builder on the device failed at SNP %d", snp);
+          return RL_EHIP;
+        }
+        if (st > 0) {
+          // The device hands this tree to the host (more tied candidates than its lists hold, or no room for
+          // the symmetric matrix): the device matrices are half merged by now, so the distance matrix comes
+          // again, to the host, with the penalty and the prior of the host path.  tb is untouched.
+          if ((rc = matrix(user, snp, d.data()))) return rc;
+          if (consistency) {
+            parallel_rows(N, [&](int c) {
+              if (ts->member[c]) {
+                float *row = &d[(size_t)c * N];
+                for (int col = 0; col < N; col++) row[col] += val;
+                for (int c2 = 0; c2 < N; c2++)
+                  if (ts->member[c2]) row[c2] -= val;
+              }
+            });
+            clade_prior(pt, val, dist);
+          }
+          ts->host_trees++;
+          tb.quick_build(d.data(), consistency ? dist.data() : nullptr, nt);
+        } else {
+          ts->gpu_trees++;
+        }
       } else if ((rc = matrix(user, snp, d.data()))) {
         return rc;
       } else if (consistency) {

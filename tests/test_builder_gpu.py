@@ -36,14 +36,14 @@ def coalescent_matrix(rng, N):
     return d
 
 
-def run_sequence(N, mats, theta=0.001):
+def run_sequence(N, mats, theta=0.001, all_on_gpu=True):
     host, dev = api.Builder(N, theta), api.Builder(N, theta, device=0)
     on_gpu = 0
     for t, (d, prior) in enumerate(mats):
         ref = host.build(d, prior)
         got = dev.build(d, prior)
         on_gpu += dev.last_on_gpu
-        assert dev.last_on_gpu  # (the symmetric fallback included)
+        assert dev.last_on_gpu or not all_on_gpu  # (the symmetric fallback included)
         for name, a, b in zip(("parent", "child_left", "child_right"), ref, got):
             assert np.array_equal(a, b), (t, name, int(np.argmax(a != b)))
     host.close()
@@ -94,3 +94,25 @@ def test_no_mutually_closest_pair_symmetric_fallback(N, seed):
             (circ + np.floor(rng.rand(N, N) * 3).astype(np.float32), (np.floor(rng.rand(N, N) * 3) * 6.9).astype(np.float32)),
             (tied_matrix(rng, N), None)]
     run_sequence(N, mats)
+
+
+def test_too_many_tied_candidates_go_to_the_host():
+    """a flat matrix: every pair is a candidate and every cluster rebuilds at the first merge -- more than the
+    kernel's lists hold (status 2): the host builds that tree from the carried state, the next one is the device's"""
+    N = 1300
+    rng = np.random.RandomState(3)
+    flat = np.full((N, N), 2.5, np.float32)
+    np.fill_diagonal(flat, 0)
+    mats = [(coalescent_matrix(rng, N), None), (flat, None), (coalescent_matrix(rng, N), flat * 2),
+            (coalescent_matrix(rng, N), None)]
+    assert run_sequence(N, mats, all_on_gpu=False) == 3
+
+
+@pytest.mark.parametrize("N", [5121, 5300])
+def test_state_in_global_memory_above_the_lds_limit(N):
+    """N > 5120: the per-cluster state does not fit in LDS next to the pair lists; the same kernel on global arrays"""
+    rng = np.random.RandomState(N)
+    d = (rng.rand(N, N) * 3 + rng.rand(N)[:, None]).astype(np.float32)
+    np.fill_diagonal(d, 0)
+    prior = (np.floor(rng.rand(N, N) * 3) * 6.9).astype(np.float32)
+    run_sequence(N, [(d, None), (d.T.copy(), prior)])
