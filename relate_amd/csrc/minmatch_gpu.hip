@@ -34,19 +34,26 @@ namespace rl {
 
 namespace {
 
-constexpr int MM_BLOCK = 1024;
+constexpr int MM_BLOCK = 512;   // (8 waves: 256 registers per lane -- a thread keeps ~10 clusters of a merge in registers)
 constexpr int MM_WAVES = MM_BLOCK / 64;
-constexpr int MM_ROWS = 4;        // rows of rebuilt clusters scanned per pass of a merge
+constexpr int MM_ROWS = 2;        // rows of rebuilt clusters scanned per pass of a merge
 constexpr int MM_UPD_MAX = 1024;  // rebuilt clusters of one merge (list in LDS); more: the host builds the tree
 constexpr int MM_PAIRS_LDS = 768; // feasible pairs of one merge kept in LDS; more go through global scratch
-constexpr int MM_MAXN = 10240;    // one thread holds up to 10 clusters of a merge in registers
+constexpr int MM_MAXN = 10240;    // one thread holds up to 20 clusters of a merge in registers
 
 struct MMParams {
   int N;
   int lds_state;  // the per-cluster state lives in LDS for the build (it fits: N <= ~5200)
   float threshold, threshold_CF;
-  float *D;   // [N*N] destroyed
-  float *CF;  // [N*N] destroyed, or nullptr
+  // The matrices of a build, woven: M[a][b] = (d(a,b), d(b,a), cf(a,b), cf(b,a)).  A merge needs, per cluster k,
+  // the entries (i,k), (k,i), (j,k), (k,j) of both matrices: two 16-byte loads along the rows of i and j instead of
+  // four loads along rows and four down columns (a scattered 4-byte access costs one CU ~3.5 cycles: measured
+  // 3.7 us per column of 2500 clusters, six of them per merge in the plain layout); what stays scattered is ONE
+  // 16-byte store per cluster, M[k][j], which waits for nobody.  Packed from the distance matrix (K3 + carrier
+  // penalty) and the clade prior by pack_kernel; row minima of both by rowmin_kernel.
+  float4 *M;          // [N*N] destroyed
+  int has_prior;      // the cf halves of M are in use
+  const float *rowmin_D, *rowmin_CF;  // [N] minimum of each row off the diagonal
   float *SYM;  // [N*N] room for the symmetric matrix
   float *min_values_sym, *mcs_dist;
   int *mcs_lin1, *mcs_lin2;
@@ -213,8 +220,8 @@ __device__ inline void block_min3(float &f, int &a, int &b, float *bf, int *ba, 
 }
 
 // (32-bit element offsets from a scalar base -- N <= 10240: one address register per load instead of two)
-#define DD(a, b) p.D[(unsigned)(a) * (unsigned)N + (unsigned)(b)]
-#define CC(a, b) p.CF[(unsigned)(a) * (unsigned)N + (unsigned)(b)]
+#define MM(a, b) p.M[(unsigned)(a) * (unsigned)N + (unsigned)(b)]
+#define MM2(a, b) (reinterpret_cast<const float2 *>(p.M + ((unsigned)(a) * (unsigned)N + (unsigned)(b)))[0])  // (d(a,b), d(b,a))
 #define SS(a, b) p.SYM[(unsigned)(a) * (unsigned)N + (unsigned)(b)]
 
 // Symmetric distance of a feasible pair (tree_builder.cpp:1699-1702): 0 when the pair is also mutually closest
@@ -222,11 +229,9 @@ __device__ inline void block_min3(float &f, int &a, int &b, float *bf, int *ba, 
 template <bool LDS>
 __device__ inline float pair_sym(const MMParams &p, const State<LDS> &st, int x, int y) {
   const int N = p.N;
-  if (p.CF) {
-    const bool both = (CC(x, y) <= st.mvcf[x]) && (CC(y, x) <= st.mvcf[y]);
-    return both ? 0.0f : DD(y, x) + DD(x, y);
-  }
-  return DD(y, x) + DD(x, y);
+  const float4 e = MM(x, y);
+  if (p.has_prior && e.z <= st.mvcf[x] && e.w <= st.mvcf[y]) return 0.0f;
+  return e.y + e.x;
 }
 // One feasible pair in the reference's order (one lane): one draw, both clusters' best candidate (:1704-1716).
 template <bool LDS>
@@ -273,6 +278,7 @@ __device__ inline void apply_pair(const State<LDS> &st, Shared &sh, int x, int y
 template <bool LDS, int MAXQ>
 __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *__restrict__ params) {
   typedef typename State<LDS>::idx_t idx_t;
+  constexpr int ROWS = MM_ROWS;  // rows of rebuilt clusters per pass (ROWS * MAXQ <= 64 bits of survivors)
   const MMParams p = params[blockIdx.x];
   if ((p.lds_state != 0) != LDS) return;  // (the launch carries trees of one kind)
   __shared__ Shared sh;
@@ -348,27 +354,13 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
   }
   __syncthreads();
 
-  // ---- Initialize (:59-146 / :1647-1735): row minima (+ threshold), one wave per row
-  for (int a = wave; a < N; a += MM_WAVES) {
-    const float *row = p.D + (size_t)a * N;
-    float mv = INF;
-#pragma unroll 8
-    for (int l = lane; l < N; l += 64)  // (unrolled: eight loads in flight per lane, a row is 20 KB)
-      if (l != a) mv = fminf(mv, row[l]);
-    mv = wave_min_f(mv);
-    if (p.CF) {
-      const float *crow = p.CF + (size_t)a * N;
-      float mc_ = INF;
-#pragma unroll 8
-      for (int l = lane; l < N; l += 64)
-        if (l != a) mc_ = fminf(mc_, crow[l]);
-      mc_ = wave_min_f(mc_);
-      if (lane == 0) {
-        const float old = st.mvcf[a];  // carried over from the previous build (:2399-2400)
-        st.mvcf[a] = (old > mc_ ? mc_ : old) + threshold_CF;
-      }
+  // ---- Initialize (:59-146 / :1647-1735): row minima (+ threshold); the minima themselves come from rowmin_kernel
+  for (int a = tid; a < N; a += MM_BLOCK) {
+    st.mv[a] = p.rowmin_D[a] + threshold;
+    if (p.has_prior) {
+      const float old = st.mvcf[a], mc_ = p.rowmin_CF[a];  // old: carried over from the previous build (:2399-2400)
+      st.mvcf[a] = (old > mc_ ? mc_ : old) + threshold_CF;
     }
-    if (lane == 0) st.mv[a] = mv + threshold;
   }
   __syncthreads();
   LAP(0);
@@ -378,12 +370,14 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
     int cnt = 0;
     if (a < N) {
       const float mva = st.mv[a];
-      const float *row = p.D + (size_t)a * N;
       int *out = p.rowlist + (size_t)wave * N;
       for (int b0 = a + 1; b0 < N; b0 += 64) {
         const int b = b0 + lane;
         bool hit = false;
-        if (b < N && mva >= row[b]) hit = st.mv[b] >= DD(b, a);
+        if (b < N) {
+          const float2 e = MM2(a, b);
+          hit = mva >= e.x && st.mv[b] >= e.y;
+        }
         const unsigned long long m = __ballot(hit);
         if (hit) out[cnt + __popcll(m & ((1ull << lane) - 1ull))] = b;
         cnt += __popcll(m);
@@ -433,7 +427,8 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
         for (int il = lane; il < n; il += 64) {
           const int l = st.ci[il];
           if (l == a) continue;
-          const float v = DD(a, l) + DD(l, a);
+          const float2 e = MM2(a, l);
+          const float v = e.x + e.y;
           SS(a, l) = v;
           if (v < mv) {  // (ascending per lane: the first one stays)
             mv = v;
@@ -488,33 +483,23 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
 
     // -- A: this thread's clusters
     int a_k[MAXQ];
-    float a_njk[MAXQ], a_nkj[MAXQ], a_cjk[MAXQ], a_ckj[MAXQ];  // d(j,k), d(k,j), cf(j,k), cf(k,j) after the merge
     float mv_cf = INF, mvj = INF, bd = INF, bd2 = INF;
     int bpos = n;
 #pragma unroll
     for (int q = 0; q < MAXQ; q++) {
       const int ik = q * MM_BLOCK + tid;
       a_k[q] = ik < n ? (int)st.ci[ik] : -1;
-      a_njk[q] = a_nkj[q] = a_cjk[q] = a_ckj[q] = INF;
     }
 #pragma unroll
     for (int q0 = 0; q0 < MAXQ; q0 += 5) {
       if (q0 * MM_BLOCK >= n) break;
-      float d4[5][4], c4[5][4];
+      float4 ei[5], ej[5];
 #pragma unroll
       for (int qq = 0; qq < 5; qq++) {  // (every load of the five issued before the first store)
         const int k = a_k[q0 + qq];
         if (k < 0 || k == j || k == i) continue;
-        if (p.CF) {
-          c4[qq][0] = CC(k, j);
-          c4[qq][1] = CC(k, i);
-          c4[qq][2] = CC(i, k);
-          c4[qq][3] = CC(j, k);
-        }
-        d4[qq][0] = DD(k, j);
-        d4[qq][1] = DD(k, i);
-        d4[qq][2] = DD(i, k);
-        d4[qq][3] = DD(j, k);
+        ei[qq] = MM(i, k);
+        ej[qq] = MM(j, k);
       }
 #pragma unroll
       for (int qq = 0; qq < 5; qq++) {
@@ -526,34 +511,23 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
           if (k == i) sh.ipos = ik;
           continue;
         }
-        if (p.CF) {
-          const float ckj = c4[qq][0], cki = c4[qq][1], cik = c4[qq][2], cjk = c4[qq][3];
-          float ncjk = cjk, nckj = ckj;
-          if (cik != cjk) {
-            ncjk = (csi * cik + csj * cjk) / added;
-            CC(j, k) = ncjk;
-          }
-          if (cki != ckj) {
-            nckj = (csi * cki + csj * ckj) / added;
-            CC(k, j) = nckj;
-          }
+        float ncjk = 0.0f, nckj = 0.0f;
+        if (p.has_prior) {
+          const float ckj = ej[qq].w, cki = ei[qq].w, cik = ei[qq].z, cjk = ej[qq].z;
+          ncjk = cjk;
+          nckj = ckj;
+          if (cik != cjk) ncjk = (csi * cik + csj * cjk) / added;
+          if (cki != ckj) nckj = (csi * cki + csj * ckj) / added;
           if (mv_cf > ncjk) mv_cf = ncjk;
-          a_cjk[q] = ncjk;
-          a_ckj[q] = nckj;
         }
-        const float dkj = d4[qq][0], dki = d4[qq][1], dik = d4[qq][2], djk = d4[qq][3];
+        const float dkj = ej[qq].y, dki = ei[qq].y, dik = ei[qq].x, djk = ej[qq].x;
         float njk = djk, nkj = dkj;
-        if (dik != djk) {
-          njk = (csi * dik + csj * djk) / added;
-          DD(j, k) = njk;
-        }
-        if (dki != dkj) {
-          nkj = (csi * dki + csj * dkj) / added;
-          DD(k, j) = nkj;
-        }
+        if (dik != djk) njk = (csi * dik + csj * djk) / added;
+        if (dki != dkj) nkj = (csi * dki + csj * dkj) / added;
+        // (written whether changed or not: the same bits where the reference leaves the entry alone)
+        MM(j, k) = make_float4(njk, nkj, ncjk, nckj);
+        MM(k, j) = make_float4(nkj, njk, nckj, ncjk);
         if (njk < mvj) mvj = njk;
-        a_njk[q] = njk;
-        a_nkj[q] = nkj;
         bool rescan = false;
         if (dkj != dki) {
           const float mvk = st.mv[k];
@@ -603,30 +577,33 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
       return;
     }
 
-    // -- B: rows of the rebuilt clusters.  First the row-minimum rescans (:1875-1890) ...
-    float v[MM_ROWS][MAXQ];
-    const bool single = nupd <= MM_ROWS;  // one pass: the rows stay in registers for the candidate tests
-    for (int u0 = 0; u0 < nupd; u0 += MM_ROWS) {
-      bool anyres = false;
-      int ups[MM_ROWS], kus[MM_ROWS];
-      bool res[MM_ROWS];
+    // -- B: rows of the rebuilt clusters.  First the row-minimum rescans (:1875-1890), ROWS flagged rows at a time ...
+    for (int u = 0; u < nupd;) {
+      int kus[ROWS];
+      int cnt = 0;
 #pragma unroll
-      for (int r = 0; r < MM_ROWS; r++) {
-        const unsigned e = u0 + r < nupd ? sh.upd[u0 + r] : 0u;
-        ups[r] = (int)(e & 0xffffu);
-        res[r] = u0 + r < nupd && (e >> 16) != 0;
-        kus[r] = u0 + r < nupd ? (int)st.ci[ups[r]] : -1;
-        anyres |= res[r];
-        if (kus[r] >= 0 && (single || res[r])) {
+      for (int r = 0; r < ROWS; r++) kus[r] = -1;
+      for (; u < nupd && cnt < ROWS; u++) {
+        const unsigned e = sh.upd[u];
+        if (!(e >> 16)) continue;
+        const int k = st.ci[e & 0xffffu];
 #pragma unroll
-          for (int q = 0; q < MAXQ; q++) v[r][q] = a_k[q] >= 0 ? DD(kus[r], a_k[q]) : INF;
-        }
+        for (int r = 0; r < ROWS; r++)
+          if (r == cnt) kus[r] = k;
+        cnt++;
       }
-      if (!anyres) continue;
+      if (cnt == 0) break;
+      float v[ROWS][MAXQ];
 #pragma unroll
-      for (int r = 0; r < MM_ROWS; r++) {
-        if (!res[r]) continue;
+      for (int r = 0; r < ROWS; r++) {
+        if (kus[r] < 0) continue;
+#pragma unroll
+        for (int q = 0; q < MAXQ; q++) v[r][q] = a_k[q] >= 0 ? MM(kus[r], a_k[q]).x : INF;
+      }
+#pragma unroll
+      for (int r = 0; r < ROWS; r++) {
         const int k = kus[r];
+        if (k < 0) continue;
         const float old = st.mv[k] - threshold;
         float fm = INF;
         int pos_old = n, pos_less = n;
@@ -649,15 +626,11 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
         }
       }
       __syncthreads();
-      bool mine = false;  // one wave finishes one row
-      int myk = -1;
+      int myk = -1;  // one wave finishes one row
 #pragma unroll
-      for (int r = 0; r < MM_ROWS; r++)
-        if (wave == r) {
-          mine = res[r];
-          myk = kus[r];
-        }
-      if (mine) {
+      for (int r = 0; r < ROWS; r++)
+        if (wave == r) myk = kus[r];
+      if (myk >= 0) {
         float fm = lane < MM_WAVES ? sh.red_f[wave][lane] : INF;
         int pos_old = lane < MM_WAVES ? sh.red_a[wave][lane] : n;
         int pos_less = lane < MM_WAVES ? sh.red_b[wave][lane] : n;
@@ -665,17 +638,16 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
         pos_old = wave_min_i(pos_old);
         pos_less = wave_min_i(pos_less);
         if (lane == 0) {
-          const int k = myk;
-          const float old = st.mv[k] - threshold;
-          st.mv[k] = ((pos_old < n && pos_old < pos_less) ? old : fm) + threshold;
+          const float old = st.mv[myk] - threshold;
+          st.mv[myk] = ((pos_old < n && pos_old < pos_less) ? old : fm) + threshold;
         }
       }
       __syncthreads();
     }
     LAP(3);
     // ... then the candidate tests of every pair a rebuilt cluster is part of (:1893-1911 for the clusters before
-    // it, :1913-2018 for the ones behind): the row half on the values at hand, the column half fetched by the few
-    // survivors
+    // it, :1913-2018 for the ones behind it): both halves at once, d(k,l) <= min_k from k's row of D and
+    // d(l,k) <= min_l from k's row of the transpose
     auto append_pair = [&](unsigned key, int x, int y, float sym) {
       const int slot = atomicAdd(&sh.npairs, 1);
       if (slot < MM_PAIRS_LDS) {
@@ -689,22 +661,35 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
         g[2] = __float_as_uint(sym);
       }
     };
-    for (int u0 = 0; u0 < nupd; u0 += MM_ROWS) {
-      unsigned long long surv = 0;  // bit r * MAXQ + q: the row half holds for (row r, this thread's cluster q)
+    for (int u0 = 0; u0 < nupd; u0 += ROWS) {
+      unsigned long long surv = 0;  // bit r * MAXQ + q: (row r, this thread's cluster q) is a feasible pair
+      float v[ROWS][MAXQ], w[ROWS][MAXQ];
 #pragma unroll
-      for (int r = 0; r < MM_ROWS; r++) {
+      for (int r = 0; r < ROWS; r++) {  // (all loads of the pass first)
+        if (u0 + r >= nupd) continue;
+        const int ku = st.ci[sh.upd[u0 + r] & 0xffffu];
+#pragma unroll
+        for (int q = 0; q < MAXQ; q++) {
+          const float2 e = a_k[q] >= 0 ? MM2(ku, a_k[q]) : make_float2(INF, INF);
+          v[r][q] = e.x;
+          w[r][q] = e.y;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < ROWS; r++) {
         if (u0 + r >= nupd) continue;
         const int up = (int)(sh.upd[u0 + r] & 0xffffu);
         const int ku = st.ci[up];
-        if (!single) {
-#pragma unroll
-          for (int q = 0; q < MAXQ; q++) v[r][q] = a_k[q] >= 0 ? DD(ku, a_k[q]) : INF;
-        }
         const float mvk = st.mv[ku];
 #pragma unroll
         for (int q = 0; q < MAXQ; q++) {
           const int l = a_k[q];
-          const bool ok = l >= 0 && l != i && l != j && l != ku && v[r][q] <= mvk;
+          bool ok = l >= 0 && l != i && l != j && l != ku && v[r][q] <= mvk;
+          if (ok) {
+            // a later cluster meets the rebuilt ones before it; a rebuilt one meets them from its own row
+            if (q * MM_BLOCK + tid > up && st.flag[l]) ok = false;
+            if (!(w[r][q] <= st.mv[l])) ok = false;
+          }
           surv |= ok ? 1ull << (r * MAXQ + q) : 0ull;
         }
       }
@@ -720,35 +705,34 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
           x = ku;
           y = l;
           key = ((unsigned)up << 16) | (unsigned)il;
-        } else {  // a later cluster meets the rebuilt ones before it (a rebuilt one: from its own row)
-          if (st.flag[l]) continue;
+        } else {
           x = l;
           y = ku;
           key = ((unsigned)il << 16) | (unsigned)up;
         }
-        const float dlk = DD(l, ku);
-        if (!(dlk <= st.mv[l])) continue;
-        float sym = dlk + DD(ku, l);
-        if (p.CF && CC(x, y) <= st.mvcf[x] && CC(y, x) <= st.mvcf[y]) sym = 0.0f;
+        const float4 e = MM(ku, l);  // (d(ku,l), d(l,ku), cf(ku,l), cf(l,ku))
+        float sym = e.y + e.x;
+        if (p.has_prior && e.z <= st.mvcf[ku] && e.w <= st.mvcf[l]) sym = 0.0f;
         append_pair(key, x, y, sym);
       }
     }
-    // -- C: candidates with the merged cluster j, behind all others (:2033-2064)
+    // -- C: candidates with the merged cluster j, behind all others (:2033-2064); its row as this thread wrote it in A
     {
-      unsigned cand = 0;
+      float4 ej[MAXQ];
 #pragma unroll
       for (int q = 0; q < MAXQ; q++) {
         const int k = a_k[q];
-        const bool ok = k >= 0 && k != i && k != j && a_njk[q] <= min_value_j && a_nkj[q] <= st.mv[k];
-        cand |= ok ? 1u << q : 0u;
+        ej[q] = (k >= 0 && k != i && k != j) ? MM(j, k) : make_float4(INF, INF, INF, INF);  // (d(j,k), d(k,j), cf(j,k), cf(k,j))
       }
 #pragma unroll
       for (int q = 0; q < MAXQ; q++) {
-        if (!(cand & (1u << q))) continue;
         const int k = a_k[q];
-        float sym = a_njk[q] + a_nkj[q];
-        if (p.CF && a_ckj[q] <= st.mvcf[k] && a_cjk[q] <= mvcf_j) sym = 0.0f;
-        append_pair(0x80000000u | (unsigned)(q * MM_BLOCK + tid), k, j, sym);
+        if (k < 0 || k == i || k == j) continue;
+        if (ej[q].x <= min_value_j && ej[q].y <= st.mv[k]) {
+          float sym = ej[q].x + ej[q].y;
+          if (p.has_prior && ej[q].w <= st.mvcf[k] && ej[q].z <= mvcf_j) sym = 0.0f;
+          append_pair(0x80000000u | (unsigned)(q * MM_BLOCK + tid), k, j, sym);
+        }
       }
     }
     __syncthreads();
@@ -861,7 +845,7 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
         }
       }
       st.mv[j] = min_value_j;
-      if (p.CF) st.mvcf[j] = mvcf_j;
+      if (p.has_prior) st.mvcf[j] = mvcf_j;
       st.mcd[j] = INF;
       st.mcd2[j] = INF;
       for (; e < m; e++) {
@@ -891,7 +875,9 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
       for (int ik = tid; ik < n; ik += MM_BLOCK) {
         const int k = st.ci[ik];
         if (k == j || k == i) continue;
-        const float dkj = SS(k, j), dki = SS(k, i), dik = SS(i, k), djk = SS(j, k);
+        // (the symmetric matrix is symmetric bit for bit -- a float sum commutes, and the two updates below
+        //  apply one formula to equal operands --: the column entries are read from the rows of i and j)
+        const float dik = SS(i, k), djk = SS(j, k), dkj = djk, dki = dik;
         const float mvk = p.min_values_sym[k];
         if (dik != djk) SS(j, k) = (csi * dik + csj * djk) / added;
         if (dki != dkj) SS(k, j) = (csi * dki + csj * dkj) / added;
@@ -1018,6 +1004,46 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
   }
 }
 
+// M[a][b] = (d(a,b), d(b,a), cf(a,b), cf(b,a)) from the row-major matrices (cf may be null), 32 x 32 tiles
+// through LDS
+__global__ void __launch_bounds__(256) pack_kernel(const float *__restrict__ D, const float *__restrict__ CF,
+                                                   float4 *__restrict__ M, int N) {
+  __shared__ float t1[32][33], t2[32][33], c1[32][33], c2[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    if (by + r < N && bx + tx < N) {
+      t1[r][tx] = D[(size_t)(by + r) * N + bx + tx];
+      if (CF) c1[r][tx] = CF[(size_t)(by + r) * N + bx + tx];
+    }
+    if (bx + r < N && by + tx < N) {
+      t2[r][tx] = D[(size_t)(bx + r) * N + by + tx];
+      if (CF) c2[r][tx] = CF[(size_t)(bx + r) * N + by + tx];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = ty; r < 32; r += 8)
+    if (by + r < N && bx + tx < N)
+      M[(size_t)(by + r) * N + bx + tx] =
+          make_float4(t1[r][tx], t2[tx][r], CF ? c1[r][tx] : 0.0f, CF ? c2[tx][r] : 0.0f);
+}
+
+// out[a] = min over l != a of in[a][l]: the row minima of tree_builder.cpp:1659-1666, a workgroup per row
+__global__ void __launch_bounds__(256) rowmin_kernel(const float *__restrict__ in, float *__restrict__ out, int N) {
+  __shared__ float part[4];
+  const int a = blockIdx.x;
+  const float *row = in + (size_t)a * N;
+  float mv = INFINITY;
+  for (int l = threadIdx.x; l < N; l += 256)
+    if (l != a) mv = fminf(mv, row[l]);
+  mv = wave_min_f(mv);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mv;
+  __syncthreads();
+  if (threadIdx.x == 0) out[a] = fminf(fminf(part[0], part[1]), fminf(part[2], part[3]));
+}
+
 // Carrier penalty of AncesTreeBuilder::BuildTopology (anc_builder.cpp:563-581) on the device: every entry of a
 // carrier's row gets + val, and - val again where the column is a carrier too (the same two operations in
 // the same order per entry as the host loop).
@@ -1074,10 +1100,10 @@ static bool lds_state_fits(int N) {
   static size_t fixed = 0;
   if (!fixed) {
     hipFuncAttributes a;
-    if (hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&minmatch_kernel<true, 5>)) != hipSuccess) return false;
+    if (hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&minmatch_kernel<true, 10>)) != hipSuccess) return false;
     fixed = a.sharedSizeBytes;
   }
-  return N <= 5 * MM_BLOCK && fixed + lds_state_bytes(N) <= (size_t)160 * 1024;
+  return N <= 10 * MM_BLOCK && fixed + lds_state_bytes(N) <= (size_t)160 * 1024;
 }
 
 // Trees of different sections are built at the same time, but a process has a handful of hardware queues (4 by
@@ -1122,8 +1148,8 @@ class BuildDispatcher {
     (void)hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
     {  // the per-cluster state of a build in LDS: more than the default 64 KB of dynamic LDS
       hipFuncAttributes a;
-      if (hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&minmatch_kernel<true, 5>)) == hipSuccess)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&minmatch_kernel<true, 5>),
+      if (hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&minmatch_kernel<true, 10>)) == hipSuccess)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&minmatch_kernel<true, 10>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)a.sharedSizeBytes);
     }
     DevBuf d_params;
@@ -1167,10 +1193,10 @@ class BuildDispatcher {
           }
         }
         if (any_lds)
-          hipLaunchKernelGGL((minmatch_kernel<true, 5>), dim3((unsigned)batch.size()), dim3(MM_BLOCK), dyn, stream,
+          hipLaunchKernelGGL((minmatch_kernel<true, 10>), dim3((unsigned)batch.size()), dim3(MM_BLOCK), dyn, stream,
                              d_params.as<MMParams>());
         if (any_glob && !rc)
-          hipLaunchKernelGGL((minmatch_kernel<false, 10>), dim3((unsigned)batch.size()), dim3(MM_BLOCK), 0, stream,
+          hipLaunchKernelGGL((minmatch_kernel<false, 20>), dim3((unsigned)batch.size()), dim3(MM_BLOCK), 0, stream,
                              d_params.as<MMParams>());
         if (rc || hipGetLastError() != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) rc = RL_EHIP;
         if (getenv("RELATE_AMD_TIMING"))
@@ -1200,7 +1226,7 @@ class BuildDispatcher {
 struct DeviceMinMatch::Impl {
   int N = 0, device = 0;
   hipStream_t stream = nullptr;
-  DevBuf d_D, d_CF, d_SYM, d_f, d_i, d_feas, d_rowlist, d_status, d_flags, d_member, d_tab, d_acc;
+  DevBuf d_D, d_CF, d_M, d_SYM, d_f, d_i, d_feas, d_rowlist, d_status, d_flags, d_member, d_tab, d_acc;
   long long builds = 0;
 };
 
@@ -1299,8 +1325,9 @@ int DeviceMinMatch::build_impl(MinMatch &tb, const float *d, const float *prior_
   const long long pair_cap = (long long)8 * N;
   int rc = m.d_D.alloc(NN * 4);
   rc = rc ? rc : (prior ? m.d_CF.alloc(NN * 4) : 0);
+  rc = rc ? rc : m.d_M.alloc(NN * 16);
   rc = rc ? rc : m.d_SYM.alloc(NN * 4);
-  rc = rc ? rc : m.d_f.alloc((size_t)6 * N * 4);  // min_values, min_values_CF, mc_dist, mc_dist2, + 2 of the symmetric path
+  rc = rc ? rc : m.d_f.alloc((size_t)8 * N * 4);  // min_values, min_values_CF, mc_dist, mc_dist2, 2 of the symmetric path, 2 row minima
   rc = rc ? rc : m.d_i.alloc(((size_t)12 * N + 8) * 4);  // ints, see below
   rc = rc ? rc : m.d_feas.alloc((size_t)pair_cap * 6 * 4);
   rc = rc ? rc : m.d_rowlist.alloc((size_t)MM_WAVES * N * 4);
@@ -1312,9 +1339,11 @@ int DeviceMinMatch::build_impl(MinMatch &tb, const float *d, const float *prior_
   p.lds_state = lds_state_fits(N) ? 1 : 0;
   p.threshold = tb.threshold;
   p.threshold_CF = tb.threshold_CF;
-  p.D = m.d_D.as<float>();
-  p.CF = prior ? m.d_CF.as<float>() : nullptr;
+  p.M = m.d_M.as<float4>();
+  p.has_prior = prior ? 1 : 0;
   float *f = m.d_f.as<float>();
+  p.rowmin_D = f + 6 * (size_t)N;
+  p.rowmin_CF = f + 7 * (size_t)N;
   p.min_values = f;
   p.min_values_CF = f + N;
   p.mc_dist = f + 2 * (size_t)N;
@@ -1351,8 +1380,17 @@ int DeviceMinMatch::build_impl(MinMatch &tb, const float *d, const float *prior_
   RL_HIP(hipMemcpyAsync(p.mc_lin1, lin.data(), (size_t)2 * N * 4, hipMemcpyHostToDevice, m.stream));
   RL_HIP(hipMemcpyAsync(p.min_values_CF, tb.min_values_CF.data(), (size_t)N * 4, hipMemcpyHostToDevice, m.stream));
   if (!resident) {
-    RL_HIP(hipMemcpyAsync(p.D, d, NN * 4, hipMemcpyHostToDevice, m.stream));
-    if (prior) RL_HIP(hipMemcpyAsync(p.CF, prior_host, NN * 4, hipMemcpyHostToDevice, m.stream));
+    RL_HIP(hipMemcpyAsync(m.d_D.p, d, NN * 4, hipMemcpyHostToDevice, m.stream));
+    if (prior) RL_HIP(hipMemcpyAsync(m.d_CF.p, prior_host, NN * 4, hipMemcpyHostToDevice, m.stream));
+  }
+  {
+    // the woven matrix and the row minima, on the whole chip; the build itself is one workgroup
+    const dim3 grid((N + 31) / 32, (N + 31) / 32);
+    const float *dD = m.d_D.as<float>(), *dCF = prior ? m.d_CF.as<float>() : nullptr;
+    hipLaunchKernelGGL(pack_kernel, grid, dim3(256), 0, m.stream, dD, dCF, p.M, N);
+    hipLaunchKernelGGL(rowmin_kernel, dim3(N), dim3(256), 0, m.stream, dD, f + 6 * (size_t)N, N);
+    if (prior) hipLaunchKernelGGL(rowmin_kernel, dim3(N), dim3(256), 0, m.stream, dCF, f + 7 * (size_t)N, N);
+    RL_HIP(hipGetLastError());
   }
   const int minus1 = -1;
   RL_HIP(hipMemcpyAsync(p.status, &minus1, 4, hipMemcpyHostToDevice, m.stream));

@@ -108,11 +108,32 @@ def test_too_many_tied_candidates_go_to_the_host():
     assert run_sequence(N, mats, all_on_gpu=False) == 3
 
 
-@pytest.mark.parametrize("N", [5121, 5300])
-def test_state_in_global_memory_above_the_lds_limit(N):
-    """N > 5120: the per-cluster state does not fit in LDS next to the pair lists; the same kernel on global arrays"""
-    rng = np.random.RandomState(N)
-    d = (rng.rand(N, N) * 3 + rng.rand(N)[:, None]).astype(np.float32)
+def split_tree_matrix(rng, N):
+    """near-ultrametric distances from random recursive splits of a random leaf order (cheap at N = 5000),
+    plus asymmetric noise -- the shape of the path's matrices"""
+    order = rng.permutation(N)
+    h = np.zeros((N, N), np.float32)
+    stack = [(0, N, 1.0)]
+    while stack:
+        lo, hi, t = stack.pop()
+        if hi - lo < 2:
+            continue
+        mid = lo + 1 + rng.randint(0, hi - lo - 1)
+        a, b = order[lo:mid], order[mid:hi]
+        h[np.ix_(a, b)] = t
+        h[np.ix_(b, a)] = t
+        stack.append((lo, mid, t * (0.55 + 0.4 * rng.rand())))
+        stack.append((mid, hi, t * (0.55 + 0.4 * rng.rand())))
+    d = (h * 20 + rng.rand(N, N) * 0.05).astype(np.float32)
+    d -= d.min(axis=1, keepdims=True)
     np.fill_diagonal(d, 0)
+    return d
+
+
+@pytest.mark.parametrize("N", [5000, 5121, 5300])
+def test_large_trees_state_in_lds_and_in_global_memory(N):
+    """N = 5000: the headline size, per-cluster state in LDS; N > 5120: the state does not fit next to the pair
+    lists, the same kernel on global arrays"""
+    rng = np.random.RandomState(N)
     prior = (np.floor(rng.rand(N, N) * 3) * 6.9).astype(np.float32)
-    run_sequence(N, [(d, None), (d.T.copy(), prior)])
+    run_sequence(N, [(split_tree_matrix(rng, N), None), (split_tree_matrix(rng, N), prior)])
