@@ -120,187 +120,206 @@ extern "C" int rl_make_chunks(const char *haps_fn, const char *sample_fn, const 
   std::vector<int> bp_pos((size_t)L + 1);
   std::vector<std::string> ancestral(L), alternative(L), rsid(L);
 
-  // ---- chunk / window sizing (data.cpp:129-139)
-  const double min_memory_size = (memory_gb) * 1e9 / 4.0 - (2.0 * N * N + 3.0 * N);
-  double actual_min_memory_size = 0.0;
-  if (min_memory_size <= 0) {
+  // The budget of a window (data.cpp:129): `memory_gb` of floats minus the two N x N matrices and three vectors
+  // the tree builder holds next to a window's posteriors.
+  const double window_budget = (memory_gb) * 1e9 / 4.0 - (2.0 * N * N + 3.0 * N);
+  if (window_budget <= 0) {
     set_error("Error: Need larger memory allowance.");
     return RL_EINVAL;
   }
-  const int windows_per_section = 500;
-  int max_windows_per_section = 0;
-  const int overlap = 20000;
-  int max_chunk_size = std::min(L + 1, (int)(min_memory_size / N));
-  if (memory_gb >= 100) max_chunk_size = 2500000;
+  const int max_windows = 500;  // per chunk, the carried ones included (data.cpp:131)
+  const int overlap = 20000;    // SNPs a chunk repeats from its predecessor (data.cpp:133)
+  int max_chunk_snps = std::min(L + 1, (int)(window_budget / N));
+  if (memory_gb >= 100) max_chunk_snps = 2500000;
 
-  std::vector<std::vector<char>> p_seq(max_chunk_size, std::vector<char>(N)), p_overlap(overlap);
-  std::vector<int> window_boundaries(windows_per_section + 1), window_boundaries_overlap(windows_per_section + 1);
-  std::vector<int> section_boundary_start(1, 0), section_boundary_end;
-  int state_val = 1;
-  int min_snps_in_window = max_chunk_size;
-  int num_windows = 0, num_windows_overlap = 0, overlap_in_section = 0, chunk_size = 0, chunk_index = 0;
-  double window_memory_size = 0.0;
-
-  InFile haps;
-  if (!haps.open(haps_fn)) {
-    set_error("Failed to open file %s", haps_fn);
-    return RL_EIO;
-  }
+  // ---- pass 1 over the haps file (haps::ReadSNP, data.cpp:543-573): positions, alleles and, per SNP, what its row
+  // of posteriors will cost a window: (number of derived alleles) * (N + 1) floats (data.cpp:216).  cost[s] is the
+  // running total before SNP s -- integers far below 2^53, so the doubles are exact and a window boundary is a
+  // binary search instead of the reference's accumulate-and-compare over the SNPs.
+  std::vector<double> cost((size_t)L + 1, 0.0);
   std::vector<char> line((size_t)2 * N + 10);
-  char chr[1024], rs[1024], anc[1024], alt[1024];
-
-  auto transition_state = [&](int snp_tmp) {
-    if (use_transitions) return state_val;  // stays 1 (data.cpp:307-309)
-    const std::string &a = ancestral[snp_tmp], &b = alternative[snp_tmp];
-    const bool ts = (a == "C" && b == "T") || (a == "T" && b == "C") || (a == "G" && b == "A") || (a == "A" && b == "G");
-    state_val = ts ? 0 : 1;
-    return state_val;
-  };
-
-  int snp = 0;
-  while (snp < L) {
-    const std::string cbase = file_out + "/chunk_" + std::to_string(chunk_index);
-    FILE *fp_hap = fopen((cbase + ".hap").c_str(), "wb");
-    FILE *fp_state = fopen((cbase + ".state").c_str(), "wb");
-    if (!fp_hap || !fp_state) {
-      set_error("cannot write chunk files under %s", out_dir);
-      haps.close();
-      return RL_EIO;
+  auto read_snp = [&](FILE *fp, int snp, char *row, bool keep_meta) -> int {
+    char chr[1024], rs[1024], anc[1024], alt[1024];
+    int bp = 0;
+    if (fscanf(fp, "%1023s %1023s %d %1023s %1023s", chr, rs, &bp, anc, alt) != 5 ||
+        !fgets(line.data(), 2 * N + 10, fp)) {
+      set_error("%s: malformed line %d", haps_fn, snp + 1);
+      return -1;
     }
-    if (snp > 0) {  // data.cpp:166-195: carry the last `overlap` SNPs into the next chunk
-      if (snp - section_boundary_start.back() < overlap || overlap > chunk_size) {
-        set_error("MakeChunks: chunk shorter than the %d-SNP overlap (raise --memory)", overlap);
-        haps.close();
-        return RL_EINVAL;
+    int filled = 0, derived = 0;
+    for (int i = 0; line[i] != '\0' && filled < N; i++)
+      if (line[i] == '0' || line[i] == '1') {
+        derived += line[i] == '1';
+        if (row) row[filled] = line[i];
+        filled++;
       }
-      overlap_in_section = overlap;
-      const int snp_section_begin = snp - overlap_in_section;
-      section_boundary_start.push_back(snp_section_begin);
-      for (int i = 0; i < overlap_in_section; i++) p_overlap[i] = p_seq[chunk_size - overlap_in_section + i];
-      window_boundaries_overlap[0] = snp_section_begin;
-      num_windows_overlap = 1;
-      for (int w = 0; w < num_windows; w++)
-        if (window_boundaries[w] > snp_section_begin) window_boundaries_overlap[num_windows_overlap++] = window_boundaries[w];
-      if (num_windows_overlap >= windows_per_section - 1) {
-        set_error("MakeChunks: too many windows in the overlap (raise --memory)");
-        haps.close();
-        return RL_EINVAL;
-      }
+    if (filled != N) {
+      set_error("%s: SNP %s %s %d has %d alleles, %d expected", haps_fn, chr, rs, bp, filled, N);
+      return -1;
     }
-
-    const int snp_begin = snp;
-    window_memory_size = 0.0;
-    chunk_size = 0;
-    window_boundaries[0] = snp_begin;
-    num_windows = 1;
-    int snps_in_window = 0;
-    while (num_windows + num_windows_overlap < windows_per_section && chunk_size < max_chunk_size && snp < L) {
-      // haps::ReadSNP (data.cpp:543-573)
-      std::vector<char> &row = p_seq[chunk_size];
-      if (fscanf(haps.fp, "%1023s %1023s %d %1023s %1023s", chr, rs, &bp_pos[snp], anc, alt) != 5 ||
-          !fgets(line.data(), 2 * N + 10, haps.fp)) {
-        set_error("%s: malformed line %d", haps_fn, snp + 1);
-        haps.close();
-        return RL_EFORMAT;
-      }
-      int filled = 0;
-      for (int i = 0; line[i] != '\0' && filled < N; i++)
-        if (line[i] == '0' || line[i] == '1') row[filled++] = line[i];
-      if (filled != N) {
-        set_error("%s: SNP %s %s %d has %d alleles, %d expected", haps_fn, chr, rs, bp_pos[snp], filled, N);
-        haps.close();
-        return RL_EFORMAT;
-      }
+    if (keep_meta) {
+      bp_pos[snp] = bp;
       ancestral[snp] = anc;
       alternative[snp] = alt;
       rsid[snp] = rs;
-
-      int num_derived = 0;
-      for (char ch : row) num_derived += (ch == '1');
-      window_memory_size += num_derived * (N + 1);
-      if (window_memory_size >= min_memory_size && snps_in_window > 10) {  // data.cpp:219-229
-        if (actual_min_memory_size < window_memory_size) actual_min_memory_size = window_memory_size;
-        if (min_snps_in_window > snps_in_window) min_snps_in_window = snps_in_window;
-        snps_in_window = 0;
-        window_memory_size = 0.0;
-        window_boundaries[num_windows] = snp;
-        num_windows++;
-      }
-      snp++;
-      snps_in_window++;
-      chunk_size++;
     }
-    if (actual_min_memory_size < window_memory_size) actual_min_memory_size = window_memory_size;
-    if (min_snps_in_window > snps_in_window) min_snps_in_window = snps_in_window;
-    const float mean_snps_in_window = chunk_size / num_windows;
-    window_boundaries[num_windows] = snp;
-    if (num_windows > max_windows_per_section) max_windows_per_section = num_windows;
-    if (mean_snps_in_window < 100) {
-      std::cerr << "Memory allowance should be set " << 100 / mean_snps_in_window << " times larger than" << std::endl;
-      std::cerr << "the current setting using --memory (Default 5GB)." << std::endl;
-    }
-    section_boundary_end.push_back(snp);
-
-    int snp_tmp = section_boundary_start.back();
-    const uint64_t uN = (uint64_t)N;
-    const std::string pfn = file_out + "/parameters_c" + std::to_string(chunk_index) + ".bin";
-    FILE *fp = fopen(pfn.c_str(), "w");
-    if (!fp) {
-      set_error("cannot write %s", pfn.c_str());
-      haps.close();
+    return derived;
+  };
+  {
+    InFile haps;
+    if (!haps.open(haps_fn)) {
+      set_error("Failed to open file %s", haps_fn);
       return RL_EIO;
     }
-    if (snp_begin == 0) {  // data.cpp:254-270
-      const uint64_t uL = (uint64_t)chunk_size;
-      fwrite(&uL, 8, 1, fp_hap);
-      fwrite(&uN, 8, 1, fp_hap);
-      const int nw = num_windows + 1;
-      fwrite(&N, 4, 1, fp);
-      fwrite(&chunk_size, 4, 1, fp);
-      fwrite(&nw, 4, 1, fp);
-      fwrite(window_boundaries.data(), 4, nw, fp);
-      fclose(fp);
-      fwrite(&chunk_size, 4, 1, fp_state);
-    } else {  // data.cpp:272-325
-      const int L_chunk = chunk_size + overlap_in_section;
-      const uint64_t uL = (uint64_t)L_chunk;
-      fwrite(&uL, 8, 1, fp_hap);
-      fwrite(&uN, 8, 1, fp_hap);
-      const int window_start = window_boundaries_overlap[0];
-      for (int w = 0; w < num_windows_overlap; w++) window_boundaries_overlap[w] -= window_start;
-      for (int w = 0; w <= num_windows; w++) window_boundaries[w] -= window_start;
-      const int nw = num_windows + num_windows_overlap + 1;
-      fwrite(&N, 4, 1, fp);
-      fwrite(&L_chunk, 4, 1, fp);
-      fwrite(&nw, 4, 1, fp);
-      fwrite(window_boundaries_overlap.data(), 4, num_windows_overlap, fp);
-      fwrite(window_boundaries.data(), 4, num_windows + 1, fp);
-      fclose(fp);
-      for (int w = 0; w <= num_windows; w++) window_boundaries[w] += window_start;
-      fwrite(&L_chunk, 4, 1, fp_state);
-      for (int i = 0; i < overlap_in_section; i++) {
-        const int sv = transition_state(snp_tmp);
-        fwrite(&sv, 4, 1, fp_state);
-        snp_tmp++;
-        fwrite(p_overlap[i].data(), 1, (size_t)N, fp_hap);
+    for (int s = 0; s < L; s++) {
+      const int derived = read_snp(haps.fp, s, nullptr, true);
+      if (derived < 0) {
+        haps.close();
+        return RL_EFORMAT;
       }
+      cost[(size_t)s + 1] = cost[s] + (double)derived * (N + 1);
     }
-    for (int i = 0; i < chunk_size; i++) {
-      const int sv = transition_state(snp_tmp);
-      fwrite(&sv, 4, 1, fp_state);
-      snp_tmp++;
-      fwrite(p_seq[i].data(), 1, (size_t)N, fp_hap);
-    }
-    fclose(fp_hap);
-    fclose(fp_state);
-    chunk_index++;
+    haps.close();
   }
   bp_pos[L] = bp_pos[L - 1] + 1;
-  haps.close();
-  const int num_chunks = (int)section_boundary_start.size();
 
-  std::cerr << std::setprecision(2) << "Warning: Will use min "
-            << 2.0 * (4.0 * N * N * (max_windows_per_section + 2.0)) / 1e9 << "GB of hard disc." << std::endl;
+  // ---- the plan: chunks and their windows from the running cost alone
+  struct ChunkPlan {
+    int begin = 0, end = 0;      // the chunk's own SNPs [begin, end)
+    int first_snp = 0;           // where its files start: begin, or begin - overlap behind the first chunk
+    std::vector<int> cuts;       // window starts among its own SNPs, cuts[0] == begin
+    std::vector<int> carried;    // window starts inside the repeated stretch, carried[0] == first_snp
+  };
+  std::vector<ChunkPlan> plan;
+  double largest_window = 0.0;   // floats: what the biggest window of the data set costs (parameters.bin)
+  int most_windows = 0;
+  for (int begin = 0; begin < L;) {
+    ChunkPlan c;
+    c.begin = c.first_snp = begin;
+    if (!plan.empty()) {
+      const ChunkPlan &prev = plan.back();
+      // the reference asserts here (data.cpp:170): a chunk must be longer than what it hands on
+      if (begin - prev.first_snp < overlap || overlap > prev.end - prev.begin) {
+        set_error("MakeChunks: chunk shorter than the %d-SNP overlap (raise --memory)", overlap);
+        return RL_EINVAL;
+      }
+      c.first_snp = begin - overlap;
+      c.carried.push_back(c.first_snp);
+      for (int cut : prev.cuts)
+        if (cut > c.first_snp) c.carried.push_back(cut);
+      if ((int)c.carried.size() >= max_windows - 1) {
+        set_error("MakeChunks: too many windows in the overlap (raise --memory)");
+        return RL_EINVAL;
+      }
+    }
+    const int limit = std::min(L, begin + max_chunk_snps);
+    c.cuts.push_back(begin);
+    c.end = limit;
+    int open = begin;          // start of the window being filled
+    double open_cost = cost[begin];  // running cost where the window's own account starts
+    while (true) {
+      // A window closes at the first SNP t, more than 10 SNPs in, whose row brings its account to the budget
+      // (data.cpp:219-229); t opens the next window, whose account starts BEHIND t (t's own row is charged to the
+      // window it closed).
+      const size_t idx = std::lower_bound(cost.begin(), cost.end(), open_cost + window_budget) - cost.begin();
+      const long t = std::max<long>((long)idx - 1, (long)open + 11);
+      if (idx > (size_t)L || t >= limit) break;
+      largest_window = std::max(largest_window, cost[t + 1] - open_cost);
+      c.cuts.push_back((int)t);
+      open = (int)t;
+      open_cost = cost[t + 1];
+      if ((int)c.cuts.size() + (int)c.carried.size() == max_windows) {  // the chunk is full of windows:
+        c.end = (int)t + 1;                                             // it ends behind the SNP that opened the last
+        break;
+      }
+    }
+    largest_window = std::max(largest_window, cost[c.end] - open_cost);  // the window left open at the chunk's end
+    most_windows = std::max(most_windows, (int)c.cuts.size());
+    const float snps_per_window = (c.end - c.begin) / (int)c.cuts.size();
+    if (snps_per_window < 100)
+      std::cerr << "Windows hold " << snps_per_window << " SNPs on average: raise --memory (default 5 GB) about "
+                << 100 / snps_per_window << "-fold." << std::endl;
+    begin = c.end;
+    plan.push_back(std::move(c));
+  }
+  const int num_chunks = (int)plan.size();
+  std::vector<int> section_boundary_start(num_chunks), section_boundary_end(num_chunks);
+  for (int c = 0; c < num_chunks; c++) {
+    section_boundary_start[c] = plan[c].first_snp;
+    section_boundary_end[c] = plan[c].end;
+  }
+
+  // ---- parameters_c<i>.bin (data.cpp:254-298) and chunk_<i>.state (:307-345): from the plan and the alleles
+  auto snp_state = [&](int snp) {  // 0: a transition left out with --transversion
+    if (use_transitions) return 1;
+    const std::string &a = ancestral[snp], &b = alternative[snp];
+    const bool ts = (a == "C" && b == "T") || (a == "T" && b == "C") || (a == "G" && b == "A") || (a == "A" && b == "G");
+    return ts ? 0 : 1;
+  };
+  for (int ci = 0; ci < num_chunks; ci++) {
+    const ChunkPlan &c = plan[ci];
+    const int Lc = c.end - c.first_snp;
+    std::vector<int> rec = {N, Lc, (int)(c.carried.size() + c.cuts.size()) + 1};
+    for (int cut : c.carried) rec.push_back(cut - c.first_snp);
+    for (int cut : c.cuts) rec.push_back(cut - c.first_snp);
+    rec.push_back(c.end - c.first_snp);
+    std::vector<int> state((size_t)Lc + 1);
+    state[0] = Lc;
+    for (int t = 0; t < Lc; t++) state[(size_t)t + 1] = snp_state(c.first_snp + t);
+    FILE *fp = fopen((file_out + "/parameters_c" + std::to_string(ci) + ".bin").c_str(), "w");
+    FILE *fs = fopen((file_out + "/chunk_" + std::to_string(ci) + ".state").c_str(), "wb");
+    if (!fp || !fs) {
+      if (fp) fclose(fp);
+      if (fs) fclose(fs);
+      set_error("cannot write chunk files under %s", out_dir);
+      return RL_EIO;
+    }
+    fwrite(rec.data(), 4, rec.size(), fp);
+    fwrite(state.data(), 4, state.size(), fs);
+    fclose(fp);
+    fclose(fs);
+  }
+
+  // ---- pass 2: the alleles into chunk_<i>.hap (u64 L, u64 N, L rows of N chars; collapsed_matrix.hpp:204-225).  The
+  // rows stream through; the last `overlap` of them wait in a ring for the next chunk, which starts with them.
+  {
+    InFile haps;
+    if (!haps.open(haps_fn)) {
+      set_error("Failed to open file %s", haps_fn);
+      return RL_EIO;
+    }
+    std::vector<char> ring(num_chunks > 1 ? (size_t)overlap * N : 0), row(N);
+    FILE *fh = nullptr;
+    int ci = -1;
+    int rc = RL_OK;
+    for (int s = 0; s < L && rc == RL_OK; s++) {
+      if (ci + 1 < num_chunks && s == plan[ci + 1].begin) {
+        if (fh) fclose(fh);
+        ci++;
+        fh = fopen((file_out + "/chunk_" + std::to_string(ci) + ".hap").c_str(), "wb");
+        if (!fh) {
+          set_error("cannot write chunk files under %s", out_dir);
+          rc = RL_EIO;
+          break;
+        }
+        const uint64_t dims[2] = {(uint64_t)(plan[ci].end - plan[ci].first_snp), (uint64_t)N};
+        fwrite(dims, 8, 2, fh);
+        for (int t = plan[ci].first_snp; t < s; t++) fwrite(&ring[(size_t)(t % overlap) * N], 1, (size_t)N, fh);
+      }
+      if (read_snp(haps.fp, s, row.data(), false) < 0) {
+        rc = RL_EFORMAT;
+        break;
+      }
+      fwrite(row.data(), 1, (size_t)N, fh);
+      if (!ring.empty()) memcpy(&ring[(size_t)(s % overlap) * N], row.data(), (size_t)N);
+    }
+    if (fh) fclose(fh);
+    haps.close();
+    if (rc) return rc;
+  }
+
+  std::cerr << std::setprecision(2) << "Paint files will take at least "
+            << 2.0 * (4.0 * N * N * (most_windows + 2.0)) / 1e9 << " GB of disc." << std::endl;
 
   {  // parameters.bin (data.cpp:361-375)
     FILE *fp = fopen((file_out + "/parameters.bin").c_str(), "w");
@@ -308,12 +327,11 @@ extern "C" int rl_make_chunks(const char *haps_fn, const char *sample_fn, const 
       set_error("cannot write parameters.bin");
       return RL_EIO;
     }
-    actual_min_memory_size += (2 * N * N + 3 * N);
-    actual_min_memory_size *= 4.0 / 1e9;
+    const double needed_gb = (largest_window + (2 * N * N + 3 * N)) * (4.0 / 1e9);
     fwrite(&N, 4, 1, fp);
     fwrite(&L, 4, 1, fp);
     fwrite(&num_chunks, 4, 1, fp);
-    fwrite(&actual_min_memory_size, 8, 1, fp);
+    fwrite(&needed_gb, 8, 1, fp);
     fwrite(section_boundary_start.data(), 4, num_chunks, fp);
     fwrite(section_boundary_end.data(), 4, num_chunks, fp);
     fclose(fp);

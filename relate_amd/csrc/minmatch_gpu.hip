@@ -36,8 +36,9 @@ namespace {
 
 constexpr int MM_BLOCK = 512;   // (8 waves: 256 registers per lane -- a thread keeps ~10 clusters of a merge in registers)
 constexpr int MM_WAVES = MM_BLOCK / 64;
-constexpr int MM_ROWS = 2;        // rows of rebuilt clusters scanned per pass of a merge
-constexpr int MM_UPD_MAX = 1024;  // rebuilt clusters of one merge (list in LDS); more: the host builds the tree
+constexpr int MM_ROWS = 3;        // rows of rebuilt clusters scanned per pass of a merge (2 once a thread holds > 10 clusters)
+constexpr int MM_HITS = 32;       // mutually close pairs per row pairscan_kernel keeps; more: the host builds the tree
+constexpr int MM_UPD_MAX = 512;   // rebuilt clusters of one merge (list in LDS); more: the host builds the tree
 constexpr int MM_PAIRS_LDS = 768; // feasible pairs of one merge kept in LDS; more go through global scratch
 constexpr int MM_MAXN = 10240;    // one thread holds up to 20 clusters of a merge in registers
 
@@ -54,6 +55,10 @@ struct MMParams {
   float4 *M;          // [N*N] destroyed
   int has_prior;      // the cf halves of M are in use
   const float *rowmin_D, *rowmin_CF;  // [N] minimum of each row off the diagonal
+  // the mutually close pairs (a, b > a) of the untouched matrix, row by row in order, from pairscan_kernel
+  const int *hit_cnt;        // [N] (more than MM_HITS: not all kept)
+  const unsigned *hit_b;     // [N][MM_HITS]
+  const float *hit_sym;      // [N][MM_HITS] symmetric distance of the pair (0 if the prior makes it a certain pair)
   float *SYM;  // [N*N] room for the symmetric matrix
   float *min_values_sym, *mcs_dist;
   int *mcs_lin1, *mcs_lin2;
@@ -96,6 +101,24 @@ __host__ __device__ inline uint32_t rng_next(Rng &r) {
   y ^= y >> 18;
   return y;
 }
+// The state renewal of rng_next by one wavefront: word i takes the old words i, i+1 and word i+397 -- old for
+// i < 227, already renewed (word i-227) behind that; 64 consecutive words per round, every lane reads before any
+// lane writes, and a round never needs a word of its own round (227 > 64).  The last word takes the new word 0.
+__device__ inline void rng_renew_wave(Rng &r, int lane) {
+  for (int base = 0; base < 623; base += 64) {
+    const int i = base + lane;
+    uint32_t v = 0;
+    if (i < 623) {
+      const uint32_t y = (r.mt[i] & 0x80000000u) | (r.mt[i + 1] & 0x7fffffffu);
+      v = r.mt[i < 227 ? i + 397 : i - 227] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    if (i < 623) r.mt[i] = v;
+  }
+  if (lane == 0) {
+    const uint32_t y = (r.mt[623] & 0x80000000u) | (r.mt[0] & 0x7fffffffu);
+    r.mt[623] = r.mt[396] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+  }
+}
 // std::uniform_real_distribution<double>(0,1)(rng) of libstdc++: generate_canonical<double, 53> = two draws,
 // sum = g1 + g2 * 2^32 in double, / 2^64, a result of 1 replaced by nextafter(1, 0)
 __host__ __device__ inline double rng_unif(Rng &r) {
@@ -132,6 +155,7 @@ struct Shared {
   float red_f[MM_ROWS][MM_WAVES];
   int red_a[MM_ROWS][MM_WAVES], red_b[MM_ROWS][MM_WAVES];
   unsigned upd[MM_UPD_MAX];  // rebuilt clusters of the merge: position | rescan << 16, any order
+  float updv[MM_UPD_MAX];    // ... and their new d(k, j), which is not in memory until the end of the merge
   // feasible pairs of the merge, [0]: as found, [1]: in the reference's order
   unsigned pk[2][MM_PAIRS_LDS];   // key: position of the later cluster << 16 | position of the earlier one
   unsigned pxy[2][MM_PAIRS_LDS];  // later cluster << 16 | earlier cluster
@@ -159,6 +183,26 @@ __device__ inline int wave_min_i(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
   return v;
+}
+// exclusive prefix of v over the threads in order; *total = sum
+__device__ inline int block_scan(int v, int *total, int *buf) {
+  int x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int y = __shfl_up(x, o, 64);
+    if ((int)(threadIdx.x & 63) >= o) x += y;
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 63) buf[threadIdx.x >> 6] = x;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < MM_WAVES; w++) {
+    if (w < (int)(threadIdx.x >> 6)) base += buf[w];
+    tot += buf[w];
+  }
+  *total = tot;
+  return base + x - v;
 }
 // lexicographic minimum of (d1, d2, pos)
 __device__ inline bool lex_less(float a1, float a2, int ap, float b1, float b2, int bp) {
@@ -224,36 +268,6 @@ __device__ inline void block_min3(float &f, int &a, int &b, float *bf, int *ba, 
 #define MM2(a, b) (reinterpret_cast<const float2 *>(p.M + ((unsigned)(a) * (unsigned)N + (unsigned)(b)))[0])  // (d(a,b), d(b,a))
 #define SS(a, b) p.SYM[(unsigned)(a) * (unsigned)N + (unsigned)(b)]
 
-// Symmetric distance of a feasible pair (tree_builder.cpp:1699-1702): 0 when the pair is also mutually closest
-// under the prior.
-template <bool LDS>
-__device__ inline float pair_sym(const MMParams &p, const State<LDS> &st, int x, int y) {
-  const int N = p.N;
-  const float4 e = MM(x, y);
-  if (p.has_prior && e.z <= st.mvcf[x] && e.w <= st.mvcf[y]) return 0.0f;
-  return e.y + e.x;
-}
-// One feasible pair in the reference's order (one lane): one draw, both clusters' best candidate (:1704-1716).
-template <bool LDS>
-__device__ inline void apply_pair(const State<LDS> &st, Shared &sh, int x, int y, float sym) {
-  typedef typename State<LDS>::idx_t idx_t;
-  const float rnd = (float)rng_unif(sh.rng);
-  const float ad = st.mcd[x], ad2 = st.mcd2[x];
-  if (ad > sym || (ad == sym && ad2 > rnd)) {
-    st.lin1[x] = (idx_t)x;
-    st.lin2[x] = (idx_t)y;
-    st.mcd[x] = sym;
-    st.mcd2[x] = rnd;
-  }
-  const float bd = st.mcd[y], bd2 = st.mcd2[y];
-  if (bd > sym || (bd == sym && bd2 > rnd)) {
-    st.lin1[y] = (idx_t)x;
-    st.lin2[y] = (idx_t)y;
-    st.mcd[y] = sym;
-    st.mcd2[y] = rnd;
-  }
-}
-
 // One workgroup per tree: workgroup b builds the tree of params[b].
 //
 // A merge (i into j) on the workgroup, thread t holding the clusters at positions t, t + 1024, ... of the live list:
@@ -278,7 +292,7 @@ __device__ inline void apply_pair(const State<LDS> &st, Shared &sh, int x, int y
 template <bool LDS, int MAXQ>
 __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *__restrict__ params) {
   typedef typename State<LDS>::idx_t idx_t;
-  constexpr int ROWS = MM_ROWS;  // rows of rebuilt clusters per pass (ROWS * MAXQ <= 64 bits of survivors)
+  constexpr int ROWS = MAXQ > 10 ? 2 : MM_ROWS;  // rows of rebuilt clusters per pass (ROWS * MAXQ <= 64 bits of survivors)
   const MMParams p = params[blockIdx.x];
   if ((p.lds_state != 0) != LDS) return;  // (the launch carries trees of one kind)
   __shared__ Shared sh;
@@ -364,44 +378,84 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
   }
   __syncthreads();
   LAP(0);
-  // mutually close pairs in (a, b) order: the waves test 16 rows at a time, thread 0 draws in order
-  for (int base = 0; base < N; base += MM_WAVES) {
-    const int a = base + wave;
-    int cnt = 0;
-    if (a < N) {
-      const float mva = st.mv[a];
-      int *out = p.rowlist + (size_t)wave * N;
-      for (int b0 = a + 1; b0 < N; b0 += 64) {
-        const int b = b0 + lane;
-        bool hit = false;
-        if (b < N) {
-          const float2 e = MM2(a, b);
-          hit = mva >= e.x && st.mv[b] >= e.y;
-        }
-        const unsigned long long m = __ballot(hit);
-        if (hit) out[cnt + __popcll(m & ((1ull << lane) - 1ull))] = b;
-        cnt += __popcll(m);
+  // One wave runs every ordered part in step -- the values are the same in all 64 lanes (LDS reads of one address),
+  // lane 0 does the writes; the lanes matter when the generator's state is renewed (624 words, 64 at a time).
+  // Per pair the LDS reads -- two words of the generator, both clusters' candidates, the next pair's record -- are
+  // independent and go out together: one LDS latency per pair.
+  int ridx = 624;  // (wave 0: position in the generator's state)
+  auto next_word = [&]() -> uint32_t {
+    if (ridx >= 624) {
+      rng_renew_wave(sh.rng, lane);
+      ridx = 0;
+    }
+    uint32_t y = sh.rng.mt[ridx++];
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+  };
+  // one feasible pair in the reference's order: one draw, both clusters' best candidate (:1704-1716); -> the draw
+  auto apply = [&](int x, int y, float sym) -> float {
+    const uint32_t w1 = next_word(), w2 = next_word();
+    const float ad = st.mcd[x], ad2 = st.mcd2[x], bdd = st.mcd[y], bdd2 = st.mcd2[y];
+    // std::uniform_real_distribution<double>(0,1) of libstdc++ (rng_unif), narrowed to float (tree_builder.hpp:60)
+    const double sum = (double)w1 + (double)w2 * 4294967296.0;
+    double ret = sum / 18446744073709551616.0;
+    if (ret >= 1.0) ret = 0.99999999999999988897769753748434595763683319091796875;
+    const float rnd = (float)ret;
+    if (lane == 0) {
+      if (ad > sym || (ad == sym && ad2 > rnd)) {
+        st.lin1[x] = (idx_t)x;
+        st.lin2[x] = (idx_t)y;
+        st.mcd[x] = sym;
+        st.mcd2[x] = rnd;
+      }
+      if (bdd > sym || (bdd == sym && bdd2 > rnd)) {
+        st.lin1[y] = (idx_t)x;
+        st.lin2[y] = (idx_t)y;
+        st.mcd[y] = sym;
+        st.mcd2[y] = rnd;
       }
     }
-    if (lane == 0) sh.rowcount[wave] = cnt;
+    return rnd;
+  };
+  // mutually close pairs in (a, b) order (:1690-1722): pairscan_kernel has found them; MM_BLOCK rows at a time they
+  // are staged in LDS in order and wave 0 draws
+  for (int a0 = 0; a0 < N; a0 += MM_BLOCK) {
+    const int a = a0 + tid;
+    const int c = a < N ? p.hit_cnt[a] : 0;
+    int total;
+    const int off = block_scan(c, &total, sh.wave_i);
+    const bool bad = __syncthreads_or(c > MM_HITS) || total > MM_PAIRS_LDS;
+    if (bad) {  // (degenerate matrices: this tree is the host's)
+      if (tid == 0) *p.status = 2;
+      return;
+    }
+    for (int e = 0; e < c; e++) {
+      sh.pxy[0][off + e] = ((unsigned)a << 16) | p.hit_b[(size_t)a * MM_HITS + e];
+      sh.psym[0][off + e] = p.hit_sym[(size_t)a * MM_HITS + e];
+    }
     __syncthreads();
-    if (tid == 0) {
-      for (int w = 0; w < MM_WAVES && base + w < N; w++) {
-        const int aa = base + w;
-        const int *lst = p.rowlist + (size_t)w * N;
-        for (int e = 0; e < sh.rowcount[w]; e++) {
-          const int b = lst[e];
-          const float sym = pair_sym<LDS>(p, st, aa, b);
-          apply_pair<LDS>(st, sh, aa, b, sym);
-          const float md = st.mcd[b], md2 = st.mcd2[b];
-          if (sh.best.dist > md || (sh.best.dist == md && sh.best.dist2 > md2)) {
-            sh.best.lin1 = aa;
-            sh.best.lin2 = b;
-            sh.best.dist = sym;
-            sh.best.dist2 = md2;
-          }
+    if (wave == 0) {
+      Best bb = sh.best;
+      for (int e = 0; e < total; e++) {
+        const unsigned xy = sh.pxy[0][e];
+        const float sym = sh.psym[0][e];
+        const int aa = (int)(xy >> 16), b = (int)(xy & 0xffffu);
+        // (b's candidate after this pair: what apply() is about to leave there)
+        const float od = st.mcd[b], od2 = st.mcd2[b];
+        const float rnd = apply(aa, b, sym);
+        const bool took = od > sym || (od == sym && od2 > rnd);
+        const float md = took ? sym : od, md2 = took ? rnd : od2;
+        if (bb.dist > md || (bb.dist == md && bb.dist2 > md2)) {
+          bb.lin1 = aa;
+          bb.lin2 = b;
+          bb.dist = sym;
+          bb.dist2 = md2;
         }
       }
+      if (lane == 0) sh.best = bb;
     }
     __syncthreads();
   }
@@ -489,6 +543,7 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
     for (int q = 0; q < MAXQ; q++) {
       const int ik = q * MM_BLOCK + tid;
       a_k[q] = ik < n ? (int)st.ci[ik] : -1;
+
     }
 #pragma unroll
     for (int q0 = 0; q0 < MAXQ; q0 += 5) {
@@ -524,9 +579,10 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
         float njk = djk, nkj = dkj;
         if (dik != djk) njk = (csi * dik + csj * djk) / added;
         if (dki != dkj) nkj = (csi * dki + csj * dkj) / added;
-        // (written whether changed or not: the same bits where the reference leaves the entry alone)
+        // (written whether changed or not: the same bits where the reference leaves the entry alone.)  The row of j
+        // goes out now; the column -- one scattered 16-byte store per cluster, ~3.5 cycles each on the one CU -- is
+        // held back until the merge's loads are out (from the row, read back in C), and drains under the ordered part.
         MM(j, k) = make_float4(njk, nkj, ncjk, nckj);
-        MM(k, j) = make_float4(nkj, njk, nckj, ncjk);
         if (njk < mvj) mvj = njk;
         bool rescan = false;
         if (dkj != dki) {
@@ -540,7 +596,10 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
           st.mcd[k] = INF;
           st.mcd2[k] = INF;
           const int slot = atomicAdd(&sh.nupd, 1);
-          if (slot < MM_UPD_MAX) sh.upd[slot] = (unsigned)ik | (rescan ? 0x10000u : 0u);
+          if (slot < MM_UPD_MAX) {
+            sh.upd[slot] = (unsigned)ik | (rescan ? 0x10000u : 0u);
+            sh.updv[slot] = nkj;
+          }
         } else {  // k keeps its candidate: what the reference's running best sees at k's turn
           const float d1 = st.mcd[k], d2 = st.mcd2[k];
           if (bd > d1 || (bd == d1 && bd2 > d2)) {  // (ascending positions per thread: the first one wins)
@@ -577,32 +636,29 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
       return;
     }
 
-    // -- B: rows of the rebuilt clusters.  First the row-minimum rescans (:1875-1890), ROWS flagged rows at a time ...
-    for (int u = 0; u < nupd;) {
-      int kus[ROWS];
-      int cnt = 0;
-#pragma unroll
-      for (int r = 0; r < ROWS; r++) kus[r] = -1;
-      for (; u < nupd && cnt < ROWS; u++) {
-        const unsigned e = sh.upd[u];
-        if (!(e >> 16)) continue;
-        const int k = st.ci[e & 0xffffu];
-#pragma unroll
-        for (int r = 0; r < ROWS; r++)
-          if (r == cnt) kus[r] = k;
-        cnt++;
-      }
-      if (cnt == 0) break;
-      float v[ROWS][MAXQ];
+    // -- B: rows of the rebuilt clusters: (d(k,l), d(l,k)) along row k of M, ROWS rows per pass.  The row-minimum
+    // rescans (:1875-1890) come first -- the reference's scan with early exit = "the old minimum if it occurs before
+    // any smaller entry, else the row's minimum", three reductions finished by one wave per row --, then the
+    // candidate tests of every pair a rebuilt cluster is part of (:1893-1911 for the clusters before it, :1913-2018
+    // for the ones behind it), on the same registers when the merge has no more than ROWS rebuilt clusters.
+    float v[ROWS][MAXQ], w[ROWS][MAXQ];
+    auto load_rows = [&](const int (&ks)[ROWS]) {
 #pragma unroll
       for (int r = 0; r < ROWS; r++) {
-        if (kus[r] < 0) continue;
+        if (ks[r] < 0) continue;
 #pragma unroll
-        for (int q = 0; q < MAXQ; q++) v[r][q] = a_k[q] >= 0 ? MM(kus[r], a_k[q]).x : INF;
+        for (int q = 0; q < MAXQ; q++) {
+          const float2 e = a_k[q] >= 0 ? MM2(ks[r], a_k[q]) : make_float2(INF, INF);
+          v[r][q] = e.x;
+          w[r][q] = e.y;
+        }
       }
+    };
+    // rescans of the rows ks[r] >= 0 held in v; patch[r]: the row's new entry at column j (not in memory yet)
+    auto rescan_rows = [&](const int (&ks)[ROWS], const float (&patch)[ROWS]) {
 #pragma unroll
       for (int r = 0; r < ROWS; r++) {
-        const int k = kus[r];
+        const int k = ks[r];
         if (k < 0) continue;
         const float old = st.mv[k] - threshold;
         float fm = INF;
@@ -611,7 +667,7 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
         for (int q = 0; q < MAXQ; q++) {
           const int l = a_k[q];
           if (l < 0 || l == i || l == k) continue;
-          const float x = v[r][q];
+          const float x = l == j ? patch[r] : v[r][q];
           fm = fminf(fm, x);
           if (x == old) pos_old = min(pos_old, q * MM_BLOCK + tid);
           if (x < old) pos_less = min(pos_less, q * MM_BLOCK + tid);
@@ -629,7 +685,7 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
       int myk = -1;  // one wave finishes one row
 #pragma unroll
       for (int r = 0; r < ROWS; r++)
-        if (wave == r) myk = kus[r];
+        if (wave == r) myk = ks[r];
       if (myk >= 0) {
         float fm = lane < MM_WAVES ? sh.red_f[wave][lane] : INF;
         int pos_old = lane < MM_WAVES ? sh.red_a[wave][lane] : n;
@@ -643,11 +699,7 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
         }
       }
       __syncthreads();
-    }
-    LAP(3);
-    // ... then the candidate tests of every pair a rebuilt cluster is part of (:1893-1911 for the clusters before
-    // it, :1913-2018 for the ones behind it): both halves at once, d(k,l) <= min_k from k's row of D and
-    // d(l,k) <= min_l from k's row of the transpose
+    };
     auto append_pair = [&](unsigned key, int x, int y, float sym) {
       const int slot = atomicAdd(&sh.npairs, 1);
       if (slot < MM_PAIRS_LDS) {
@@ -661,20 +713,9 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
         g[2] = __float_as_uint(sym);
       }
     };
-    for (int u0 = 0; u0 < nupd; u0 += ROWS) {
+    // candidate tests of the rows u0 .. u0+ROWS-1 of the list, held in v / w
+    auto test_rows = [&](int u0) {
       unsigned long long surv = 0;  // bit r * MAXQ + q: (row r, this thread's cluster q) is a feasible pair
-      float v[ROWS][MAXQ], w[ROWS][MAXQ];
-#pragma unroll
-      for (int r = 0; r < ROWS; r++) {  // (all loads of the pass first)
-        if (u0 + r >= nupd) continue;
-        const int ku = st.ci[sh.upd[u0 + r] & 0xffffu];
-#pragma unroll
-        for (int q = 0; q < MAXQ; q++) {
-          const float2 e = a_k[q] >= 0 ? MM2(ku, a_k[q]) : make_float2(INF, INF);
-          v[r][q] = e.x;
-          w[r][q] = e.y;
-        }
-      }
 #pragma unroll
       for (int r = 0; r < ROWS; r++) {
         if (u0 + r >= nupd) continue;
@@ -715,10 +756,62 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
         if (p.has_prior && e.z <= st.mvcf[ku] && e.w <= st.mvcf[l]) sym = 0.0f;
         append_pair(key, x, y, sym);
       }
+    };
+    if (nupd <= ROWS) {  // (the usual case) one pass
+      int ks[ROWS], kres[ROWS];
+      float patch[ROWS];
+      bool anyres = false;
+#pragma unroll
+      for (int r = 0; r < ROWS; r++) {
+        const unsigned e = r < nupd ? sh.upd[r] : 0u;
+        ks[r] = r < nupd ? (int)st.ci[e & 0xffffu] : -1;
+        kres[r] = (r < nupd && (e >> 16)) ? ks[r] : -1;
+        patch[r] = r < nupd ? sh.updv[r] : INF;
+        anyres |= kres[r] >= 0;
+      }
+      load_rows(ks);
+      if (anyres) rescan_rows(kres, patch);
+      LAP(3);
+      test_rows(0);
+    } else {
+      for (int u = 0; u < nupd;) {  // the flagged rows, ROWS at a time
+        int ks[ROWS];
+        float patch[ROWS];
+        int cnt = 0;
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+          ks[r] = -1;
+          patch[r] = INF;
+        }
+        for (; u < nupd && cnt < ROWS; u++) {
+          const unsigned e = sh.upd[u];
+          if (!(e >> 16)) continue;
+          const int k = st.ci[e & 0xffffu];
+          const float pv = sh.updv[u];
+#pragma unroll
+          for (int r = 0; r < ROWS; r++)
+            if (r == cnt) {
+              ks[r] = k;
+              patch[r] = pv;
+            }
+          cnt++;
+        }
+        if (cnt == 0) break;
+        load_rows(ks);
+        rescan_rows(ks, patch);
+      }
+      LAP(3);
+      for (int u0 = 0; u0 < nupd; u0 += ROWS) {
+        int ks[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) ks[r] = u0 + r < nupd ? (int)st.ci[sh.upd[u0 + r] & 0xffffu] : -1;
+        load_rows(ks);
+        test_rows(u0);
+      }
     }
     // -- C: candidates with the merged cluster j, behind all others (:2033-2064); its row as this thread wrote it in A
+    float4 ej[MAXQ];
     {
-      float4 ej[MAXQ];
 #pragma unroll
       for (int q = 0; q < MAXQ; q++) {
         const int k = a_k[q];
@@ -737,6 +830,12 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
     }
     __syncthreads();
     LAP(4);
+    // the column of the merged cluster (held back in A): out now, to drain under the ordered part
+#pragma unroll
+    for (int q = 0; q < MAXQ; q++) {
+      const int k = a_k[q];
+      if (k >= 0 && k != i && k != j) MM(k, j) = make_float4(ej[q].y, ej[q].x, ej[q].w, ej[q].z);
+    }
     // -- D: the pairs in the reference's order
     const int m = sh.npairs;
     if (m - MM_PAIRS_LDS > p.pair_cap) {
@@ -779,17 +878,12 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
       __syncthreads();
     }
     LAP(5);
-    if (tid == 0) {
-      // the best among the clusters that keep their candidate (a copy taken before the draws: they may still
+    if (wave == 0) {
+      // The best among the clusters that keep their candidate (a copy taken before the draws: they may still
       // change such a cluster's candidate, behind its turn)
-      float ud = sh.lex_d[0], ud2 = sh.lex_d2[0];
-      int upos = sh.lex_p[0];
-      for (int w = 1; w < MM_WAVES; w++)
-        if (lex_less(sh.lex_d[w], sh.lex_d2[w], sh.lex_p[w], ud, ud2, upos)) {
-          ud = sh.lex_d[w];
-          ud2 = sh.lex_d2[w];
-          upos = sh.lex_p[w];
-        }
+      float ud = lane < MM_WAVES ? sh.lex_d[lane] : INF, ud2 = lane < MM_WAVES ? sh.lex_d2[lane] : INF;
+      int upos = lane < MM_WAVES ? sh.lex_p[lane] : n;
+      wave_lex_min(ud, ud2, upos);
       const int bl1 = upos < n ? (int)st.lin1[st.ci[upos]] : -1;
       const int bl2 = upos < n ? (int)st.lin2[st.ci[upos]] : -1;
       // the clusters whose candidates change, at their turn: after their own pairs
@@ -798,27 +892,30 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
       int cur = -1, curk = -1;
       auto settle = [&]() {
         const float d1 = st.mcd[curk], d2 = st.mcd2[curk];
+        const int c1 = st.lin1[curk], c2 = st.lin2[curk];
         if (sd > d1 || (sd == d1 && sd2 > d2)) {
           sd = d1;
           sd2 = d2;
-          sl1 = st.lin1[curk];
-          sl2 = st.lin2[curk];
+          sl1 = c1;
+          sl2 = c2;
           spos = cur;
         }
       };
       int e = 0;
+      unsigned key = 0, xy = 0;
+      float sym = 0.0f;
+      if (m > 0) pair_at(side, 0, key, xy, sym);
       for (; e < m; e++) {
-        unsigned key, xy;
-        float sym;
-        pair_at(side, e, key, xy, sym);
         if (key & 0x80000000u) break;
         const int pos = (int)(key >> 16), x = (int)(xy >> 16), y = (int)(xy & 0xffffu);
+        const float symc = sym;
+        if (e + 1 < m) pair_at(side, e + 1, key, xy, sym);  // the next record, requested along with this pair's reads
         if (pos != cur) {
           if (cur >= 0) settle();
           cur = pos;
           curk = x;
         }
-        apply_pair<LDS>(st, sh, x, y, sym);
+        apply(x, y, symc);
       }
       if (cur >= 0) settle();
       // the loop's running "best": smallest (dist, dist2), the earliest cluster among exact ties
@@ -844,15 +941,18 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
           pos = spos;
         }
       }
-      st.mv[j] = min_value_j;
-      if (p.has_prior) st.mvcf[j] = mvcf_j;
-      st.mcd[j] = INF;
-      st.mcd2[j] = INF;
+      const int szi = st.csz[i], szj = st.csz[j];
+      if (lane == 0) {
+        st.mv[j] = min_value_j;
+        if (p.has_prior) st.mvcf[j] = mvcf_j;
+        st.mcd[j] = INF;
+        st.mcd2[j] = INF;
+      }
       for (; e < m; e++) {
-        unsigned key, xy;
-        float sym;
-        pair_at(side, e, key, xy, sym);
-        apply_pair<LDS>(st, sh, (int)(xy >> 16), j, sym);
+        const int x = (int)(xy >> 16);
+        const float symc = sym;
+        if (e + 1 < m) pair_at(side, e + 1, key, xy, sym);
+        apply(x, j, symc);
       }
       const float jd = st.mcd[j], jd2 = st.mcd2[j];
       if (b.dist > jd || (b.dist == jd && b.dist2 > jd2)) {
@@ -861,11 +961,13 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
         b.lin1 = st.lin1[j];
         b.lin2 = st.lin2[j];
       }
-      sh.best = b;
-      st.csz[j] = (idx_t)((int)st.csz[i] + (int)st.csz[j]);
-      p.convert_index[j] = num_nodes;
-      sh.nupd = 0;
-      sh.npairs = 0;
+      if (lane == 0) {
+        sh.best = b;
+        st.csz[j] = (idx_t)(szi + szj);
+        p.convert_index[j] = num_nodes;
+        sh.nupd = 0;
+        sh.npairs = 0;
+      }
     }
     LAP(6);
     // -- the same merge in the symmetric matrix once it is in use (coalesce_sym, tree_builder.cpp:968-1058)
@@ -1042,6 +1144,53 @@ __global__ void __launch_bounds__(256) rowmin_kernel(const float *__restrict__ i
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mv;
   __syncthreads();
   if (threadIdx.x == 0) out[a] = fminf(fminf(part[0], part[1]), fminf(part[2], part[3]));
+}
+
+// The pair scan of MinMatch's initialisation (tree_builder.cpp:1690-1722) on the whole chip: row a's partners
+// b > a with d(a,b) <= min_a and d(b,a) <= min_b (minima + threshold), in order, with the symmetric distance the
+// reference's loop would compute for the pair (0 when the pair is also mutually closest under the prior, :1699-1702).
+// mvcf_old: min_values_CF as carried over from the previous tree (:2399-2400).
+__global__ void __launch_bounds__(256) pairscan_kernel(const float4 *__restrict__ M, const float *__restrict__ rowmin_D,
+                                                       const float *__restrict__ rowmin_CF,
+                                                       const float *__restrict__ mvcf_old, int has_prior, float threshold,
+                                                       float threshold_CF, int N, int *__restrict__ hit_cnt,
+                                                       unsigned *__restrict__ hit_b, float *__restrict__ hit_sym) {
+  __shared__ int wcnt[4];
+  const int a = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float mva = rowmin_D[a] + threshold;
+  float mvcf_a = 0.0f;
+  if (has_prior) {
+    const float old = mvcf_old[a], mc_ = rowmin_CF[a];
+    mvcf_a = (old > mc_ ? mc_ : old) + threshold_CF;
+  }
+  int base = 0;
+  for (int b0 = a + 1; b0 < N; b0 += 256) {
+    const int b = b0 + (int)threadIdx.x;
+    bool hit = false;
+    float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (b < N) {
+      e = M[(size_t)a * N + b];
+      hit = mva >= e.x && rowmin_D[b] + threshold >= e.y;
+    }
+    const unsigned long long m = __ballot(hit);
+    if (lane == 0) wcnt[wave] = __popcll(m);
+    __syncthreads();
+    int at = base + __popcll(m & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; w++) at += wcnt[w];
+    if (hit && at < MM_HITS) {
+      float sym = e.y + e.x;
+      if (has_prior) {
+        const float old = mvcf_old[b], mc_ = rowmin_CF[b];
+        const float mvcf_b = (old > mc_ ? mc_ : old) + threshold_CF;
+        if (e.z <= mvcf_a && e.w <= mvcf_b) sym = 0.0f;
+      }
+      hit_b[(size_t)a * MM_HITS + at] = (unsigned)b;
+      hit_sym[(size_t)a * MM_HITS + at] = sym;
+    }
+    base += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) hit_cnt[a] = base;
 }
 
 // Carrier penalty of AncesTreeBuilder::BuildTopology (anc_builder.cpp:563-581) on the device: every entry of a
@@ -1226,7 +1375,7 @@ class BuildDispatcher {
 struct DeviceMinMatch::Impl {
   int N = 0, device = 0;
   hipStream_t stream = nullptr;
-  DevBuf d_D, d_CF, d_M, d_SYM, d_f, d_i, d_feas, d_rowlist, d_status, d_flags, d_member, d_tab, d_acc;
+  DevBuf d_D, d_CF, d_M, d_SYM, d_hits, d_f, d_i, d_feas, d_rowlist, d_status, d_flags, d_member, d_tab, d_acc;
   long long builds = 0;
 };
 
@@ -1326,6 +1475,7 @@ int DeviceMinMatch::build_impl(MinMatch &tb, const float *d, const float *prior_
   int rc = m.d_D.alloc(NN * 4);
   rc = rc ? rc : (prior ? m.d_CF.alloc(NN * 4) : 0);
   rc = rc ? rc : m.d_M.alloc(NN * 16);
+  rc = rc ? rc : m.d_hits.alloc(((size_t)N + (size_t)2 * N * MM_HITS) * 4);
   rc = rc ? rc : m.d_SYM.alloc(NN * 4);
   rc = rc ? rc : m.d_f.alloc((size_t)8 * N * 4);  // min_values, min_values_CF, mc_dist, mc_dist2, 2 of the symmetric path, 2 row minima
   rc = rc ? rc : m.d_i.alloc(((size_t)12 * N + 8) * 4);  // ints, see below
@@ -1344,6 +1494,10 @@ int DeviceMinMatch::build_impl(MinMatch &tb, const float *d, const float *prior_
   float *f = m.d_f.as<float>();
   p.rowmin_D = f + 6 * (size_t)N;
   p.rowmin_CF = f + 7 * (size_t)N;
+  int *hits = m.d_hits.as<int>();
+  p.hit_cnt = hits;
+  p.hit_b = reinterpret_cast<unsigned *>(hits + N);
+  p.hit_sym = reinterpret_cast<float *>(hits + N + (size_t)N * MM_HITS);
   p.min_values = f;
   p.min_values_CF = f + N;
   p.mc_dist = f + 2 * (size_t)N;
@@ -1390,6 +1544,9 @@ int DeviceMinMatch::build_impl(MinMatch &tb, const float *d, const float *prior_
     hipLaunchKernelGGL(pack_kernel, grid, dim3(256), 0, m.stream, dD, dCF, p.M, N);
     hipLaunchKernelGGL(rowmin_kernel, dim3(N), dim3(256), 0, m.stream, dD, f + 6 * (size_t)N, N);
     if (prior) hipLaunchKernelGGL(rowmin_kernel, dim3(N), dim3(256), 0, m.stream, dCF, f + 7 * (size_t)N, N);
+    hipLaunchKernelGGL(pairscan_kernel, dim3(N), dim3(256), 0, m.stream, p.M, p.rowmin_D, p.rowmin_CF, p.min_values_CF,
+                       p.has_prior, p.threshold, p.threshold_CF, N, hits, reinterpret_cast<unsigned *>(hits + N),
+                       reinterpret_cast<float *>(hits + N + (size_t)N * MM_HITS));
     RL_HIP(hipGetLastError());
   }
   const int minus1 = -1;

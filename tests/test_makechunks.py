@@ -63,6 +63,32 @@ def test_makechunks_matches_reference(tmp_path, N, L, memory, extra):
     assert p.returncode != 0 and b"already exists" in p.stderr
 
 
+@pytest.mark.parametrize("tag,memory,extra", [("a", "0.0005", []), ("b", "0.0002", ["--transversion"])])
+def test_makechunks_matches_committed_reference_outputs(tmp_path, tag, memory, extra):
+    """runs anywhere: inputs regenerated from the seed (md5-checked), outputs against tests/golden/makechunks.npz --
+    the md5 of every file the reference's MakeChunks wrote for them (tools/make_golden.py makechunks), the
+    parameter files byte for byte"""
+    import hashlib
+    z = np.load(os.path.join(ROOT, "tests", "golden", "makechunks.npz"))
+    N, L = [int(x) for x in z["%s/args" % tag]]
+    work = str(tmp_path)
+    write_synth_haps(work, N, L, seed=N)
+    for fn in ("s.haps", "s.sample", "s.map"):
+        assert hashlib.md5(open(os.path.join(work, fn), "rb").read()).digest() == z["%s/in_md5/%s" % (tag, fn)].tobytes(), fn
+    p = subprocess.run([CLI, "--mode", "MakeChunks", "--haps", "s.haps", "--sample", "s.sample", "--map", "s.map",
+                        "--memory", memory] + extra + ["-o", "ours"], cwd=work, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr.decode()
+    want = sorted(k.split("/", 2)[2] for k in z.files if k.startswith(tag + "/md5/"))
+    assert sorted(os.listdir(os.path.join(work, "ours"))) == want
+    for fn in want:
+        b = open(os.path.join(work, "ours", fn), "rb").read()
+        if "%s/file/%s" % (tag, fn) in z.files:
+            assert b == z["%s/file/%s" % (tag, fn)].tobytes(), fn
+        assert hashlib.md5(b).digest() == z["%s/md5/%s" % (tag, fn)].tobytes(), fn
+    if tag == "a":
+        assert "chunk_2.hap" in want  # several overlapping chunks
+
+
 @pytest.mark.skipif(not os.path.exists("/root/reference/example/data/example.haps.gz"),
                     reason="reference example data not present")
 def test_makechunks_example_data_matches_fixture(tmp_path):

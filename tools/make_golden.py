@@ -180,9 +180,38 @@ def n5000_fixture(N=5000, L=1200, mem=10.0):
           "%.1f KB" % (os.path.getsize(os.path.join(GOLD, "n5000.npz")) / 1e3))
 
 
+def makechunks_fixture():
+    """MakeChunks off the build container: the synthetic .haps/.sample/map of tests/test_makechunks.py (regenerated
+    from the seed by the test) through the reference's MakeChunks; the fixture keeps the md5 of every output file and
+    the parameter files in full (multi-chunk case with the 20000-SNP overlap, and --transversion)."""
+    import hashlib
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_makechunks import write_synth_haps
+    data = {}
+    for tag, N, L, memory, extra in (("a", 6, 50000, "0.0005", []), ("b", 8, 3000, "0.0002", ["--transversion"])):
+        with tempfile.TemporaryDirectory() as work:
+            write_synth_haps(work, N, L, seed=N)
+            for fn in ("s.haps", "s.sample", "s.map"):
+                data["%s/in_md5/%s" % (tag, fn)] = np.frombuffer(
+                    hashlib.md5(open(os.path.join(work, fn), "rb").read()).digest(), dtype=np.uint8)
+            run([rlutil.REF_RELATE, "--mode", "MakeChunks", "--haps", "s.haps", "--sample", "s.sample", "--map",
+                 "s.map", "--memory", memory] + extra + ["-o", "ref"], work)
+            for fn in sorted(os.listdir(os.path.join(work, "ref"))):
+                b = open(os.path.join(work, "ref", fn), "rb").read()
+                data["%s/md5/%s" % (tag, fn)] = np.frombuffer(hashlib.md5(b).digest(), dtype=np.uint8)
+                if fn.startswith("parameters"):
+                    data["%s/file/%s" % (tag, fn)] = np.frombuffer(b, dtype=np.uint8)
+        data["%s/args" % tag] = np.array([N, L], dtype=np.int64)
+    np.savez_compressed(os.path.join(GOLD, "makechunks.npz"), **data)
+    print("makechunks fixture: %d entries, %.1f KB" % (len(data), os.path.getsize(os.path.join(GOLD, "makechunks.npz")) / 1e3))
+
+
 if __name__ == "__main__":
     assert rlutil.have_ref(), "run `make -C oracle ref` first (needs /root/reference)"
     os.makedirs(GOLD, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "makechunks":
+        makechunks_fixture()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "n5000":  # ~15 minutes of the single-threaded reference
         n5000_fixture()
         sys.exit(0)
