@@ -40,6 +40,15 @@ constexpr int MM_ROWS = 3;        // rows of rebuilt clusters scanned per pass o
 constexpr int MM_HITS = 32;       // mutually close pairs per row pairscan_kernel keeps; more: the host builds the tree
 constexpr int MM_UPD_MAX = 512;   // rebuilt clusters of one merge (list in LDS); more: the host builds the tree
 constexpr int MM_PAIRS_LDS = 768; // feasible pairs of one merge kept in LDS; more go through global scratch
+// M is stored in column panels of 64: element (a, b) at ((b / 64) * N + a) * 64 + b % 64.  A row is N / 64 runs of
+// 1 KB (a wavefront's 64 consecutive clusters: one run), 64 * N elements apart; a COLUMN -- what a merge scatters its
+// one store per cluster down -- strides by 1 KB inside one panel of N KB, a few 2 MB pages, instead of by a whole
+// row (80 KB at N = 5000: every store on another page, the address translation of 2500 pages per merge).
+constexpr int MM_PANEL = 64;
+__host__ __device__ inline unsigned mm_index(unsigned a, unsigned b, unsigned N) {
+  return ((b / MM_PANEL) * N + a) * MM_PANEL + (b % MM_PANEL);
+}
+__host__ __device__ inline size_t mm_elements(size_t N) { return ((N + MM_PANEL - 1) / MM_PANEL) * N * MM_PANEL; }
 constexpr int MM_MAXN = 10240;    // one thread holds up to 20 clusters of a merge in registers
 
 struct MMParams {
@@ -54,6 +63,7 @@ struct MMParams {
   // penalty) and the clade prior by pack_kernel; row minima of both by rowmin_kernel.
   float4 *M;          // [N*N] destroyed
   int has_prior;      // the cf halves of M are in use
+  int debug;          // experiments (RELATE_AMD_MM_DEBUG): 1 = never the one-pass form of B
   const float *rowmin_D, *rowmin_CF;  // [N] minimum of each row off the diagonal
   // the mutually close pairs (a, b > a) of the untouched matrix, row by row in order, from pairscan_kernel
   const int *hit_cnt;        // [N] (more than MM_HITS: not all kept)
@@ -104,7 +114,9 @@ __host__ __device__ inline uint32_t rng_next(Rng &r) {
 // The state renewal of rng_next by one wavefront: word i takes the old words i, i+1 and word i+397 -- old for
 // i < 227, already renewed (word i-227) behind that; 64 consecutive words per round, every lane reads before any
 // lane writes, and a round never needs a word of its own round (227 > 64).  The last word takes the new word 0.
-__device__ inline void rng_renew_wave(Rng &r, int lane) {
+// (The lanes exchange words through LDS between rounds: to the compiler one thread's next-round loads are
+// provably other words than its store and may move above it -- the fences pin the rounds.)
+__device__ __noinline__ void rng_renew_wave(Rng &r, int lane) {
   for (int base = 0; base < 623; base += 64) {
     const int i = base + lane;
     uint32_t v = 0;
@@ -112,12 +124,18 @@ __device__ inline void rng_renew_wave(Rng &r, int lane) {
       const uint32_t y = (r.mt[i] & 0x80000000u) | (r.mt[i + 1] & 0x7fffffffu);
       v = r.mt[i < 227 ? i + 397 : i - 227] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     if (i < 623) r.mt[i] = v;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
   if (lane == 0) {
     const uint32_t y = (r.mt[623] & 0x80000000u) | (r.mt[0] & 0x7fffffffu);
     r.mt[623] = r.mt[396] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
   }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
 }
 // std::uniform_real_distribution<double>(0,1)(rng) of libstdc++: generate_canonical<double, 53> = two draws,
 // sum = g1 + g2 * 2^32 in double, / 2^64, a result of 1 replaced by nextafter(1, 0)
@@ -264,8 +282,8 @@ __device__ inline void block_min3(float &f, int &a, int &b, float *bf, int *ba, 
 }
 
 // (32-bit element offsets from a scalar base -- N <= 10240: one address register per load instead of two)
-#define MM(a, b) p.M[(unsigned)(a) * (unsigned)N + (unsigned)(b)]
-#define MM2(a, b) (reinterpret_cast<const float2 *>(p.M + ((unsigned)(a) * (unsigned)N + (unsigned)(b)))[0])  // (d(a,b), d(b,a))
+#define MM(a, b) p.M[mm_index((unsigned)(a), (unsigned)(b), (unsigned)N)]
+#define MM2(a, b) (reinterpret_cast<const float2 *>(p.M + mm_index((unsigned)(a), (unsigned)(b), (unsigned)N))[0])  // (d(a,b), d(b,a))
 #define SS(a, b) p.SYM[(unsigned)(a) * (unsigned)N + (unsigned)(b)]
 
 // One workgroup per tree: workgroup b builds the tree of params[b].
@@ -579,10 +597,9 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
         float njk = djk, nkj = dkj;
         if (dik != djk) njk = (csi * dik + csj * djk) / added;
         if (dki != dkj) nkj = (csi * dki + csj * dkj) / added;
-        // (written whether changed or not: the same bits where the reference leaves the entry alone.)  The row of j
-        // goes out now; the column -- one scattered 16-byte store per cluster, ~3.5 cycles each on the one CU -- is
-        // held back until the merge's loads are out (from the row, read back in C), and drains under the ordered part.
+        // (written whether changed or not: the same bits where the reference leaves the entry alone)
         MM(j, k) = make_float4(njk, nkj, ncjk, nckj);
+        if (!(p.debug & 2)) MM(k, j) = make_float4(nkj, njk, nckj, ncjk);
         if (njk < mvj) mvj = njk;
         bool rescan = false;
         if (dkj != dki) {
@@ -757,7 +774,7 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
         append_pair(key, x, y, sym);
       }
     };
-    if (nupd <= ROWS) {  // (the usual case) one pass
+    if (nupd <= ROWS && !(p.debug & 1)) {  // (the usual case) one pass
       int ks[ROWS], kres[ROWS];
       float patch[ROWS];
       bool anyres = false;
@@ -810,8 +827,8 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
       }
     }
     // -- C: candidates with the merged cluster j, behind all others (:2033-2064); its row as this thread wrote it in A
-    float4 ej[MAXQ];
     {
+      float4 ej[MAXQ];
 #pragma unroll
       for (int q = 0; q < MAXQ; q++) {
         const int k = a_k[q];
@@ -830,12 +847,6 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
     }
     __syncthreads();
     LAP(4);
-    // the column of the merged cluster (held back in A): out now, to drain under the ordered part
-#pragma unroll
-    for (int q = 0; q < MAXQ; q++) {
-      const int k = a_k[q];
-      if (k >= 0 && k != i && k != j) MM(k, j) = make_float4(ej[q].y, ej[q].x, ej[q].w, ej[q].z);
-    }
     // -- D: the pairs in the reference's order
     const int m = sh.npairs;
     if (m - MM_PAIRS_LDS > p.pair_cap) {
@@ -1128,7 +1139,7 @@ __global__ void __launch_bounds__(256) pack_kernel(const float *__restrict__ D, 
 #pragma unroll
   for (int r = ty; r < 32; r += 8)
     if (by + r < N && bx + tx < N)
-      M[(size_t)(by + r) * N + bx + tx] =
+      M[mm_index(by + r, bx + tx, N)] =
           make_float4(t1[r][tx], t2[tx][r], CF ? c1[r][tx] : 0.0f, CF ? c2[tx][r] : 0.0f);
 }
 
@@ -1169,7 +1180,7 @@ __global__ void __launch_bounds__(256) pairscan_kernel(const float4 *__restrict_
     bool hit = false;
     float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
     if (b < N) {
-      e = M[(size_t)a * N + b];
+      e = M[mm_index(a, b, N)];
       hit = mva >= e.x && rowmin_D[b] + threshold >= e.y;
     }
     const unsigned long long m = __ballot(hit);
@@ -1474,7 +1485,7 @@ int DeviceMinMatch::build_impl(MinMatch &tb, const float *d, const float *prior_
   const long long pair_cap = (long long)8 * N;
   int rc = m.d_D.alloc(NN * 4);
   rc = rc ? rc : (prior ? m.d_CF.alloc(NN * 4) : 0);
-  rc = rc ? rc : m.d_M.alloc(NN * 16);
+  rc = rc ? rc : m.d_M.alloc(mm_elements(N) * 16);
   rc = rc ? rc : m.d_hits.alloc(((size_t)N + (size_t)2 * N * MM_HITS) * 4);
   rc = rc ? rc : m.d_SYM.alloc(NN * 4);
   rc = rc ? rc : m.d_f.alloc((size_t)8 * N * 4);  // min_values, min_values_CF, mc_dist, mc_dist2, 2 of the symmetric path, 2 row minima
@@ -1491,6 +1502,7 @@ int DeviceMinMatch::build_impl(MinMatch &tb, const float *d, const float *prior_
   p.threshold_CF = tb.threshold_CF;
   p.M = m.d_M.as<float4>();
   p.has_prior = prior ? 1 : 0;
+  p.debug = getenv("RELATE_AMD_MM_DEBUG") ? atoi(getenv("RELATE_AMD_MM_DEBUG")) : 0;
   float *f = m.d_f.as<float>();
   p.rowmin_D = f + 6 * (size_t)N;
   p.rowmin_CF = f + 7 * (size_t)N;

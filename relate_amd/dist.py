@@ -12,6 +12,9 @@ haplotype instead: every rank holds the bit panel, paints / re-paints its own
 contiguous range of targets (rl_set_target_range) and owns those rows of every
 distance matrix; one all-gather (RCCL over xGMI) assembles the N x N matrix for
 the tree builder (target_range, all_gather_rows)."""
+import os
+import struct
+
 import torch
 import torch.distributed as dist
 
@@ -79,7 +82,7 @@ def run_chunk(out_dir, chunk_index=0, painting=None, device=None, stages=None):
     live = dist.is_available() and dist.is_initialized()
     rank = dist.get_rank() if live else 0
     world = dist.get_world_size() if live else 1
-    dev = device if device is not None else (rank if live and dist.get_backend() == "nccl" else 0)
+    dev = device if device is not None else local_device()
     if rank == 0:
         stages.stage_paint(out_dir, chunk_index, painting=painting, device=dev)
     if live:
@@ -94,3 +97,44 @@ def run_chunk(out_dir, chunk_index=0, painting=None, device=None, stages=None):
     if live:
         dist.barrier()
     return rng
+
+
+def local_device():
+    """the GPU of this process: LOCAL_RANK under torch.distributed.run (one process per GPU of the node), else 0"""
+    return int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def read_parameters(out_dir):
+    """parameters.bin of MakeChunks (data.cpp:365-375): int N, L, num_chunks; double memory; int start[], end[]
+    -> dict(N, L, num_chunks, memory_gb, start, end)"""
+    buf = open(os.path.join(out_dir, "parameters.bin"), "rb").read()
+    N, L, C = struct.unpack_from("<iii", buf, 0)
+    mem, = struct.unpack_from("<d", buf, 12)
+    if C < 1 or len(buf) < 20 + 8 * C:
+        raise ValueError("%s/parameters.bin is malformed" % out_dir)
+    start = list(struct.unpack_from("<%di" % C, buf, 20))
+    end = list(struct.unpack_from("<%di" % C, buf, 20 + 4 * C))
+    return dict(N=N, L=L, num_chunks=C, memory_gb=mem, start=start, end=end)
+
+
+def run_chunks(out_dir, painting=None, device=None, stages=None, chunks=None):
+    """The many-chunks route (BASELINE.json config #4; scripts/RelateParallel/RelateParallel.sh:216-262): the chunks of
+    a MakeChunks directory are dealt round-robin to the ranks of the job (one process per GPU) and every rank runs
+    its chunks start to end -- Paint, BuildTopology of all sections (on host threads sharing the GPU),
+    FindEquivalentBranches -- with NO data-path collective: chunks share nothing but the input directory.
+    Returns the chunk indices this rank ran.  `chunks`: a subset to run (default: all of parameters.bin)."""
+    if stages is None:
+        from relate_amd import api as stages
+    live = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank() if live else 0
+    world = dist.get_world_size() if live else 1
+    dev = device if device is not None else local_device()
+    todo = list(range(read_parameters(out_dir)["num_chunks"])) if chunks is None else list(chunks)
+    mine = shard(todo, rank, world)
+    for c in mine:
+        stages.stage_paint(out_dir, c, painting=painting, device=dev)
+        stages.stage_build_topology(out_dir, c, 0, stages.num_sections(out_dir, c) - 1, painting=painting, device=dev)
+        stages.stage_find_equivalent_branches(out_dir, c)
+    if live:
+        dist.barrier()  # (the job ends together; nothing is exchanged)
+    return mine

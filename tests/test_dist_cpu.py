@@ -154,3 +154,62 @@ def test_chunk_pipeline_shards_sections_three_ranks(tmp_path):
     assert [r[1] for r in res] == [(0, 2), (3, 4), (5, 6)]
     assert res[0][2] == [("paint", 0), ("build", 0, 2), ("feb", 0)]
     assert res[1][2] == [("build", 3, 4)] and res[2][2] == [("build", 5, 6)]
+
+
+def _chunks_worker(rank, world, port, q, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["LOCAL_RANK"] = str(rank)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from relate_amd import dist as rdist
+
+    class Stages:  # records what each rank is asked to do (the real stages need a GPU)
+        calls = []
+
+        def stage_paint(self, out, c, painting=None, device=0):
+            assert device == dist.get_rank()  # LOCAL_RANK picks the GPU
+            self.calls.append(("paint", c))
+
+        def num_sections(self, out, c):
+            return 3 + c
+
+        def stage_build_topology(self, out, c, first, last, painting=None, device=0):
+            assert self.calls[-1] == ("paint", c)
+            self.calls.append(("build", c, first, last))
+
+        def stage_find_equivalent_branches(self, out, c):
+            self.calls.append(("feb", c))
+
+    st = Stages()
+    mine = rdist.run_chunks(out_dir, stages=st)
+    q.put((rank, mine, st.calls))
+    dist.destroy_process_group()
+
+
+def test_many_chunks_dealt_to_ranks(tmp_path):
+    """config #4's route: the chunks of parameters.bin dealt round-robin, each rank runs its chunks start to end"""
+    import struct
+    from relate_amd import dist as rdist
+    C = 7
+    with open(tmp_path / "parameters.bin", "wb") as f:
+        f.write(struct.pack("<iii", 2000, 5000000, C) + struct.pack("<d", 1.0))
+        f.write(struct.pack("<%di" % C, *[max(0, 100000 * c - 20000) for c in range(C)]))
+        f.write(struct.pack("<%di" % C, *[100000 * (c + 1) for c in range(C)]))
+    par = rdist.read_parameters(str(tmp_path))
+    assert (par["N"], par["L"], par["num_chunks"], par["start"][1], par["end"][-1]) == (2000, 5000000, C, 80000, 700000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 3
+    port = 35500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_chunks_worker, args=(r, world, port, q, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [[0, 3, 6], [1, 4], [2, 5]]              # a disjoint cover of the chunks
+    assert sorted(sum((r[1] for r in res), [])) == list(range(C))
+    for _, mine, calls in res:
+        assert calls == sum(([("paint", c), ("build", c, 0, 2 + c), ("feb", c)] for c in mine), [])
