@@ -817,7 +817,12 @@ int rl_write_paint_files(rl_ctx *ctx, const char *paint_dir) {
         return;
       }
       for (int k = 0; k < N; k++) fwrite(recs.data() + (size_t)k * maxrec, 1, lens[k], fp);
-      fclose(fp);
+      const bool bad = ferror(fp) != 0;
+      if (fclose(fp) != 0 || bad) {  // (a full disc must not pass for a paint file)
+        std::lock_guard<std::mutex> lk(gpu_mutex);
+        if (!failed.exchange(RL_EIO)) first_error = "writing " + fn + " failed";
+        return;
+      }
     }
   };
   if (nthreads == 1) {

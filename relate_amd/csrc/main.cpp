@@ -29,6 +29,9 @@ static void usage_line() {
 }
 
 int main(int argc, char **argv) {
+  // BuildTopology keeps several tree-builder launches and window kernels in flight from its section threads: more
+  // hardware queues than HIP's default four (read when the runtime starts; an explicit setting wins)
+  setenv("GPU_MAX_HW_QUEUES", "16", 0);
   // option table of Relate.cpp:19-45 restricted to what the two modes read
   const std::map<std::string, bool> known = {  // name -> takes a value
       {"mode", true}, {"chunk_index", true}, {"first_section", true}, {"last_section", true},

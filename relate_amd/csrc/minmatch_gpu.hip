@@ -37,7 +37,7 @@ namespace {
 constexpr int MM_BLOCK = 512;   // (8 waves: 256 registers per lane -- a thread keeps ~10 clusters of a merge in registers)
 constexpr int MM_WAVES = MM_BLOCK / 64;
 constexpr int MM_ROWS = 3;        // rows of rebuilt clusters scanned per pass of a merge (2 once a thread holds > 10 clusters)
-constexpr int MM_HITS = 32;       // mutually close pairs per row pairscan_kernel keeps; more: the host builds the tree
+constexpr int MM_HITS = 64;       // mutually close pairs per row pairscan_kernel keeps; more: the host builds the tree
 constexpr int MM_UPD_MAX = 512;   // rebuilt clusters of one merge (list in LDS); more: the host builds the tree
 constexpr int MM_PAIRS_LDS = 768; // feasible pairs of one merge kept in LDS; more go through global scratch
 // M is stored in column panels of 64: element (a, b) at ((b / 64) * N + a) * 64 + b % 64.  A row is N / 64 runs of
@@ -75,12 +75,12 @@ struct MMParams {
   float *min_values, *min_values_CF;  // min_values_CF, mc_lin1, mc_lin2: carried from tree to tree (in and out)
   float *mc_dist, *mc_dist2;
   int *mc_lin1, *mc_lin2;
-  int *cluster_index, *cluster_size, *convert_index;
+  int *cluster_index, *cluster_size;
   unsigned char *kflag;
   int *upd_pos;         // [N] scratch of the symmetric path
   unsigned *pair_g;     // [6 * pair_cap] feasible pairs of a merge beyond MM_PAIRS_LDS: key, x<<16|y, sym; unsorted, sorted
   int *rowlist;         // [MM_WAVES][N] pair-scan survivors per wave
-  int *parent, *child_left, *child_right;
+  int *merge_i, *merge_j;  // [N-1] the merges as (cluster i, cluster j) in order; the host names the tree's nodes from them
   int *status;
   long long pair_cap;
   long long *timers;  // optional: 100 MHz ticks per phase (RELATE_AMD_TIMING)
@@ -192,15 +192,29 @@ struct State {
   unsigned char *flag;             // rebuilt in this merge
 };
 
+// Wave reductions on the DPP crossbar (quad swaps, half-row and row mirrors, the two row broadcasts: the total
+// lands in lane 63 and is read back to all lanes) -- a __shfl_xor butterfly is six dependent LDS round trips per value,
+// and a merge has a dozen reductions on its critical path.  Lanes a step does not write keep their own value.
+template <int CTRL, int RM>
+__device__ inline float dpp_keep_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, RM, 0xf, false));
+}
+template <int CTRL, int RM>
+__device__ inline int dpp_keep_i(int v) {
+  return __builtin_amdgcn_update_dpp(v, v, CTRL, RM, 0xf, false);
+}
+#define MM_DPP_STEPS(X) X(0xB1, 0xf) X(0x4E, 0xf) X(0x141, 0xf) X(0x140, 0xf) X(0x142, 0xa) X(0x143, 0xc)
 __device__ inline float wave_min_f(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-  return v;
+#define MM_STEP(C, R) v = fminf(v, dpp_keep_f<C, R>(v));
+  MM_DPP_STEPS(MM_STEP)
+#undef MM_STEP
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ inline int wave_min_i(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
-  return v;
+#define MM_STEP(C, R) v = min(v, dpp_keep_i<C, R>(v));
+  MM_DPP_STEPS(MM_STEP)
+#undef MM_STEP
+  return __builtin_amdgcn_readlane(v, 63);
 }
 // exclusive prefix of v over the threads in order; *total = sum
 __device__ inline int block_scan(int v, int *total, int *buf) {
@@ -227,16 +241,21 @@ __device__ inline bool lex_less(float a1, float a2, int ap, float b1, float b2, 
   return a1 < b1 || (a1 == b1 && (a2 < b2 || (a2 == b2 && ap < bp)));
 }
 __device__ inline void wave_lex_min(float &d1, float &d2, int &pos) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float o1 = __shfl_xor(d1, o, 64), o2 = __shfl_xor(d2, o, 64);
-    const int op = __shfl_xor(pos, o, 64);
-    if (lex_less(o1, o2, op, d1, d2, pos)) {
-      d1 = o1;
-      d2 = o2;
-      pos = op;
-    }
+#define MM_STEP(C, R)                                                          \
+  {                                                                            \
+    const float o1 = dpp_keep_f<C, R>(d1), o2 = dpp_keep_f<C, R>(d2);          \
+    const int op = dpp_keep_i<C, R>(pos);                                      \
+    if (lex_less(o1, o2, op, d1, d2, pos)) {                                   \
+      d1 = o1;                                                                 \
+      d2 = o2;                                                                 \
+      pos = op;                                                                \
+    }                                                                          \
   }
+  MM_DPP_STEPS(MM_STEP)
+#undef MM_STEP
+  d1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d1), 63));
+  d2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d2), 63));
+  pos = __builtin_amdgcn_readlane(pos, 63);
 }
 __device__ inline void block_lex_min(float &d1, float &d2, int &pos, float *b1, float *b2, int *bp) {
   wave_lex_min(d1, d2, pos);
@@ -359,7 +378,6 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
   // ---- QuickBuild set-up (:1061-1100)
   for (int c = tid; c < N; c += MM_BLOCK) {
     st.ci[c] = (idx_t)c;
-    p.convert_index[c] = c;
     st.csz[c] = (idx_t)1;
     st.mv[c] = INF;
     st.mcd[c] = INF;
@@ -371,7 +389,6 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
       st.mvcf[c] = p.min_values_CF[c];
     }
   }
-  for (int c = tid; c < 2 * N - 1; c += MM_BLOCK) p.parent[c] = -1;
   if (tid == 0) {
     rng_seed(sh.rng, 1u);
     sh.best.dist = INF;
@@ -440,42 +457,78 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
   };
   // mutually close pairs in (a, b) order (:1690-1722): pairscan_kernel has found them; MM_BLOCK rows at a time they
   // are staged in LDS in order and wave 0 draws
+  auto draw_staged = [&](int count) {  // wave 0: the staged pairs sh.pxy[0] / sh.psym[0] in order (:1704-1722)
+    Best bb = sh.best;
+    for (int e = 0; e < count; e++) {
+      const unsigned xy = sh.pxy[0][e];
+      const float sym = sh.psym[0][e];
+      const int aa = (int)(xy >> 16), b = (int)(xy & 0xffffu);
+      // (b's candidate after this pair: what apply() is about to leave there)
+      const float od = st.mcd[b], od2 = st.mcd2[b];
+      const float rnd = apply(aa, b, sym);
+      const bool took = od > sym || (od == sym && od2 > rnd);
+      const float md = took ? sym : od, md2 = took ? rnd : od2;
+      if (bb.dist > md || (bb.dist == md && bb.dist2 > md2)) {
+        bb.lin1 = aa;
+        bb.lin2 = b;
+        bb.dist = sym;
+        bb.dist2 = md2;
+      }
+    }
+    if (lane == 0) sh.best = bb;
+  };
   for (int a0 = 0; a0 < N; a0 += MM_BLOCK) {
     const int a = a0 + tid;
     const int c = a < N ? p.hit_cnt[a] : 0;
     int total;
     const int off = block_scan(c, &total, sh.wave_i);
-    const bool bad = __syncthreads_or(c > MM_HITS) || total > MM_PAIRS_LDS;
-    if (bad) {  // (degenerate matrices: this tree is the host's)
-      if (tid == 0) *p.status = 2;
-      return;
-    }
-    for (int e = 0; e < c; e++) {
-      sh.pxy[0][off + e] = ((unsigned)a << 16) | p.hit_b[(size_t)a * MM_HITS + e];
-      sh.psym[0][off + e] = p.hit_sym[(size_t)a * MM_HITS + e];
-    }
-    __syncthreads();
-    if (wave == 0) {
-      Best bb = sh.best;
-      for (int e = 0; e < total; e++) {
-        const unsigned xy = sh.pxy[0][e];
-        const float sym = sh.psym[0][e];
-        const int aa = (int)(xy >> 16), b = (int)(xy & 0xffffu);
-        // (b's candidate after this pair: what apply() is about to leave there)
-        const float od = st.mcd[b], od2 = st.mcd2[b];
-        const float rnd = apply(aa, b, sym);
-        const bool took = od > sym || (od == sym && od2 > rnd);
-        const float md = took ? sym : od, md2 = took ? rnd : od2;
-        if (bb.dist > md || (bb.dist == md && bb.dist2 > md2)) {
-          bb.lin1 = aa;
-          bb.lin2 = b;
-          bb.dist = sym;
-          bb.dist2 = md2;
+    if (__syncthreads_or(c > MM_HITS)) {
+      // a row of this stretch has more partners than the pair scan keeps (flat matrices): its rows are scanned here,
+      // one by one, MM_BLOCK columns at a time
+      for (int ar = a0; ar < min(N, a0 + MM_BLOCK); ar++) {
+        const float mva = st.mv[ar];
+        for (int b0 = ar + 1; b0 < N; b0 += MM_BLOCK) {
+          const int b = b0 + tid;
+          float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+          bool hit = false;
+          if (b < N) {
+            e = MM(ar, b);
+            hit = mva >= e.x && st.mv[b] >= e.y;
+          }
+          int cnt;
+          const int at = block_scan(hit ? 1 : 0, &cnt, sh.wave_i);
+          if (hit) {
+            float sym = e.y + e.x;
+            if (p.has_prior && e.z <= st.mvcf[ar] && e.w <= st.mvcf[b]) sym = 0.0f;
+            sh.pxy[0][at] = ((unsigned)ar << 16) | (unsigned)b;
+            sh.psym[0][at] = sym;
+          }
+          __syncthreads();
+          if (wave == 0) draw_staged(cnt);
+          __syncthreads();
         }
       }
-      if (lane == 0) sh.best = bb;
+      continue;
     }
-    __syncthreads();
+    // whole rows, as many as the staging area holds (all of them, usually), pass by pass
+    for (int base = 0; base < total;) {
+      if (tid == 0) sh.count = total;
+      __syncthreads();
+      const bool mine = c > 0 && off >= base && off + c <= base + MM_PAIRS_LDS;
+      if (mine) {
+        for (int e = 0; e < c; e++) {
+          sh.pxy[0][off - base + e] = ((unsigned)a << 16) | p.hit_b[(size_t)a * MM_HITS + e];
+          sh.psym[0][off - base + e] = p.hit_sym[(size_t)a * MM_HITS + e];
+        }
+      } else if (c > 0 && off >= base) {
+        atomicMin(&sh.count, off);  // the first row that has to wait
+      }
+      __syncthreads();
+      const int next = sh.count;
+      if (wave == 0) draw_staged(next - base);
+      __syncthreads();
+      base = next;
+    }
   }
   LAP(1);
 
@@ -507,14 +560,9 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
             mp = il;
           }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-          const float ov = __shfl_xor(mv, o, 64);
-          const int op = __shfl_xor(mp, o, 64);
-          if (ov < mv || (ov == mv && op < mp)) {
-            mv = ov;
-            mp = op;
-          }
+        {
+          float zero = 0.0f;
+          wave_lex_min(mv, zero, mp);  // (value, position)
         }
         if (lane == 0) {
           p.min_values_sym[a] = mv;
@@ -545,15 +593,21 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
     const int i = by_sym ? sh.best_sym.lin1 : sh.best.lin1, j = by_sym ? sh.best_sym.lin2 : sh.best.lin2;
     const float csi = (float)st.csz[i], csj = (float)st.csz[j];
     const float added = csi + csj;
-    if (tid == 0) {
-      const int conv_i = p.convert_index[i], conv_j = p.convert_index[j];
-      p.parent[conv_i] = num_nodes;
-      p.parent[conv_j] = num_nodes;
-      p.child_left[num_nodes - N] = conv_i;
-      p.child_right[num_nodes - N] = conv_j;
+    if (tid == 0) {  // (:2437-2460 happens on the host, from this log: no loads on the merge's path)
+      p.merge_i[num_nodes - N] = i;
+      p.merge_j[num_nodes - N] = j;
     }
 
     // -- A: this thread's clusters
+    // (a / added for the size-weighted means: `added` is one integer <= 10240 for the whole merge, so the quotient
+    //  comes from a double product with its reciprocal -- the exact quotient of a 24-bit by a 14-bit number is at
+    //  least 2^-39 (relative) off every rounding boundary of float unless it is a float itself, the product is
+    //  within 2^-51: the same float as the division's.  Quotients in the subnormal range take the division.)
+    const double rc_added = 1.0 / (double)added;
+    auto over_added = [&](float a) -> float {
+      const float q = (float)((double)a * rc_added);
+      return fabsf(q) >= 1e-30f || a == 0.0f ? q : a / added;
+    };
     int a_k[MAXQ];
     float mv_cf = INF, mvj = INF, bd = INF, bd2 = INF;
     int bpos = n;
@@ -589,17 +643,17 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
           const float ckj = ej[qq].w, cki = ei[qq].w, cik = ei[qq].z, cjk = ej[qq].z;
           ncjk = cjk;
           nckj = ckj;
-          if (cik != cjk) ncjk = (csi * cik + csj * cjk) / added;
-          if (cki != ckj) nckj = (csi * cki + csj * ckj) / added;
+          if (cik != cjk) ncjk = over_added(csi * cik + csj * cjk);
+          if (cki != ckj) nckj = over_added(csi * cki + csj * ckj);
           if (mv_cf > ncjk) mv_cf = ncjk;
         }
         const float dkj = ej[qq].y, dki = ei[qq].y, dik = ei[qq].x, djk = ej[qq].x;
         float njk = djk, nkj = dkj;
-        if (dik != djk) njk = (csi * dik + csj * djk) / added;
-        if (dki != dkj) nkj = (csi * dki + csj * dkj) / added;
+        if (dik != djk) njk = over_added(csi * dik + csj * djk);
+        if (dki != dkj) nkj = over_added(csi * dki + csj * dkj);
         // (written whether changed or not: the same bits where the reference leaves the entry alone)
         MM(j, k) = make_float4(njk, nkj, ncjk, nckj);
-        if (!(p.debug & 2)) MM(k, j) = make_float4(nkj, njk, nckj, ncjk);
+        MM(k, j) = make_float4(nkj, njk, nckj, ncjk);
         if (njk < mvj) mvj = njk;
         bool rescan = false;
         if (dkj != dki) {
@@ -757,21 +811,13 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
         const int r = bit / MAXQ, q = bit - r * MAXQ;
         const int il = q * MM_BLOCK + tid, l = st.ci[il];
         const int up = (int)(sh.upd[u0 + r] & 0xffffu), ku = st.ci[up];
-        int x, y;
-        unsigned key;
-        if (il < up) {  // the rebuilt cluster meets the clusters before it
-          x = ku;
-          y = l;
-          key = ((unsigned)up << 16) | (unsigned)il;
-        } else {
-          x = l;
-          y = ku;
-          key = ((unsigned)il << 16) | (unsigned)up;
-        }
         const float4 e = MM(ku, l);  // (d(ku,l), d(l,ku), cf(ku,l), cf(l,ku))
         float sym = e.y + e.x;
         if (p.has_prior && e.z <= st.mvcf[ku] && e.w <= st.mvcf[l]) sym = 0.0f;
-        append_pair(key, x, y, sym);
+        if (il < up)  // the rebuilt cluster meets the clusters before it
+          append_pair(((unsigned)up << 16) | (unsigned)il, ku, l, sym);
+        else
+          append_pair(((unsigned)il << 16) | (unsigned)up, l, ku, sym);
       }
     };
     if (nupd <= ROWS && !(p.debug & 1)) {  // (the usual case) one pass
@@ -828,21 +874,27 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
     }
     // -- C: candidates with the merged cluster j, behind all others (:2033-2064); its row as this thread wrote it in A
     {
-      float4 ej[MAXQ];
+      float2 ej[MAXQ];
+      unsigned cand = 0;
 #pragma unroll
       for (int q = 0; q < MAXQ; q++) {
         const int k = a_k[q];
-        ej[q] = (k >= 0 && k != i && k != j) ? MM(j, k) : make_float4(INF, INF, INF, INF);  // (d(j,k), d(k,j), cf(j,k), cf(k,j))
+        ej[q] = (k >= 0 && k != i && k != j) ? MM2(j, k) : make_float2(INF, INF);  // (d(j,k), d(k,j))
       }
 #pragma unroll
       for (int q = 0; q < MAXQ; q++) {
         const int k = a_k[q];
-        if (k < 0 || k == i || k == j) continue;
-        if (ej[q].x <= min_value_j && ej[q].y <= st.mv[k]) {
-          float sym = ej[q].x + ej[q].y;
-          if (p.has_prior && ej[q].w <= st.mvcf[k] && ej[q].z <= mvcf_j) sym = 0.0f;
-          append_pair(0x80000000u | (unsigned)(q * MM_BLOCK + tid), k, j, sym);
-        }
+        const bool ok = k >= 0 && k != i && k != j && ej[q].x <= min_value_j && ej[q].y <= st.mv[k];
+        cand |= ok ? 1u << q : 0u;
+      }
+      while (cand) {  // (few)
+        const int q = __ffs((int)cand) - 1;
+        cand &= cand - 1;
+        const int ik = q * MM_BLOCK + tid, k = st.ci[ik];
+        const float4 e = MM(j, k);  // (d(j,k), d(k,j), cf(j,k), cf(k,j))
+        float sym = e.x + e.y;
+        if (p.has_prior && e.w <= st.mvcf[k] && e.z <= mvcf_j) sym = 0.0f;
+        append_pair(0x80000000u | (unsigned)ik, k, j, sym);
       }
     }
     __syncthreads();
@@ -889,14 +941,47 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
       __syncthreads();
     }
     LAP(5);
+    // -- E (first half): the merged-away cluster leaves the list, the rebuilt marks are taken back -- under the
+    // ordered part, which names clusters, not positions, from here on (the symmetric path, rare, keeps the list
+    // until it is through)
+    const bool sym_now = sh.use_sym != 0;
+    int nxt[MAXQ];
+    auto erase_read = [&]() {
+      const int ipos = sh.ipos;
+#pragma unroll
+      for (int q = 0; q < MAXQ; q++) {
+        const int ik = q * MM_BLOCK + tid;
+        nxt[q] = (ik >= ipos && ik + 1 < n) ? (int)st.ci[ik + 1] : -1;
+      }
+      for (int u = tid; u < nupd; u += MM_BLOCK) st.flag[st.ci[sh.upd[u] & 0xffffu]] = 0;
+    };
+    auto erase_write = [&]() {
+#pragma unroll
+      for (int q = 0; q < MAXQ; q++)
+        if (nxt[q] >= 0) st.ci[q * MM_BLOCK + tid] = (idx_t)nxt[q];
+      if (tid == 0) sh.n = n - 1;
+    };
+    // The best among the clusters that keep their candidate (a copy taken before the draws: they may still
+    // change such a cluster's candidate, behind its turn)
+    float ud = INF, ud2 = INF;
+    int upos = n, bl1 = -1, bl2 = -1;
     if (wave == 0) {
-      // The best among the clusters that keep their candidate (a copy taken before the draws: they may still
-      // change such a cluster's candidate, behind its turn)
-      float ud = lane < MM_WAVES ? sh.lex_d[lane] : INF, ud2 = lane < MM_WAVES ? sh.lex_d2[lane] : INF;
-      int upos = lane < MM_WAVES ? sh.lex_p[lane] : n;
+      ud = lane < MM_WAVES ? sh.lex_d[lane] : INF;
+      ud2 = lane < MM_WAVES ? sh.lex_d2[lane] : INF;
+      upos = lane < MM_WAVES ? sh.lex_p[lane] : n;
       wave_lex_min(ud, ud2, upos);
-      const int bl1 = upos < n ? (int)st.lin1[st.ci[upos]] : -1;
-      const int bl2 = upos < n ? (int)st.lin2[st.ci[upos]] : -1;
+      if (upos < n) {
+        const int kb = st.ci[upos];
+        bl1 = st.lin1[kb];
+        bl2 = st.lin2[kb];
+      }
+    }
+    if (!sym_now) {
+      erase_read();
+      __syncthreads();
+      erase_write();
+    }
+    if (wave == 0) {
       // the clusters whose candidates change, at their turn: after their own pairs
       float sd = INF, sd2 = INF;
       int sl1 = -1, sl2 = -1, spos = n;
@@ -975,7 +1060,6 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
       if (lane == 0) {
         sh.best = b;
         st.csz[j] = (idx_t)(szi + szj);
-        p.convert_index[j] = num_nodes;
         sh.nupd = 0;
         sh.npairs = 0;
       }
@@ -1080,24 +1164,13 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
         sh.best_sym = b;
       }
     }
-    __syncthreads();
-    LAP(7);
-    // -- E: the merged-away cluster leaves the list; the rebuilt marks are taken back
-    {
-      const int ipos = sh.ipos;
-      int nxt[MAXQ];
-#pragma unroll
-      for (int q = 0; q < MAXQ; q++) {
-        const int ik = q * MM_BLOCK + tid;
-        nxt[q] = (ik >= ipos && ik + 1 < n) ? (int)st.ci[ik + 1] : -1;
-      }
-      for (int u = tid; u < nupd; u += MM_BLOCK) st.flag[st.ci[sh.upd[u] & 0xffffu]] = 0;
+    if (sym_now) {
       __syncthreads();
-#pragma unroll
-      for (int q = 0; q < MAXQ; q++)
-        if (nxt[q] >= 0) st.ci[q * MM_BLOCK + tid] = (idx_t)nxt[q];
+      erase_read();
+      __syncthreads();
+      erase_write();
     }
-    if (tid == 0) sh.n = n - 1;
+    LAP(7);
     __syncthreads();
     LAP(8);
   }
@@ -1299,7 +1372,7 @@ class BuildDispatcher {
 
  private:
   explicit BuildDispatcher(int device) : device_(device) {
-    for (int t = 0; t < 3; t++) workers_.emplace_back([this] { worker(); });
+    for (int t = 0; t < 6; t++) workers_.emplace_back([this] { worker(); });
     for (auto &w : workers_) w.detach();
   }
   void worker() {
@@ -1322,7 +1395,7 @@ class BuildDispatcher {
         // The builders that are not being served right now are about to ask too (they come in bursts, after a
         // launch completes and their hosts have prepared the next matrices): wait for them a little, a launch
         // takes as long as its slowest tree however many it carries.
-        const auto until = std::chrono::steady_clock::now() + std::chrono::milliseconds(40);
+        const auto until = std::chrono::steady_clock::now() + std::chrono::milliseconds(6);
         while ((int)pending_.size() < builders_ - inflight_ && std::chrono::steady_clock::now() < until) {
           lk.unlock();
           std::this_thread::sleep_for(std::chrono::milliseconds(1));
@@ -1522,13 +1595,11 @@ int DeviceMinMatch::build_impl(MinMatch &tb, const float *d, const float *prior_
   p.mc_lin2 = q + N;
   p.cluster_index = q + 2 * (size_t)N;
   p.cluster_size = q + 3 * (size_t)N;
-  p.convert_index = q + 4 * (size_t)N;
   p.upd_pos = q + 5 * (size_t)N;
   p.mcs_lin1 = q + 6 * (size_t)N;
   p.mcs_lin2 = q + 7 * (size_t)N;
-  p.parent = q + 8 * (size_t)N;            // [2N-1]
-  p.child_left = q + 10 * (size_t)N;       // [N-1]
-  p.child_right = q + 11 * (size_t)N;      // [N-1]
+  p.merge_i = q + 8 * (size_t)N;           // [N-1]
+  p.merge_j = q + 9 * (size_t)N;           // [N-1]
   p.kflag = m.d_flags.as<unsigned char>();
   p.pair_g = m.d_feas.as<unsigned>();
   p.pair_cap = pair_cap;
@@ -1586,16 +1657,27 @@ int DeviceMinMatch::build_impl(MinMatch &tb, const float *d, const float *prior_
     fprintf(stderr, " shader_MHz %lld\n", tk[11]);
   }
   // out: the tree and the carried state
-  std::vector<int> tr((size_t)4 * N);  // parent [2N), child_left [N), child_right [N) lie back to back
-  RL_HIP(hipMemcpyAsync(tr.data(), p.parent, ((size_t)4 * N - 1) * 4, hipMemcpyDeviceToHost, m.stream));
+  std::vector<int> tr((size_t)2 * N);  // merge_i [N), merge_j [N) lie back to back
+  RL_HIP(hipMemcpyAsync(tr.data(), p.merge_i, ((size_t)2 * N - 1) * 4, hipMemcpyDeviceToHost, m.stream));
   RL_HIP(hipMemcpyAsync(lin.data(), p.mc_lin1, (size_t)2 * N * 4, hipMemcpyDeviceToHost, m.stream));
   RL_HIP(hipMemcpyAsync(tb.min_values_CF.data(), p.min_values_CF, (size_t)N * 4, hipMemcpyDeviceToHost, m.stream));
   RL_HIP(hipStreamSynchronize(m.stream));
   tree.reset(N);
-  for (int c = 0; c < 2 * N - 1; c++) tree.parent[c] = tr[c];
-  for (int c = 0; c < N - 1; c++) {
-    tree.child_left[N + c] = tr[(size_t)2 * N + c];
-    tree.child_right[N + c] = tr[(size_t)3 * N + c];
+  {  // the nodes of the tree from the merges (tree_builder.cpp:2437-2460, 2631-2636): cluster j lives on as the new node
+    std::vector<int> node(N);
+    for (int c = 0; c < N; c++) node[c] = c;
+    for (int mth = 0; mth < N - 1; mth++) {
+      const int ci = tr[mth], cj = tr[(size_t)N + mth], nn = N + mth;
+      if (ci < 0 || ci >= N || cj < 0 || cj >= N) {
+        set_error("tree builder on the device: merge %d names clusters %d and %d", mth, ci, cj);
+        return -1;
+      }
+      tree.parent[node[ci]] = nn;
+      tree.parent[node[cj]] = nn;
+      tree.child_left[nn] = node[ci];
+      tree.child_right[nn] = node[cj];
+      node[cj] = nn;
+    }
   }
   for (int c = 0; c < N; c++) {
     tb.mc[c].lin1 = lin[c];

@@ -617,7 +617,11 @@ int rl_treeseq_write(const rl_treeseq *ts, const char *anc_path, const char *mut
       }
       fwrite(buf.data(), 1, buf.size(), fp);
     }
-    fclose(fp);
+    const bool bad = ferror(fp) != 0;
+    if (fclose(fp) != 0 || bad) {  // (a full disc must not pass for a tree sequence)
+      set_error("writing %s failed", anc_path);
+      return RL_EIO;
+    }
   }
   if (mut_path) {
     FILE *fp = fopen(mut_path, "w");
@@ -632,7 +636,11 @@ int rl_treeseq_write(const rl_treeseq *ts, const char *anc_path, const char *mut
       fputs(si.branch.size() > 1 ? ";1;" : ";0;", fp);
       fprintf(fp, "%d;0;0;\n", si.flipped ? 1 : 0);
     }
-    fclose(fp);
+    const bool bad = ferror(fp) != 0;
+    if (fclose(fp) != 0 || bad) {
+      set_error("writing %s failed", mut_path);
+      return RL_EIO;
+    }
   }
   return RL_OK;
 }
@@ -717,17 +725,27 @@ int rl_stage_build_topology(const char *out_dir, int chunk_index, int first_sect
   const size_t sl = base.find_last_of('/');
   if (sl != std::string::npos) base = base.substr(sl + 1);
   std::vector<int> bp(L, 0), state(L, 1);
-  auto read_ints = [&](const std::string &fn, std::vector<int> &v) {
+  // chunk_<c>.bp / .state (data.cpp:485-516, :307-345): --fb and the mapping of transitions read them; a missing or
+  // short file would give wrong trees without a word
+  auto read_ints = [&](const std::string &fn, std::vector<int> &v) -> int {
     FILE *fp = fopen(fn.c_str(), "rb");
-    if (!fp) return;
-    int n = 0;
-    if (fread(&n, 4, 1, fp) == 1 && n == L) {
-      if (fread(v.data(), 4, (size_t)L, fp) != (size_t)L) v.assign(L, v[0]);
+    if (!fp) {
+      set_error("cannot open %s", fn.c_str());
+      return RL_EIO;
     }
+    int n = 0;
+    const bool ok = fread(&n, 4, 1, fp) == 1 && n == L && fread(v.data(), 4, (size_t)L, fp) == (size_t)L;
     fclose(fp);
+    if (!ok) {
+      set_error("%s does not hold %d values", fn.c_str(), L);
+      return RL_EFORMAT;
+    }
+    return RL_OK;
   };
-  read_ints(od + "/chunk_" + c + ".bp", bp);
-  read_ints(od + "/chunk_" + c + ".state", state);
+  if ((rc = read_ints(od + "/chunk_" + c + ".bp", bp)) || (rc = read_ints(od + "/chunk_" + c + ".state", state))) {
+    rl_destroy(ctx);
+    return rc;
+  }
   std::cerr << "---------------------------------------------------------" << std::endl;
   std::cerr << "Estimating topologies of AncesTrees in sections " << first_section << "-" << last_section << "..."
             << std::endl;
@@ -753,13 +771,22 @@ int rl_stage_build_topology(const char *out_dir, int chunk_index, int first_sect
     }
     max_rows = std::max(max_rows, rows_of[w]);
   }
-  // stones + matrix + cursors next to the rows; RePaint's strips are one buffer of the context (reserved below)
-  const double fixed_bytes = 3.0 * 4.0 * ctx->N * ctx->nloc + 4.0 * max_rows + 64e6;
+  // The trees themselves are built on the GPU too (minmatch_gpu.hip) when the call covers several sections: a tree
+  // takes one workgroup ~115 ms at N = 5000 against ~85 ms on 8 host threads, but the workgroups of different
+  // sections run side by side (40 sections: 98 s against 331 s).  RELATE_AMD_GPU_BUILD=0 / 1 decides otherwise.
+  const bool gpu_build = getenv("RELATE_AMD_GPU_BUILD") ? atoi(getenv("RELATE_AMD_GPU_BUILD")) != 0
+                                                        : last_section > first_section;
+  // stones + matrix + cursors next to the rows; RePaint's strips are one buffer of the context (reserved below);
+  // a tree builder on the device keeps the distance matrix, the prior, the symmetric matrix and the woven float4
+  // matrix of the build (minmatch_gpu.hip): 7 N^2 floats and change
+  const double fixed_bytes = 3.0 * 4.0 * ctx->N * ctx->nloc + 4.0 * max_rows + 64e6 +
+                             (gpu_build ? 29.0 * ctx->N * (ctx->N + 64.0) : 0.0);
   auto window_bytes = [&](int w) {
     const double kept = cap_rows > 0 ? std::min(rows_of[w], (double)cap_rows) : rows_of[w];
     return kept * row_bytes + fixed_bytes;
   };
-  int nthreads = std::max(1, std::min(host_threads() / 2, 64));
+  // (section threads of device builds mostly wait for their tree: as many as there are CUs to build on)
+  int nthreads = gpu_build ? 256 : std::max(1, std::min(host_threads() / 2, 64));
   if (const char *e = getenv("RELATE_AMD_SECTION_THREADS")) nthreads = std::max(1, atoi(e));
   nthreads = std::min(nthreads, last_section - first_section + 1);
   int concurrent = nthreads;
@@ -791,11 +818,16 @@ int rl_stage_build_topology(const char *out_dir, int chunk_index, int first_sect
   // core stalls every merge, so they get a quarter of the physical cores at most: measured on 2 x 64 cores with 8
   // sections open, 4 helpers each finished in 109 s, 8 in 177 s, none in 165 s.
   set_build_threads(std::min(8, std::max(1, host_threads() / (8 * std::max(1, concurrent)))));
-  // RELATE_AMD_GPU_BUILD=1: the trees themselves are built on the GPU too (minmatch_gpu.hip)
-  const bool gpu_build = getenv("RELATE_AMD_GPU_BUILD") && atoi(getenv("RELATE_AMD_GPU_BUILD")) != 0;
   std::atomic<int> open_sections(0);
   std::atomic<int> next(first_section);
   std::atomic<int> first_error(0);
+  std::mutex err_mutex;
+  std::string first_message;  // (rl_last_error is per thread: the failing worker's text is carried to the caller)
+  auto fail = [&](int code) {
+    std::lock_guard<std::mutex> lk(err_mutex);
+    int expected = 0;
+    if (first_error.compare_exchange_strong(expected, code)) first_message = rl_last_error();
+  };
   const std::vector<cpu_set_t> groups = cache_groups();
   std::atomic<int> next_slot(0);
   auto worker = [&]() {
@@ -810,7 +842,7 @@ int rl_stage_build_topology(const char *out_dir, int chunk_index, int first_sect
     rl_treeseq *ts = rl_treeseq_create(ctx->N, L, ctx->bits.data(), ctx->row_words, ctx->rpos.data(), bp.data(),
                                        state.data(), ctx->theta);
     if (!ts) {
-      first_error = RL_EINVAL;
+      fail(RL_EINVAL);
       if (pinned) sched_setaffinity(0, sizeof(before), &before);
       return;
     }
@@ -853,8 +885,7 @@ int rl_stage_build_topology(const char *out_dir, int chunk_index, int first_sect
         r = rl_treeseq_write(ts, (b + ".anc").c_str(), (b + ".mut").c_str());
       }
       if (r) {
-        int expected = 0;
-        first_error.compare_exchange_strong(expected, r);
+        fail(r);
         break;
       }
       std::cerr << "[" << section << "/" << last_section << "]\r";
@@ -871,6 +902,7 @@ int rl_stage_build_topology(const char *out_dir, int chunk_index, int first_sect
     for (auto &x : th) x.join();
   }
   rc = first_error.load();
+  if (rc) set_error("%s", first_message.c_str());
   rl_destroy(ctx);
   if (!rc) {
     rusage usage;

@@ -58,7 +58,9 @@ def test_tied_matrices_with_and_without_prior(N, seed):
     for t in range(3):  # row minima of the prior rise from tree to tree: the minima carried over stay below them
         mats.append((tied_matrix(rng, N), ((np.floor(rng.rand(N, N) * 4) + t) * 6.9).astype(np.float32)))
     mats.append((tied_matrix(rng, N, 0.0), None))
-    run_sequence(N, mats)
+    # (a quarter of all pairs are candidates in these matrices: from N = 130 on a row has more mutually close
+    #  partners than the pair scan keeps -- MM_HITS -- and such a tree is the host's)
+    run_sequence(N, mats, all_on_gpu=N < 130)
 
 
 @pytest.mark.parametrize("N,seed", [(90, 7), (400, 8), (1500, 9)])
