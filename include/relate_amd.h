@@ -220,6 +220,9 @@ typedef struct rl_builder rl_builder;
 rl_builder *rl_builder_create(int N, double theta, int device);
 int rl_builder_build(rl_builder *b, float *d, const float *d_prior,
                      int *parent, int *child_left, int *child_right);
+/* MinMatch::QuickBuild's sample_ages (N doubles): from here on the builder's trees are built with the sample-age
+ * key and clock of src/tree_builder.cpp:1123-1233 / :2407-2531, on the host. */
+int rl_builder_set_sample_ages(rl_builder *b, const double *ages, int n);
 int rl_builder_last_on_gpu(const rl_builder *b);
 void rl_builder_destroy(rl_builder *b);
 /* Test hook (host only): the device builder's restatement of std::mt19937 +
@@ -247,6 +250,9 @@ rl_treeseq *rl_treeseq_create(int N, int L, const uint32_t *bits, int row_words,
                               const double *rpos, const int *bp_pos,
                               const int *state, double theta);
 void rl_treeseq_destroy(rl_treeseq *ts);
+/* sample ages (N doubles; n = 0: none) for the trees of rl_treeseq_build: MinMatch::QuickBuild's sample_ages argument
+ * (src/anc_builder.cpp:373-390). */
+int rl_treeseq_set_sample_ages(rl_treeseq *ts, const double *ages, int n);
 /* device >= 0: rl_treeseq_build builds its trees on that GPU (see rl_builder_create),
  * < 0 (default): on the host. */
 int rl_treeseq_set_build_device(rl_treeseq *ts, int device);
@@ -271,6 +277,24 @@ int rl_treeseq_write(const rl_treeseq *ts, const char *anc_path,
  * <out>/chunk_<c>/<out>_<section>.anc and .mut.
  * flags: bit0 = --no_consistency, fb = --fb value (0 = off). */
 int rl_stage_build_topology(const char *out_dir, int chunk_index,
+                            int first_section, int last_section,
+                            int use_painting, double theta, double rho,
+                            int flags, int fb, int sum_mode, int device);
+
+/* `--sample_ages <file>` of BuildTopology (pipeline/BuildTopology.cpp:93-108; ancient samples): the file (plain or
+ * gzip text, one age per haplotype) the FOLLOWING rl_stage_build_topology / rl_stage_paint_build_topology calls of
+ * this process read; NULL or "" for none.  With ages the trees are built by the host's sequential restatement of
+ * MinMatch's third candidate key and coalescence clock (src/tree_builder.cpp:7-22, 149-252, 601-965, 1123-1233,
+ * 1738-1841, 2073-2355, 2407-2531). */
+int rl_stage_set_sample_ages(const char *file);
+
+/* Paint and BuildTopology of one chunk in one process, as `Relate --mode All` runs
+ * them back to back per chunk (pipeline/Relate.cpp:257-283): the stepping stones
+ * never leave HBM -- no chunk_<c>/paint/relate_<w>.bin (2.4 GB per 20 windows at
+ * N = 5000) is written or read; the float / run-length quantisation the file
+ * would apply (src/collapsed_matrix.hpp:228-296) is applied on the device.  Same
+ * .anc / .mut as rl_stage_paint followed by rl_stage_build_topology. */
+int rl_stage_paint_build_topology(const char *out_dir, int chunk_index,
                             int first_section, int last_section,
                             int use_painting, double theta, double rho,
                             int flags, int fb, int sum_mode, int device);

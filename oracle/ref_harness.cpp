@@ -107,6 +107,44 @@ int main(int argc, char **argv) {
     return 0;
   }
 
+  if (mode == "quickbuild_seq_ages") {
+    // ref_harness quickbuild_seq_ages <N> <parents.out> <ages.bin: N doubles> (<d.bin> <prior.bin|->)...
+    // as quickbuild_seq, with MinMatch::QuickBuild's sample_ages (ancient samples; Ne as BuildTopology.cpp:36 sets it)
+    int N = atoi(argv[2]);
+    Data data(N, 1);
+    data.Ne = std::max(17.5f * data.N, 30000.0f);
+    MinMatch tb(data);
+    std::vector<double> ages(N);
+    FILE *fa = fopen(argv[4], "rb");
+    if (!fa || fread(&ages[0], 8, (size_t)N, fa) != (size_t)N) return 1;
+    fclose(fa);
+    FILE *fo = fopen(argv[3], "wb");
+    if (!fo) return 1;
+    for (int a = 5; a + 1 < argc; a += 2) {
+      CollapsedMatrix<float> d, prior;
+      d.resize(N, N);
+      FILE *fp = fopen(argv[a], "rb");
+      if (!fp || fread(&d[0][0], 4, (size_t)N * N, fp) != (size_t)N * N) return 1;
+      fclose(fp);
+      Tree tree;
+      if (std::string(argv[a + 1]) != "-") {
+        prior.resize(N, N);
+        fp = fopen(argv[a + 1], "rb");
+        if (!fp || fread(&prior[0][0], 4, (size_t)N * N, fp) != (size_t)N * N) return 1;
+        fclose(fp);
+        tb.QuickBuild(d, tree, ages, prior);
+      } else {
+        tb.QuickBuild(d, tree, ages);
+      }
+      for (int i = 0; i < 2 * N - 1; i++) {
+        int p = tree.nodes[i].parent ? (*tree.nodes[i].parent).label : -1;
+        fwrite(&p, 4, 1, fo);
+      }
+    }
+    fclose(fo);
+    return 0;
+  }
+
   if (mode == "quickbuild") {
     int N = atoi(argv[2]);
     Data data(N, 1);

@@ -283,6 +283,10 @@ class Builder:
         _check(lib().rl_builder_build(C.c_void_p(self._h), _p(d), _p(pr), _p(parent), _p(cl), _p(cr)))
         return parent, cl, cr
 
+    def set_sample_ages(self, ages):
+        ages = np.ascontiguousarray(ages, dtype=np.float64)
+        _check(lib().rl_builder_set_sample_ages(C.c_void_p(self._h), _p(ages), len(ages)))
+
     @property
     def last_on_gpu(self):
         return lib().rl_builder_last_on_gpu(C.c_void_p(self._h)) == 1
@@ -307,6 +311,16 @@ def stage_build_topology(out_dir, chunk_index, first_section, last_section, pain
     _check(lib().rl_stage_build_topology(out_dir.encode(), chunk_index, first_section, last_section,
                                          1 if painting else 0, th, rho, 1 if no_consistency else 0, fb,
                                          sum_mode, device))
+
+
+def stage_paint_build_topology(out_dir, chunk_index, first_section, last_section, painting=None,
+                               no_consistency=False, fb=0, sum_mode=RL_SUM_EXACT, device=0):
+    """Paint + BuildTopology of a chunk with the stepping stones kept in HBM (no paint files)"""
+    th, rho = painting if painting else (0.001, 1.0)
+    f = lib().rl_stage_paint_build_topology
+    f.argtypes = lib().rl_stage_build_topology.argtypes
+    _check(f(out_dir.encode(), chunk_index, first_section, last_section, 1 if painting else 0, th, rho,
+             1 if no_consistency else 0, fb, sum_mode, device))
 
 
 def stage_find_equivalent_branches(out_dir, chunk_index=0):

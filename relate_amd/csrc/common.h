@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -101,6 +102,9 @@ struct rl_ctx {
   rl::DevBuf d_k2_scratch, d_k2_counter;  // RePaint's per-launch strips, shared by the context's windows (window.cpp)
   bool have_chunk = false, plan_on_device = false, painted = false;
   int paint_mode = -1;
+  // RePaint launches of the context's windows share the forward strips, the target counter and stream s0: one at a
+  // time (the windows' other work -- distance matrices -- runs on their own streams, side by side)
+  std::mutex repaint_mutex;
   float ms_fwd = 0.f, ms_bwd = 0.f, ms_paint = 0.f;
   int paint_split = 0;  // rl_set_paint_split: one launch per direction instead of one for both
 };

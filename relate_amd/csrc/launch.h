@@ -71,6 +71,8 @@ inline hipError_t launch_repaint(const RepaintParams &p, int S, int waves, int n
     default: return launch_repaint_mode<2>(p, S, waves, nblocks, counter, stream);
   }
 }
+// the paint file's run-length quantisation of `rows` stones of N floats, in place (panel_kernels.hip)
+hipError_t launch_quantise(float *stones, int rows, int N, hipStream_t stream);
 hipError_t launch_matrix(const MatrixParams &p, const Layout &lay, int S, int waves, hipStream_t stream);
 
 }  // namespace rl

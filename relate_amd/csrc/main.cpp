@@ -31,7 +31,7 @@ static void usage_line() {
 int main(int argc, char **argv) {
   // BuildTopology keeps several tree-builder launches and window kernels in flight from its section threads: more
   // hardware queues than HIP's default four (read when the runtime starts; an explicit setting wins)
-  setenv("GPU_MAX_HW_QUEUES", "16", 0);
+  setenv("GPU_MAX_HW_QUEUES", "24", 0);
   // option table of Relate.cpp:19-45 restricted to what the two modes read
   const std::map<std::string, bool> known = {  // name -> takes a value
       {"mode", true}, {"chunk_index", true}, {"first_section", true}, {"last_section", true},
@@ -145,16 +145,23 @@ int main(int argc, char **argv) {
     std::cerr << "Painting sequences..." << std::endl;
     rc = rl_stage_paint(out.c_str(), chunk, use_painting, theta, rho, sum_mode, device);
     if (rc == 0) usage_line();
+  } else if (mode == "PaintBuildTopology") {
+    // Paint + BuildTopology of the chunk in one process, the stepping stones kept in HBM: what `--mode All` does per
+    // chunk (Relate.cpp:257-283) without the paint files.  Sections default to all of the chunk's.
+    if (opt.count("sample_ages")) rl_stage_set_sample_ages(opt["sample_ages"].c_str());
+    const int flags = opt.count("no_consistency") ? 1 : 0;
+    const int fb = opt.count("fb") ? (int)std::stof(opt["fb"]) : 0;
+    rc = rl_stage_paint_build_topology(out.c_str(), chunk, opt.count("first_section") ? atoi(opt["first_section"].c_str()) : 0,
+                                       opt.count("last_section") ? atoi(opt["last_section"].c_str()) : 1 << 30,
+                                       use_painting, theta, rho, flags, fb, sum_mode, device);
+    if (rc == 1) return 1;
   } else if (mode == "BuildTopology") {
     if (!opt.count("first_section") || !opt.count("last_section")) {
       std::cerr << "Not enough arguments supplied." << std::endl;
       std::cerr << "Needed: first_section, last_section." << std::endl;
       return 1;
     }
-    if (opt.count("sample_ages")) {
-      std::cerr << "--sample_ages is not supported by this build (use the reference binary)." << std::endl;
-      return 1;
-    }
+    if (opt.count("sample_ages")) rl_stage_set_sample_ages(opt["sample_ages"].c_str());  // BuildTopology.cpp:93-108
     const int flags = opt.count("no_consistency") ? 1 : 0;
     const int fb = opt.count("fb") ? (int)std::stof(opt["fb"]) : 0;  // BuildTopology.cpp:111-114
     rc = rl_stage_build_topology(out.c_str(), chunk, atoi(opt["first_section"].c_str()),

@@ -159,6 +159,51 @@ class MinMatch {
   size_t min_parallel = 512;
 };
 
+// MinMatch::QuickBuild with sample ages (`--sample_ages`; minmatch_ages.cpp): the candidates carry the older of the two
+// sample ages as a third key, gated by an expected-coalescence clock.  Sequential, stateful across builds where the
+// reference is (min_values_CF, the unique-age table, the `cand` scratch candidate).
+class MinMatchAges {
+ public:
+  MinMatchAges(int N, double theta);
+  // d: N*N floats, destroyed.  prior: N*N floats or nullptr.  sample_ages: N values.
+  void quick_build(float *d, const float *prior, const std::vector<double> &sample_ages, HostTree &tree);
+
+ private:
+  struct Cand {
+    int lin1 = -1, lin2 = -1;
+    double dist = std::numeric_limits<float>::infinity();
+    double dist2 = std::numeric_limits<float>::infinity();
+    double dist3 = std::numeric_limits<float>::infinity();
+    bool replace = false;
+  };
+  static bool gt(const Cand &a, const Cand &b);
+  void offer(int slot, int lin1, int lin2);
+  void consider(int x, int y, float sym, const std::vector<double> &ages);
+  void take_best(const Cand &m);
+  float sym_of(int x, int y) const;
+  void initialize(const std::vector<double> &ages);
+  void initialize_sym();
+  void coalesce(int i, int j, const std::vector<double> &ages);
+  void coalesce_sym(int i, int j);
+  inline float &d(int a, int b) { return D[(size_t)a * N + b]; }
+
+  int N, Ne;
+  float threshold, threshold_CF;
+  std::mt19937 rng;
+  std::uniform_real_distribution<double> unif{0.0, 1.0};
+  std::vector<int> cluster_index, convert_index, updated_cluster;
+  std::vector<float> cluster_size;
+  std::vector<Cand> mc, mc_sym;
+  Cand best, best_sym, cand;
+  double age = 0.0;
+  std::vector<double> unique_ages;
+  std::vector<int> ages_count;
+  std::vector<float> min_values, min_values_sym, min_values_CF;
+  std::vector<float> sym_d, d_CF;
+  float *D = nullptr;
+  const float *CF = nullptr;
+};
+
 // The same builder on the GPU (minmatch_gpu.hip): one workgroup per tree, matrices in HBM.  build() takes the
 // state a MinMatch carries from tree to tree from `tb` and puts it back, so the two can alternate: it returns
 // 0 when the tree is built, > 0 when this tree needs the host (symmetric fallback; tb untouched), < 0 on error.

@@ -17,10 +17,12 @@
 // out after every build, so host and device builders can alternate on a section.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstdint>
+#include <memory>
 #include <mutex>
 #include <random>
 #include <thread>
@@ -82,6 +84,9 @@ struct MMParams {
   int *rowlist;         // [MM_WAVES][N] pair-scan survivors per wave
   int *merge_i, *merge_j;  // [N-1] the merges as (cluster i, cluster j) in order; the host names the tree's nodes from them
   int *status;
+  // (pinned host memory, or null) the status again, stored when everything else of the tree is out and flushed: the
+  // builder's host thread watches it and takes its tree while the launch's other workgroups still build theirs
+  volatile int *host_done;
   long long pair_cap;
   long long *timers;  // optional: 100 MHz ticks per phase (RELATE_AMD_TIMING)
 };
@@ -540,7 +545,10 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
       // (initialize_sym, tree_builder.cpp:255-293): s(a,l) = d(a,l) + d(l,a) over the live clusters, row minima
       // with the first cluster that reaches them, the smallest of those (first row, first cluster)
       if (!p.SYM) {  // (the caller gave no room for it)
-        if (tid == 0) *p.status = 1;
+        if (tid == 0) {
+          *p.status = 1;
+          if (p.host_done) *p.host_done = 1;
+        }
         return;
       }
       float bs = INF;
@@ -617,19 +625,32 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
       a_k[q] = ik < n ? (int)st.ci[ik] : -1;
 
     }
+    constexpr int QC = MAXQ <= 10 ? MAXQ : 10;  // clusters per pass: all of them when the state is in LDS
 #pragma unroll
-    for (int q0 = 0; q0 < MAXQ; q0 += 5) {
+    for (int q0 = 0; q0 < MAXQ; q0 += QC) {
       if (q0 * MM_BLOCK >= n) break;
-      float4 ei[5], ej[5];
+      // every load of the pass first: the two rows from memory, then -- under their latency -- the clusters' state
+      float4 ei[QC], ej[QC];
 #pragma unroll
-      for (int qq = 0; qq < 5; qq++) {  // (every load of the five issued before the first store)
+      for (int qq = 0; qq < QC; qq++) {
         const int k = a_k[q0 + qq];
         if (k < 0 || k == j || k == i) continue;
         ei[qq] = MM(i, k);
         ej[qq] = MM(j, k);
       }
+      float s_mv[QC], s_d1[QC], s_d2[QC];
+      int s_l1[QC], s_l2[QC];
 #pragma unroll
-      for (int qq = 0; qq < 5; qq++) {
+      for (int qq = 0; qq < QC; qq++) {
+        const int k = a_k[q0 + qq] >= 0 ? a_k[q0 + qq] : 0;
+        s_mv[qq] = st.mv[k];
+        s_l1[qq] = st.lin1[k];
+        s_l2[qq] = st.lin2[k];
+        s_d1[qq] = st.mcd[k];
+        s_d2[qq] = st.mcd2[k];
+      }
+#pragma unroll
+      for (int qq = 0; qq < QC; qq++) {
         const int q = q0 + qq;
         const int ik = q * MM_BLOCK + tid;
         const int k = a_k[q];
@@ -657,10 +678,10 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
         if (njk < mvj) mvj = njk;
         bool rescan = false;
         if (dkj != dki) {
-          const float mvk = st.mv[k];
+          const float mvk = s_mv[qq];
           rescan = (double)fabsf(mvk - threshold - dkj) < 1e-4 || (double)fabsf(mvk - threshold - dki) < 1e-4;
         }
-        const int l1 = st.lin1[k], l2 = st.lin2[k];
+        const int l1 = s_l1[qq], l2 = s_l2[qq];
         const bool touches = l1 == j || l2 == j || l1 == i || l2 == i;
         if (rescan || touches) {  // k rebuilds its candidates (:1893-1911)
           st.flag[k] = 1;
@@ -672,7 +693,7 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
             sh.updv[slot] = nkj;
           }
         } else {  // k keeps its candidate: what the reference's running best sees at k's turn
-          const float d1 = st.mcd[k], d2 = st.mcd2[k];
+          const float d1 = s_d1[qq], d2 = s_d2[qq];
           if (bd > d1 || (bd == d1 && bd2 > d2)) {  // (ascending positions per thread: the first one wins)
             bd = d1;
             bd2 = d2;
@@ -703,7 +724,10 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
     mvcf_j += threshold_CF;
     const int nupd = sh.nupd;
     if (nupd > MM_UPD_MAX) {  // (degenerate matrices: this tree is the host's)
-      if (tid == 0) *p.status = 2;
+      if (tid == 0) {
+        *p.status = 2;
+        if (p.host_done) *p.host_done = 2;
+      }
       return;
     }
 
@@ -712,6 +736,12 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
     // any smaller entry, else the row's minimum", three reductions finished by one wave per row --, then the
     // candidate tests of every pair a rebuilt cluster is part of (:1893-1911 for the clusters before it, :1913-2018
     // for the ones behind it), on the same registers when the merge has no more than ROWS rebuilt clusters.
+    float2 cj[MAXQ];  // row j of M as this thread wrote it in A, (d(j,k), d(k,j)): asked for now, used in C
+#pragma unroll
+    for (int q = 0; q < MAXQ; q++) {
+      const int k = a_k[q];
+      cj[q] = (k >= 0 && k != i && k != j) ? MM2(j, k) : make_float2(INF, INF);
+    }
     float v[ROWS][MAXQ], w[ROWS][MAXQ];
     auto load_rows = [&](const int (&ks)[ROWS]) {
 #pragma unroll
@@ -771,17 +801,17 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
       }
       __syncthreads();
     };
-    auto append_pair = [&](unsigned key, int x, int y, float sym) {
+    // (a feasible pair: its symmetric distance is worked out when the pairs are put in order -- one more element of
+    //  M per pair, fetched for all pairs at once)
+    auto append_pair = [&](unsigned key, int x, int y) {
       const int slot = atomicAdd(&sh.npairs, 1);
       if (slot < MM_PAIRS_LDS) {
         sh.pk[0][slot] = key;
         sh.pxy[0][slot] = ((unsigned)x << 16) | (unsigned)y;
-        sh.psym[0][slot] = sym;
       } else if (slot - MM_PAIRS_LDS < p.pair_cap) {
         unsigned *g = p.pair_g + (size_t)(slot - MM_PAIRS_LDS) * 3;
         g[0] = key;
         g[1] = ((unsigned)x << 16) | (unsigned)y;
-        g[2] = __float_as_uint(sym);
       }
     };
     // candidate tests of the rows u0 .. u0+ROWS-1 of the list, held in v / w
@@ -811,13 +841,10 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
         const int r = bit / MAXQ, q = bit - r * MAXQ;
         const int il = q * MM_BLOCK + tid, l = st.ci[il];
         const int up = (int)(sh.upd[u0 + r] & 0xffffu), ku = st.ci[up];
-        const float4 e = MM(ku, l);  // (d(ku,l), d(l,ku), cf(ku,l), cf(l,ku))
-        float sym = e.y + e.x;
-        if (p.has_prior && e.z <= st.mvcf[ku] && e.w <= st.mvcf[l]) sym = 0.0f;
         if (il < up)  // the rebuilt cluster meets the clusters before it
-          append_pair(((unsigned)up << 16) | (unsigned)il, ku, l, sym);
+          append_pair(((unsigned)up << 16) | (unsigned)il, ku, l);
         else
-          append_pair(((unsigned)il << 16) | (unsigned)up, l, ku, sym);
+          append_pair(((unsigned)il << 16) | (unsigned)up, l, ku);
       }
     };
     if (nupd <= ROWS && !(p.debug & 1)) {  // (the usual case) one pass
@@ -872,29 +899,20 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
         test_rows(u0);
       }
     }
-    // -- C: candidates with the merged cluster j, behind all others (:2033-2064); its row as this thread wrote it in A
+    // -- C: candidates with the merged cluster j, behind all others (:2033-2064)
     {
-      float2 ej[MAXQ];
       unsigned cand = 0;
 #pragma unroll
       for (int q = 0; q < MAXQ; q++) {
         const int k = a_k[q];
-        ej[q] = (k >= 0 && k != i && k != j) ? MM2(j, k) : make_float2(INF, INF);  // (d(j,k), d(k,j))
-      }
-#pragma unroll
-      for (int q = 0; q < MAXQ; q++) {
-        const int k = a_k[q];
-        const bool ok = k >= 0 && k != i && k != j && ej[q].x <= min_value_j && ej[q].y <= st.mv[k];
+        const bool ok = k >= 0 && k != i && k != j && cj[q].x <= min_value_j && cj[q].y <= st.mv[k];
         cand |= ok ? 1u << q : 0u;
       }
       while (cand) {  // (few)
         const int q = __ffs((int)cand) - 1;
         cand &= cand - 1;
-        const int ik = q * MM_BLOCK + tid, k = st.ci[ik];
-        const float4 e = MM(j, k);  // (d(j,k), d(k,j), cf(j,k), cf(k,j))
-        float sym = e.x + e.y;
-        if (p.has_prior && e.w <= st.mvcf[k] && e.z <= mvcf_j) sym = 0.0f;
-        append_pair(0x80000000u | (unsigned)ik, k, j, sym);
+        const int ik = q * MM_BLOCK + tid;
+        append_pair(0x80000000u | (unsigned)ik, st.ci[ik], j);
       }
     }
     __syncthreads();
@@ -902,7 +920,10 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
     // -- D: the pairs in the reference's order
     const int m = sh.npairs;
     if (m - MM_PAIRS_LDS > p.pair_cap) {
-      if (tid == 0) *p.status = 2;
+      if (tid == 0) {
+        *p.status = 2;
+        if (p.host_done) *p.host_done = 2;
+      }
       return;
     }
     auto pair_at = [&](int side, int e, unsigned &key, unsigned &xy, float &sym) {
@@ -917,16 +938,23 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
         sym = __uint_as_float(g[2]);
       }
     };
-    const int side = m > 1 ? 1 : 0;
-    if (m > 1) {
+    // Every pair's symmetric distance (tree_builder.cpp:1699-1702): d(y,x) + d(x,y), or 0 when the pair is also
+    // mutually closest under the prior -- one element M[x][y] per pair, all pairs at once -- and its place in the
+    // reference's order (rank = number of smaller keys).
+    const int side = m > 0 ? 1 : 0;
+    if (m > 0) {
       for (int e = tid; e < m; e += MM_BLOCK) {
         unsigned key, xy;
         float sym;
         pair_at(0, e, key, xy, sym);
+        const int x = (int)(xy >> 16), y = (int)(xy & 0xffffu);
+        const float4 f = MM(x, y);  // (d(x,y), d(y,x), cf(x,y), cf(y,x))
         int rank = 0;
         const int ml = min(m, MM_PAIRS_LDS);
-        for (int f = 0; f < ml; f++) rank += sh.pk[0][f] < key ? 1 : 0;
-        for (int f = MM_PAIRS_LDS; f < m; f++) rank += p.pair_g[(size_t)(f - MM_PAIRS_LDS) * 3] < key ? 1 : 0;
+        for (int g = 0; g < ml; g++) rank += sh.pk[0][g] < key ? 1 : 0;
+        for (int g = MM_PAIRS_LDS; g < m; g++) rank += p.pair_g[(size_t)(g - MM_PAIRS_LDS) * 3] < key ? 1 : 0;
+        sym = f.y + f.x;
+        if (p.has_prior && f.z <= st.mvcf[x] && f.w <= (y == j ? mvcf_j : st.mvcf[y])) sym = 0.0f;
         if (rank < MM_PAIRS_LDS) {
           sh.pk[1][rank] = key;
           sh.pxy[1][rank] = xy;
@@ -940,6 +968,7 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
       }
       __syncthreads();
     }
+    if (p.timers && tid == 0) sh.tacc[9] += m;  // (pairs drawn)
     LAP(5);
     // -- E (first half): the merged-away cluster leaves the list, the rebuilt marks are taken back -- under the
     // ordered part, which names clusters, not positions, from here on (the symmetric path, rare, keeps the list
@@ -1188,6 +1217,14 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
       for (int x = 0; x < 12; x++) p.timers[x] = sh.tacc[x];
     }
   }
+  if (p.host_done) {  // the tree, the carried state and the status reach memory before the host hears of them
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) {
+      *p.host_done = 0;
+      __threadfence_system();
+    }
+  }
 }
 
 // M[a][b] = (d(a,b), d(b,a), cf(a,b), cf(b,a)) from the row-major matrices (cf may be null), 32 x 32 tiles
@@ -1347,7 +1384,7 @@ class BuildDispatcher {
  public:
   struct Request {
     MMParams p;
-    bool done = false;
+    std::atomic<bool> done{false};  // the launch that carried it is over
     int rc = 0;
   };
   static BuildDispatcher &of(int device) {
@@ -1362,17 +1399,32 @@ class BuildDispatcher {
     std::lock_guard<std::mutex> lk(m_);
     builders_ += delta;
   }
-  int run(Request &r) {
-    std::unique_lock<std::mutex> lk(m_);
-    pending_.push_back(&r);
+  // Hands the tree to the next launch and returns when ITS workgroup is through -- it says so in pinned host memory
+  // (p.host_done, -1 until then) -- not when the launch is: a launch lasts as long as its slowest tree.
+  int run(const std::shared_ptr<Request> &r) {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      pending_.push_back(r);
+      waiting_++;
+    }
     cv_work_.notify_one();
-    cv_done_.wait(lk, [&] { return r.done; });
-    return r.rc;
+    int rc = 0;
+    for (;;) {
+      if (r->p.host_done && *r->p.host_done != -1) break;
+      if (r->done.load(std::memory_order_acquire)) {
+        rc = r->rc;
+        break;
+      }
+      std::this_thread::sleep_for(std::chrono::microseconds(100));
+    }
+    std::lock_guard<std::mutex> lk(m_);
+    waiting_--;
+    return rc;
   }
 
  private:
   explicit BuildDispatcher(int device) : device_(device) {
-    for (int t = 0; t < 6; t++) workers_.emplace_back([this] { worker(); });
+    for (int t = 0; t < 4; t++) workers_.emplace_back([this] { worker(); });
     for (auto &w : workers_) w.detach();
   }
   void worker() {
@@ -1386,27 +1438,27 @@ class BuildDispatcher {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)a.sharedSizeBytes);
     }
     DevBuf d_params;
-    std::vector<Request *> batch;
+    std::vector<std::shared_ptr<Request>> batch;
     std::vector<MMParams> params;
     for (;;) {
       {
         std::unique_lock<std::mutex> lk(m_);
         cv_work_.wait(lk, [&] { return !pending_.empty(); });
-        // The builders that are not being served right now are about to ask too (they come in bursts, after a
-        // launch completes and their hosts have prepared the next matrices): wait for them a little, a launch
-        // takes as long as its slowest tree however many it carries.
-        const auto until = std::chrono::steady_clock::now() + std::chrono::milliseconds(6);
-        while ((int)pending_.size() < builders_ - inflight_ && std::chrono::steady_clock::now() < until) {
+        // The builders whose tree is not being built right now are about to ask too (their hosts are preparing the
+        // next matrices): wait for them a little -- concurrent launches are few (hardware queues), so a launch
+        // should carry what there is.
+        const auto until = std::chrono::steady_clock::now() + std::chrono::milliseconds(10);
+        while ((int)pending_.size() < builders_ - (waiting_ - (int)pending_.size()) &&
+               std::chrono::steady_clock::now() < until) {
           lk.unlock();
           std::this_thread::sleep_for(std::chrono::milliseconds(1));
           lk.lock();
         }
         batch.swap(pending_);
-        inflight_ += (int)batch.size();
       }
       if (batch.empty()) continue;
       params.clear();
-      for (Request *r : batch) params.push_back(r->p);
+      for (const auto &r : batch) params.push_back(r->p);
       int rc = d_params.alloc(params.size() * sizeof(MMParams));
       if (!rc && hipMemcpyAsync(d_params.p, params.data(), params.size() * sizeof(MMParams), hipMemcpyHostToDevice,
                                 stream) != hipSuccess)
@@ -1436,23 +1488,18 @@ class BuildDispatcher {
           fprintf(stderr, "[tree builder launch] %zu trees, %.1f ms\n", batch.size(),
                   1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
       }
-      {
-        std::lock_guard<std::mutex> lk(m_);
-        for (Request *r : batch) {
-          r->rc = rc;
-          r->done = true;
-        }
-        inflight_ -= (int)batch.size();
+      for (const auto &r : batch) {
+        r->rc = rc;
+        r->done.store(true, std::memory_order_release);
       }
-      cv_done_.notify_all();
       batch.clear();
     }
   }
   int device_;
-  int builders_ = 0, inflight_ = 0;  // builders alive on this device; requests in a launch
+  int builders_ = 0, waiting_ = 0;  // builders alive on this device; builders waiting for a tree (asked or being built)
   std::mutex m_;
-  std::condition_variable cv_work_, cv_done_;
-  std::vector<Request *> pending_;
+  std::condition_variable cv_work_;
+  std::vector<std::shared_ptr<Request>> pending_;
   std::vector<std::thread> workers_;
 };
 
@@ -1461,6 +1508,7 @@ struct DeviceMinMatch::Impl {
   hipStream_t stream = nullptr;
   DevBuf d_D, d_CF, d_M, d_SYM, d_hits, d_f, d_i, d_feas, d_rowlist, d_status, d_flags, d_member, d_tab, d_acc;
   long long builds = 0;
+  int *h_done = nullptr;  // pinned: the build kernel's "this tree is out" (BuildDispatcher::run)
 };
 
 DeviceMinMatch::DeviceMinMatch(int N, int device) : impl(new Impl()) {
@@ -1471,6 +1519,7 @@ DeviceMinMatch::DeviceMinMatch(int N, int device) : impl(new Impl()) {
 DeviceMinMatch::~DeviceMinMatch() {
   BuildDispatcher::of(impl->device).enroll(-1);
   if (impl->stream) (void)hipStreamDestroy(impl->stream);
+  if (impl->h_done) (void)hipHostFree(impl->h_done);
   delete impl;
 }
 
@@ -1605,6 +1654,9 @@ int DeviceMinMatch::build_impl(MinMatch &tb, const float *d, const float *prior_
   p.pair_cap = pair_cap;
   p.rowlist = m.d_rowlist.as<int>();
   p.status = m.d_status.as<int>();
+  if (!m.h_done && hipHostMalloc(reinterpret_cast<void **>(&m.h_done), 64, hipHostMallocCoherent) != hipSuccess)
+    m.h_done = nullptr;  // (without it the builder waits for the whole launch)
+  p.host_done = m.h_done;
   const bool timing = getenv("RELATE_AMD_TIMING") != nullptr;
   p.timers = timing ? reinterpret_cast<long long *>(m.d_status.as<char>() + 16) : nullptr;
 
@@ -1636,8 +1688,9 @@ int DeviceMinMatch::build_impl(MinMatch &tb, const float *d, const float *prior_
   RL_HIP(hipMemcpyAsync(p.status, &minus1, 4, hipMemcpyHostToDevice, m.stream));
   RL_HIP(hipStreamSynchronize(m.stream));  // inputs in place
   {
-    BuildDispatcher::Request req;
-    req.p = p;
+    if (m.h_done) *m.h_done = -1;
+    auto req = std::make_shared<BuildDispatcher::Request>();
+    req->p = p;
     if (BuildDispatcher::of(m.device).run(req)) {
       set_error("tree builder launch failed");
       return -1;
@@ -1652,8 +1705,8 @@ int DeviceMinMatch::build_impl(MinMatch &tb, const float *d, const float *prior_
     RL_HIP(hipMemcpy(tk, p.timers, sizeof(tk), hipMemcpyDeviceToHost));
     fprintf(stderr, "[gpu tree builder] N=%d, us:", N);
     static const char *names[12] = {"row minima", "pair scan", "updates", "rescans", "pair tests", "pair order",
-                                    "ordered", "symmetric", "erase", "", "", ""};
-    for (int x = 0; x < 9; x++) fprintf(stderr, " %s %.0f", names[x], tk[x] / 100.0);
+                                    "ordered", "symmetric", "erase", "pairs_x100", "", ""};
+    for (int x = 0; x < 10; x++) fprintf(stderr, " %s %.0f", names[x], tk[x] / 100.0);
     fprintf(stderr, " shader_MHz %lld\n", tk[11]);
   }
   // out: the tree and the carried state
@@ -1691,12 +1744,18 @@ int DeviceMinMatch::build_impl(MinMatch &tb, const float *d, const float *prior_
 // ---- C ABI: a tree builder that keeps MinMatch's state from tree to tree
 struct rl_builder {
   int N;
+  double theta;
   rl::MinMatch tb;
   rl::DeviceMinMatch *dev;
+  rl::MinMatchAges *ages_tb = nullptr;  // rl_builder_set_sample_ages: the builder with the third key and the clock
+  std::vector<double> ages;
   int last_on_gpu;
-  rl_builder(int n, double theta, int device)
-      : N(n), tb(n, theta), dev(device >= 0 ? new rl::DeviceMinMatch(n, device) : nullptr), last_on_gpu(0) {}
-  ~rl_builder() { delete dev; }
+  rl_builder(int n, double th, int device)
+      : N(n), theta(th), tb(n, th), dev(device >= 0 ? new rl::DeviceMinMatch(n, device) : nullptr), last_on_gpu(0) {}
+  ~rl_builder() {
+    delete dev;
+    delete ages_tb;
+  }
 };
 
 extern "C" {
@@ -1718,18 +1777,35 @@ int rl_builder_build(rl_builder *b, float *d, const float *d_prior, int *parent,
   }
   rl::HostTree t;
   int st = 1;
-  if (b->dev) {
+  if (b->ages_tb) {
+    b->ages_tb->quick_build(d, d_prior, b->ages, t);
+    b->last_on_gpu = 0;
+    st = 0;
+  } else if (b->dev) {
     st = b->dev->build(b->tb, d, d_prior, t);
     if (st < 0) return RL_EHIP;
   }
-  b->last_on_gpu = st == 0;
-  if (st != 0) b->tb.quick_build(d, d_prior, t);
+  if (!b->ages_tb) {
+    b->last_on_gpu = st == 0;
+    if (st != 0) b->tb.quick_build(d, d_prior, t);
+  }
   const int N = b->N;
   for (int i = 0; i < 2 * N - 1; i++) parent[i] = t.parent[i];
   for (int i = N; i < 2 * N - 1; i++) {
     if (child_left) child_left[i - N] = t.child_left[i];
     if (child_right) child_right[i - N] = t.child_right[i];
   }
+  return RL_OK;
+}
+
+int rl_builder_set_sample_ages(rl_builder *b, const double *ages, int n) {
+  if (!b || n != b->N || !ages) {
+    rl::set_error("rl_builder_set_sample_ages: one age per haplotype");
+    return RL_EINVAL;
+  }
+  b->ages.assign(ages, ages + n);
+  delete b->ages_tb;
+  b->ages_tb = new rl::MinMatchAges(b->N, b->theta);
   return RL_OK;
 }
 

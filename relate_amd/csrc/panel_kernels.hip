@@ -39,4 +39,46 @@ hipError_t launch_lane_masks(const uint32_t *bits, int row_words, int L, const L
   return hipGetLastError();
 }
 
+// The paint file's quantisation of a stepping stone (CollapsedMatrix::DumpToFile / ReadFromFile,
+// collapsed_matrix.hpp:228-296) without the file: a value joins the current run -- and is replaced by the run's FIRST
+// value -- while |first - v| < 1e-3 * min(first, v) (float difference, double product), otherwise it starts the next
+// run.  The rule is sequential along a stone, so a lane walks one stone; the 64 stones of a wave move through LDS in
+// tiles of 64 x 64 so that HBM sees whole 256-byte segments.
+__global__ void __launch_bounds__(64) quantise_kernel(float *__restrict__ stones, int rows, int N) {
+  __shared__ float tile[64][65];
+  const int lane = threadIdx.x, r0 = blockIdx.x * 64;
+  const int nr = rows - r0 < 64 ? rows - r0 : 64;
+  float current = 0.0f;
+  for (int c0 = 0; c0 < N; c0 += 64) {
+    const int nc = N - c0 < 64 ? N - c0 : 64;
+    for (int r = 0; r < nr; r++)
+      if (lane < nc) tile[r][lane] = stones[(size_t)(r0 + r) * N + c0 + lane];
+    __syncthreads();
+    if (lane < nr) {
+      for (int c = 0; c < nc; c++) {
+        const float v = tile[lane][c];
+        if (c0 + c == 0) {
+          current = v;
+        } else {
+          const float diff = fabsf(current - v);
+          const float mn = v < current ? v : current;
+          if ((double)diff < 1e-3 * (double)mn)
+            tile[lane][c] = current;
+          else
+            current = v;
+        }
+      }
+    }
+    __syncthreads();
+    for (int r = 0; r < nr; r++)
+      if (lane < nc) stones[(size_t)(r0 + r) * N + c0 + lane] = tile[r][lane];
+    __syncthreads();
+  }
+}
+
+hipError_t launch_quantise(float *stones, int rows, int N, hipStream_t stream) {
+  hipLaunchKernelGGL(quantise_kernel, dim3((rows + 63) / 64), dim3(64), 0, stream, stones, rows, N);
+  return hipGetLastError();
+}
+
 }  // namespace rl

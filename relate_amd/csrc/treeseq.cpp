@@ -66,6 +66,7 @@ struct rl_treeseq {
   int build_device = -1;  // >= 0: trees are built on that GPU (minmatch_gpu.hip), the host builder as fallback
   rl_matrix_dev_fn matrix_dev = nullptr;  // with it the distance matrices never leave the device
   long long gpu_trees = 0, host_trees = 0;
+  std::vector<double> sample_ages;  // N values (--sample_ages) or empty
 
   bool derived(int snp, int n) const { return (bits[(size_t)snp * row_words + (n >> 5)] >> (n & 31)) & 1u; }
 };
@@ -398,10 +399,18 @@ int rl_treeseq_build(rl_treeseq *ts, int start, int end, rl_matrix_fn matrix, rl
         }
   };
   MinMatch tb(N, ts->theta);
+  // with sample ages (ancient samples) the candidates carry a third key and a clock: its own builder, on the host
+  std::unique_ptr<MinMatchAges> tb_ages;
+  if ((int)ts->sample_ages.size() == N) tb_ages.reset(new MinMatchAges(N, ts->theta));
   std::unique_ptr<DeviceMinMatch> dev;
-  if (ts->build_device >= 0 && N <= 10240) dev.reset(new DeviceMinMatch(N, ts->build_device));  // (its registers per thread)
+  if (ts->build_device >= 0 && N <= 10240 && !tb_ages) dev.reset(new DeviceMinMatch(N, ts->build_device));  // (its registers per thread)
   int build_rc = 0;
   auto build_tree = [&](float *dm, const float *prior, HostTree &t) {
+    if (tb_ages) {
+      ts->host_trees++;
+      tb_ages->quick_build(dm, prior, ts->sample_ages, t);
+      return;
+    }
     if (dev) {
       const int st = dev->build(tb, dm, prior, t);
       if (st == 0) {
@@ -564,6 +573,15 @@ int rl_treeseq_build(rl_treeseq *ts, int start, int end, rl_matrix_fn matrix, rl
   return RL_OK;
 }
 
+int rl_treeseq_set_sample_ages(rl_treeseq *ts, const double *ages, int n) {
+  if (!ts || (n != 0 && (n != ts->N || !ages))) {
+    rl::set_error("rl_treeseq_set_sample_ages: one age per haplotype (%d), or none", ts ? ts->N : 0);
+    return RL_EINVAL;
+  }
+  ts->sample_ages.assign(ages, ages + n);
+  return RL_OK;
+}
+
 int rl_treeseq_set_build_device(rl_treeseq *ts, int device) {
   if (!ts) return RL_EINVAL;
   ts->build_device = device;
@@ -653,13 +671,12 @@ int rl_treeseq_write(const rl_treeseq *ts, const char *anc_path, const char *mut
 // matrix go through one mutex, the GPU work per call being milliseconds.
 namespace {
 std::mutex g_gpu_mutex;
+std::string g_stage_sample_ages;  // rl_stage_set_sample_ages: the --sample_ages file of the following stage calls
 }
-static int win_matrix(void *user, int snp, float *d) {
-  std::lock_guard<std::mutex> lk(g_gpu_mutex);
-  return rl_window_matrix((rl_window *)user, snp, d, nullptr);
-}
+// (a window's matrices run on the window's own stream; what the windows of a context share -- RePaint's strips --
+//  is locked inside, window.cpp)
+static int win_matrix(void *user, int snp, float *d) { return rl_window_matrix((rl_window *)user, snp, d, nullptr); }
 static int win_matrix_dev(void *user, int snp, void *d_dev) {
-  std::lock_guard<std::mutex> lk(g_gpu_mutex);
   return rl_window_matrix_rows_device((rl_window *)user, snp, d_dev, nullptr);
 }
 static int win_advance(void *user, int snp) { return rl_window_advance((rl_window *)user, snp); }
@@ -700,18 +717,38 @@ static std::vector<cpu_set_t> cache_groups() {
   return groups;
 }
 
-int rl_stage_build_topology(const char *out_dir, int chunk_index, int first_section, int last_section,
-                            int use_painting, double theta, double rho, int flags, int fb, int sum_mode,
-                            int device) {
-  if (!out_dir) return RL_EINVAL;
-  rl_ctx *ctx = rl_create(device);
-  if (!ctx) return RL_ENODEVICE;
-  int rc = rl_load_chunk(ctx, out_dir, chunk_index);
-  if (!rc && use_painting) rc = rl_set_painting(ctx, theta, rho);
-  if (rc) {
-    rl_destroy(ctx);
-    return rc;
+// The sections [first_section, last_section] of the chunk loaded in ctx: windows from the paint files of the Paint
+// stage (from_files) or from the stepping stones the context has just painted, which never leave HBM (the file's
+// float / run-length quantisation applied on the device, window.cpp).  Consumes ctx.
+// --sample_ages file (pipeline/BuildTopology.cpp:93-108): the first N numbers of a plain or gzip text file.  A file
+// that cannot be opened leaves N zeros (and a warning), one with fewer than N numbers no ages at all -- as there.
+static std::vector<double> read_sample_ages(const char *fn, int N) {
+  std::vector<double> ages(N, 0.0);
+  FILE *chk = fopen(fn, "rb");
+  if (!chk) {
+    std::cerr << "Warning: unable to open sample ages file" << std::endl;
+    return ages;
   }
+  unsigned char b[3] = {0, 0, 0};
+  const bool gz = fread(b, 1, 3, chk) == 3 && b[0] == 0x1f && b[1] == 0x8b && b[2] == 0x08;
+  fclose(chk);
+  FILE *fp = gz ? popen((std::string("gunzip -c '") + fn + "'").c_str(), "r") : fopen(fn, "r");
+  int i = 0;
+  if (fp) {
+    while (i < N && fscanf(fp, "%lf", &ages[i]) == 1) i++;
+    if (gz)
+      pclose(fp);
+    else
+      fclose(fp);
+  }
+  if (i < N) ages.clear();
+  return ages;
+}
+
+static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int first_section, int last_section,
+                          int flags, int fb, int sum_mode, int device, bool from_files,
+                          const char *sample_ages_file = nullptr) {
+  int rc = RL_OK;
   const int W = ctx->W, L = ctx->L;
   if (first_section >= W) {  // BuildTopology.cpp:45
     rl_destroy(ctx);
@@ -724,6 +761,8 @@ int rl_stage_build_topology(const char *out_dir, int chunk_index, int first_sect
   while (!base.empty() && base.back() == '/') base.pop_back();
   const size_t sl = base.find_last_of('/');
   if (sl != std::string::npos) base = base.substr(sl + 1);
+  std::vector<double> sample_ages;
+  if (sample_ages_file) sample_ages = read_sample_ages(sample_ages_file, ctx->N);
   std::vector<int> bp(L, 0), state(L, 1);
   // chunk_<c>.bp / .state (data.cpp:485-516, :307-345): --fb and the mapping of transitions read them; a missing or
   // short file would give wrong trees without a word
@@ -846,7 +885,8 @@ int rl_stage_build_topology(const char *out_dir, int chunk_index, int first_sect
       if (pinned) sched_setaffinity(0, sizeof(before), &before);
       return;
     }
-    if (gpu_build) {
+    if (!sample_ages.empty()) rl_treeseq_set_sample_ages(ts, sample_ages.data(), (int)sample_ages.size());
+    if (gpu_build && sample_ages.empty()) {
       rl_treeseq_set_build_device(ts, device);
       if (ctx->nloc == ctx->N) rl_treeseq_set_device_matrix(ts, win_matrix_dev);
     }
@@ -865,7 +905,8 @@ int rl_stage_build_topology(const char *out_dir, int chunk_index, int first_sect
           size_t free_b = 0, total_b = 0;
           const bool known = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
           if (!known || (double)free_b >= need || open_sections.load() == 0) {
-            win = rl_window_open_bounded(ctx, section, pf.c_str(), start, sum_mode, cap_rows, nullptr);
+            win = rl_window_open_bounded(ctx, section, from_files ? pf.c_str() : nullptr, start, sum_mode, cap_rows,
+                                         nullptr);
             if (win) open_sections++;
             break;
           }
@@ -913,6 +954,55 @@ int rl_stage_build_topology(const char *out_dir, int chunk_index, int first_sect
     std::cerr << "---------------------------------------------------------" << std::endl << std::endl;
   }
   return rc;
+}
+
+int rl_stage_build_topology(const char *out_dir, int chunk_index, int first_section, int last_section,
+                            int use_painting, double theta, double rho, int flags, int fb, int sum_mode,
+                            int device) {
+  if (!out_dir) return RL_EINVAL;
+  rl_ctx *ctx = rl_create(device);
+  if (!ctx) return RL_ENODEVICE;
+  int rc = rl_load_chunk(ctx, out_dir, chunk_index);
+  if (!rc && use_painting) rc = rl_set_painting(ctx, theta, rho);
+  if (rc) {
+    rl_destroy(ctx);
+    return rc;
+  }
+  return build_sections(ctx, out_dir, chunk_index, first_section, last_section, flags, fb, sum_mode, device, true,
+                        g_stage_sample_ages.empty() ? nullptr : g_stage_sample_ages.c_str());
+}
+
+int rl_stage_set_sample_ages(const char *file) {
+  g_stage_sample_ages = file ? file : "";
+  return RL_OK;
+}
+
+int rl_stage_paint_build_topology(const char *out_dir, int chunk_index, int first_section, int last_section,
+                                  int use_painting, double theta, double rho, int flags, int fb, int sum_mode,
+                                  int device) {
+  if (!out_dir) return RL_EINVAL;
+  rl_ctx *ctx = rl_create(device);
+  if (!ctx) return RL_ENODEVICE;
+  int rc = rl_load_chunk(ctx, out_dir, chunk_index);
+  if (!rc && use_painting) rc = rl_set_painting(ctx, theta, rho);
+  if (!rc) {
+    std::cerr << "---------------------------------------------------------" << std::endl;
+    std::cerr << "Painting sequences (stepping stones stay on the device)..." << std::endl;
+    rc = rl_paint(ctx, sum_mode, nullptr);
+  }
+  if (!rc) {  // (the Paint stage makes this directory for its files; the trees go there)
+    const std::string cdir = std::string(out_dir) + "/chunk_" + std::to_string(chunk_index);
+    if (mkdir(cdir.c_str(), 0777) != 0 && errno != EEXIST) {
+      set_error("cannot create %s", cdir.c_str());
+      rc = RL_EIO;
+    }
+  }
+  if (rc) {
+    rl_destroy(ctx);
+    return rc;
+  }
+  return build_sections(ctx, out_dir, chunk_index, first_section, last_section, flags, fb, sum_mode, device, false,
+                        g_stage_sample_ages.empty() ? nullptr : g_stage_sample_ages.c_str());
 }
 
 }  // extern "C"

@@ -34,6 +34,17 @@ struct rl_window {
   int64_t cap_rows = 0;                      // rows d_top holds; >= all rows: the whole window is resident
   int maxD = 0, sum_mode = 0, repaints = 0;
   bool have_logscales = false;
+  // a window's distance matrices run on its own stream: the sections of a stage ask for theirs at the same time
+  hipStream_t stream = nullptr;
+  hipEvent_t e0 = nullptr, e2 = nullptr;
+  unsigned char *h_stage = nullptr;  // pinned: the per-target arguments of one matrix, sent in one copy
+  DevBuf d_stage;
+  ~rl_window() {
+    if (stream) (void)hipStreamDestroy(stream);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e2) (void)hipEventDestroy(e2);
+    if (h_stage) (void)hipHostFree(h_stage);
+  }
 };
 
 static inline bool derived(const rl_ctx *ctx, int snp, int n) {
@@ -48,6 +59,7 @@ static int repaint_rows(rl_window *win, float *kernel_ms) {
   const int64_t side_offset = (int64_t)((win->maxD + REPAINT_CHECKPOINT - 1) / REPAINT_CHECKPOINT) * S * 64 * waves;
   const int64_t scratch_stride = side_offset + (int64_t)win->maxD * REPAINT_SIDE;
   // the strips of the forward rows are scratch of the launch: one buffer per context, launches are serialised
+  std::unique_lock<std::mutex> one_at_a_time(ctx->repaint_mutex);
   int rc = ctx->d_k2_scratch.alloc((size_t)nblocks * scratch_stride * sizeof(double));
   rc = rc ? rc : ctx->d_k2_counter.alloc(sizeof(int));
   if (rc) return rc;
@@ -94,6 +106,7 @@ static int repaint_rows(rl_window *win, float *kernel_ms) {
     return RL_EHIP;
   }
   if (kernel_ms) (void)hipEventElapsedTime(kernel_ms, ctx->ev0, ctx->ev2);
+  one_at_a_time.unlock();
   win->repaints++;
   if (!win->have_logscales) {  // (every launch writes all of them, with the same values)
     const int64_t rows = win->top_off[nloc];
@@ -243,17 +256,10 @@ rl_window *rl_window_open_bounded(rl_ctx *ctx, int w, const char *paint_file, in
       set_error("rl_window_open: no paint file given and rl_paint has not run");
       return nullptr;
     }
-    if (rl_get_stones(ctx, w, ab.data(), be.data(), la.data(), lb.data(), bb.data(), bend.data()))
-      return nullptr;
-    // decode(encode(x)): the file round trip is part of the numerics
-    std::vector<unsigned char> tmp(28 + (size_t)N * 8);
+    // the stones stay in HBM: copied and run through the file's quantisation on the device below
     for (int t = 0; t < nloc; t++) {
-      int bs;
-      float ls;
-      encode_stone(&ab[(size_t)t * N], N, bb[t], la[t], tmp.data());
-      decode_stone(tmp.data(), tmp.size(), N, &ab[(size_t)t * N], &bs, &ls);
-      encode_stone(&be[(size_t)t * N], N, bend[t], lb[t], tmp.data());
-      decode_stone(tmp.data(), tmp.size(), N, &be[(size_t)t * N], &bs, &ls);
+      bb[t] = pl.bb[(size_t)(k0 + t) * W + w];
+      bend[t] = pl.be[(size_t)(k0 + t) * W + w];
     }
   }
 
@@ -303,10 +309,34 @@ rl_window *rl_window_open_bounded(rl_ctx *ctx, int w, const char *paint_file, in
   win->row_lo.assign(nloc, 0);
   win->row_hi.assign(nloc, 0);
   int rc = 0;
-  rc = rc ? rc : win->d_ab.upload(ab);
-  rc = rc ? rc : win->d_be.upload(be);
-  rc = rc ? rc : win->d_la.upload(la);
-  rc = rc ? rc : win->d_lb.upload(lb);
+  if (paint_file) {
+    rc = rc ? rc : win->d_ab.upload(ab);
+    rc = rc ? rc : win->d_be.upload(be);
+    rc = rc ? rc : win->d_la.upload(la);
+    rc = rc ? rc : win->d_lb.upload(lb);
+  } else {
+    // decode(encode(x)): the paint file's round trip is part of the numerics -- floats, and runs of
+    // nearly equal values replaced by their first (collapsed_matrix.hpp:228-296) -- applied where the stones are
+    const size_t sn = (size_t)nloc * N;
+    rc = rc ? rc : win->d_ab.alloc(sn * 4);
+    rc = rc ? rc : win->d_be.alloc(sn * 4);
+    rc = rc ? rc : win->d_la.alloc((size_t)nloc * 4);
+    rc = rc ? rc : win->d_lb.alloc((size_t)nloc * 4);
+    std::lock_guard<std::mutex> s0_is_mine(ctx->repaint_mutex);
+    auto d2d = [&](void *dst, const float *src, size_t n) {
+      return hipMemcpyAsync(dst, src, n * 4, hipMemcpyDeviceToDevice, ctx->s0) == hipSuccess ? 0 : RL_EHIP;
+    };
+    rc = rc ? rc : d2d(win->d_ab.p, ctx->d_alpha.as<float>() + (size_t)w * sn, sn);
+    rc = rc ? rc : d2d(win->d_be.p, ctx->d_beta.as<float>() + (size_t)w * sn, sn);
+    rc = rc ? rc : d2d(win->d_la.p, ctx->d_lsa.as<float>() + (size_t)w * nloc, nloc);
+    rc = rc ? rc : d2d(win->d_lb.p, ctx->d_lsb.as<float>() + (size_t)w * nloc, nloc);
+    if (!rc && (launch_quantise(win->d_ab.as<float>(), nloc, N, ctx->s0) != hipSuccess ||
+                launch_quantise(win->d_be.as<float>(), nloc, N, ctx->s0) != hipSuccess ||
+                hipStreamSynchronize(ctx->s0) != hipSuccess)) {
+      set_error("stone quantisation on the device failed");
+      rc = RL_EHIP;
+    }
+  }
   rc = rc ? rc : win->d_ib.upload(ib);
   rc = rc ? rc : win->d_ie.upload(ie);
   rc = rc ? rc : win->d_cfl.upload(cf_last);
@@ -460,14 +490,27 @@ static int window_matrix(rl_window *win, int snp, float *d_host, void *d_dev, fl
     const int prc = place_rows(win, snp, nullptr);
     if (prc) return prc;
   }
-  int rc = 0;
-  rc = rc ? rc : win->d_vsp.upload(win->v_snp_prev);
-  rc = rc ? rc : win->d_direct.upload(direct);
-  rc = rc ? rc : win->d_wl.upload(wl);
-  rc = rc ? rc : win->d_wr.upload(wr);
-  rc = rc ? rc : win->d_epn.upload(epn);
-  rc = rc ? rc : win->d_enp.upload(enp);
+  // the per-target arguments in one pinned block, one copy, on the window's stream
+  const size_t o_wl = 0, o_wr = o_wl + (size_t)nloc * 8, o_vsp = o_wr + (size_t)nloc * 8, o_epn = o_vsp + (size_t)nloc * 4,
+               o_enp = o_epn + (size_t)nloc * 4, o_dir = o_enp + (size_t)nloc * 4, stage_bytes = o_dir + (size_t)nloc;
+  if (!win->stream) {
+    if (hipStreamCreateWithFlags(&win->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&win->e0) != hipSuccess || hipEventCreate(&win->e2) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void **>(&win->h_stage), ((stage_bytes + 7) & ~(size_t)7) + 8, 0) != hipSuccess) {
+      set_error("rl_window_matrix: stream / staging buffer creation failed");
+      return RL_EHIP;
+    }
+  }
+  int rc = win->d_stage.alloc(((stage_bytes + 7) & ~(size_t)7) + 8);
   if (rc) return rc;
+  memcpy(win->h_stage + o_vsp, win->v_snp_prev.data(), (size_t)nloc * 4);
+  memcpy(win->h_stage + o_wl, wl.data(), (size_t)nloc * 8);
+  memcpy(win->h_stage + o_wr, wr.data(), (size_t)nloc * 8);
+  memcpy(win->h_stage + o_epn, epn.data(), (size_t)nloc * 4);
+  memcpy(win->h_stage + o_enp, enp.data(), (size_t)nloc * 4);
+  memcpy(win->h_stage + o_dir, direct.data(), (size_t)nloc);
+  RL_HIP(hipMemcpyAsync(win->d_stage.p, win->h_stage, stage_bytes, hipMemcpyHostToDevice, win->stream));
+  const unsigned char *ds = win->d_stage.as<unsigned char>();
   MatrixParams p;
   p.N = N;
   p.k0 = k0;
@@ -476,20 +519,20 @@ static int window_matrix(rl_window *win, int snp, float *d_host, void *d_dev, fl
   p.logscales = win->d_ls.as<float>();
   p.top_off = win->d_top_off.as<int64_t>();
   p.slab_base = win->d_slab_base.as<int64_t>();
-  p.v_snp_prev = win->d_vsp.as<int32_t>();
-  p.direct = win->d_direct.as<uint8_t>();
-  p.wl = win->d_wl.as<double>();
-  p.wr = win->d_wr.as<double>();
-  p.e_pn = win->d_epn.as<float>();
-  p.e_np = win->d_enp.as<float>();
+  p.v_snp_prev = reinterpret_cast<const int32_t *>(ds + o_vsp);
+  p.direct = ds + o_dir;
+  p.wl = reinterpret_cast<const double *>(ds + o_wl);
+  p.wr = reinterpret_cast<const double *>(ds + o_wr);
+  p.e_pn = reinterpret_cast<const float *>(ds + o_epn);
+  p.e_np = reinterpret_cast<const float *>(ds + o_enp);
   p.matrix = d_dev ? static_cast<float *>(d_dev) : win->d_matrix.as<float>();
-  RL_HIP(hipEventRecord(ctx->ev0, ctx->s0));
-  RL_HIP(launch_matrix(p, ctx->lay, ctx->S, ctx->waves, ctx->s0));
-  RL_HIP(hipEventRecord(ctx->ev2, ctx->s0));
+  RL_HIP(hipEventRecord(win->e0, win->stream));
+  RL_HIP(launch_matrix(p, ctx->lay, ctx->S, ctx->waves, win->stream));
+  RL_HIP(hipEventRecord(win->e2, win->stream));
   if (d_host)
-    RL_HIP(hipMemcpyAsync(d_host, p.matrix, (size_t)nloc * N * sizeof(float), hipMemcpyDeviceToHost, ctx->s0));
-  RL_HIP(hipStreamSynchronize(ctx->s0));
-  if (kernel_ms) RL_HIP(hipEventElapsedTime(kernel_ms, ctx->ev0, ctx->ev2));
+    RL_HIP(hipMemcpyAsync(d_host, p.matrix, (size_t)nloc * N * sizeof(float), hipMemcpyDeviceToHost, win->stream));
+  RL_HIP(hipStreamSynchronize(win->stream));
+  if (kernel_ms) RL_HIP(hipEventElapsedTime(kernel_ms, win->e0, win->e2));
   return RL_OK;
 }
 

@@ -180,3 +180,54 @@ def test_builder_sequences_match_one_reference_minmatch(tmp_path, seed, N):
         fresh_differs += not np.array_equal(api.quickbuild(d, 0.001, prior), ref[t])
     b.close()
     assert fresh_differs > 0  # (the carried state matters: a fresh builder per tree gives other trees)
+
+
+@pytest.mark.ref
+@pytest.mark.skipif(not rlutil.have_ref(), reason="oracle/_ref not built (no /root/reference)")
+@pytest.mark.parametrize("seed,N,levels", [(21, 40, 1), (22, 90, 3), (23, 260, 5), (24, 2000, 4)])
+def test_builder_with_sample_ages_matches_reference_minmatch(tmp_path, seed, N, levels):
+    """MinMatch::QuickBuild with sample ages (--sample_ages: the third candidate key and the coalescence clock,
+    tree_builder.cpp:7-22, 149-252, 601-965, 1123-1233, 1738-1841, 2073-2355, 2407-2531): sequences of trees from ONE
+    builder, with and without prior, tied and coalescent-shaped matrices, against ONE MinMatch of the reference"""
+    import subprocess
+    from relate_amd import api
+    from test_builder_gpu import coalescent_matrix, split_tree_matrix
+    rng = np.random.RandomState(seed)
+    # ancient samples: a few sampling times, most haplotypes modern
+    ages = np.zeros(N)
+    for lv in range(1, levels):
+        ages[rng.rand(N) < 0.15] = lv * 400.0 * (1 + rng.randint(0, 3))
+    mats = []
+    for t in range(5):
+        if t == 4:
+            d = split_tree_matrix(rng, N) if N > 400 else coalescent_matrix(rng, N)
+        else:
+            d = (rng.rand(N, N) * 4 + rng.rand(N)[:, None]).astype(np.float32)
+            d[rng.rand(N, N) < (0.3 if N < 1000 else 0.02)] = 1.5
+            np.fill_diagonal(d, 0)
+        prior = None if t in (0, 3) else ((np.floor(rng.rand(N, N) * 4) + (t >= 2)) * 6.9).astype(np.float32)
+        mats.append((d, prior))
+    ages.tofile(str(tmp_path / "ages.bin"))
+    args = [rlutil.REF_HARNESS, "quickbuild_seq_ages", str(N), str(tmp_path / "p.bin"), str(tmp_path / "ages.bin")]
+    for t, (d, prior) in enumerate(mats):
+        d.tofile(str(tmp_path / ("d%d.bin" % t)))
+        args.append(str(tmp_path / ("d%d.bin" % t)))
+        if prior is None:
+            args.append("-")
+        else:
+            prior.tofile(str(tmp_path / ("c%d.bin" % t)))
+            args.append(str(tmp_path / ("c%d.bin" % t)))
+    subprocess.run(args, check=True)
+    ref = np.fromfile(str(tmp_path / "p.bin"), dtype=np.int32).reshape(len(mats), 2 * N - 1)
+    b = api.Builder(N)
+    b.set_sample_ages(ages)
+    plain = api.Builder(N)
+    differs = 0
+    for t, (d, prior) in enumerate(mats):
+        got = b.build(d, prior)[0]
+        assert np.array_equal(got, ref[t]), (t, int(np.argmax(got != ref[t])))
+        differs += not np.array_equal(plain.build(d, prior)[0], ref[t])
+    b.close()
+    plain.close()
+    if levels > 1:
+        assert differs > 0  # (the ages matter: the builder without them gives other trees)

@@ -149,3 +149,65 @@ def test_cli_gpu_build_options(tmp_path, tag, opts):
     for w in range(fx.W):
         assert open(work / "out" / "chunk_0" / ("out_%d.mut" % w), "rb").read() == fx.z["mut_%s/%d" % (tag, w)].tobytes(), w
         assert open(work / "out" / "chunk_0" / ("out_%d.anc" % w), "rb").read() == fx.z["anc_%s/%d" % (tag, w)].tobytes(), w
+
+
+@pytest.mark.parametrize("name", ["synth24", "synth70", "example8"])
+def test_paint_and_build_topology_without_paint_files(tmp_path, name):
+    """--mode PaintBuildTopology (rl_stage_paint_build_topology): the stepping stones stay in HBM, the paint file's
+    float / run-length quantisation is applied on the device -- no chunk_0/paint directory, and the same .anc / .mut
+    as the reference's Paint + BuildTopology through its paint files (Relate.cpp:257-283)"""
+    work = tmp_path / "work"
+    (work / "out").mkdir(parents=True)
+    fx = Fixture(name, work / "out")
+    run_cli(["--mode", "PaintBuildTopology", "--chunk_index", "0", "-o", "out"], str(work))
+    assert not (work / "out" / "chunk_0" / "paint").exists()
+    for w in range(fx.W):
+        assert open(work / "out" / "chunk_0" / ("out_%d.mut" % w), "rb").read() == fx.z["mut/%d" % w].tobytes(), w
+        assert open(work / "out" / "chunk_0" / ("out_%d.anc" % w), "rb").read() == fx.z["anc/%d" % w].tobytes(), w
+
+
+def test_in_memory_window_matches_the_paint_file_window(tmp_path):
+    """a window opened from the context's stones (quantised on the device) against the same window opened from the
+    paint file the context wrote: posterior rows and matrices bit for bit"""
+    import numpy as np
+    import rlutil
+    from relate_amd import api
+    ch = rlutil.synth_chunk(200, 1500, seed=7, budget=400000)
+    ctx = api.Context()
+    ctx.set_chunk(ch.seq, ch.r, ch.rpos, ch.wb)
+    ctx.paint(api.RL_SUM_EXACT)
+    ctx.write_paint_files(str(tmp_path))
+    for w in sorted(set([0, ch.W // 2, ch.W - 1])):
+        s0 = int(ch.wb[w])
+        a = ctx.open_window(w, os.path.join(str(tmp_path), "relate_%d.bin" % w), s0)
+        b = ctx.open_window(w, None, s0)
+        for n in (0, 77, 199):
+            ta, la = a.topology(n)
+            tb, lb = b.topology(n)
+            assert np.array_equal(ta.view(np.uint32), tb.view(np.uint32)) and np.array_equal(la.view(np.uint32), lb.view(np.uint32))
+        assert np.array_equal(a.matrix(s0).view(np.uint32), b.matrix(s0).view(np.uint32))
+        a.close()
+        b.close()
+    ctx.close()
+
+
+@pytest.mark.parametrize("tag,opts", [("", []), ("_nc", ["--no_consistency"])])
+def test_cli_build_topology_with_sample_ages(tmp_path, tag, opts):
+    """--sample_ages (ancient samples; pipeline/BuildTopology.cpp:93-108, the third candidate key and the clock of
+    tree_builder.cpp): .anc / .mut of every section as the reference writes them for the same ages file
+    (tests/golden/synth24_ages.npz, tools/make_golden.py ages); and the ages do change the trees"""
+    work = tmp_path / "work"
+    (work / "out").mkdir(parents=True)
+    fx = Fixture("synth24_ages", work / "out")
+    with open(work / "ages.txt", "w") as f:
+        f.write("\n".join("%g" % a for a in fx.z["ages"]) + "\n")
+    paint = work / "out" / "chunk_0" / "paint"
+    fx.write_paint_files(str(paint))
+    run_cli(["--mode", "BuildTopology", "--chunk_index", "0", "--first_section", "0", "--last_section", str(fx.W - 1),
+             "--sample_ages", "ages.txt", "-o", "out"] + opts, str(work))
+    for w in range(fx.W):
+        assert open(work / "out" / "chunk_0" / ("out_%d.mut" % w), "rb").read() == fx.z["mut%s/%d" % (tag, w)].tobytes(), w
+        assert open(work / "out" / "chunk_0" / ("out_%d.anc" % w), "rb").read() == fx.z["anc%s/%d" % (tag, w)].tobytes(), w
+    if not tag:
+        plain = Fixture("synth24", tmp_path / "plain") if (tmp_path / "plain").mkdir() is None else None
+        assert any(fx.z["anc/%d" % w].tobytes() != plain.z["anc/%d" % w].tobytes() for w in range(fx.W))

@@ -180,6 +180,34 @@ def n5000_fixture(N=5000, L=1200, mem=10.0):
           "%.1f KB" % (os.path.getsize(os.path.join(GOLD, "n5000.npz")) / 1e3))
 
 
+def ages_fixture(name="synth24_ages", N=24, L=900, seed=21, budget=4000):
+    """BuildTopology --sample_ages (ancient samples) of the synth24 chunk: the ages file and the reference's .anc / .mut
+    of every section, with the default consistency prior and with --no_consistency"""
+    ch = rlutil.synth_chunk(N, L, seed=seed, budget=budget)
+    rng = np.random.RandomState(seed)
+    ages = np.zeros(N)
+    ages[rng.permutation(N)[:5]] = [300.0, 300.0, 1200.0, 1200.0, 4000.0]
+    data = {"meta": np.array([N, L, ch.W, seed], dtype=np.int64), "ages": ages}
+    with tempfile.TemporaryDirectory() as work:
+        ch.write(os.path.join(work, "out"))
+        with open(os.path.join(work, "ages.txt"), "w") as f:
+            f.write("\n".join("%g" % a for a in ages) + "\n")
+        run([rlutil.REF_RELATE, "--mode", "Paint", "--chunk_index", "0", "-o", "out"], work)
+        for f in ["parameters_c0.bin", "chunk_0.hap", "chunk_0.r", "chunk_0.rpos", "chunk_0.bp", "chunk_0.dist",
+                  "chunk_0.state"]:
+            data["in/" + f] = fbytes(os.path.join(work, "out", f))
+        for w in range(ch.W):
+            data["paint/relate_%d.bin" % w] = fbytes(os.path.join(work, "out", "chunk_0", "paint", "relate_%d.bin" % w))
+        for tag, opts in (("", []), ("_nc", ["--no_consistency"])):
+            run([rlutil.REF_RELATE, "--mode", "BuildTopology", "--chunk_index", "0", "--first_section", "0",
+                 "--last_section", str(ch.W - 1), "--sample_ages", "ages.txt", "-o", "out"] + opts, work)
+            for w in range(ch.W):
+                data["anc%s/%d" % (tag, w)] = fbytes(os.path.join(work, "out", "chunk_0", "out_%d.anc" % w))
+                data["mut%s/%d" % (tag, w)] = fbytes(os.path.join(work, "out", "chunk_0", "out_%d.mut" % w))
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **data)
+    print(name, "W", ch.W, "%.1f KB" % (os.path.getsize(os.path.join(GOLD, name + ".npz")) / 1e3))
+
+
 def makechunks_fixture():
     """MakeChunks off the build container: the synthetic .haps/.sample/map of tests/test_makechunks.py (regenerated
     from the seed by the test) through the reference's MakeChunks; the fixture keeps the md5 of every output file and
@@ -209,6 +237,9 @@ def makechunks_fixture():
 if __name__ == "__main__":
     assert rlutil.have_ref(), "run `make -C oracle ref` first (needs /root/reference)"
     os.makedirs(GOLD, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "ages":
+        ages_fixture()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "makechunks":
         makechunks_fixture()
         sys.exit(0)
