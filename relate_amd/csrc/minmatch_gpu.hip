@@ -625,7 +625,7 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
       a_k[q] = ik < n ? (int)st.ci[ik] : -1;
 
     }
-    constexpr int QC = MAXQ <= 10 ? MAXQ : 10;  // clusters per pass: all of them when the state is in LDS
+    constexpr int QC = 5;  // clusters per pass (ten at once cost more in spilled registers than the second round trip)
 #pragma unroll
     for (int q0 = 0; q0 < MAXQ; q0 += QC) {
       if (q0 * MM_BLOCK >= n) break;
@@ -1429,8 +1429,14 @@ class BuildDispatcher {
   }
   void worker() {
     (void)hipSetDevice(device_);
+    // A build kernel runs for ~0.1 s; the short kernels of the stage (distance matrices, penalty, prior, the weave of
+    // the next tree) must not queue up behind one in a hardware queue they happen to share: the builds go to the
+    // lowest-priority streams, which the runtime maps to hardware queues of their own.
     hipStream_t stream = nullptr;
-    (void)hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess ||
+        hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, least) != hipSuccess)
+      (void)hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
     {  // the per-cluster state of a build in LDS: more than the default 64 KB of dynamic LDS
       hipFuncAttributes a;
       if (hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&minmatch_kernel<true, 10>)) == hipSuccess)
@@ -1508,6 +1514,8 @@ struct DeviceMinMatch::Impl {
   hipStream_t stream = nullptr;
   DevBuf d_D, d_CF, d_M, d_SYM, d_hits, d_f, d_i, d_feas, d_rowlist, d_status, d_flags, d_member, d_tab, d_acc;
   long long builds = 0;
+  double t_prep = 0, t_wait = 0, t_out = 0;  // RELATE_AMD_TIMING: uploads + weave, submit -> tree done, copy-out (s)
+  long long n_timed = 0;
   int *h_done = nullptr;  // pinned: the build kernel's "this tree is out" (BuildDispatcher::run)
 };
 
@@ -1518,6 +1526,10 @@ DeviceMinMatch::DeviceMinMatch(int N, int device) : impl(new Impl()) {
 }
 DeviceMinMatch::~DeviceMinMatch() {
   BuildDispatcher::of(impl->device).enroll(-1);
+  if (getenv("RELATE_AMD_TIMING") && impl->n_timed)
+    fprintf(stderr, "[gpu tree builder] %lld trees: ms per tree on the host side: uploads + weave %.2f, submit -> done %.2f, "
+                    "copy-out %.2f\n", impl->n_timed, 1e3 * impl->t_prep / impl->n_timed,
+            1e3 * impl->t_wait / impl->n_timed, 1e3 * impl->t_out / impl->n_timed);
   if (impl->stream) (void)hipStreamDestroy(impl->stream);
   if (impl->h_done) (void)hipHostFree(impl->h_done);
   delete impl;
@@ -1604,6 +1616,7 @@ int DeviceMinMatch::build_impl(MinMatch &tb, const float *d, const float *prior_
   if (!m.stream) RL_HIP(hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking));
   const bool prior = with_prior;
   const size_t NN = (size_t)N * N;
+  const auto tb0 = std::chrono::steady_clock::now();
   const long long pair_cap = (long long)8 * N;
   int rc = m.d_D.alloc(NN * 4);
   rc = rc ? rc : (prior ? m.d_CF.alloc(NN * 4) : 0);
@@ -1687,6 +1700,7 @@ int DeviceMinMatch::build_impl(MinMatch &tb, const float *d, const float *prior_
   const int minus1 = -1;
   RL_HIP(hipMemcpyAsync(p.status, &minus1, 4, hipMemcpyHostToDevice, m.stream));
   RL_HIP(hipStreamSynchronize(m.stream));  // inputs in place
+  const auto tb1 = std::chrono::steady_clock::now();
   {
     if (m.h_done) *m.h_done = -1;
     auto req = std::make_shared<BuildDispatcher::Request>();
@@ -1696,6 +1710,7 @@ int DeviceMinMatch::build_impl(MinMatch &tb, const float *d, const float *prior_
       return -1;
     }
   }
+  const auto tb2 = std::chrono::steady_clock::now();
   int status = -1;
   RL_HIP(hipMemcpyAsync(&status, p.status, 4, hipMemcpyDeviceToHost, m.stream));
   RL_HIP(hipStreamSynchronize(m.stream));
@@ -1735,6 +1750,13 @@ int DeviceMinMatch::build_impl(MinMatch &tb, const float *d, const float *prior_
   for (int c = 0; c < N; c++) {
     tb.mc[c].lin1 = lin[c];
     tb.mc[c].lin2 = lin[(size_t)N + c];
+  }
+  {
+    const auto tb3 = std::chrono::steady_clock::now();
+    m.t_prep += std::chrono::duration<double>(tb1 - tb0).count();
+    m.t_wait += std::chrono::duration<double>(tb2 - tb1).count();
+    m.t_out += std::chrono::duration<double>(tb3 - tb2).count();
+    m.n_timed++;
   }
   return 0;
 }

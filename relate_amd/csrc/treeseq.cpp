@@ -793,7 +793,7 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
   // host could work on do not fit, every window keeps a part of its rows and repaints as its builder moves on
   // (rl_window_open_bounded; RELATE_AMD_WINDOW_ROWS sets the rows per window by hand).  Every open is admitted
   // against the HBM that is free at that moment (window_bytes below); the estimate here sizes the thread pools.
-  if (!ctx->plan.valid && build_plan(ctx)) {
+  if ((!ctx->plan.valid && build_plan(ctx)) || upload_plan(ctx)) {  // (before the section threads open their windows)
     rl_destroy(ctx);
     return RL_EINVAL;
   }
@@ -858,6 +858,7 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
   // sections open, 4 helpers each finished in 109 s, 8 in 177 s, none in 165 s.
   set_build_threads(std::min(8, std::max(1, host_threads() / (8 * std::max(1, concurrent)))));
   std::atomic<int> open_sections(0);
+  double reserved_bytes = 0.0;  // (under g_gpu_mutex) HBM promised to windows that are being opened
   std::atomic<int> next(first_section);
   std::atomic<int> first_error(0);
   std::mutex err_mutex;
@@ -899,17 +900,24 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
       const std::string pf = od + "/chunk_" + c + "/paint/relate_" + std::to_string(section) + ".bin";
       rl_window *win = nullptr;
       const double need = window_bytes(section);
-      for (;;) {  // admission: wait until the window fits next to the ones that are open
+      for (;;) {  // admission: wait until the window fits next to the ones that are open or being opened
+        bool admitted = false;
         {
           std::lock_guard<std::mutex> lk(g_gpu_mutex);
           size_t free_b = 0, total_b = 0;
           const bool known = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
-          if (!known || (double)free_b >= need || open_sections.load() == 0) {
-            win = rl_window_open_bounded(ctx, section, from_files ? pf.c_str() : nullptr, start, sum_mode, cap_rows,
-                                         nullptr);
-            if (win) open_sections++;
-            break;
+          if (!known || (double)free_b - reserved_bytes >= need || (open_sections.load() == 0 && reserved_bytes == 0.0)) {
+            reserved_bytes += need;
+            admitted = true;
           }
+        }
+        if (admitted) {  // (reading and decoding the paint file, the uploads and RePaint: outside the lock)
+          win = rl_window_open_bounded(ctx, section, from_files ? pf.c_str() : nullptr, start, sum_mode, cap_rows,
+                                       nullptr);
+          std::lock_guard<std::mutex> lk(g_gpu_mutex);
+          reserved_bytes -= need;
+          if (win) open_sections++;
+          break;
         }
         if (first_error.load()) break;
         std::this_thread::sleep_for(std::chrono::milliseconds(50));

@@ -49,7 +49,10 @@ with tempfile.TemporaryDirectory() as work:
     t1 = time.time()
     if sections > 0:
         pre = []
-        if os.environ.get("CHUNK_ROCPROF"):  # kernel trace of the BuildTopology process (the program itself after --)
+        if os.environ.get("CHUNK_PMC"):  # counters of the BuildTopology process: CHUNK_PMC="out_dir:COUNTER COUNTER ..."
+            odir, ctrs = os.environ["CHUNK_PMC"].split(":")
+            pre = ["rocprofv3", "--pmc"] + ctrs.split() + ["--kernel-trace", "-d", os.path.abspath(odir), "-o", "bt", "--"]
+        elif os.environ.get("CHUNK_ROCPROF"):  # kernel trace of the BuildTopology process (the program itself after --)
             pre = ["rocprofv3", "--kernel-trace", "--stats", "-d", os.path.abspath(os.environ["CHUNK_ROCPROF"]), "-o", "bt",
                    "--"]
         p = subprocess.run(pre + [exe, "--mode", "BuildTopology", "--chunk_index", "0", "--first_section", "0", "--last_section",
@@ -57,6 +60,12 @@ with tempfile.TemporaryDirectory() as work:
                            env=dict(os.environ, RELATE_AMD_TIMING="1"))
         assert p.returncode == 0, p.stderr.decode()[-400:]
         out["build_topology_phases"] = [l.strip() for l in p.stderr.decode().split("\n") if "[tree sequence]" in l]
+        out["builder_host_side"] = [l.strip() for l in p.stderr.decode().split("\n") if "host side" in l][:4]
+        launches = [l for l in p.stderr.decode().split("\n") if "[tree builder launch]" in l]
+        if launches:
+            import re as _re
+            sizes = [int(_re.search(r"launch\] (\d+) trees", l).group(1)) for l in launches]
+            out["builder_launches"] = {"launches": len(sizes), "mean_trees_per_launch": sum(sizes) / len(sizes)}
         import re
         acc, ntr = {}, 0
         for l in p.stderr.decode().split("\n"):
