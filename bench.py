@@ -240,6 +240,13 @@ def main():
         win.close()
     extra = None
     roofline_k2 = None
+    pmc = None
+    try:  # HBM bytes per launch: separate rocprofv3 --pmc runs (tools/gpu_profile_r02.sh), committed summary
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_c3.json")))
+        if pmc["N"] != N or pmc["L"] != L or by_target or args.workload != "c3":
+            pmc = None
+    except Exception:
+        pmc = None
     if rank == 0 and not args.skip_k23 and not by_target:
         try:
             w = (len(wb) - 1) // 2
@@ -254,7 +261,9 @@ def main():
             k2_gbs = k2_bytes / (win.repaint_ms * 1e-3) / 1e9
             roofline_k2 = {"bound": "hbm", "kernel": "repaint_kernel (one window, all targets)",
                            "achieved": k2_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k2_gbs / HBM_PEAK_GBS,
-                           "traffic": None, "window": w, "target_site_rows": rows, "ms": win.repaint_ms}
+                           "traffic": pmc["kernels"]["repaint"]["hbm_bytes_per_launch"] if pmc else None,
+                           "traffic_static_from": "profiles/r02_pmc_c3.json" if pmc else None,
+                           "algorithmic_bytes": k2_bytes, "window": w, "target_site_rows": rows, "ms": win.repaint_ms}
             extra = {"window": w,
                      "k2_repaint_ms": win.repaint_ms,
                      "k2_topology_write_GBps": rows * N * 4.0 / (win.repaint_ms * 1e-3) / 1e9,
@@ -276,14 +285,8 @@ def main():
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         # HBM bytes per launch: PMC passes (FETCH_SIZE + WRITE_SIZE) are separate rocprofv3 runs
         # (tools/gpu_profile_r02.sh); the committed summary is read here, NOT measured in this run
-        traffic, traffic_from = None, None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_c3.json")))
-            if pmc["N"] == N and pmc["L"] == L and not by_target:
-                traffic = pmc["kernels"][args.mode]["hbm_bytes_per_launch"]
-                traffic_from = "profiles/r02_pmc_c3.json"
-        except Exception:
-            pass
+        traffic = pmc["kernels"][args.mode]["hbm_bytes_per_launch"] if pmc and args.mode in pmc["kernels"] else None
+        traffic_from = "profiles/r02_pmc_c3.json" if traffic is not None else None
         # SURVEY.md 8d caveat H5: at 1 bit per update the FP64 vector pipe, not HBM, is the resource that binds.
         # USEFUL f64 instructions per pair of directional updates (one donor at one visited site, both passes):
         # 3 forward (add, masked mul, add into the sum) + 6 backward (masked add, add, masked mul, two for the
@@ -323,7 +326,7 @@ def main():
                 "target_shard_matrix": gather,
             },
             "roofline": {"bound": "fp64_valu", "kernel": "paint_kernel (forward + backward, one launch)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "algorithmic_bytes": alg_bytes, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_static_from": traffic_from,
                          "fp64_valu": {"useful_instr_per_update_pair": 9,
                                        "achieved_Tinstr_per_s": useful,

@@ -1527,7 +1527,7 @@ DeviceMinMatch::DeviceMinMatch(int N, int device) : impl(new Impl()) {
 DeviceMinMatch::~DeviceMinMatch() {
   BuildDispatcher::of(impl->device).enroll(-1);
   if (getenv("RELATE_AMD_TIMING") && impl->n_timed)
-    fprintf(stderr, "[gpu tree builder] %lld trees: ms per tree on the host side: uploads + weave %.2f, submit -> done %.2f, "
+    fprintf(stderr, "[gpu tree builder] %lld trees, host ms per tree: uploads + weave %.2f, submit -> done %.2f, "
                     "copy-out %.2f\n", impl->n_timed, 1e3 * impl->t_prep / impl->n_timed,
             1e3 * impl->t_wait / impl->n_timed, 1e3 * impl->t_out / impl->n_timed);
   if (impl->stream) (void)hipStreamDestroy(impl->stream);

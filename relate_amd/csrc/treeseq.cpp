@@ -53,7 +53,8 @@ struct PropLocal {
 struct rl_treeseq {
   int N = 0, L = 0;
   double theta = 0.001;
-  std::vector<uint32_t> bits;  // panel
+  std::vector<uint32_t> bits_own;  // panel (a copy: rl_treeseq_create), or
+  const uint32_t *bits = nullptr;  // ... the caller's, which outlives the object (the stage: its context's panel)
   int row_words = 0;
   std::vector<double> rpos;
   std::vector<int> bp, state;
@@ -356,7 +357,8 @@ rl_treeseq *rl_treeseq_create(int N, int L, const uint32_t *bits, int row_words,
   ts->L = L;
   ts->theta = theta;
   ts->row_words = row_words;
-  ts->bits.assign(bits, bits + (size_t)L * row_words);
+  ts->bits_own.assign(bits, bits + (size_t)L * row_words);
+  ts->bits = ts->bits_own.data();
   ts->rpos.assign(rpos, rpos + L + 1);
   if (bp_pos) ts->bp.assign(bp_pos, bp_pos + L);
   if (state)
@@ -369,6 +371,27 @@ rl_treeseq *rl_treeseq_create(int N, int L, const uint32_t *bits, int row_words,
 }
 
 void rl_treeseq_destroy(rl_treeseq *ts) { delete ts; }
+
+}  // extern "C"
+
+// as rl_treeseq_create, the panel borrowed instead of copied
+static rl_treeseq *treeseq_borrowing(int N, int L, const uint32_t *bits, int row_words, const double *rpos,
+                                     const int *bp_pos, const int *state, double theta) {
+  rl_treeseq *ts = new rl_treeseq();
+  ts->N = N;
+  ts->L = L;
+  ts->theta = theta;
+  ts->row_words = row_words;
+  ts->bits = bits;
+  ts->rpos.assign(rpos, rpos + L + 1);
+  ts->bp.assign(bp_pos, bp_pos + L);
+  ts->state.assign(state, state + L);
+  ts->thr = (int)(0.03 * N);  // anc_builder.cpp:383
+  ts->member.assign(N, 0);
+  return ts;
+}
+
+extern "C" {
 
 int rl_treeseq_build(rl_treeseq *ts, int start, int end, rl_matrix_fn matrix, rl_advance_fn advance, void *user,
                      int flags, int fb) {
@@ -879,7 +902,8 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
       const int g = ((slot % 2) * half + (slot / 2) % half) % G;
       sched_setaffinity(0, sizeof(cpu_set_t), &groups[g]);
     }
-    rl_treeseq *ts = rl_treeseq_create(ctx->N, L, ctx->bits.data(), ctx->row_words, ctx->rpos.data(), bp.data(),
+    // (the panel is the context's, immutable for the stage: a copy per section thread would be 0.3 GB each at C3)
+    rl_treeseq *ts = treeseq_borrowing(ctx->N, L, ctx->bits.data(), ctx->row_words, ctx->rpos.data(), bp.data(),
                                        state.data(), ctx->theta);
     if (!ts) {
       fail(RL_EINVAL);

@@ -60,7 +60,7 @@ with tempfile.TemporaryDirectory() as work:
                            env=dict(os.environ, RELATE_AMD_TIMING="1"))
         assert p.returncode == 0, p.stderr.decode()[-400:]
         out["build_topology_phases"] = [l.strip() for l in p.stderr.decode().split("\n") if "[tree sequence]" in l]
-        out["builder_host_side"] = [l.strip() for l in p.stderr.decode().split("\n") if "host side" in l][:4]
+        out["builder_host_side"] = [l.strip() for l in p.stderr.decode().split("\n") if "host ms per tree" in l][:4]
         launches = [l for l in p.stderr.decode().split("\n") if "[tree builder launch]" in l]
         if launches:
             import re as _re
