@@ -6,6 +6,7 @@
 // block 2i+1 its forward pass; longest target first), so that the last round
 // of workgroups of one direction does not leave the chip half empty while the
 // other direction waits.  DIR = 0 / 1 launch one direction alone (profiling).
+#include <cstdlib>
 #include "paint_device.h"
 #include "exact_sum.h"
 #include "launch.h"
@@ -315,12 +316,14 @@ __global__ void __launch_bounds__(64 * WAVES, 2) paint_kernel(const PaintParams 
 template <int S, int TAIL, int WAVES>
 static hipError_t launch_paint_t(const PaintParams &p, int dir, hipStream_t stream) {
   const dim3 grid(dir == 2 ? 2 * p.nloc : p.nloc), block(64 * WAVES);
+  // experiments: extra LDS per workgroup caps the waves a SIMD holds (RELATE_AMD_PAINT_LDS bytes)
+  static const int lds = getenv("RELATE_AMD_PAINT_LDS") ? atoi(getenv("RELATE_AMD_PAINT_LDS")) : 0;
   if (dir == 2)
-    hipLaunchKernelGGL((paint_kernel<S, TAIL, RL_MODE, WAVES, 2>), grid, block, 0, stream, p);
+    hipLaunchKernelGGL((paint_kernel<S, TAIL, RL_MODE, WAVES, 2>), grid, block, lds, stream, p);
   else if (dir == 1)
-    hipLaunchKernelGGL((paint_kernel<S, TAIL, RL_MODE, WAVES, 1>), grid, block, 0, stream, p);
+    hipLaunchKernelGGL((paint_kernel<S, TAIL, RL_MODE, WAVES, 1>), grid, block, lds, stream, p);
   else
-    hipLaunchKernelGGL((paint_kernel<S, TAIL, RL_MODE, WAVES, 0>), grid, block, 0, stream, p);
+    hipLaunchKernelGGL((paint_kernel<S, TAIL, RL_MODE, WAVES, 0>), grid, block, lds, stream, p);
   return hipGetLastError();
 }
 
