@@ -99,7 +99,8 @@ struct rl_ctx {
   rl::PaintConsts consts{};
   rl::DevBuf d_bits, d_masks, d_off, d_sites, d_cf, d_nxt, d_ia, d_ie, d_binit, d_order;
   rl::DevBuf d_alpha, d_beta, d_lsa, d_lsb, d_stats;
-  rl::DevBuf d_k2_scratch, d_k2_counter;  // RePaint's per-launch strips, shared by the context's windows (window.cpp)
+  rl::DevBuf d_k2_scratch;  // RePaint's checkpoint rows and side records of one launch, shared by the context's
+                            // windows (window.cpp)
   bool have_chunk = false, plan_on_device = false, painted = false;
   int paint_mode = -1;
   // RePaint launches of the context's windows share the forward strips, the target counter and stream s0: one at a

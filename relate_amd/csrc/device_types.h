@@ -47,9 +47,15 @@ struct PaintParams {
 };
 
 // RePaintSection over one window, all targets.
-// The forward pass keeps every REPAINT_CHECKPOINT-th alpha row in the scratch strip; the backward pass rebuilds
-// the rows in between from the nearest one (repaint_kernels.hip).  Per step it also keeps 3 doubles (side record).
+// The forward kernel keeps every REPAINT_CHECKPOINT-th alpha row of every target in HBM; the backward kernel
+// rebuilds the rows in between from the nearest one (repaint_kernels.hip).  Per step it also keeps 3 doubles (side
+// record).
 constexpr int REPAINT_CHECKPOINT = 4;
+// bytes of the forward kernel's output for a window of `rows` target-site rows over nloc targets (an upper bound:
+// every target rounds its checkpoint rows up)
+inline size_t repaint_scratch_bytes(int64_t rows, int nloc, int S, int waves) {
+  return (size_t)((rows / REPAINT_CHECKPOINT + nloc) * (int64_t)S * 64 * waves + rows * 3) * sizeof(double);
+}
 constexpr int REPAINT_SIDE = 3;  // doubles per step: the step's additive constant, its rescaling divisor (0: none), logscale
 struct RepaintParams {
   Layout lay;
@@ -78,10 +84,10 @@ struct RepaintParams {
   const int32_t *row_lo, *row_hi;  // [nloc]
   float *topology;            // [kept rows][S*64] register-major: row[i*64 + lane] = donor start_lane + i
   float *logscales;           // [sum D]
-  double *scratch;            // per block: checkpoint alpha rows [ceil(maxD/CHECKPOINT)][waves][S*64], then the
-                              // side records [maxD][REPAINT_SIDE]
-  int64_t scratch_stride;     // doubles per block
-  int64_t side_offset;        // doubles from the block's strip to its side records
+  double *scratch;            // checkpoint alpha rows [ck_off[nloc]][waves][S*64]: target t's rows 0, CK, 2CK ... of
+                              // its D_t forward rows start at row ck_off[t]
+  const int64_t *ck_off;      // [nloc+1]
+  double *side;               // side records [top_off[nloc]][REPAINT_SIDE], target t's at top_off[t]
   const int32_t *order;       // [nloc] targets (global index), longest first
   int sum_mode;
 };

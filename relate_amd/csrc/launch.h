@@ -47,13 +47,13 @@ hipError_t launch_lane_masks(const uint32_t *bits, int row_words, int L, const L
 template <int MODE>
 hipError_t launch_paint_mode(const PaintParams &p, int S, int waves, int dir, hipStream_t stream);
 template <int MODE>
-hipError_t launch_repaint_mode(const RepaintParams &p, int S, int waves, int nblocks, int *counter, hipStream_t stream);
+hipError_t launch_repaint_mode(const RepaintParams &p, int S, int waves, hipStream_t stream);
 template <> hipError_t launch_paint_mode<0>(const PaintParams &, int, int, int, hipStream_t);
 template <> hipError_t launch_paint_mode<1>(const PaintParams &, int, int, int, hipStream_t);
 template <> hipError_t launch_paint_mode<2>(const PaintParams &, int, int, int, hipStream_t);
-template <> hipError_t launch_repaint_mode<0>(const RepaintParams &, int, int, int, int *, hipStream_t);
-template <> hipError_t launch_repaint_mode<1>(const RepaintParams &, int, int, int, int *, hipStream_t);
-template <> hipError_t launch_repaint_mode<2>(const RepaintParams &, int, int, int, int *, hipStream_t);
+template <> hipError_t launch_repaint_mode<0>(const RepaintParams &, int, int, hipStream_t);
+template <> hipError_t launch_repaint_mode<1>(const RepaintParams &, int, int, hipStream_t);
+template <> hipError_t launch_repaint_mode<2>(const RepaintParams &, int, int, hipStream_t);
 
 inline int kernel_mode(int sum_mode) { return sum_mode == 0 ? 1 : (sum_mode == 1 ? 0 : 2); }
 inline hipError_t launch_paint(const PaintParams &p, int S, int waves, int dir, hipStream_t stream) {
@@ -63,12 +63,13 @@ inline hipError_t launch_paint(const PaintParams &p, int S, int waves, int dir, 
     default: return launch_paint_mode<2>(p, S, waves, dir, stream);
   }
 }
-inline hipError_t launch_repaint(const RepaintParams &p, int S, int waves, int nblocks, int *counter,
-                                 hipStream_t stream) {
+// K2: the forward kernel (checkpoint rows + side records of every target), then the backward kernel, one workgroup
+// per target each
+inline hipError_t launch_repaint(const RepaintParams &p, int S, int waves, hipStream_t stream) {
   switch (kernel_mode(p.sum_mode)) {
-    case 0: return launch_repaint_mode<0>(p, S, waves, nblocks, counter, stream);
-    case 1: return launch_repaint_mode<1>(p, S, waves, nblocks, counter, stream);
-    default: return launch_repaint_mode<2>(p, S, waves, nblocks, counter, stream);
+    case 0: return launch_repaint_mode<0>(p, S, waves, stream);
+    case 1: return launch_repaint_mode<1>(p, S, waves, stream);
+    default: return launch_repaint_mode<2>(p, S, waves, stream);
   }
 }
 // the paint file's run-length quantisation of `rows` stones of N floats, in place (panel_kernels.hip)

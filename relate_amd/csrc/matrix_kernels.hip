@@ -2,7 +2,7 @@
 //
 // Replaces the row loop of DistanceMeasure::GetMatrix (anc_builder.cpp:116-194).
 // One 256-thread block per target row n: reads one (derived at snp) or two
-// (interpolated) posterior rows of target n, applies fast_log (fast_log.hpp),
+// (interpolated) posterior rows of target n in the rows' register-major order, applies fast_log (fast_log.hpp),
 // reduces the row minimum over all N computed entries (the diagonal's
 // fast_log(0) value included), writes d[n][j] - min (diagonal 0).
 // Traffic: <= 8N^2 B read + 4N^2 B written per call: HBM-bound.
@@ -10,23 +10,6 @@
 #include "launch.h"
 
 namespace rl {
-
-// register-major index of donor j in a posterior row (layout over all N donors;
-// the target's own entry holds 0 = alpha[n]*beta[n])
-RL_DEV int phys_index(const Layout &lay, int S, int j) {
-  const int p = j;
-  const int big = lay.rem * (lay.q + 1);
-  int l, i;
-  if (p < big) {
-    l = p / (lay.q + 1);
-    i = p - l * (lay.q + 1);
-  } else {
-    const int p2 = p - big;
-    l = lay.rem + p2 / lay.q;  // q > 0 here because p2 >= 0 implies lanes of length q exist
-    i = p2 - (l - lay.rem) * lay.q;
-  }
-  return ((l >> 6) * S + i) * 64 + (l & 63);  // [wave][register][lane], l = virtual lane
-}
 
 __global__ void __launch_bounds__(256) matrix_kernel(const MatrixParams p, const Layout lay, int S, int waves) {
   extern __shared__ float vals[];  // N floats
@@ -45,25 +28,33 @@ __global__ void __launch_bounds__(256) matrix_kernel(const MatrixParams p, const
   const float e_pn = p.e_pn[t], e_np = p.e_np[t];
   const float scale = -1.0f;
 
+  // The posterior rows are read in their own (register-major) order: thread = lane, four registers per pass, every
+  // wavefront 256 contiguous bytes; the entry of donor j = start(lane) + register lands in LDS in donor order.
   float mn = INFINITY;
-  for (int j = threadIdx.x; j < N; j += blockDim.x) {
-    float v;
-    if (direct) {
-      const float x = tp[phys_index(lay, S, j)];
-      v = (fast_log_dev(x) + ls_prev) * scale;  // :128
-    } else {
-      const int idx = phys_index(lay, S, j);
-      const float xp = tp[idx], xn = tn[idx];
-      if (ls_prev <= ls_next) {  // :172-178
-        const float x = (float)(wl * xp * e_pn + wr * xn);
-        v = (fast_log_dev(x) + ls_next) * scale;
+  const int lane = threadIdx.x & 63;
+  for (int w = 0; w < waves; w++) {
+    const int l = w * 64 + lane;                             // virtual lane: a run of consecutive donors
+    const int len = lay.q + (l < lay.rem ? 1 : 0);
+    const int start = l * lay.q + (l < lay.rem ? l : lay.rem);
+    for (int i = threadIdx.x >> 6; i < len; i += blockDim.x >> 6) {
+      const int idx = (w * S + i) * 64 + lane;
+      float v;
+      if (direct) {
+        const float x = tp[idx];
+        v = (fast_log_dev(x) + ls_prev) * scale;  // :128
       } else {
-        const float x = (float)(wl * xp + wr * xn * e_np);
-        v = (fast_log_dev(x) + ls_prev) * scale;
+        const float xp = tp[idx], xn = tn[idx];
+        if (ls_prev <= ls_next) {  // :172-178
+          const float x = (float)(wl * xp * e_pn + wr * xn);
+          v = (fast_log_dev(x) + ls_next) * scale;
+        } else {
+          const float x = (float)(wl * xp + wr * xn * e_np);
+          v = (fast_log_dev(x) + ls_prev) * scale;
+        }
       }
+      vals[start + i] = v;
+      if (v < mn) mn = v;
     }
-    vals[j] = v;
-    if (v < mn) mn = v;
   }
   red[threadIdx.x] = mn;
   __syncthreads();

@@ -39,9 +39,41 @@ RL_DEV void load_stone(const PaintLane<S> &pl, const float *__restrict__ in, dou
   }
 }
 
+// ---- rows of the scratch strip / of the posterior slab: [register][lane], one address per chunk of 8 registers
+// (the registers of a chunk are immediates from it), so that no table of addresses is kept
+typedef __attribute__((address_space(1))) double *GlobalF64;
+typedef const __attribute__((address_space(1))) double *GlobalF64In;
+typedef __attribute__((address_space(1))) float *GlobalF32;
+template <int S>
+RL_DEV void store_row(double *row_lane, const double (&a)[S]) {
+#pragma unroll
+  for (int c = 0; c < S / 8; c++) {
+    GlobalF64 q = (GlobalF64)(row_lane + c * 8 * 64);
+    asm volatile("" : "+v"(q));
+#pragma unroll
+    for (int jj = 0; jj < 8; jj++) q[jj * 64] = a[c * 8 + jj];
+  }
+}
+template <int S>
+RL_DEV void load_row(const double *row_lane, double (&a)[S]) {
+#pragma unroll
+  for (int c = 0; c < S / 8; c++) {
+    GlobalF64In q = (GlobalF64In)(row_lane + c * 8 * 64);
+    asm volatile("" : "+v"(q));
+#pragma unroll
+    for (int jj = 0; jj < 8; jj++) a[c * 8 + jj] = q[jj * 64];
+  }
+}
+// the double that lane `l` holds (l wave-uniform), as a uniform value
+RL_DEV double lane_value(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+
+// ---------------- K2a: the forward pass of one target (fast_painting.cpp:769-885)
+// Leaves every CK-th alpha row (double) in the target's strip of checkpoint rows and one side record per step.
 template <int S, int TAIL, int MODE, int WAVES>
-RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ scratch, float *stage,
-                           WaveLink<WAVES> &lk) {
+RL_DEV void repaint_forward(const RepaintParams &p, int n, float *stage, WaveLink<WAVES> &lk) {
   const int wv = lk.w;  // this wave of the target's workgroup (wave-uniform)
   PaintLane<S> pl;
   pl.init(p.lay, n, wv);
@@ -53,21 +85,17 @@ RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ s
   const int32_t *__restrict__ st = p.sites + off;
   const double *__restrict__ cfp = p.cf + off;
   const double *__restrict__ nx = p.nxt + off;
-  const double cf_last = p.cf_last[t], nxt_last = p.nxt_last[t];
+  const double cf_last = p.cf_last[t];
   constexpr int CK = REPAINT_CHECKPOINT;
-  constexpr int WROW = S * 64;          // doubles per wave and scratch row
-  constexpr int ROW = WROW * WAVES;     // a scratch row: [wave][register][lane]
-  constexpr int TROW = S * 64 * WAVES;  // a posterior row, same order
-  double *__restrict__ side = scratch + p.side_offset;  // [step][cfac, rescaling divisor or 0, logscale]
-  scratch += (size_t)wv * WROW;
+  constexpr int ROW = S * 64 * WAVES;  // a checkpoint row: [wave][register][lane]
+  double *__restrict__ side = p.side + p.top_off[t] * REPAINT_SIDE;  // [step][cfac, rescaling divisor or 0, logscale]
+  double *__restrict__ ckrows = p.scratch + p.ck_off[t] * (int64_t)ROW + (size_t)wv * (S * 64) + pl.lane;
   const bool scribe = pl.lane == 0 && wv == 0;  // writes the side records
-  constexpr int CH = S % 16 == 0 ? 16 : 8;  // registers per chunk of masks (forward)
+  constexpr int CH = S % 16 == 0 ? 16 : 8;  // registers per chunk of masks
   typedef typename MaskChunk<CH>::type Chunk;
   const double K1 = in_vgpr(c.K1);
 
   double a[S];
-
-  // ---------------- forward (fast_painting.cpp:769-885)
   {
     const ColdRepaint cp = cold_params<RepaintParams>();
     load_stone<S>(pl, cp->alpha_begin + (size_t)t * cp->lay.N, a, stage);
@@ -76,155 +104,292 @@ RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ s
   double ssum = wave_sum<MODE, S, WAVES>(RegTerm<S>{a}, local_sum<S>(RegTerm<S>{a}), lk);
   float lsf = p.ls_alpha[t];
   double prev_ls = (double)lsf;
-  {
-    double *row = scratch;  // row 0 is a checkpoint
-#pragma unroll
-    for (int i = 0; i < S; i++) row[i * 64 + pl.lane] = a[i];
-    if (scribe) {
-      side[0] = 0.0;
-      side[1] = 0.0;
-      side[2] = (double)lsf;
-    }
+  store_row<S>(ckrows, a);  // row 0 is a checkpoint
+  if (scribe) {
+    side[0] = 0.0;
+    side[1] = 0.0;
+    side[2] = (double)lsf;
   }
   double cfac = (D == 1 ? cf_last : cfp[0]) * ssum;
-  {
-    int s1 = D > 1 ? st[1] : 0, s2 = D > 2 ? st[2] : 0;  // row pipeline as in paint_forward
-    uint32_t touched = 0;
-    MaskRow row = site_row(p.masks, S, p.L, s1, WAVES, wv);
-    Chunk first = load_masks<CH>(row, 0);
-    for (int i = 1; i < D; i++) {
-      retire_touch(touched);
-      if (i + 1 < D) touched = touch_row(p.masks, S, s2, pl.lane, WAVES, wv);
-      s1 = s2;
-      if (i + 2 < D) s2 = st[i + 2];
-      const double nx_i = nx[i - 1], cf_i = (i == D - 1 ? cf_last : cfp[i]);
-      const double cfac_used = cfac;
-      double divisor = 0.0;
-      set_slot<S>(a, pl.jk, pl.kbit, -cfac);  // the target's own slot: (-c) + c = +0.0
-      double lsum = 0.0;
-      for_each_chunk_from<S, CH>(row, first, [&](int j0, const Chunk &m) {
-        double v[CH];
+  int s1 = D > 1 ? st[1] : 0, s2 = D > 2 ? st[2] : 0;  // row pipeline as in paint_forward
+  uint32_t touched = 0;
+  MaskRow row = site_row(p.masks, S, p.L, s1, WAVES, wv);
+  Chunk first = load_masks<CH>(row, 0);
+  for (int i = 1; i < D; i++) {
+    retire_touch(touched);
+    if (i + 1 < D) touched = touch_row(p.masks, S, s2, pl.lane, WAVES, wv);
+    s1 = s2;
+    if (i + 2 < D) s2 = st[i + 2];
+    const double nx_i = nx[i - 1], cf_i = (i == D - 1 ? cf_last : cfp[i]);
+    const double cfac_used = cfac;
+    double divisor = 0.0;
+    set_slot<S>(a, pl.jk, pl.kbit, -cfac);  // the target's own slot: (-c) + c = +0.0
+    double lsum = 0.0;
+    for_each_chunk_from<S, CH>(row, first, [&](int j0, const Chunk &m) {
+      double v[CH];
 #pragma unroll
-        for (int jj = 0; jj < CH; jj++) {
-          v[jj] = a[j0 + jj];
-          if (j0 + jj < S - TAIL)
-            v[jj] = v[jj] + cfac;
-          else
-            tail_add(v[jj], pl.len, j0 + jj, cfac);
-        }
-        masked_mul8<0>(v, m, K1);  // v *= (mismatch ? K1 : 1.0)
-        if constexpr (CH == 16) masked_mul8<8>(v + 8, m, K1);
-#pragma unroll
-        for (int jj = 0; jj < CH; jj++) {
-          a[j0 + jj] = v[jj];
-          lsum += v[jj];
-        }
-      });
-      row = site_row(p.masks, S, p.L, s1, WAVES, wv);
-      first = load_masks<CH>(row, 0);
-      ssum = wave_sum<MODE, S, WAVES>(RegTerm<S>{a}, lsum, lk);
-      prev_ls += nx_i;
-      lsf = (float)prev_ls;  // :806-807
-      cfac = ssum;
-      if (cfac < c.lower || cfac > c.upper) {  // :865-877
-#pragma unroll
-        for (int j = 0; j < S; j++) a[j] /= ssum;
-        divisor = ssum;
-        const double lg = log(ssum);
-        prev_ls += lg;
-        lsf = (float)((double)lsf + lg);
-        cfac = 1.0;
+      for (int jj = 0; jj < CH; jj++) {
+        v[jj] = a[j0 + jj];
+        if (j0 + jj < S - TAIL)
+          v[jj] = v[jj] + cfac;
+        else
+          tail_add(v[jj], pl.len, j0 + jj, cfac);
       }
-      cfac *= cf_i;
-      if (i % CK == 0) {  // checkpoint row
-        double *srow = scratch + (int64_t)(i / CK) * ROW;
+      masked_mul8<0>(v, m, K1);  // v *= (mismatch ? K1 : 1.0)
+      if constexpr (CH == 16) masked_mul8<8>(v + 8, m, K1);
 #pragma unroll
-        for (int j = 0; j < S; j++) srow[j * 64 + pl.lane] = a[j];
+      for (int jj = 0; jj < CH; jj++) {
+        a[j0 + jj] = v[jj];
+        lsum += v[jj];
       }
-      if (scribe) {  // what the backward pass needs to redo this step from the previous row
-        side[(size_t)i * REPAINT_SIDE + 0] = cfac_used;
-        side[(size_t)i * REPAINT_SIDE + 1] = divisor;
-        side[(size_t)i * REPAINT_SIDE + 2] = (double)lsf;
+    });
+    row = site_row(p.masks, S, p.L, s1, WAVES, wv);
+    first = load_masks<CH>(row, 0);
+    ssum = wave_sum<MODE, S, WAVES>(RegTerm<S>{a}, lsum, lk);
+    prev_ls += nx_i;
+    lsf = (float)prev_ls;  // :806-807
+    cfac = ssum;
+    if (cfac < c.lower || cfac > c.upper) {  // :865-877
+#pragma unroll
+      for (int j = 0; j < S; j++) a[j] /= ssum;
+      divisor = ssum;
+      const double lg = log(ssum);
+      prev_ls += lg;
+      lsf = (float)((double)lsf + lg);
+      cfac = 1.0;
+    }
+    cfac *= cf_i;
+    if (i % CK == 0) store_row<S>(ckrows + (int64_t)(i / CK) * ROW, a);  // checkpoint row
+    if (scribe) {  // what the backward pass needs to redo this step from the previous row
+      side[(size_t)i * REPAINT_SIDE + 0] = cfac_used;
+      side[(size_t)i * REPAINT_SIDE + 1] = divisor;
+      side[(size_t)i * REPAINT_SIDE + 2] = (double)lsf;
+    }
+  }
+  retire_touch(touched);
+}
+
+// ---------------- K2b: the backward pass of one target (:887-1073) and its posterior rows
+// The block's checkpoint row is held on chip while the pass walks down the block: registers 0 .. LREG-1 in the
+// wave's LDS strip [register][lane] (filled by global->LDS loads that bypass the VGPRs), the rest in VGPRs.
+template <int S>
+struct HeldRow {
+  static constexpr int LREG = S < 72 ? S : 72;  // 72 * 512 B = 36 KB: four waves of a CU fit their strips in LDS
+  static constexpr int VREG = S - LREG;
+  double *lds;  // the wave's strip (wave-uniform)
+  double v[VREG > 0 ? VREG : 1];
+  RL_DEV double get(int i, int lane) const { return i < LREG ? lds[i * 64 + lane] : v[i - LREG < 0 ? 0 : i - LREG]; }
+  // request the [register][lane] row of doubles at `row` (wave-uniform)
+  RL_DEV void request(const double *row, int lane) {
+    typedef const __attribute__((address_space(1))) void *GP;
+    typedef __attribute__((address_space(3))) void *LP;
+    // one scalar base per 4 KB (four instructions with immediate offsets 0 .. 3 KB), the lane's 16 bytes as a
+    // 32-bit offset: the address registers are not rewritten between the requests
+    const uint64_t r64 = (uint64_t)row;
+    const uint64_t base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(r64 >> 32)) << 32) |
+                          (uint32_t)__builtin_amdgcn_readfirstlane((int)r64);
+    const uint32_t voff = (uint32_t)lane * 16u;
+#ifdef RL_K2_NO_DMA
+    (void)base; (void)voff;
+#pragma unroll
+    for (int i = 0; i < LREG; i++) lds[i * 64 + lane] = row[i * 64 + lane];
+#else
+    static_assert(LREG % 8 == 0, "the strip is requested 4 KB at a time");
+#pragma unroll
+    for (int g = 0; g < LREG / 8; g++) {
+      GP src = (GP)((const char *)base + g * 4096 + voff);
+      LP dst = (LP)(lds + g * 512);
+      __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(src, dst, 16, 1024, 0);
+      __builtin_amdgcn_global_load_lds(src, dst, 16, 2048, 0);
+      __builtin_amdgcn_global_load_lds(src, dst, 16, 3072, 0);
+    }
+#endif
+    if constexpr (VREG > 0) {
+      GlobalF64In q = (GlobalF64In)(row + LREG * 64 + lane);
+      asm volatile("" : "+v"(q));
+#pragma unroll
+      for (int i = 0; i < VREG; i++) v[i] = q[i * 64];
+    }
+  }
+};
+// Posterior row of the block's checkpoint row itself (no forward step): trow = float(ck * b)
+template <int S>
+RL_DEV void product_last(const HeldRow<S> &ck, int lane, const double (&b)[S], float *trow_lane) {
+#pragma unroll
+  for (int c = 0; c < S / 8; c++) {
+    GlobalF32 q = (GlobalF32)(trow_lane + c * 8 * 64);
+    asm volatile("" : "+v"(q));
+#pragma unroll
+    for (int jj = 0; jj < 8; jj++) q[jj * 64] = (float)(ck.get(c * 8 + jj, lane) * b[c * 8 + jj]);
+  }
+}
+// Posterior row r steps above the checkpoint row: every chunk of 8 registers walks the steps cp+1 .. cp+r (add the
+// step's constant, multiply the mismatching donors by K1, divide where the step rescaled) and is stored as
+// float(alpha * b).  !DIV: exactly R steps, no divisions, straight-line; DIV: r <= R steps, each tested.
+// The masks of the (chunk, step) pairs come in one behind the other (scalar loads, one pair ahead).
+template <int S, int R, bool DIV, int CKN>
+RL_DEV void product_steps(const HeldRow<S> &ck, int lane, const double (&b)[S], float *trow_lane,
+                          const MaskRow (&rows)[CKN], const double (&cfs)[CKN], const double (&dvs)[CKN], int r,
+                          double K1) {
+  constexpr int NC = S / 8;
+  u64x8 m = load_masks<8>(rows[1], 0);
+#pragma unroll
+  for (int c = 0; c < NC; c++) {
+    double v[8];
+#pragma unroll
+    for (int jj = 0; jj < 8; jj++) v[jj] = ck.get(c * 8 + jj, lane);
+#pragma unroll
+    for (int q = 1; q <= R; q++) {
+      if (DIV && q > r) break;  // (wave-uniform)
+      const u64x8 mc = m;
+      const bool last_step = DIV ? (q == r) : (q == R);
+      if (!(last_step && c + 1 == NC)) {
+        MaskRow nr = last_step ? rows[1] : rows[q < R ? q + 1 : 1];
+        const int nc = last_step ? c + 1 : c;
+        asm volatile("" : "+s"(nr) : "s"(mc[0]));
+        m = load_masks<8>(nr, nc);
+      }
+#pragma unroll
+      for (int jj = 0; jj < 8; jj++) v[jj] = v[jj] + cfs[q];
+      masked_mul8<0>(v, mc, K1);
+      if (DIV && dvs[q] != 0.0) {
+#pragma unroll
+        for (int jj = 0; jj < 8; jj++) v[jj] /= dvs[q];
       }
     }
-    retire_touch(touched);
+    GlobalF32 qo = (GlobalF32)(trow_lane + c * 8 * 64);
+    asm volatile("" : "+v"(qo));
+#pragma unroll
+    for (int jj = 0; jj < 8; jj++) qo[jj * 64] = (float)(v[jj] * b[c * 8 + jj]);
   }
+}
 
-  // ---------------- backward (:887-1073)
+template <int S, int TAIL, int MODE, int WAVES>
+RL_DEV void repaint_backward(const RepaintParams &p, int n, float *stage, double *strip, WaveLink<WAVES> &lk) {
+  const int wv = lk.w;
+  PaintLane<S> pl;
+  pl.init(p.lay, n, wv);
+  const PaintConsts &c = p.c;
+  const int t = n - p.k0;
+  const int ib = p.ib[t], ie = p.ie[t];
+  const int D = ie - ib + 1;
+  const int64_t off = p.plan_off[n] + ib;
+  const int32_t *__restrict__ st = p.sites + off;
+  const double *__restrict__ cfp = p.cf + off;
+  const double *__restrict__ nx = p.nxt + off;
+  const double cf_last = p.cf_last[t], nxt_last = p.nxt_last[t];
+  constexpr int CK = REPAINT_CHECKPOINT;
+  constexpr int ROW = S * 64 * WAVES;
+  constexpr int TROW = S * 64 * WAVES;  // a posterior row, same order
+  const double *__restrict__ side = p.side + p.top_off[t] * REPAINT_SIDE;
+  const double *__restrict__ ckrows = p.scratch + p.ck_off[t] * (int64_t)ROW + (size_t)wv * (S * 64) + pl.lane;
+  const double K1 = in_vgpr(c.K1);
   const int row_lo = p.row_lo[t], row_hi = p.row_hi[t];  // posterior rows that are kept
-  float *__restrict__ top = p.topology + p.slab_off[t] * (int64_t)TROW + (size_t)wv * (S * 64);
+  float *__restrict__ top = p.topology + p.slab_off[t] * (int64_t)TROW + (size_t)wv * (S * 64) + pl.lane;
   float *__restrict__ lsout = p.logscales + p.top_off[t];
   const double theta = in_vgpr(c.theta), ntheta = in_vgpr(c.ntheta);
+
+  // The rows go by blocks of CK: the block's checkpoint row alpha_cp (cp = j - j % CK) is read ONCE and held on
+  // chip while the pass walks down the block; row j is rebuilt from it chunk by chunk with j - cp forward steps
+  // (the same operations on the same operands: same bits) and topology row j = float(alpha_j * beta_j).  The
+  // alpha slots of the target itself and past a lane's run come out as finite garbage there; beta is +0.0 in
+  // both.  The next block's checkpoint row is requested as soon as the block's last product (row cp) has let
+  // go of the strip, so those loads land during the following beta step.
+  int cpb = (D - 1) - (D - 1) % CK;  // checkpoint row of the current block
+  auto block_kept = [&](int c0) { return c0 >= 0 && c0 < row_hi && c0 + CK > row_lo; };
+  // a block's side records and sites in one vector load each: lane l holds double l of side[cp ...], site cp + l
+  auto block_records = [&](int c0, double &sd, int &sw) {
+    const int l = pl.lane;
+    const bool in = c0 >= 0;
+    sd = (in && l < CK * REPAINT_SIDE && (c0 + l / REPAINT_SIDE) < D) ? side[(size_t)c0 * REPAINT_SIDE + l] : 0.0;
+    sw = (in && l < CK && c0 + l < D) ? st[c0 + l] : 0;
+  };
+  double rec, rec_next;
+  int sit, sit_next;
+  block_records(cpb, rec, sit);
+  block_records(cpb - CK, rec_next, sit_next);
   double b[S];
+  float lsf = (float)lane_value(rec, (D - 1 - cpb) * REPAINT_SIDE + 2);  // the forward pass's last logscale
   lsf = lsf + p.ls_beta[t];  // float += float (:895)
   {
     const ColdRepaint cp = cold_params<RepaintParams>();
     load_stone<S>(pl, cp->beta_end + (size_t)t * cp->lay.N, b, stage);
   }
-  if constexpr (WAVES > 1) __syncthreads();  // the side records of wave 0 are visible to wave 1
-  __threadfence_block();
   set_slot<S>(b, pl.jk, pl.kbit, 0.0);  // the target's own slot of beta is +0.0 (fast_painting.cpp: b[k] = 0)
-  // topology row j = float(alpha_j * beta_j).  alpha_j is rebuilt chunk by chunk from the nearest checkpoint row
-  // at or before j: up to CK-1 forward steps (the same operations on the same operands: same bits).  Its slots of
-  // the target itself and past a lane's run come out as finite garbage there; beta is +0.0 in both.
-  auto product_row = [&](int j) {
-    if (j < row_lo || j >= row_hi) return;  // (uniform over the workgroup)
-    const int cp = j - j % CK, r = j - cp;
-    const double *__restrict__ arow = scratch + (int64_t)(cp / CK) * ROW;
-    float *__restrict__ trow = top + (int64_t)(j - row_lo) * TROW;
-    MaskRow rows[CK];
-    double cfs[CK], dvs[CK];
+  HeldRow<S> ck;  // (the strip shares its LDS with `stage`, which is done with by now)
+  ck.lds = strip;
+#pragma unroll
+  for (int i = 0; i < (HeldRow<S>::VREG > 0 ? HeldRow<S>::VREG : 1); i++) ck.v[i] = 0.0;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  if (block_kept(cpb)) ck.request(ckrows + (int64_t)(cpb / CK) * ROW - pl.lane, pl.lane);
+  MaskRow rows[CK];
+  double cfs[CK], dvs[CK];
+  auto open_block = [&]() {
 #pragma unroll
     for (int q = 1; q < CK; q++) {
-      const int i = cp + q <= j ? cp + q : j;  // (unused beyond r)
-      rows[q] = site_row(p.masks, S, p.L, st[i], WAVES, wv);
-      cfs[q] = side[(size_t)i * REPAINT_SIDE + 0];
-      dvs[q] = side[(size_t)i * REPAINT_SIDE + 1];
-    }
-#pragma unroll
-    for (int c0 = 0; c0 < S / 8; c0++) {
-      double a8[8];
-#pragma unroll
-      for (int jj = 0; jj < 8; jj++) a8[jj] = arow[(c0 * 8 + jj) * 64 + pl.lane];
-#pragma unroll
-      for (int q = 1; q < CK; q++) {
-        if (q <= r) {  // wave-uniform
-          const u64x8 m = load_masks<8>(rows[q], c0);
-#pragma unroll
-          for (int jj = 0; jj < 8; jj++) a8[jj] = a8[jj] + cfs[q];
-          masked_mul8<0>(a8, m, K1);
-          if (dvs[q] != 0.0) {
-#pragma unroll
-            for (int jj = 0; jj < 8; jj++) a8[jj] /= dvs[q];
-          }
-        }
-      }
-#pragma unroll
-      for (int jj = 0; jj < 8; jj++) trow[(c0 * 8 + jj) * 64 + pl.lane] = (float)(a8[jj] * b[c0 * 8 + jj]);
+      rows[q] = site_row(p.masks, S, p.L, __builtin_amdgcn_readlane(sit, q), WAVES, wv);
+      cfs[q] = lane_value(rec, q * REPAINT_SIDE + 0);
+      dvs[q] = lane_value(rec, q * REPAINT_SIDE + 1);
     }
   };
-  product_row(D - 1);  // :930
-  if (pl.lane == 0 && wv == 0) lsout[D - 1] = lsf;
+  open_block();
+  auto product_row = [&](int j, bool first) {
+    const int r = j - cpb;
+    const bool kept = j >= row_lo && j < row_hi;  // (uniform over the workgroup)
+    float *__restrict__ trow = top + (int64_t)(j - row_lo) * TROW;
+    if (r == 0) {
+      if (kept) product_last<S>(ck, pl.lane, b, trow);
+      if (block_kept(cpb - CK)) ck.request(ckrows + (int64_t)(cpb / CK - 1) * ROW - pl.lane, pl.lane);
+      return;
+    }
+    if (!kept) return;
+    bool div = first;  // (the window's last row goes the tested way: one copy of the straight-line variants)
+#pragma unroll
+    for (int q = 1; q < CK; q++) div = div || (q <= r && dvs[q] != 0.0);
+    if (div) {
+      product_steps<S, CK - 1, true>(ck, pl.lane, b, trow, rows, cfs, dvs, r, K1);
+      return;
+    }
+    static_assert(CK <= 8, "one straight-line variant per distance from the checkpoint");
+    switch (r) {
+      case 1: product_steps<S, 1, false>(ck, pl.lane, b, trow, rows, cfs, dvs, r, K1); break;
+      case 2: if constexpr (CK > 2) product_steps<S, 2, false>(ck, pl.lane, b, trow, rows, cfs, dvs, r, K1); break;
+      case 3: if constexpr (CK > 3) product_steps<S, 3, false>(ck, pl.lane, b, trow, rows, cfs, dvs, r, K1); break;
+      case 4: if constexpr (CK > 4) product_steps<S, 4, false>(ck, pl.lane, b, trow, rows, cfs, dvs, r, K1); break;
+      case 5: if constexpr (CK > 5) product_steps<S, 5, false>(ck, pl.lane, b, trow, rows, cfs, dvs, r, K1); break;
+      case 6: if constexpr (CK > 6) product_steps<S, 6, false>(ck, pl.lane, b, trow, rows, cfs, dvs, r, K1); break;
+      default: if constexpr (CK > 7) product_steps<S, 7, false>(ck, pl.lane, b, trow, rows, cfs, dvs, r, K1); break;
+    }
+  };
   int s0 = st[D - 1], s1 = D > 1 ? st[D - 2] : 0, s2 = D > 2 ? st[D - 3] : 0;
   MaskRow rown = site_row(p.masks, S, p.L, s0, WAVES, wv);
   double bsum;
-  {
+  {  // the window's last row: beta is the stone (:930)
     const MaskTerm<S> term{rown, b, theta, ntheta};
     bsum = wave_sum<MODE, S, WAVES>(term, local_sum<S>(term), lk);
   }
-  cfac = cf_last * bsum;
-  prev_ls = (double)p.ls_beta[t];  // :951
+  product_row(D - 1, true);
+  if (pl.lane == 0 && wv == 0) lsout[D - 1] = lsf;
+  double cfac = cf_last * bsum;
+  double prev_ls = (double)p.ls_beta[t];  // :951
   MaskRow rowh = site_row(p.masks, S, p.L, s1, WAVES, wv);
   u64x4 firstn = load_masks<4>(rown, 0), firsth = load_masks<4>(rowh, 0);
   uint32_t touched = 0;
   for (int j = D - 2; j >= 0; j--) {
+    if (j < cpb) {  // the pass enters the block below: its records were requested a block ago
+      cpb -= CK;
+      rec = rec_next;
+      sit = sit_next;
+      block_records(cpb - CK, rec_next, sit_next);
+      open_block();
+    }
     retire_touch(touched);
     if (j > 0) touched = touch_row(p.masks, S, s2, pl.lane, WAVES, wv);
     s0 = s1;
     s1 = s2;
     if (j > 1) s2 = st[j - 2];
     const double nx_j = (j + 1 == D - 1 ? nxt_last : nx[j + 1]), cf_j = cfp[j];
-    const double als = side[(size_t)j * REPAINT_SIDE + 2];  // the forward logscale of this site
     const double b1 = cfac / ntheta;
     const double bt = cfac / theta - b1;
     set_slot<S>(b, pl.jk, pl.kbit, -b1);
@@ -258,10 +423,11 @@ RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ s
       firstn = load_masks<4>(rown, 0);
       firsth = load_masks<4>(rowh, 0);
     }
+    const double als = lane_value(rec, (j - cpb) * REPAINT_SIDE + 2);  // the forward logscale of this site
     prev_ls += nx_j;
     lsf = (float)(als + prev_ls);  // :962-963
     cfac = bsum;
-    product_row(j);  // topology = float(alpha * beta) before the rescale of this step (:1039 vs :1047)
+    product_row(j, false);  // topology = float(alpha * beta) before the rescale of this step (:1039 vs :1047)
     if (cfac < c.lower || cfac > c.upper) {  // :1047-1061
 #pragma unroll
       for (int i = 0; i < S; i++) b[i] /= bsum;
@@ -277,32 +443,40 @@ RL_DEV void repaint_target(const RepaintParams &p, int n, double *__restrict__ s
 }
 
 template <int S, int TAIL, int MODE, int WAVES>
-__global__ void __launch_bounds__(64 * WAVES, (S <= 80 ? 2 : 1)) repaint_kernel(const RepaintParams p, int *counter) {
+__global__ void __launch_bounds__(64 * WAVES, 2) repaint_fwd_kernel(const RepaintParams p) {
   __shared__ float stage[WAVES][16 * 64];
   __shared__ WaveLinkStorage link;
-  __shared__ int s_t;
   WaveLink<WAVES> lk;
   lk.s = &link;
   lk.w = WAVES > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
-  double *scratch = p.scratch + (int64_t)blockIdx.x * p.scratch_stride;
-  for (;;) {
-    if (threadIdx.x == 0) s_t = atomicAdd(counter, 1);
-    __syncthreads();
-    const int t = s_t;
-    __syncthreads();
-    if (t >= p.nloc) break;
-    repaint_target<S, TAIL, MODE, WAVES>(p, p.order[t], scratch, stage[lk.w], lk);
-  }
+  repaint_forward<S, TAIL, MODE, WAVES>(p, p.order[blockIdx.x], stage[lk.w], lk);
+}
+// One wave per SIMD (the LDS strips decide that): beta in registers, the block's checkpoint row in LDS.  The strips
+// are dynamic LDS so that the compiler budgets registers for two waves per SIMD (256 VGPRs, no AGPR copies).
+template <int S>
+constexpr int strip_doubles() {
+  return HeldRow<S>::LREG * 64 > 16 * 64 / 2 ? HeldRow<S>::LREG * 64 : 16 * 64 / 2;
+}
+template <int S, int TAIL, int MODE, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES, 2) repaint_bwd_kernel(const RepaintParams p) {
+  extern __shared__ double strips[];  // [WAVES][strip]: stage (16 * 64 floats) first, then the held checkpoint row
+  __shared__ WaveLinkStorage link;
+  WaveLink<WAVES> lk;
+  lk.s = &link;
+  lk.w = WAVES > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+  double *strip = strips + lk.w * strip_doubles<S>();
+  repaint_backward<S, TAIL, MODE, WAVES>(p, p.order[blockIdx.x], (float *)strip, strip, lk);
 }
 
 template <>
-hipError_t launch_repaint_mode<RL_MODE>(const RepaintParams &p, int S, int waves, int nblocks, int *counter,
-                                        hipStream_t stream) {
+hipError_t launch_repaint_mode<RL_MODE>(const RepaintParams &p, int S, int waves, hipStream_t stream) {
   if (waves == 1) {
     switch (S) {
-#define RL_CASE(s, t)                                                                                           \
-  case s:                                                                                                       \
-    hipLaunchKernelGGL((repaint_kernel<s, t, RL_MODE, 1>), dim3(nblocks), dim3(64), 0, stream, p, counter); \
+#define RL_CASE(s, t)                                                                                    \
+  case s:                                                                                                \
+    hipLaunchKernelGGL((repaint_fwd_kernel<s, t, RL_MODE, 1>), dim3(p.nloc), dim3(64), 0, stream, p);    \
+    hipLaunchKernelGGL((repaint_bwd_kernel<s, t, RL_MODE, 1>), dim3(p.nloc), dim3(64),                   \
+                       strip_doubles<s>() * sizeof(double), stream, p);                                  \
     return hipGetLastError();
       RL_FOR_EACH_S(RL_CASE)
 #undef RL_CASE
@@ -310,9 +484,11 @@ hipError_t launch_repaint_mode<RL_MODE>(const RepaintParams &p, int S, int waves
   } else if (waves == 2) {
 #ifndef RL_ONLY_S
     switch (S) {
-#define RL_CASE(s, t)                                                                                            \
-  case s:                                                                                                        \
-    hipLaunchKernelGGL((repaint_kernel<s, t, RL_MODE, 2>), dim3(nblocks), dim3(128), 0, stream, p, counter); \
+#define RL_CASE(s, t)                                                                                    \
+  case s:                                                                                                \
+    hipLaunchKernelGGL((repaint_fwd_kernel<s, t, RL_MODE, 2>), dim3(p.nloc), dim3(128), 0, stream, p);   \
+    hipLaunchKernelGGL((repaint_bwd_kernel<s, t, RL_MODE, 2>), dim3(p.nloc), dim3(128),                  \
+                       2 * strip_doubles<s>() * sizeof(double), stream, p);                              \
     return hipGetLastError();
       RL_FOR_EACH_S_2WAVES(RL_CASE)
 #undef RL_CASE

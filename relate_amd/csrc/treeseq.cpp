@@ -853,9 +853,7 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
   nthreads = std::min(nthreads, last_section - first_section + 1);
   int concurrent = nthreads;
   {
-    const size_t strips = (size_t)8 * std::min(ctx->nloc, 2048) *
-                          ((size_t)((maxD + REPAINT_CHECKPOINT - 1) / REPAINT_CHECKPOINT) * ctx->S * 64 * ctx->waves +
-                           (size_t)maxD * REPAINT_SIDE);
+    const size_t strips = repaint_scratch_bytes((int64_t)max_rows, ctx->nloc, ctx->S, ctx->waves);
     if (ctx->d_k2_scratch.alloc(strips)) {
       rl_destroy(ctx);
       return RL_ENOMEM;

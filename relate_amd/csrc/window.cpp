@@ -20,6 +20,7 @@ struct rl_window {
   int start = 0, end = 0;  // section_startpos / section_endpos as stored in the paint file
   int k0 = 0, nloc = 0;          // targets of the context when the window was opened; arrays below are [nloc]
   std::vector<int64_t> top_off;  // [nloc+1]
+  std::vector<int64_t> ck_off;   // [nloc+1] checkpoint rows of the targets' forward passes (repaint_kernels.hip)
   std::vector<float> logscales;  // host copy, [sum D]
   std::vector<int32_t> v_snp_prev;
   std::vector<double> v_rpos_prev, v_rpos_next;
@@ -27,7 +28,7 @@ struct rl_window {
   DevBuf d_vsp, d_direct, d_wl, d_wr, d_epn, d_enp;
   // What RePaint needs to run again (a bounded window keeps part of its posterior rows and recomputes as the
   // tree builder moves on): the decoded stones, the plan slices, the last-interval coefficients.
-  DevBuf d_ab, d_be, d_la, d_lb, d_ib, d_ie, d_cfl, d_nxl, d_order;
+  DevBuf d_ab, d_be, d_la, d_lb, d_ib, d_ie, d_cfl, d_nxl, d_order, d_ck_off;
   DevBuf d_slab_off, d_row_lo, d_row_hi, d_slab_base;
   std::vector<int64_t> slab_off, slab_base;  // [nloc]
   std::vector<int32_t> row_lo, row_hi;       // [nloc] resident posterior rows [lo, hi) of each target
@@ -55,13 +56,11 @@ static inline bool derived(const rl_ctx *ctx, int snp, int n) {
 static int repaint_rows(rl_window *win, float *kernel_ms) {
   rl_ctx *ctx = win->ctx;
   const int N = ctx->N, S = ctx->S, waves = ctx->waves, nloc = win->nloc;
-  const int nblocks = std::min(nloc, 2048);
-  const int64_t side_offset = (int64_t)((win->maxD + REPAINT_CHECKPOINT - 1) / REPAINT_CHECKPOINT) * S * 64 * waves;
-  const int64_t scratch_stride = side_offset + (int64_t)win->maxD * REPAINT_SIDE;
-  // the strips of the forward rows are scratch of the launch: one buffer per context, launches are serialised
+  // the checkpoint rows and side records of the forward kernel are scratch of the launch: one buffer per context,
+  // launches are serialised
+  const int64_t ck_doubles = win->ck_off[nloc] * (int64_t)S * 64 * waves;
   std::unique_lock<std::mutex> one_at_a_time(ctx->repaint_mutex);
-  int rc = ctx->d_k2_scratch.alloc((size_t)nblocks * scratch_stride * sizeof(double));
-  rc = rc ? rc : ctx->d_k2_counter.alloc(sizeof(int));
+  int rc = ctx->d_k2_scratch.alloc(repaint_scratch_bytes(win->top_off[nloc], nloc, S, waves));
   if (rc) return rc;
   RepaintParams p;
   p.lay = ctx->lay;
@@ -89,14 +88,13 @@ static int repaint_rows(rl_window *win, float *kernel_ms) {
   p.topology = win->d_top.as<float>();
   p.logscales = win->d_ls.as<float>();
   p.scratch = ctx->d_k2_scratch.as<double>();
-  p.scratch_stride = scratch_stride;
-  p.side_offset = side_offset;
+  p.ck_off = win->d_ck_off.as<int64_t>();
+  p.side = p.scratch + ck_doubles;
   p.order = win->d_order.as<int32_t>();
   p.sum_mode = win->sum_mode;
   (void)N;
-  bool ok = hipMemsetAsync(ctx->d_k2_counter.p, 0, sizeof(int), ctx->s0) == hipSuccess;
-  ok = ok && hipEventRecord(ctx->ev0, ctx->s0) == hipSuccess;
-  hipError_t le = ok ? launch_repaint(p, S, waves, nblocks, ctx->d_k2_counter.as<int>(), ctx->s0) : hipErrorUnknown;
+  bool ok = hipEventRecord(ctx->ev0, ctx->s0) == hipSuccess;
+  hipError_t le = ok ? launch_repaint(p, S, waves, ctx->s0) : hipErrorUnknown;
   ok = ok && le == hipSuccess;
   ok = ok && hipEventRecord(ctx->ev2, ctx->s0) == hipSuccess;
   hipError_t se = hipEventSynchronize(ctx->ev2);
@@ -277,6 +275,7 @@ rl_window *rl_window_open_bounded(rl_ctx *ctx, int w, const char *paint_file, in
   win->k0 = k0;
   win->nloc = nloc;
   win->top_off.assign((size_t)nloc + 1, 0);
+  win->ck_off.assign((size_t)nloc + 1, 0);
   int maxD = 0;
   for (int t = 0; t < nloc; t++) {
     const int n = k0 + t;
@@ -291,6 +290,7 @@ rl_window *rl_window_open_bounded(rl_ctx *ctx, int w, const char *paint_file, in
     const int D = ie[t] - ib[t] + 1;
     maxD = std::max(maxD, D);
     win->top_off[t + 1] = win->top_off[t] + D;
+    win->ck_off[t + 1] = win->ck_off[t] + (D + REPAINT_CHECKPOINT - 1) / REPAINT_CHECKPOINT;
     // last interval of RePaintSection: r[last_snp] only (fast_painting.cpp:702-716)
     interval_coeffs(ctx->consts, N, r[bend[t]], &cf_last[t], &nxt_last[t]);
   }
@@ -343,6 +343,7 @@ rl_window *rl_window_open_bounded(rl_ctx *ctx, int w, const char *paint_file, in
   rc = rc ? rc : win->d_nxl.upload(nxt_last);
   rc = rc ? rc : win->d_order.upload(order);
   rc = rc ? rc : win->d_top_off.upload(win->top_off);
+  rc = rc ? rc : win->d_ck_off.upload(win->ck_off);
   rc = rc ? rc : win->d_top.alloc((size_t)std::min(rows, win->cap_rows) * S * 64 * waves * sizeof(float));
   rc = rc ? rc : win->d_ls.alloc((size_t)rows * sizeof(float));
   rc = rc ? rc : win->d_matrix.alloc((size_t)nloc * N * sizeof(float));
