@@ -264,7 +264,7 @@ def main():
             # panel read (forward and backward pass), SURVEY.md 8d
             k2_bytes = rows * N * 4.25
             k2_gbs = k2_bytes / (win.repaint_ms * 1e-3) / 1e9
-            roofline_k2 = {"bound": "hbm", "kernel": "repaint_kernel (one window, all targets)",
+            roofline_k2 = {"bound": "hbm", "kernel": "repaint_fwd_kernel + repaint_bwd_kernel (one window, all targets)",
                            "achieved": k2_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k2_gbs / HBM_PEAK_GBS,
                            "traffic": pmc["kernels"]["repaint"]["hbm_bytes_per_launch"] if pmc else None,
                            "traffic_static_from": "profiles/r02_pmc_c3.json" if pmc else None,
