@@ -138,3 +138,31 @@ def run_chunks(out_dir, painting=None, device=None, stages=None, chunks=None):
     if live:
         dist.barrier()  # (the job ends together; nothing is exchanged)
     return mine
+
+
+def main(argv=None):
+    """`python -m torch.distributed.run --nproc-per-node G -m relate_amd.dist OUT_DIR [--painting theta,rho]`:
+    every chunk of OUT_DIR/parameters.bin through Paint, BuildTopology and FindEquivalentBranches, chunk c on rank
+    c mod G (RelateParallel.sh:216-262 for one process per GPU).  Without a launcher it is one rank on the local GPU."""
+    import argparse
+    ap = argparse.ArgumentParser(prog="python -m relate_amd.dist")
+    ap.add_argument("out_dir")
+    ap.add_argument("--painting", default=None, help="theta,rho (Relate's --painting)")
+    ap.add_argument("--chunks", default=None, help="comma-separated subset of chunk indices")
+    args = ap.parse_args(argv)
+    painting = tuple(float(x) for x in args.painting.split(",")) if args.painting else None
+    chunks = [int(x) for x in args.chunks.split(",")] if args.chunks else None
+    launched = "RANK" in os.environ
+    if launched:
+        import torch
+        torch.cuda.set_device(local_device())
+        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+    mine = run_chunks(args.out_dir, painting=painting, chunks=chunks)
+    print("rank %d ran chunks %s" % (dist.get_rank() if launched else 0, mine), flush=True)
+    if launched:
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""The C3 chunk (synthetic N = 5000 x L = 500000, 267 sections) through `Relate --mode PaintBuildTopology` (stepping
+stones kept in HBM, no paint files): Paint of the whole chunk + BuildTopology of sections [0, sections).
+
+    python tools/chunk_c3_fused.py sections [N L memory_GB]
+
+Prints one JSON line: wall-clock, trees, trees/s, the stage's own phase lines."""
+import ctypes as C, json, os, re, shutil, subprocess, sys, tempfile, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from relate_amd import api
+import rlutil
+
+sections = int(sys.argv[1])
+N, L, mem = (int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4])) if len(sys.argv) > 4 else (5000, 500000, 20.0)
+lib = api.lib()
+seq = np.zeros((L, N), dtype=np.uint8)
+bp = np.zeros(L, dtype=np.int32)
+r = np.zeros(L); rpos = np.zeros(L + 1)
+assert lib.rl_synth_panel(N, L, C.c_uint64(1), 100, 1, seq.ctypes.data_as(C.c_void_p), None, 0,
+                          bp.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p),
+                          rpos.ctypes.data_as(C.c_void_p)) == 0
+budget = mem * 1e9 / 4.0 - (2.0 * N * N + 3.0 * N)
+wb = np.zeros(L + 2, dtype=np.int32)
+W = lib.rl_synth_windows(N, L, seq.ctypes.data_as(C.c_void_p), C.c_double(budget), wb.ctypes.data_as(C.c_void_p), 499)
+assert W > 0
+sections = min(sections, W)
+out = {"N": N, "L": L, "windows": int(W), "sections": sections}
+work = tempfile.mkdtemp()
+try:
+    d = os.path.join(work, "out")
+    os.makedirs(d)
+    lib.rl_write_chunk_files.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int]
+    assert lib.rl_write_chunk_files(d.encode(), 0, N, L, seq.ctypes.data_as(C.c_void_p), bp.ctypes.data_as(C.c_void_p),
+                                    r.ctypes.data_as(C.c_void_p), rpos.ctypes.data_as(C.c_void_p),
+                                    wb.ctypes.data_as(C.c_void_p), W) == 0
+    del seq
+    exe = os.path.join(ROOT, "relate_amd", "Relate")
+    t0 = time.time()
+    p = subprocess.run([exe, "--mode", "PaintBuildTopology", "--chunk_index", "0", "--first_section", "0",
+                        "--last_section", str(sections - 1), "-o", "out"], cwd=work, stderr=subprocess.PIPE,
+                       env=dict(os.environ, RELATE_AMD_TIMING="1"))
+    out["wall_s"] = time.time() - t0
+    err = p.stderr.decode()
+    assert p.returncode == 0, err[-600:]
+    trees = 0
+    for l in err.split("\n"):
+        m = re.search(r"(\d+) trees kept of (\d+) built", l)
+        if m:
+            trees += int(m.group(2))
+    out["trees_built"] = trees
+    out["trees_per_s"] = trees / out["wall_s"]
+    out["anc_GB"] = sum(os.path.getsize(os.path.join(d, "chunk_0", f)) for f in os.listdir(os.path.join(d, "chunk_0"))
+                        if f.endswith(".anc")) / 1e9
+    out["stage_lines"] = [l.strip() for l in err.split("\n") if l.startswith("[") and "tree sequence" not in l][:12]
+    out["one_section"] = [l.strip() for l in err.split("\n") if "[tree sequence]" in l][:1]
+finally:
+    shutil.rmtree(work, ignore_errors=True)
+print(json.dumps(out))
