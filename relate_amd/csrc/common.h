@@ -1,5 +1,6 @@
 // common.h -- internal host-side declarations of librelate_amd.
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
@@ -25,6 +26,21 @@ void set_error(const char *fmt, ...);
       return RL_EHIP;                                                             \
     }                                                                             \
   } while (0)
+
+// Streams of the stage: the tree builder's long-running workgroups go to lowest-priority streams, which the runtime
+// maps to hardware queues of their own -- the short kernels of the stage (distance matrices, penalty, prior, the weave
+// of the next tree) must not queue up behind one.  (Tried: CU masks that keep the other kernels off the builder's
+// CUs, hipExtStreamCreateWithCUMask with 3 or 4 of every 8 CUs for the trees -- the 80-section stage did not finish
+// in four times its usual time.)
+inline hipError_t make_stream(hipStream_t *s, bool tree_builder) {
+  if (tree_builder) {
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess &&
+        hipStreamCreateWithPriority(s, hipStreamNonBlocking, least) == hipSuccess)
+      return hipSuccess;
+  }
+  return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
 
 // owning device buffer
 struct DevBuf {

@@ -1424,7 +1424,11 @@ class BuildDispatcher {
 
  private:
   explicit BuildDispatcher(int device) : device_(device) {
-    for (int t = 0; t < 4; t++) workers_.emplace_back([this] { worker(); });
+    // launches in flight at once (each on a stream of its own) and how long a launch waits for more trees
+    int launchers = 4;
+    if (const char *e = getenv("RELATE_AMD_BUILD_LAUNCHERS")) launchers = std::max(1, std::min(16, atoi(e)));
+    if (const char *e = getenv("RELATE_AMD_BUILD_GATHER_MS")) gather_ms_ = std::max(0, atoi(e));
+    for (int t = 0; t < launchers; t++) workers_.emplace_back([this] { worker(); });
     for (auto &w : workers_) w.detach();
   }
   void worker() {
@@ -1433,10 +1437,7 @@ class BuildDispatcher {
     // the next tree) must not queue up behind one in a hardware queue they happen to share: the builds go to the
     // lowest-priority streams, which the runtime maps to hardware queues of their own.
     hipStream_t stream = nullptr;
-    int least = 0, greatest = 0;
-    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess ||
-        hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, least) != hipSuccess)
-      (void)hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+    (void)make_stream(&stream, true);
     {  // the per-cluster state of a build in LDS: more than the default 64 KB of dynamic LDS
       hipFuncAttributes a;
       if (hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&minmatch_kernel<true, 10>)) == hipSuccess)
@@ -1453,7 +1454,7 @@ class BuildDispatcher {
         // The builders whose tree is not being built right now are about to ask too (their hosts are preparing the
         // next matrices): wait for them a little -- concurrent launches are few (hardware queues), so a launch
         // should carry what there is.
-        const auto until = std::chrono::steady_clock::now() + std::chrono::milliseconds(10);
+        const auto until = std::chrono::steady_clock::now() + std::chrono::milliseconds(gather_ms_);
         while ((int)pending_.size() < builders_ - (waiting_ - (int)pending_.size()) &&
                std::chrono::steady_clock::now() < until) {
           lk.unlock();
@@ -1502,6 +1503,7 @@ class BuildDispatcher {
     }
   }
   int device_;
+  int gather_ms_ = 10;
   int builders_ = 0, waiting_ = 0;  // builders alive on this device; builders waiting for a tree (asked or being built)
   std::mutex m_;
   std::condition_variable cv_work_;
@@ -1546,7 +1548,7 @@ int DeviceMinMatch::apply_penalty(const char *member, float val) {
   Impl &m = *impl;
   const int N = m.N;
   RL_HIP(hipSetDevice(m.device));
-  if (!m.stream) RL_HIP(hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking));
+  if (!m.stream) RL_HIP(make_stream(&m.stream, false));
   if (m.d_member.alloc((size_t)N)) return -1;
   RL_HIP(hipMemcpyAsync(m.d_member.p, member, (size_t)N, hipMemcpyHostToDevice, m.stream));
   hipLaunchKernelGGL(penalty_kernel, dim3(N), dim3(256), 0, m.stream, m.d_D.as<float>(), N,
@@ -1559,7 +1561,7 @@ int DeviceMinMatch::apply_prior(const HostTree &t, float val) {
   Impl &m = *impl;
   const int N = m.N, T = 2 * N - 1;
   RL_HIP(hipSetDevice(m.device));
-  if (!m.stream) RL_HIP(hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking));
+  if (!m.stream) RL_HIP(make_stream(&m.stream, false));
   // the same tables as the host's clade_prior (treeseq.cpp)
   std::vector<int> tab((size_t)6 * T + N);
   int *parent = tab.data(), *cl = parent + T, *cr = cl + T, *depth = cr + T, *lo = depth + T, *size = lo + T,
@@ -1613,7 +1615,7 @@ int DeviceMinMatch::build_impl(MinMatch &tb, const float *d, const float *prior_
     if (every > 0 && ++m.builds % every == 0) return 2;
   }
   RL_HIP(hipSetDevice(m.device));
-  if (!m.stream) RL_HIP(hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking));
+  if (!m.stream) RL_HIP(make_stream(&m.stream, false));
   const bool prior = with_prior;
   const size_t NN = (size_t)N * N;
   const auto tb0 = std::chrono::steady_clock::now();

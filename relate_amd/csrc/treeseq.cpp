@@ -879,6 +879,8 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
   // sections open, 4 helpers each finished in 109 s, 8 in 177 s, none in 165 s.
   set_build_threads(std::min(8, std::max(1, host_threads() / (8 * std::max(1, concurrent)))));
   std::atomic<int> open_sections(0);
+  int most_open = 0;            // (under g_gpu_mutex)
+  const auto stage_t0 = std::chrono::steady_clock::now();
   double reserved_bytes = 0.0;  // (under g_gpu_mutex) HBM promised to windows that are being opened
   std::atomic<int> next(first_section);
   std::atomic<int> first_error(0);
@@ -938,7 +940,7 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
                                        nullptr);
           std::lock_guard<std::mutex> lk(g_gpu_mutex);
           reserved_bytes -= need;
-          if (win) open_sections++;
+          if (win) most_open = std::max(most_open, ++open_sections);
           break;
         }
         if (first_error.load()) break;
@@ -974,6 +976,11 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
   }
   rc = first_error.load();
   if (rc) set_error("%s", first_message.c_str());
+  if (getenv("RELATE_AMD_TIMING"))
+    fprintf(stderr, "[stage] sections %d..%d on %d threads, up to %d open at once, %lld of at most %.0f posterior rows "
+            "resident per window, trees on the %s, %.1f s\n", first_section, last_section, nthreads, most_open,
+            cap_rows > 0 ? cap_rows : (long long)max_rows, max_rows, gpu_build ? "GPU" : "host",
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - stage_t0).count());
   rl_destroy(ctx);
   if (!rc) {
     rusage usage;

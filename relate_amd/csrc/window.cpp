@@ -495,7 +495,7 @@ static int window_matrix(rl_window *win, int snp, float *d_host, void *d_dev, fl
   const size_t o_wl = 0, o_wr = o_wl + (size_t)nloc * 8, o_vsp = o_wr + (size_t)nloc * 8, o_epn = o_vsp + (size_t)nloc * 4,
                o_enp = o_epn + (size_t)nloc * 4, o_dir = o_enp + (size_t)nloc * 4, stage_bytes = o_dir + (size_t)nloc;
   if (!win->stream) {
-    if (hipStreamCreateWithFlags(&win->stream, hipStreamNonBlocking) != hipSuccess ||
+    if (make_stream(&win->stream, false) != hipSuccess ||
         hipEventCreate(&win->e0) != hipSuccess || hipEventCreate(&win->e2) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **>(&win->h_stage), ((stage_bytes + 7) & ~(size_t)7) + 8, 0) != hipSuccess) {
       set_error("rl_window_matrix: stream / staging buffer creation failed");

@@ -40,7 +40,7 @@ try:
     t0 = time.time()
     p = subprocess.run([exe, "--mode", "PaintBuildTopology", "--chunk_index", "0", "--first_section", "0",
                         "--last_section", str(sections - 1), "-o", "out"], cwd=work, stderr=subprocess.PIPE,
-                       env=dict(os.environ, RELATE_AMD_TIMING="1"))
+                       env=dict(os.environ) if os.environ.get("C3_NO_TIMING") else dict(os.environ, RELATE_AMD_TIMING="1"))
     out["wall_s"] = time.time() - t0
     err = p.stderr.decode()
     assert p.returncode == 0, err[-600:]
@@ -53,7 +53,20 @@ try:
     out["trees_per_s"] = trees / out["wall_s"]
     out["anc_GB"] = sum(os.path.getsize(os.path.join(d, "chunk_0", f)) for f in os.listdir(os.path.join(d, "chunk_0"))
                         if f.endswith(".anc")) / 1e9
-    out["stage_lines"] = [l.strip() for l in err.split("\n") if l.startswith("[") and "tree sequence" not in l][:12]
+    out["stage_lines"] = [l.strip() for l in err.split("\n") if l.startswith("[") and "tree sequence" not in l
+                          and "tree builder" not in l][:12]
+    sizes = [int(re.search(r"launch\] (\d+) trees", l).group(1)) for l in err.split("\n") if "[tree builder launch]" in l]
+    if sizes:
+        out["builder_launches"] = {"launches": len(sizes), "mean_trees_per_launch": sum(sizes) / len(sizes), "max": max(sizes)}
+    out["builder_host_side"] = [l.strip() for l in err.split("\n") if "host ms per tree" in l][:6]
+    acc, ntr = {}, 0
+    for l in err.split("\n"):
+        if "[gpu tree builder]" in l and "us:" in l:
+            ntr += 1
+            for m in re.finditer(r"([a-z_+ ]+?) (\d+)(?= |$)", l.split("us:")[1]):
+                acc[m.group(1).strip()] = acc.get(m.group(1).strip(), 0) + int(m.group(2))
+    if ntr:
+        out["gpu_builder_ms_per_tree"] = {k: round(v / ntr / 1000.0, 2) for k, v in acc.items()}
     out["one_section"] = [l.strip() for l in err.split("\n") if "[tree sequence]" in l][:1]
 finally:
     shutil.rmtree(work, ignore_errors=True)
