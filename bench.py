@@ -344,6 +344,14 @@ def main():
             out["cpu_baseline"] = cpu_baseline(N, L, bits, r, rpos, wb)
         if chunk_sample is not None:
             out["config"]["chunk_wallclock_sample"] = chunk_sample
+            try:  # the whole C3 chunk through the fused stage: a 5-minute run (tools/chunk_c3_fused.py 267), quoted
+                  # from its committed record, NOT measured in this run
+                full = json.load(open(os.path.join(ROOT, "profiles", "r02_c3_fused_all_267_sections.json")))
+                out["config"]["chunk_wallclock_c3_static"] = {
+                    "from": "profiles/r02_c3_fused_all_267_sections.json", "wall_s": full["wall_s"],
+                    "sections": full["sections"], "trees": full["trees_built"], "trees_per_s": full["trees_per_s"]}
+            except Exception:
+                pass
         print(json.dumps(out), flush=True)
     for cx in ctxs:
         cx.close()

@@ -115,6 +115,9 @@ struct rl_ctx {
   rl::PaintConsts consts{};
   rl::DevBuf d_bits, d_masks, d_off, d_sites, d_cf, d_nxt, d_ia, d_ie, d_binit, d_order;
   rl::DevBuf d_alpha, d_beta, d_lsa, d_lsb, d_stats;
+  // the stepping stones parked in (pinned) host memory: the fused Paint + BuildTopology stage gives their HBM to the
+  // windows of the sections (rl_park_stones; a window takes its slice back when it opens)
+  float *h_alpha = nullptr, *h_beta = nullptr;
   rl::DevBuf d_k2_scratch;  // RePaint's checkpoint rows and side records of one launch, shared by the context's
                             // windows (window.cpp)
   bool have_chunk = false, plan_on_device = false, painted = false;
@@ -135,3 +138,6 @@ size_t encode_stone(const float *v, int N, int bsnp, float logscale, unsigned ch
 size_t decode_stone(const unsigned char *in, size_t avail, int N, float *v, int *bsnp, float *logscale);
 float fast_log_host(float v);
 }  // namespace rl
+
+// (context.cpp) the stepping stones of a painted chunk to pinned host memory, their device buffers released
+extern "C" int rl_park_stones(rl_ctx *ctx);

@@ -408,7 +408,36 @@ void rl_destroy(rl_ctx *ctx) {
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
+  if (ctx->h_alpha) (void)hipHostFree(ctx->h_alpha);
+  if (ctx->h_beta) (void)hipHostFree(ctx->h_beta);
   delete ctx;
+}
+
+// The stones of a painted chunk move to pinned host memory and their device buffers are released (C3: 2 x 26.7 GB,
+// a quarter of the sections the stage can keep open).  Not an error if the host has no room: they stay where they are.
+int rl_park_stones(rl_ctx *ctx) {
+  if (!ctx || !ctx->painted || ctx->h_alpha || !ctx->d_alpha.p) return RL_OK;
+  (void)hipSetDevice(ctx->device);
+  const size_t bytes = (size_t)(ctx->wb.size() - 1) * ctx->nloc * ctx->N * sizeof(float);
+  float *a = nullptr, *b = nullptr;
+  if (hipHostMalloc(reinterpret_cast<void **>(&a), bytes, hipHostMallocDefault) != hipSuccess ||
+      hipHostMalloc(reinterpret_cast<void **>(&b), bytes, hipHostMallocDefault) != hipSuccess) {
+    if (a) (void)hipHostFree(a);
+    (void)hipGetLastError();
+    return RL_OK;
+  }
+  if (hipMemcpy(a, ctx->d_alpha.p, bytes, hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(b, ctx->d_beta.p, bytes, hipMemcpyDeviceToHost) != hipSuccess) {
+    (void)hipHostFree(a);
+    (void)hipHostFree(b);
+    set_error("copying the stepping stones to the host failed");
+    return RL_EHIP;
+  }
+  ctx->h_alpha = a;
+  ctx->h_beta = b;
+  ctx->d_alpha.release();
+  ctx->d_beta.release();
+  return RL_OK;
 }
 
 static int set_common(rl_ctx *ctx, int N, int L, const double *r, const double *rpos, const int *wb, int W) {
@@ -607,6 +636,11 @@ int rl_prepare(rl_ctx *ctx) {
   int rc = upload_plan(ctx);
   if (rc) return rc;
   const size_t N = ctx->N, W = ctx->W, nloc = ctx->nloc;  // stones: this context's target rows only
+  if (ctx->h_alpha) {  // (stones of an earlier pass parked on the host)
+    (void)hipHostFree(ctx->h_alpha);
+    (void)hipHostFree(ctx->h_beta);
+    ctx->h_alpha = ctx->h_beta = nullptr;
+  }
   if ((rc = ctx->d_alpha.alloc(W * nloc * N * sizeof(float)))) return rc;
   if ((rc = ctx->d_beta.alloc(W * nloc * N * sizeof(float)))) return rc;
   if ((rc = ctx->d_lsa.alloc(W * nloc * sizeof(float)))) return rc;
@@ -628,6 +662,11 @@ int rl_paint(rl_ctx *ctx, int sum_mode, float *kernel_ms) {
   int rc = upload_plan(ctx);
   if (rc) return rc;
   const size_t N = ctx->N, W = ctx->W, nloc = ctx->nloc;  // stones: this context's target rows only
+  if (ctx->h_alpha) {  // (stones of an earlier pass parked on the host)
+    (void)hipHostFree(ctx->h_alpha);
+    (void)hipHostFree(ctx->h_beta);
+    ctx->h_alpha = ctx->h_beta = nullptr;
+  }
   if ((rc = ctx->d_alpha.alloc(W * nloc * N * sizeof(float)))) return rc;
   if ((rc = ctx->d_beta.alloc(W * nloc * N * sizeof(float)))) return rc;
   if ((rc = ctx->d_lsa.alloc(W * nloc * sizeof(float)))) return rc;
@@ -749,10 +788,15 @@ int rl_get_stones(rl_ctx *ctx, int w, float *alpha, float *beta, float *ls_alpha
   }
   RL_HIP(hipSetDevice(ctx->device));
   const size_t N = ctx->N, W = ctx->W, nloc = ctx->nloc, k0 = ctx->k0;  // rows of targets k0 .. k0+nloc-1
-  if (alpha)
-    RL_HIP(hipMemcpy(alpha, ctx->d_alpha.as<float>() + w * nloc * N, nloc * N * 4, hipMemcpyDeviceToHost));
-  if (beta)
-    RL_HIP(hipMemcpy(beta, ctx->d_beta.as<float>() + w * nloc * N, nloc * N * 4, hipMemcpyDeviceToHost));
+  if (ctx->h_alpha) {  // (parked on the host: rl_park_stones)
+    if (alpha) memcpy(alpha, ctx->h_alpha + w * nloc * N, nloc * N * 4);
+    if (beta) memcpy(beta, ctx->h_beta + w * nloc * N, nloc * N * 4);
+  } else {
+    if (alpha)
+      RL_HIP(hipMemcpy(alpha, ctx->d_alpha.as<float>() + w * nloc * N, nloc * N * 4, hipMemcpyDeviceToHost));
+    if (beta)
+      RL_HIP(hipMemcpy(beta, ctx->d_beta.as<float>() + w * nloc * N, nloc * N * 4, hipMemcpyDeviceToHost));
+  }
   if (ls_alpha)
     RL_HIP(hipMemcpy(ls_alpha, ctx->d_lsa.as<float>() + w * nloc, nloc * 4, hipMemcpyDeviceToHost));
   if (ls_beta)

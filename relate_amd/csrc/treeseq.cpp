@@ -978,7 +978,7 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
   if (rc) set_error("%s", first_message.c_str());
   if (getenv("RELATE_AMD_TIMING"))
     fprintf(stderr, "[stage] sections %d..%d on %d threads, up to %d open at once, %lld of at most %.0f posterior rows "
-            "resident per window, trees on the %s, %.1f s\n", first_section, last_section, nthreads, most_open,
+            "resident per window, %s tree builder, %.1f s\n", first_section, last_section, nthreads, most_open,
             cap_rows > 0 ? cap_rows : (long long)max_rows, max_rows, gpu_build ? "GPU" : "host",
             std::chrono::duration<double>(std::chrono::steady_clock::now() - stage_t0).count());
   rl_destroy(ctx);
@@ -1027,6 +1027,10 @@ int rl_stage_paint_build_topology(const char *out_dir, int chunk_index, int firs
     std::cerr << "Painting sequences (stepping stones stay on the device)..." << std::endl;
     rc = rl_paint(ctx, sum_mode, nullptr);
   }
+  // RELATE_AMD_PARK_STONES=1: the stones to pinned host memory, their HBM to the sections' windows -- for chunks that
+  // would not fit otherwise; at C3 (53 GB of stones) it opens 112 sections instead of 91 and the chunk takes 330 s
+  // instead of 291 s: past ~90 trees in flight the build kernels slow each other down
+  if (!rc && getenv("RELATE_AMD_PARK_STONES") && atoi(getenv("RELATE_AMD_PARK_STONES")) != 0) rc = rl_park_stones(ctx);
   if (!rc) {  // (the Paint stage makes this directory for its files; the trees go there)
     const std::string cdir = std::string(out_dir) + "/chunk_" + std::to_string(chunk_index);
     if (mkdir(cdir.c_str(), 0777) != 0 && errno != EEXIST) {

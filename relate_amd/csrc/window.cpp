@@ -326,8 +326,16 @@ rl_window *rl_window_open_bounded(rl_ctx *ctx, int w, const char *paint_file, in
     auto d2d = [&](void *dst, const float *src, size_t n) {
       return hipMemcpyAsync(dst, src, n * 4, hipMemcpyDeviceToDevice, ctx->s0) == hipSuccess ? 0 : RL_EHIP;
     };
-    rc = rc ? rc : d2d(win->d_ab.p, ctx->d_alpha.as<float>() + (size_t)w * sn, sn);
-    rc = rc ? rc : d2d(win->d_be.p, ctx->d_beta.as<float>() + (size_t)w * sn, sn);
+    auto h2d = [&](void *dst, const float *src, size_t n) {
+      return hipMemcpyAsync(dst, src, n * 4, hipMemcpyHostToDevice, ctx->s0) == hipSuccess ? 0 : RL_EHIP;
+    };
+    if (ctx->h_alpha) {  // (parked on the host by the fused stage)
+      rc = rc ? rc : h2d(win->d_ab.p, ctx->h_alpha + (size_t)w * sn, sn);
+      rc = rc ? rc : h2d(win->d_be.p, ctx->h_beta + (size_t)w * sn, sn);
+    } else {
+      rc = rc ? rc : d2d(win->d_ab.p, ctx->d_alpha.as<float>() + (size_t)w * sn, sn);
+      rc = rc ? rc : d2d(win->d_be.p, ctx->d_beta.as<float>() + (size_t)w * sn, sn);
+    }
     rc = rc ? rc : d2d(win->d_la.p, ctx->d_lsa.as<float>() + (size_t)w * nloc, nloc);
     rc = rc ? rc : d2d(win->d_lb.p, ctx->d_lsb.as<float>() + (size_t)w * nloc, nloc);
     if (!rc && (launch_quantise(win->d_ab.as<float>(), nloc, N, ctx->s0) != hipSuccess ||

@@ -166,6 +166,21 @@ def test_paint_and_build_topology_without_paint_files(tmp_path, name):
         assert open(work / "out" / "chunk_0" / ("out_%d.anc" % w), "rb").read() == fx.z["anc/%d" % w].tobytes(), w
 
 
+def test_fused_stage_with_the_stones_parked_on_the_host(tmp_path):
+    """the fused stage of a chunk whose stones would crowd out the sections' windows (C3: 53 GB) moves them to pinned
+    host memory after Paint and every window takes its slice back (rl_park_stones; RELATE_AMD_PARK_STONES=1 forces
+    it at this size): the same bytes"""
+    work = tmp_path / "work"
+    (work / "out").mkdir(parents=True)
+    fx = Fixture("synth70", work / "out")
+    p = subprocess.run([CLI, "--mode", "PaintBuildTopology", "--chunk_index", "0", "-o", "out"], cwd=str(work),
+                       stderr=subprocess.PIPE, env=dict(os.environ, RELATE_AMD_PARK_STONES="1"))
+    assert p.returncode == 0, p.stderr.decode()
+    for w in range(fx.W):
+        assert open(work / "out" / "chunk_0" / ("out_%d.mut" % w), "rb").read() == fx.z["mut/%d" % w].tobytes(), w
+        assert open(work / "out" / "chunk_0" / ("out_%d.anc" % w), "rb").read() == fx.z["anc/%d" % w].tobytes(), w
+
+
 def test_in_memory_window_matches_the_paint_file_window(tmp_path):
     """a window opened from the context's stones (quantised on the device) against the same window opened from the
     paint file the context wrote: posterior rows and matrices bit for bit"""
