@@ -468,28 +468,36 @@ __global__ void __launch_bounds__(64 * WAVES, 2) repaint_bwd_kernel(const Repain
   repaint_backward<S, TAIL, MODE, WAVES>(p, p.order[blockIdx.x], (float *)strip, strip, lk);
 }
 
+template <int S, int TAIL, int WAVES>
+static hipError_t launch_repaint_t(const RepaintParams &p, hipStream_t stream) {
+  constexpr size_t strips = (size_t)WAVES * strip_doubles<S>() * sizeof(double);
+  // (two waves of S = 80: 72 KB of dynamic LDS, more than a launch may ask for without saying so)
+  static const hipError_t allowed =
+      strips > 48 * 1024 ? hipFuncSetAttribute(reinterpret_cast<const void *>(&repaint_bwd_kernel<S, TAIL, RL_MODE, WAVES>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)strips)
+                         : hipSuccess;
+  if (allowed != hipSuccess) return allowed;
+  hipLaunchKernelGGL((repaint_fwd_kernel<S, TAIL, RL_MODE, WAVES>), dim3(p.nloc), dim3(64 * WAVES), 0, stream, p);
+  hipLaunchKernelGGL((repaint_bwd_kernel<S, TAIL, RL_MODE, WAVES>), dim3(p.nloc), dim3(64 * WAVES), strips, stream, p);
+  return hipGetLastError();
+}
+
 template <>
 hipError_t launch_repaint_mode<RL_MODE>(const RepaintParams &p, int S, int waves, hipStream_t stream) {
   if (waves == 1) {
     switch (S) {
-#define RL_CASE(s, t)                                                                                    \
-  case s:                                                                                                \
-    hipLaunchKernelGGL((repaint_fwd_kernel<s, t, RL_MODE, 1>), dim3(p.nloc), dim3(64), 0, stream, p);    \
-    hipLaunchKernelGGL((repaint_bwd_kernel<s, t, RL_MODE, 1>), dim3(p.nloc), dim3(64),                   \
-                       strip_doubles<s>() * sizeof(double), stream, p);                                  \
-    return hipGetLastError();
+#define RL_CASE(s, t) \
+  case s:             \
+    return launch_repaint_t<s, t, 1>(p, stream);
       RL_FOR_EACH_S(RL_CASE)
 #undef RL_CASE
     }
   } else if (waves == 2) {
 #ifndef RL_ONLY_S
     switch (S) {
-#define RL_CASE(s, t)                                                                                    \
-  case s:                                                                                                \
-    hipLaunchKernelGGL((repaint_fwd_kernel<s, t, RL_MODE, 2>), dim3(p.nloc), dim3(128), 0, stream, p);   \
-    hipLaunchKernelGGL((repaint_bwd_kernel<s, t, RL_MODE, 2>), dim3(p.nloc), dim3(128),                  \
-                       2 * strip_doubles<s>() * sizeof(double), stream, p);                              \
-    return hipGetLastError();
+#define RL_CASE(s, t) \
+  case s:             \
+    return launch_repaint_t<s, t, 2>(p, stream);
       RL_FOR_EACH_S_2WAVES(RL_CASE)
 #undef RL_CASE
     }

@@ -91,10 +91,11 @@ def test_gpu_paint_files_feed_window(tmp_path):
     run_case(tmp_path, 96, 1400, 60000, 9, via_gpu_paint=True)
 
 
-def test_two_wavefronts_per_target(tmp_path):
-    """N > 5120: RePaint and the matrix gather run on the 128-virtual-lane layout (two wavefronts per target)"""
+@pytest.mark.parametrize("N", [5300, 9300])
+def test_two_wavefronts_per_target(tmp_path, N):
+    """N > 5120: RePaint and the matrix gather run on the 128-virtual-lane layout (two wavefronts per target); N = 9300
+    is the S = 80 tile of that layout (72 KB of LDS strips per workgroup in the backward kernel)"""
     from test_edge_gpu import random_chunk
-    N = 5300
     ch = random_chunk(N, 70, 0.15, seed=5, wb=[0, 30, 70])
     run_case(tmp_path, N, 70, None, 5, chunk=ch, via_gpu_paint=True)
 
