@@ -90,6 +90,8 @@ struct RepaintParams {
   double *side;               // side records [top_off[nloc]][REPAINT_SIDE], target t's at top_off[t]
   const int32_t *order;       // [nloc] targets (global index), longest first
   int sum_mode;
+  int partial;                // the logscales of every row are in place (an earlier launch of this window wrote them):
+                              // the forward pass may stop below row_hi, the backward pass at row_lo
 };
 
 struct MatrixParams {

@@ -115,7 +115,9 @@ RL_DEV void repaint_forward(const RepaintParams &p, int n, float *stage, WaveLin
   uint32_t touched = 0;
   MaskRow row = site_row(p.masks, S, p.L, s1, WAVES, wv);
   Chunk first = load_masks<CH>(row, 0);
-  for (int i = 1; i < D; i++) {
+  // (a later launch of a bounded window: rows from row_hi on are of no use to the backward pass)
+  const int Dfwd = p.partial ? min(D, max(1, (int)p.row_hi[t])) : D;
+  for (int i = 1; i < Dfwd; i++) {
     retire_touch(touched);
     if (i + 1 < D) touched = touch_row(p.masks, S, s2, pl.lane, WAVES, wv);
     s1 = s2;
@@ -370,13 +372,16 @@ RL_DEV void repaint_backward(const RepaintParams &p, int n, float *stage, double
     bsum = wave_sum<MODE, S, WAVES>(term, local_sum<S>(term), lk);
   }
   product_row(D - 1, true);
-  if (pl.lane == 0 && wv == 0) lsout[D - 1] = lsf;
+  // (a later launch of a bounded window: the logscales are in place, the forward pass stopped below row_hi -- its
+  //  records above are not there -- and nothing below row_lo is asked for)
+  const int jstop = p.partial ? max(0, row_lo) : 0, jls = p.partial ? row_hi : D;
+  if (pl.lane == 0 && wv == 0 && D - 1 < jls) lsout[D - 1] = lsf;
   double cfac = cf_last * bsum;
   double prev_ls = (double)p.ls_beta[t];  // :951
   MaskRow rowh = site_row(p.masks, S, p.L, s1, WAVES, wv);
   u64x4 firstn = load_masks<4>(rown, 0), firsth = load_masks<4>(rowh, 0);
   uint32_t touched = 0;
-  for (int j = D - 2; j >= 0; j--) {
+  for (int j = D - 2; j >= jstop; j--) {
     if (j < cpb) {  // the pass enters the block below: its records were requested a block ago
       cpb -= CK;
       rec = rec_next;
@@ -437,7 +442,7 @@ RL_DEV void repaint_backward(const RepaintParams &p, int n, float *stage, double
       cfac = 1.0;
     }
     cfac *= cf_j;
-    if (pl.lane == 0 && wv == 0) lsout[j] = lsf;
+    if (pl.lane == 0 && wv == 0 && j < jls) lsout[j] = lsf;
   }
   retire_touch(touched);
 }

@@ -92,6 +92,7 @@ static int repaint_rows(rl_window *win, float *kernel_ms) {
   p.side = p.scratch + ck_doubles;
   p.order = win->d_order.as<int32_t>();
   p.sum_mode = win->sum_mode;
+  p.partial = win->have_logscales ? 1 : 0;
   (void)N;
   bool ok = hipEventRecord(ctx->ev0, ctx->s0) == hipSuccess;
   hipError_t le = ok ? launch_repaint(p, S, waves, ctx->s0) : hipErrorUnknown;
