@@ -213,3 +213,14 @@ def test_many_chunks_dealt_to_ranks(tmp_path):
     assert sorted(sum((r[1] for r in res), [])) == list(range(C))
     for _, mine, calls in res:
         assert calls == sum(([("paint", c), ("build", c, 0, 2 + c), ("feb", c)] for c in mine), [])
+
+
+def test_dist_command_line_parses():
+    """python -m relate_amd.dist OUT_DIR [--painting theta,rho] [--chunks a,b]: the many-chunks runner's entry"""
+    import pytest as _pytest
+    from relate_amd import dist as rdist
+    with _pytest.raises(SystemExit) as e:
+        rdist.main(["--help"])
+    assert e.value.code == 0
+    with _pytest.raises(SystemExit):
+        rdist.main([])  # the output directory is required
