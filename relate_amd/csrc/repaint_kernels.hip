@@ -176,7 +176,7 @@ RL_DEV void repaint_forward(const RepaintParams &p, int n, float *stage, WaveLin
 // wave's LDS strip [register][lane] (filled by global->LDS loads that bypass the VGPRs), the rest in VGPRs.
 template <int S>
 struct HeldRow {
-  static constexpr int LREG = S < 72 ? S : 72;  // 72 * 512 B = 36 KB: four waves of a CU fit their strips in LDS
+  static constexpr int LREG = S < 76 ? S : 76;  // 76 * 512 B = 38 KB: four waves of a CU fit their strips in LDS
   static constexpr int VREG = S - LREG;
   double *lds;  // the wave's strip (wave-uniform)
   double v[VREG > 0 ? VREG : 1];
@@ -196,15 +196,15 @@ struct HeldRow {
 #pragma unroll
     for (int i = 0; i < LREG; i++) lds[i * 64 + lane] = row[i * 64 + lane];
 #else
-    static_assert(LREG % 8 == 0, "the strip is requested 4 KB at a time");
+    static_assert(LREG % 2 == 0, "the strip is requested a KB (two registers) at a time, 4 KB per address");
 #pragma unroll
-    for (int g = 0; g < LREG / 8; g++) {
+    for (int g = 0; g < (LREG + 7) / 8; g++) {
       GP src = (GP)((const char *)base + g * 4096 + voff);
       LP dst = (LP)(lds + g * 512);
       __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(src, dst, 16, 1024, 0);
-      __builtin_amdgcn_global_load_lds(src, dst, 16, 2048, 0);
-      __builtin_amdgcn_global_load_lds(src, dst, 16, 3072, 0);
+      if (g * 8 + 2 < LREG) __builtin_amdgcn_global_load_lds(src, dst, 16, 1024, 0);
+      if (g * 8 + 4 < LREG) __builtin_amdgcn_global_load_lds(src, dst, 16, 2048, 0);
+      if (g * 8 + 6 < LREG) __builtin_amdgcn_global_load_lds(src, dst, 16, 3072, 0);
     }
 #endif
     if constexpr (VREG > 0) {
