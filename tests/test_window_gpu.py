@@ -91,7 +91,7 @@ def test_gpu_paint_files_feed_window(tmp_path):
     run_case(tmp_path, 96, 1400, 60000, 9, via_gpu_paint=True)
 
 
-@pytest.mark.parametrize("N", [5300, 9300])
+@pytest.mark.parametrize("N", [5300, 7000, 9300])
 def test_two_wavefronts_per_target(tmp_path, N):
     """N > 5120: RePaint and the matrix gather run on the 128-virtual-lane layout (two wavefronts per target); N = 9300
     is the S = 80 tile of that layout (72 KB of LDS strips per workgroup in the backward kernel)"""
