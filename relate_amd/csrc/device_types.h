@@ -50,7 +50,10 @@ struct PaintParams {
 // The forward kernel keeps every REPAINT_CHECKPOINT-th alpha row of every target in HBM; the backward kernel
 // rebuilds the rows in between from the nearest one (repaint_kernels.hip).  Per step it also keeps 3 doubles (side
 // record).
-constexpr int REPAINT_CHECKPOINT = 4;
+#ifndef RL_REPAINT_CHECKPOINT
+#define RL_REPAINT_CHECKPOINT 6
+#endif
+constexpr int REPAINT_CHECKPOINT = RL_REPAINT_CHECKPOINT;  // (2 .. 8; -DRL_REPAINT_CHECKPOINT=k for experiments)
 // bytes of the forward kernel's output for a window of `rows` target-site rows over nloc targets (an upper bound:
 // every target rounds its checkpoint rows up)
 inline size_t repaint_scratch_bytes(int64_t rows, int nloc, int S, int waves) {
