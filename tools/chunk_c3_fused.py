@@ -54,7 +54,7 @@ try:
     out["anc_GB"] = sum(os.path.getsize(os.path.join(d, "chunk_0", f)) for f in os.listdir(os.path.join(d, "chunk_0"))
                         if f.endswith(".anc")) / 1e9
     out["stage_lines"] = [l.strip() for l in err.split("\n") if l.startswith("[") and "tree sequence" not in l
-                          and "tree builder" not in l][:12]
+                          and "[tree builder launch]" not in l and "[gpu tree builder]" not in l][:12]
     sizes = [int(re.search(r"launch\] (\d+) trees", l).group(1)) for l in err.split("\n") if "[tree builder launch]" in l]
     if sizes:
         out["builder_launches"] = {"launches": len(sizes), "mean_trees_per_launch": sum(sizes) / len(sizes), "max": max(sizes)}
