@@ -194,3 +194,24 @@ def test_bounded_window_with_room_for_everything(tmp_path):
     assert top.shape[0] == win.rows(3) and win.repaints == 1
     win.close()
     ctx.close()
+
+
+def test_repaint_literal_serial_order_equals_the_parallel_exact_sums(tmp_path):
+    """RePaint with RL_SUM_EXACT_SERIAL (the literal lane-after-lane order, the in-kernel fallback of the exact
+    sums) gives the same posterior rows, logscales and matrices as RL_SUM_EXACT, bit for bit"""
+    ch = rlutil.synth_chunk(130, 1500, seed=5, budget=200000)
+    ctx = api.Context()
+    ctx.set_chunk(ch.seq, ch.r, ch.rpos, ch.wb)
+    ctx.paint(api.RL_SUM_EXACT)
+    for w in sorted(set([0, ch.W // 2, ch.W - 1])):
+        s0 = int(ch.wb[w])
+        a = ctx.open_window(w, None, s0, api.RL_SUM_EXACT)
+        b = ctx.open_window(w, None, s0, api.RL_SUM_EXACT_SERIAL)
+        for n in (0, 1, 64, 129):
+            ta, la = a.topology(n)
+            tb, lb = b.topology(n)
+            assert np.array_equal(u32(ta), u32(tb)) and np.array_equal(u32(la), u32(lb)), (w, n)
+        assert np.array_equal(u32(a.matrix(s0)), u32(b.matrix(s0)))
+        a.close()
+        b.close()
+    ctx.close()
