@@ -674,7 +674,7 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
         if (dki != dkj) nkj = over_added(csi * dki + csj * dkj);
         // (written whether changed or not: the same bits where the reference leaves the entry alone)
         MM(j, k) = make_float4(njk, nkj, ncjk, nckj);
-        MM(k, j) = make_float4(nkj, njk, nckj, ncjk);
+        if (!(p.debug & 2)) MM(k, j) = make_float4(nkj, njk, nckj, ncjk);  // (2: timing experiment, wrong trees)
         if (njk < mvj) mvj = njk;
         bool rescan = false;
         if (dkj != dki) {

@@ -38,16 +38,6 @@ struct SnpInfo {
   bool flipped = false;
 };
 
-struct PropGlobal {
-  int num_correct_carriers, num_correct_noncarriers;
-  int num_incorrect_carriers, num_incorrect_noncarriers;
-  int best_branch, best_flipped_branch;
-  int min, flipped_min;
-};
-struct PropLocal {
-  int num_carriers = 0, num_flipped_carriers = 0, best_branch = -1, best_flipped_branch = -1;
-};
-
 }  // namespace rl
 
 struct rl_treeseq {
@@ -74,216 +64,169 @@ struct rl_treeseq {
 
 namespace rl {
 
-// ---- anc_builder.cpp:1237-1341
-static void propagate_global(const rl_treeseq &ts, const HostTree &t, int node, PropGlobal &report) {
-  const int N = ts.N;
-  const float total_carriers = ts.num_carriers;
-  const float total_noncarriers = N - total_carriers;
-  if (t.child_left[node] >= 0) {
-    PropGlobal report2;
-    propagate_global(ts, t, t.child_left[node], report);
-    propagate_global(ts, t, t.child_right[node], report2);
-    report.num_correct_carriers += report2.num_correct_carriers;
-    report.num_incorrect_noncarriers += report2.num_incorrect_noncarriers;
-    report.num_incorrect_carriers = total_carriers - report.num_correct_carriers;
-    report.num_correct_noncarriers = total_noncarriers - report.num_incorrect_noncarriers;
+// ---- Where a SNP sits on a tree (anc_builder.cpp:1064-1413: MapMutation, ForceMapMutation and their two
+// recursions PropagateMutationGlobal / PropagateMutationLocal).
+//
+// The reference walks the tree recursively and carries eight counters per call.  Everything it decides at a node
+// follows from two numbers -- the carriers and the leaves below it -- and from what its two children decided, so
+// here the tree is swept once, bottom-up, over flat arrays:
+//   * MinMatch labels a merged node N + (merge index): children always carry smaller labels than their parent, so
+//     the label order 0 .. 2N-2 IS a bottom-up order (no stack, no recursion 5000 deep);
+//   * for the orders in which the reference *emits* branches (ForceMapMutation's lists) the post-order of the
+//     recursion (left subtree, right subtree, node) is made explicit once per call.
+// Float semantics kept: every ratio is a float division compared against the double literals 0.3 / 0.7 / 0.03.
 
-    int sum = report.num_incorrect_carriers + report.num_incorrect_noncarriers;
-    bool cond = (((float)report.num_incorrect_carriers) / total_carriers < 0.3);
-    cond *= (((float)report.num_incorrect_noncarriers) / total_noncarriers < 0.3);
-    if (report.num_correct_carriers + report.num_incorrect_noncarriers > 0.0)
-      cond *= (((float)report.num_correct_carriers) /
-                   (report.num_correct_carriers + report.num_incorrect_noncarriers) > 0.7);
-    if (report.num_incorrect_carriers + report.num_correct_noncarriers > 0.0)
-      cond *= (((float)report.num_correct_noncarriers) /
-                   (report.num_incorrect_carriers + report.num_correct_noncarriers) > 0.7);
-    if (cond && report.min > sum && report2.min > sum) {
-      report.min = sum;
-      report.best_branch = node;
-    } else if (report.min > report2.min) {
-      report.min = report2.min;
-      report.best_branch = report2.best_branch;
-    }
+// A branch and how many leaves it misplaces; `leaves == INT_MAX`: no admissible branch in the subtree.
+struct Fit {
+  int leaves = INT_MAX;
+  int branch = -1;
+};
 
-    sum = report.num_correct_carriers + report.num_correct_noncarriers;
-    cond = (((float)report.num_correct_carriers) / total_carriers < 0.3);
-    cond *= (((float)report.num_correct_noncarriers) / total_noncarriers < 0.3);
-    if (report.num_incorrect_carriers + report.num_correct_noncarriers > 0.0)
-      cond *= (((float)report.num_incorrect_carriers) /
-                   (report.num_incorrect_carriers + report.num_correct_noncarriers) > 0.7);
-    if (report.num_correct_carriers + report.num_incorrect_noncarriers > 0.0)
-      cond *= (((float)report.num_incorrect_noncarriers) /
-                   (report.num_correct_carriers + report.num_incorrect_noncarriers) > 0.7);
-    if (cond && report.flipped_min > sum && report2.flipped_min > sum) {
-      report.flipped_min = sum;
-      report.best_flipped_branch = node;
-    } else if (report.flipped_min > report2.flipped_min) {
-      report.flipped_min = report2.flipped_min;
-      report.best_flipped_branch = report2.best_flipped_branch;
-    }
-  } else {
-    if (ts.member[node] == 1) {
-      report.num_correct_carriers = 1;
-      report.num_incorrect_carriers = total_carriers - 1;
-      report.num_correct_noncarriers = total_noncarriers;
-      report.num_incorrect_noncarriers = 0;
-      if (report.num_incorrect_carriers / total_carriers < 0.3) {
-        report.min = report.num_incorrect_carriers;
-        report.best_branch = node;
-      } else {
-        report.min = INT_MAX;
-        report.best_branch = -1;
-      }
-      if (report.num_correct_carriers / total_carriers < 0.3 &&
-          report.num_correct_noncarriers / total_noncarriers < 0.3) {
-        report.flipped_min = report.num_correct_noncarriers + report.num_correct_carriers;
-        report.best_flipped_branch = node;
-      } else {
-        report.flipped_min = INT_MAX;
-        report.best_flipped_branch = -1;
-      }
+// the two ratio tests every clade has to pass in either orientation (:1265-1279, :1295-1310)
+static inline bool small_share(int part, float whole) { return (float)part / whole < 0.3; }
+static inline bool pure(int agreeing, int all) { return all <= 0 || (float)agreeing / (float)all > 0.7; }
+
+// MapMutation's search (:1237-1341): over all branches, the one whose clade is closest to the carrier set -- as it
+// stands (`direct`: the leaves below carry the derived allele) and with the alleles flipped (`flipped`).  A clade
+// replaces the best of its subtrees only when strictly better than both; of two subtrees the left one keeps ties.
+static void best_branches(const rl_treeseq &ts, const HostTree &t, Fit &direct_root, Fit &flipped_root) {
+  const int N = ts.N, T = 2 * N - 1;
+  const float carriers = (float)ts.num_carriers, others = (float)N - carriers;
+  static thread_local std::vector<int> below_c, below_n;  // carriers / non-carriers below each node
+  static thread_local std::vector<Fit> direct, flipped;
+  below_c.resize(T);
+  below_n.resize(T);
+  direct.resize(T);
+  flipped.resize(T);
+  for (int v = 0; v < N; v++) {  // leaves (:1313-1339): one ratio test per orientation, two for the "wrong" allele
+    const int c = ts.member[v] == 1 ? 1 : 0, in_c = c, in_n = 1 - c;
+    const int out_c = (int)(carriers - (float)in_c), out_n = (int)(others - (float)in_n);
+    below_c[v] = in_c;
+    below_n[v] = in_n;
+    Fit d, f;
+    if (c) {
+      if (small_share(out_c, carriers)) d = Fit{out_c, v};
+      if (small_share(in_c, carriers) && small_share(out_n, others)) f = Fit{out_n + in_c, v};
     } else {
-      report.num_correct_carriers = 0;
-      report.num_incorrect_carriers = total_carriers;
-      report.num_correct_noncarriers = total_noncarriers - 1;
-      report.num_incorrect_noncarriers = 1;
-      if (report.num_incorrect_carriers / total_carriers < 0.3 &&
-          report.num_incorrect_noncarriers / total_noncarriers < 0.3) {
-        report.min = report.num_incorrect_carriers + report.num_incorrect_noncarriers;
-        report.best_branch = node;
-      } else {
-        report.min = INT_MAX;
-        report.best_branch = -1;
-      }
-      if (report.num_correct_noncarriers / total_noncarriers < 0.3) {
-        report.flipped_min = report.num_correct_noncarriers;
-        report.best_flipped_branch = node;
-      } else {
-        report.flipped_min = INT_MAX;
-        report.best_flipped_branch = -1;
-      }
+      if (small_share(out_c, carriers) && small_share(in_n, others)) d = Fit{out_c + in_n, v};
+      if (small_share(out_n, others)) f = Fit{out_n, v};
     }
+    direct[v] = d;
+    flipped[v] = f;
   }
-}
-
-// ---- anc_builder.cpp:1344-1413
-static void propagate_local(const rl_treeseq &ts, const HostTree &t, int node, std::vector<int> &branches,
-                            std::vector<int> &branches_flipped, PropLocal &report) {
-  if (t.child_left[node] >= 0) {
-    PropLocal c1, c2;
-    propagate_local(ts, t, t.child_left[node], branches, branches_flipped, c1);
-    propagate_local(ts, t, t.child_right[node], branches, branches_flipped, c2);
-    report.num_carriers = c1.num_carriers + c2.num_carriers;
-    report.num_flipped_carriers = c1.num_flipped_carriers + c2.num_flipped_carriers;
-    const float num_leaves = report.num_carriers + report.num_flipped_carriers;
-    if (report.num_flipped_carriers / num_leaves < 0.03 && c1.best_branch != -1 && c2.best_branch != -1) {
-      if (c1.num_carriers > 0 && c2.num_carriers > 0)
-        report.best_branch = node;
-      else if (c1.num_carriers > 0)
-        report.best_branch = c1.best_branch;
+  for (int v = N; v < T; v++) {
+    const int l = t.child_left[v], r = t.child_right[v];
+    const int in_c = below_c[l] + below_c[r], in_n = below_n[l] + below_n[r];
+    const int out_c = (int)(carriers - (float)in_c), out_n = (int)(others - (float)in_n);
+    below_c[v] = in_c;
+    below_n[v] = in_n;
+    {  // as it stands: carriers outside and non-carriers inside are the misplaced leaves
+      const int wrong = out_c + in_n;
+      const bool ok = small_share(out_c, carriers) && small_share(in_n, others) && pure(in_c, in_c + in_n) &&
+                      pure(out_n, out_c + out_n);
+      if (ok && direct[l].leaves > wrong && direct[r].leaves > wrong)
+        direct[v] = Fit{wrong, v};
       else
-        report.best_branch = c2.best_branch;
-    } else {
-      if (c1.best_branch != -1) branches.push_back(c1.best_branch);
-      if (c2.best_branch != -1) branches.push_back(c2.best_branch);
-      report.best_branch = -1;
+        direct[v] = direct[l].leaves > direct[r].leaves ? direct[r] : direct[l];
     }
-    if (report.num_carriers / num_leaves < 0.03 && c1.best_flipped_branch != -1 && c2.best_flipped_branch != -1) {
-      if (c1.num_flipped_carriers > 0 && c2.num_flipped_carriers > 0)
-        report.best_flipped_branch = node;
-      else if (c1.num_flipped_carriers > 0)
-        report.best_flipped_branch = c1.best_flipped_branch;
+    {  // flipped: carriers inside and non-carriers outside
+      const int wrong = in_c + out_n;
+      const bool ok = small_share(in_c, carriers) && small_share(out_n, others) && pure(out_c, out_c + out_n) &&
+                      pure(in_n, in_c + in_n);
+      if (ok && flipped[l].leaves > wrong && flipped[r].leaves > wrong)
+        flipped[v] = Fit{wrong, v};
       else
-        report.best_flipped_branch = c2.best_flipped_branch;
-    } else {
-      if (c1.best_flipped_branch != -1) branches_flipped.push_back(c1.best_flipped_branch);
-      if (c2.best_flipped_branch != -1) branches_flipped.push_back(c2.best_flipped_branch);
-      report.best_flipped_branch = -1;
-    }
-  } else {
-    if (ts.member[node] == 1) {
-      report.num_carriers = 1;
-      report.num_flipped_carriers = 0;
-      report.best_branch = node;
-      report.best_flipped_branch = -1;
-    } else {
-      report.num_carriers = 0;
-      report.num_flipped_carriers = 1;
-      report.best_flipped_branch = node;
-      report.best_branch = -1;
+        flipped[v] = flipped[l].leaves > flipped[r].leaves ? flipped[r] : flipped[l];
     }
   }
+  direct_root = direct[T - 1];
+  flipped_root = flipped[T - 1];
 }
 
-// ---- anc_builder.cpp:1064-1139 (version without random flipping)
-static int map_mutation(rl_treeseq &ts, HostTree &t, SnpInfo &si, float &min_value, bool use) {
-  const int N = ts.N;
-  if (ts.num_carriers == N) {
-    min_value = 0.0f;
-    si.branch.resize(1);
+// MapMutation (:1064-1139, the version without random flipping): 1 = the SNP maps, 2 = maps with the alleles
+// flipped, 3 = no branch within the tolerance (si untouched).  misfit: the misplaced leaves of the best branch.
+static int map_mutation(rl_treeseq &ts, HostTree &t, SnpInfo &si, float &misfit, bool count_event) {
+  const int N = ts.N, root = 2 * N - 2;
+  if (ts.num_carriers == 0 || ts.num_carriers == N) {  // nothing to place; a fixed site sits on the root branch
+    misfit = 0.0f;
     si.flipped = false;
-    si.branch[0] = 2 * N - 2;
-    t.num_events[2 * N - 2] += 1.0f;
-    return 1;
-  }
-  if (ts.num_carriers == 0) {
-    min_value = 0.0f;
-    si.branch.resize(0);
-    si.flipped = false;
-    return 1;
-  }
-  PropGlobal report;
-  propagate_global(ts, t, 2 * N - 2, report);
-  if (report.min == report.flipped_min && report.min <= ts.thr) {
-    min_value = report.min;
-    si.branch.resize(1);
-    si.branch[0] = report.best_branch;
-    si.flipped = false;
-    if (use) t.num_events[report.best_branch] += 1.0f;
-    return 1;
-  } else if (report.min <= report.flipped_min) {
-    min_value = report.min;
-    if (report.min <= ts.thr) {
-      si.branch.resize(1);
-      si.branch[0] = report.best_branch;
-      si.flipped = false;
-      if (use) t.num_events[report.best_branch] += 1.0f;
-      return 1;
+    si.branch.clear();
+    if (ts.num_carriers == N) {
+      si.branch.push_back(root);
+      t.num_events[root] += 1.0f;  // (counted whatever the SNP's state, :1075)
     }
-    return 3;
-  } else {
-    min_value = report.flipped_min;
-    if (report.flipped_min <= ts.thr) {
-      si.branch.resize(1);
-      si.branch[0] = report.best_flipped_branch;
-      si.flipped = true;
-      if (use) t.num_events[report.best_flipped_branch] += 1.0f;
-      return 2;
-    }
-    return 3;
+    return 1;
   }
+  Fit direct, flipped;
+  best_branches(ts, t, direct, flipped);
+  const bool as_is = direct.leaves <= flipped.leaves;  // (ties go to the unflipped reading)
+  const Fit &best = as_is ? direct : flipped;
+  misfit = (float)best.leaves;
+  if (best.leaves > ts.thr) return 3;
+  si.branch.assign(1, best.branch);
+  si.flipped = !as_is;
+  if (count_event) t.num_events[best.branch] += 1.0f;
+  return as_is ? 1 : 2;
 }
 
-// ---- anc_builder.cpp:1143-1204
-static int force_map_mutation(rl_treeseq &ts, HostTree &t, SnpInfo &si, bool force) {
-  const int N = ts.N;
-  if (ts.num_carriers == 0 || ts.num_carriers == N) return 1;
-  std::vector<int> branches, branches_flipped;
-  PropLocal report;
-  propagate_local(ts, t, 2 * N - 2, branches, branches_flipped, report);
-  if (branches_flipped.size() == 0) {
-    if (branches.size() == 1 || force) si.branch = branches;
-    return (int)branches.size();
+// ForceMapMutation (:1143-1204) with PropagateMutationLocal (:1344-1413): a SNP that fits no single branch goes
+// onto the maximal clades that are (almost, < 3 % of their leaves) pure in carriers -- or, flipped, in non-carriers
+// -- whichever reading needs fewer branches.  A clade stays "open" while it is pure and both children are open; its
+// branch is the node itself if both children hold leaves of the kind, else the one child's branch.  When a clade
+// closes, its children's open branches are emitted (left, then right) -- in the order the recursion reaches the
+// closing nodes, i.e. post-order, which the sweep below follows through an explicit list.
+static void force_map_mutation(rl_treeseq &ts, const HostTree &t, SnpInfo &si) {
+  const int N = ts.N, T = 2 * N - 1;
+  if (ts.num_carriers == 0 || ts.num_carriers == N) return;
+  static thread_local std::vector<int> post, stack, kind_count[2], open_branch[2];
+  post.clear();
+  stack.assign(1, T - 1);
+  while (!stack.empty()) {  // (root, right, left) reversed = (left, right, root)
+    const int v = stack.back();
+    stack.pop_back();
+    post.push_back(v);
+    if (t.child_left[v] >= 0) {
+      stack.push_back(t.child_left[v]);
+      stack.push_back(t.child_right[v]);
+    }
   }
-  if (branches.size() <= branches_flipped.size() && branches.size() > 0) {
-    if (branches.size() == 1 || force) si.branch = branches;
-    return (int)branches.size();
+  std::reverse(post.begin(), post.end());
+  std::vector<int> emitted[2];  // [0] carriers' clades, [1] non-carriers' clades (the flipped reading)
+  for (int s = 0; s < 2; s++) {
+    kind_count[s].resize(T);
+    open_branch[s].resize(T);
   }
-  if (branches_flipped.size() == 1 || force) {
-    si.flipped = true;
-    si.branch = branches_flipped;
+  for (int v : post) {
+    const int l = t.child_left[v], r = t.child_right[v];
+    if (l < 0) {
+      const int s = ts.member[v] == 1 ? 0 : 1;
+      kind_count[s][v] = 1;
+      kind_count[1 - s][v] = 0;
+      open_branch[s][v] = v;
+      open_branch[1 - s][v] = -1;
+      continue;
+    }
+    const int n0 = kind_count[0][l] + kind_count[0][r], n1 = kind_count[1][l] + kind_count[1][r];
+    kind_count[0][v] = n0;
+    kind_count[1][v] = n1;
+    const float leaves = (float)(n0 + n1);
+    for (int s = 0; s < 2; s++) {
+      const int foreign = s == 0 ? n1 : n0;
+      const int bl = open_branch[s][l], br = open_branch[s][r];
+      if ((float)foreign / leaves < 0.03 && bl != -1 && br != -1) {
+        const bool in_l = kind_count[s][l] > 0, in_r = kind_count[s][r] > 0;
+        open_branch[s][v] = in_l && in_r ? v : (in_l ? bl : br);
+      } else {
+        if (bl != -1) emitted[s].push_back(bl);
+        if (br != -1) emitted[s].push_back(br);
+        open_branch[s][v] = -1;
+      }
+    }
   }
-  return (int)branches_flipped.size();
+  // fewer branches win, the unflipped reading on ties -- unless it found none (:1180-1203)
+  const bool as_is = emitted[1].empty() || (!emitted[0].empty() && emitted[0].size() <= emitted[1].size());
+  if (!as_is) si.flipped = true;
+  si.branch = emitted[as_is ? 0 : 1];
 }
 
 // Prior `dist` from the previous tree's clades (anc_builder.cpp:583-606):
@@ -473,7 +416,7 @@ int rl_treeseq_build(rl_treeseq *ts, int start, int end, rl_matrix_fn matrix, rl
   set_carriers(start);
   ts->info[0].tree = 0;
   int is_mapping = map_mutation(*ts, ts->trees.back(), ts->info[0], min_value, ts->state[start] != 0);
-  if (is_mapping > 2) force_map_mutation(*ts, ts->trees.back(), ts->info[0], true);
+  if (is_mapping > 2) force_map_mutation(*ts, ts->trees.back(), ts->info[0]);
 
   int num_tree = 1;
   const float val = -std::log(ts->theta / (1.0 - ts->theta));  // :555
@@ -572,12 +515,12 @@ int rl_treeseq_build(rl_treeseq *ts, int start, int end, rl_matrix_fn matrix, rl
         // new tree is not better: keep the old one (:621-630)
         if (is_mapping == 2) si.branch[0] = prev_branch;
         ts->trees.pop_back();
-        if (is_mapping > 2) force_map_mutation(*ts, ts->trees.back(), si, true);
+        if (is_mapping > 2) force_map_mutation(*ts, ts->trees.back(), si);
       } else {
         if (is_mapping == 2 || (is_mapping == 1 && force_new)) {
           if (use) pt.num_events[prev_branch] -= 1.0f;
         }
-        if (is_mapping_alt > 2) force_map_mutation(*ts, nt, si, true);
+        if (is_mapping_alt > 2) force_map_mutation(*ts, nt, si);
         si.tree = num_tree;
         std::fill(pt.snp_end.begin(), pt.snp_end.end(), snp);
         std::fill(nt.snp_begin.begin(), nt.snp_begin.end(), snp);

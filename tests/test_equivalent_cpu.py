@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLI = os.path.join(ROOT, "relate_amd", "Relate")
 
 
-@pytest.mark.parametrize("name", ["synth24", "synth70", "example8"])
+@pytest.mark.parametrize("name", ["synth24", "synth70", "example8", "synth40_noisy"])
 def test_find_equivalent_branches_matches_reference(tmp_path, name):
     out = tmp_path / "out"
     out.mkdir()

@@ -11,7 +11,8 @@ from relate_amd import api
 
 pytestmark = pytest.mark.gpu
 
-CASES = [("synth24", None), ("synth24_paint", (0.025, 2.0)), ("synth70", None), ("example8", None)]
+CASES = [("synth24", None), ("synth24_paint", (0.025, 2.0)), ("synth70", None), ("example8", None),
+         ("synth40_noisy", None)]
 
 
 def u32(a):

@@ -12,7 +12,8 @@ import pytest
 import rlutil
 from golden_util import Fixture
 
-CASES = [("synth24", None), ("synth24_paint", (0.025, 2.0)), ("synth70", None), ("example8", None)]
+CASES = [("synth24", None), ("synth24_paint", (0.025, 2.0)), ("synth70", None), ("example8", None),
+         ("synth40_noisy", None)]
 
 
 def u32(a):

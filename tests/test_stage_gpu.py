@@ -20,7 +20,7 @@ def run_cli(args, cwd):
     return p.stderr.decode()
 
 
-@pytest.mark.parametrize("name", ["synth24", "synth70", "example8"])
+@pytest.mark.parametrize("name", ["synth24", "synth70", "example8", "synth40_noisy"])
 def test_cli_stages_byte_identical_to_reference(tmp_path, name):
     work = tmp_path / "work"
     (work / "out").mkdir(parents=True)
@@ -98,7 +98,7 @@ def test_cli_build_topology_bounded_windows(tmp_path):
         assert open(work / "out" / "chunk_0" / ("out_%d.anc" % w), "rb").read() == fx.z["anc/%d" % w].tobytes(), w
 
 
-@pytest.mark.parametrize("name", ["synth24", "synth70", "example8"])
+@pytest.mark.parametrize("name", ["synth24", "synth70", "example8", "synth40_noisy"])
 def test_cli_build_topology_trees_built_on_the_gpu(tmp_path, name):
     """RELATE_AMD_GPU_BUILD=1: MinMatch itself on the GPU (one workgroup per tree), host builder as the fallback
     for trees that need the symmetric matrix -- the same .anc / .mut bytes as the reference"""
@@ -151,7 +151,7 @@ def test_cli_gpu_build_options(tmp_path, tag, opts):
         assert open(work / "out" / "chunk_0" / ("out_%d.anc" % w), "rb").read() == fx.z["anc_%s/%d" % (tag, w)].tobytes(), w
 
 
-@pytest.mark.parametrize("name", ["synth24", "synth70", "example8"])
+@pytest.mark.parametrize("name", ["synth24", "synth70", "example8", "synth40_noisy"])
 def test_paint_and_build_topology_without_paint_files(tmp_path, name):
     """--mode PaintBuildTopology (rl_stage_paint_build_topology): the stepping stones stay in HBM, the paint file's
     float / run-length quantisation is applied on the device -- no chunk_0/paint directory, and the same .anc / .mut

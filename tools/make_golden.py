@@ -96,6 +96,41 @@ def synth_fixture(name, N, L, seed, budget, painting=None, windows_dump=(1,), wi
     print(name, "N", N, "L", L, "W", ch.W, "%.1f KB" % (os.path.getsize(os.path.join(GOLD, name + ".npz")) / 1e3))
 
 
+def noisy_fixture(name="synth40_noisy", N=40, L=600, seed=9, budget=9000):
+    """A chunk the trees do NOT fit: every allele of the synthetic panel is flipped with probability 1 % and one SNP
+    in 25 has its alleles swapped altogether -- SNPs that map only with the alleles flipped (.mut is_flipped = 1),
+    SNPs that fit no branch and go onto several (ForceMapMutation, .mut is_mapping = 1), and many more trees per
+    section than the clean fixtures have."""
+    import ctypes as C
+    from relate_amd import api
+    ch = rlutil.synth_chunk(N, L, seed=seed, budget=None)
+    rng = np.random.RandomState(seed)
+    seq = ch.seq.copy()
+    flip = rng.rand(L, N) < 0.01
+    flip[rng.rand(L) < 0.04] ^= True
+    seq[flip] = ord("0") + ord("1") - seq[flip]
+    wbuf = np.zeros(L + 2, dtype=np.int32)
+    W = api.lib().rl_synth_windows(N, L, seq.ctypes.data_as(C.c_void_p), C.c_double(budget),
+                                   wbuf.ctypes.data_as(C.c_void_p), L)
+    assert W > 1
+    ch = rlutil.Chunk(seq, ch.r, ch.rpos, wbuf[:W + 1].copy(), ch.bp)
+    with tempfile.TemporaryDirectory() as work:
+        ch.write(os.path.join(work, "out"))
+        data = collect(work, "out", ch.W, None, windows_dump=(), with_trees=True)
+    data["meta"] = np.array([N, L, ch.W, seed], dtype=np.int64)
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **data)
+    multi = flipped = total = 0
+    for w in range(ch.W):
+        for line in data["mut/%d" % w].tobytes().decode().split("\n")[1:]:
+            f = line.split(";")
+            if len(f) > 3:
+                total += 1
+                multi += f[2] == "1"
+                flipped += f[3] == "1"
+    print(name, "N", N, "L", L, "W", ch.W, "SNPs", total, "on several branches", multi, "flipped", flipped,
+          "%.1f KB" % (os.path.getsize(os.path.join(GOLD, name + ".npz")) / 1e3))
+
+
 def example_fixture(nsnps=3000):
     src = "/root/reference/example/data"
     with tempfile.TemporaryDirectory() as work:
@@ -239,6 +274,9 @@ if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "ages":
         ages_fixture()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "noisy":
+        noisy_fixture()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "makechunks":
         makechunks_fixture()
