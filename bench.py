@@ -8,8 +8,9 @@ reference).
 
     python bench.py [--gpus N --steps K --warmup W] [--haplotypes 5000 --snps 500000]
 
-With --gpus N > 1 the driver launches one rank per GPU with torch.distributed.run;
-ranks paint independent chunks (chunks are embarrassingly parallel in the
+With --gpus N > 1 there is one rank per GPU: launched by torch.distributed.run (the
+driver's way), or -- when no launcher set RANK -- by bench.py itself as a child
+`python -m torch.distributed.run --nproc-per-node N bench.py ...`.  Ranks paint independent chunks (chunks are embarrassingly parallel in the
 reference too: scripts/RelateParallel/RelateParallel.sh:216) -> weak scaling,
 no data-path collective.  Rank 0 prints ONE JSON line.
 
@@ -138,6 +139,21 @@ def main():
                          "scaling; BASELINE.json config #5) and the ranks all-gather one distance matrix's rows")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks here (one process per GPU) as a CHILD --
+        # before this process has touched the GPU, and never by replacing it -- and pass rank 0's JSON line through.
+        import socket
+        import subprocess
+        import torch
+        have = torch.cuda.device_count()  # (counting devices does not initialise the GPU)
+        if have < args.gpus:
+            sys.exit("bench.py: --gpus %d but %d GPU%s visible" % (args.gpus, have, "" if have == 1 else "s"))
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd).returncode)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -133,6 +133,8 @@ namespace rl {
 int build_plan(rl_ctx *ctx);
 int upload_plan(rl_ctx *ctx);
 int host_threads();
+int local_world_size();  // ranks of the job on this host (LOCAL_WORLD_SIZE), 1 outside a launcher
+int local_rank();
 // paint-file codec (collapsed_matrix.hpp:228-296)
 size_t encode_stone(const float *v, int N, int bsnp, float logscale, unsigned char *out);
 size_t decode_stone(const unsigned char *in, size_t avail, int N, float *v, int *bsnp, float *logscale);

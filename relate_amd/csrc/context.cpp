@@ -16,6 +16,8 @@
 #include <numeric>
 #include <thread>
 
+#include <sched.h>
+
 #include "common.h"
 
 namespace rl {
@@ -31,9 +33,33 @@ void set_error(const char *fmt, ...) {
   g_err = buf;
 }
 
+// ranks of this job on this host (torch.distributed.run / mpirun export it): the host's cores are shared among them
+int local_world_size() {
+  for (const char *name : {"LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE"})
+    if (const char *e = getenv(name))
+      if (atoi(e) > 0) return atoi(e);
+  return 1;
+}
+int local_rank() {
+  for (const char *name : {"LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK"})
+    if (const char *e = getenv(name))
+      if (atoi(e) >= 0) return atoi(e);
+  return 0;
+}
+
+// host threads of this process: RELATE_AMD_THREADS, else this rank's share of the cores the process may run on
 int host_threads() {
   const char *e = getenv("RELATE_AMD_THREADS");
-  int n = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+  int n = 0;
+  if (e) {
+    n = atoi(e);
+  } else {
+    cpu_set_t allowed;
+    CPU_ZERO(&allowed);
+    n = sched_getaffinity(0, sizeof(allowed), &allowed) == 0 ? CPU_COUNT(&allowed)
+                                                             : (int)std::thread::hardware_concurrency();
+    n /= local_world_size();
+  }
   if (n < 1) n = 1;
   if (n > 256) n = 256;
   return n;
@@ -373,6 +399,10 @@ const char *rl_last_error(void) { return g_err.c_str(); }
 const char *rl_version(void) { return "relate_amd 0.1 (gfx950)"; }
 
 int rl_device_count(void) {
+  // The stage keeps a stream per open window and per tree builder; HIP maps them onto GPU_MAX_HW_QUEUES hardware
+  // queues (4 by default: 91 s -> 96 s for 80 sections; past 16 the device time-slices them).  Read by
+  // the runtime when it initialises, so set before the first HIP call of the process; the user's value wins.
+  setenv("GPU_MAX_HW_QUEUES", "12", 0);
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;

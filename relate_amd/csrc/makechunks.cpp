@@ -32,7 +32,9 @@ struct InFile {
     fclose(chk);
     piped = got == 3 && b[0] == 0x1f && b[1] == 0x8b && b[2] == 0x08;
     if (piped) {
-      std::string cmd = std::string("gunzip -c '") + fn + "'";
+      std::string cmd = "gunzip -c '";  // (a quote in the path closes, escapes and reopens the quoting)
+      for (const char *c = fn; *c; c++) cmd += *c == '\'' ? std::string("'\\''") : std::string(1, *c);
+      cmd += "'";
       fp = popen(cmd.c_str(), "r");
     } else {
       fp = fopen(fn, "r");
@@ -221,7 +223,10 @@ extern "C" int rl_make_chunks(const char *haps_fn, const char *sample_fn, const 
       // A window closes at the first SNP t, more than 10 SNPs in, whose row brings its account to the budget
       // (data.cpp:219-229); t opens the next window, whose account starts BEHIND t (t's own row is charged to the
       // window it closed).
-      const size_t idx = std::lower_bound(cost.begin(), cost.end(), open_cost + window_budget) - cost.begin();
+      // (the window's account is cost - open_cost, exact integers; open_cost + budget would round a fractional
+      //  budget -- --memory 0.3 -- and could close a window one SNP early)
+      const size_t idx = std::partition_point(cost.begin(), cost.end(),
+                                              [&](double c) { return c - open_cost < window_budget; }) - cost.begin();
       const long t = std::max<long>((long)idx - 1, (long)open + 11);
       if (idx > (size_t)L || t >= limit) break;
       largest_window = std::max(largest_window, cost[t + 1] - open_cost);

@@ -10,6 +10,8 @@
 // pass reads it back, two chunks of registers ahead of their use, and writes the
 // posterior rows `topology = float(alpha*beta)` in the same register-major
 // layout (4 B per donor per visited site: the kernel is HBM-bound).
+#include <atomic>
+
 #include "paint_device.h"
 #include "exact_sum.h"
 #include "launch.h"
@@ -477,11 +479,19 @@ template <int S, int TAIL, int WAVES>
 static hipError_t launch_repaint_t(const RepaintParams &p, hipStream_t stream) {
   constexpr size_t strips = (size_t)WAVES * strip_doubles<S>() * sizeof(double);
   // (two waves of S = 80: 72 KB of dynamic LDS, more than a launch may ask for without saying so)
-  static const hipError_t allowed =
-      strips > 48 * 1024 ? hipFuncSetAttribute(reinterpret_cast<const void *>(&repaint_bwd_kernel<S, TAIL, RL_MODE, WAVES>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)strips)
-                         : hipSuccess;
-  if (allowed != hipSuccess) return allowed;
+  // (the attribute belongs to the device: once per device and instantiation)
+  if (strips > 48 * 1024) {
+    static std::atomic<unsigned long long> done[2];  // devices 0..127
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (dev > 127 || !(done[(dev >> 6) & 1].load(std::memory_order_acquire) & bit)) {
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&repaint_bwd_kernel<S, TAIL, RL_MODE, WAVES>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)strips);
+      if (e != hipSuccess) return e;
+      if (dev <= 127) done[(dev >> 6) & 1].fetch_or(bit, std::memory_order_release);
+    }
+  }
   hipLaunchKernelGGL((repaint_fwd_kernel<S, TAIL, RL_MODE, WAVES>), dim3(p.nloc), dim3(64 * WAVES), 0, stream, p);
   hipLaunchKernelGGL((repaint_bwd_kernel<S, TAIL, RL_MODE, WAVES>), dim3(p.nloc), dim3(64 * WAVES), strips, stream, p);
   return hipGetLastError();

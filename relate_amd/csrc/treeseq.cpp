@@ -13,6 +13,7 @@
 #include <sys/resource.h>
 #include <sys/stat.h>
 #include <sys/time.h>
+#include <zlib.h>
 
 #include <algorithm>
 #include <atomic>
@@ -690,24 +691,31 @@ static std::vector<cpu_set_t> cache_groups() {
 // that cannot be opened leaves N zeros (and a warning), one with fewer than N numbers no ages at all -- as there.
 static std::vector<double> read_sample_ages(const char *fn, int N) {
   std::vector<double> ages(N, 0.0);
-  FILE *chk = fopen(fn, "rb");
-  if (!chk) {
+  gzFile gz = gzopen(fn, "rb");  // (plain text passes through zlib unchanged; no shell, whatever the path holds)
+  if (!gz) {
     std::cerr << "Warning: unable to open sample ages file" << std::endl;
     return ages;
   }
-  unsigned char b[3] = {0, 0, 0};
-  const bool gz = fread(b, 1, 3, chk) == 3 && b[0] == 0x1f && b[1] == 0x8b && b[2] == 0x08;
-  fclose(chk);
-  FILE *fp = gz ? popen((std::string("gunzip -c '") + fn + "'").c_str(), "r") : fopen(fn, "r");
+  std::string text;
+  char buf[1 << 16];
+  int got;
+  while ((got = gzread(gz, buf, sizeof(buf))) > 0) text.append(buf, (size_t)got);
+  const bool broken = got < 0;
+  gzclose(gz);
   int i = 0;
-  if (fp) {
-    while (i < N && fscanf(fp, "%lf", &ages[i]) == 1) i++;
-    if (gz)
-      pclose(fp);
-    else
-      fclose(fp);
+  const char *p = text.c_str();
+  while (i < N) {
+    char *e = nullptr;
+    const double v = strtod(p, &e);
+    if (e == p) break;
+    ages[i++] = v;
+    p = e;
   }
-  if (i < N) ages.clear();
+  if (i < N) {  // (the reference's loop leaves the vector short and the builder then ignores it: no ages)
+    std::cerr << "Warning: " << fn << (broken ? " cannot be decompressed: " : " holds ") << i << " of " << N
+              << " sample ages; building without sample ages" << std::endl;
+    ages.clear();
+  }
   return ages;
 }
 
@@ -791,7 +799,7 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
     return kept * row_bytes + fixed_bytes;
   };
   // (section threads of device builds mostly wait for their tree: as many as there are CUs to build on)
-  int nthreads = gpu_build ? 256 : std::max(1, std::min(host_threads() / 2, 64));
+  int nthreads = gpu_build ? 256 : std::max(1, std::min(host_threads() / 2, 64));  // (host_threads: this rank's share)
   if (const char *e = getenv("RELATE_AMD_SECTION_THREADS")) nthreads = std::max(1, atoi(e));
   nthreads = std::min(nthreads, last_section - first_section + 1);
   int concurrent = nthreads;
@@ -841,8 +849,11 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
     CPU_ZERO(&before);
     const bool pinned = !groups.empty() && sched_getaffinity(0, sizeof(before), &before) == 0;
     if (pinned) {  // slots alternate between the two halves of the list (= the sockets, as the cpus are numbered)
-      const int slot = next_slot.fetch_add(1), G = (int)groups.size(), half = (G + 1) / 2;
-      const int g = ((slot % 2) * half + (slot / 2) % half) % G;
+      // (several ranks on the host, one per GPU: each keeps to its own share of the groups)
+      const int LW = std::min(local_world_size(), (int)groups.size()), lr = local_rank() % LW;
+      const int g0 = (int)groups.size() * lr / LW, G = (int)groups.size() * (lr + 1) / LW - g0;
+      const int slot = next_slot.fetch_add(1), half = (G + 1) / 2;
+      const int g = g0 + ((slot % 2) * half + (slot / 2) % half) % G;
       sched_setaffinity(0, sizeof(cpu_set_t), &groups[g]);
     }
     // (the panel is the context's, immutable for the stage: a copy per section thread would be 0.3 GB each at C3)

@@ -108,6 +108,8 @@ def read_parameters(out_dir):
     """parameters.bin of MakeChunks (data.cpp:365-375): int N, L, num_chunks; double memory; int start[], end[]
     -> dict(N, L, num_chunks, memory_gb, start, end)"""
     buf = open(os.path.join(out_dir, "parameters.bin"), "rb").read()
+    if len(buf) < 20:
+        raise ValueError("%s/parameters.bin is malformed" % out_dir)
     N, L, C = struct.unpack_from("<iii", buf, 0)
     mem, = struct.unpack_from("<d", buf, 12)
     if C < 1 or len(buf) < 20 + 8 * C:
@@ -117,12 +119,14 @@ def read_parameters(out_dir):
     return dict(N=N, L=L, num_chunks=C, memory_gb=mem, start=start, end=end)
 
 
-def run_chunks(out_dir, painting=None, device=None, stages=None, chunks=None):
+def run_chunks(out_dir, painting=None, device=None, stages=None, chunks=None, paint_files=False):
     """The many-chunks route (BASELINE.json config #4; scripts/RelateParallel/RelateParallel.sh:216-262): the chunks of
     a MakeChunks directory are dealt round-robin to the ranks of the job (one process per GPU) and every rank runs
-    its chunks start to end -- Paint, BuildTopology of all sections (on host threads sharing the GPU),
-    FindEquivalentBranches -- with NO data-path collective: chunks share nothing but the input directory.
-    Returns the chunk indices this rank ran.  `chunks`: a subset to run (default: all of parameters.bin)."""
+    its chunks start to end -- Paint + BuildTopology of all sections in ONE stage call with the stepping stones kept
+    in HBM (rl_stage_paint_build_topology; paint_files=True takes the reference's two stages with the paint files in
+    between: 12.8 GB per C4-sized chunk, eight ranks on one filesystem), then FindEquivalentBranches -- with NO
+    data-path collective and no barrier: chunks share nothing but the input directory, a rank is done when its
+    chunks are.  Returns the chunk indices this rank ran.  `chunks`: a subset to run (default: all of parameters.bin)."""
     if stages is None:
         from relate_amd import api as stages
     live = dist.is_available() and dist.is_initialized()
@@ -132,11 +136,13 @@ def run_chunks(out_dir, painting=None, device=None, stages=None, chunks=None):
     todo = list(range(read_parameters(out_dir)["num_chunks"])) if chunks is None else list(chunks)
     mine = shard(todo, rank, world)
     for c in mine:
-        stages.stage_paint(out_dir, c, painting=painting, device=dev)
-        stages.stage_build_topology(out_dir, c, 0, stages.num_sections(out_dir, c) - 1, painting=painting, device=dev)
+        last = stages.num_sections(out_dir, c) - 1
+        if paint_files:
+            stages.stage_paint(out_dir, c, painting=painting, device=dev)
+            stages.stage_build_topology(out_dir, c, 0, last, painting=painting, device=dev)
+        else:
+            stages.stage_paint_build_topology(out_dir, c, 0, last, painting=painting, device=dev)
         stages.stage_find_equivalent_branches(out_dir, c)
-    if live:
-        dist.barrier()  # (the job ends together; nothing is exchanged)
     return mine
 
 
@@ -149,17 +155,25 @@ def main(argv=None):
     ap.add_argument("out_dir")
     ap.add_argument("--painting", default=None, help="theta,rho (Relate's --painting)")
     ap.add_argument("--chunks", default=None, help="comma-separated subset of chunk indices")
+    ap.add_argument("--paint-files", dest="paint_files", action="store_true",
+                    help="Paint and BuildTopology as two stages with the paint files in between (the reference's route)")
     args = ap.parse_args(argv)
     painting = tuple(float(x) for x in args.painting.split(",")) if args.painting else None
     chunks = [int(x) for x in args.chunks.split(",")] if args.chunks else None
     launched = "RANK" in os.environ
     if launched:
+        import datetime
         import torch
-        torch.cuda.set_device(local_device())
-        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
-    mine = run_chunks(args.out_dir, painting=painting, chunks=chunks)
+        on_gpu = torch.cuda.is_available()
+        if on_gpu:
+            torch.cuda.set_device(local_device())
+        # (a rank dealt one chunk fewer waits for the others at the end: a chunk's stages can take longer than the
+        #  backend's default timeout)
+        dist.init_process_group("nccl" if on_gpu else "gloo", timeout=datetime.timedelta(hours=24))
+    mine = run_chunks(args.out_dir, painting=painting, chunks=chunks, paint_files=args.paint_files)
     print("rank %d ran chunks %s" % (dist.get_rank() if launched else 0, mine), flush=True)
     if launched:
+        dist.barrier()  # (the job ends together; nothing is exchanged)
         dist.destroy_process_group()
     return 0
 

@@ -178,12 +178,19 @@ def _chunks_worker(rank, world, port, q, out_dir):
             assert self.calls[-1] == ("paint", c)
             self.calls.append(("build", c, first, last))
 
+        def stage_paint_build_topology(self, out, c, first, last, painting=None, device=0):
+            assert device == dist.get_rank()
+            self.calls.append(("fused", c, first, last))
+
         def stage_find_equivalent_branches(self, out, c):
             self.calls.append(("feb", c))
 
     st = Stages()
-    mine = rdist.run_chunks(out_dir, stages=st)
-    q.put((rank, mine, st.calls))
+    mine = rdist.run_chunks(out_dir, stages=st)  # the default: one fused stage per chunk, no paint files
+    fused_calls = list(st.calls)
+    del st.calls[:]
+    assert rdist.run_chunks(out_dir, stages=st, paint_files=True) == mine
+    q.put((rank, mine, st.calls, fused_calls))
     dist.destroy_process_group()
 
 
@@ -211,8 +218,9 @@ def test_many_chunks_dealt_to_ranks(tmp_path):
         assert p.exitcode == 0
     assert [r[1] for r in res] == [[0, 3, 6], [1, 4], [2, 5]]              # a disjoint cover of the chunks
     assert sorted(sum((r[1] for r in res), [])) == list(range(C))
-    for _, mine, calls in res:
+    for _, mine, calls, fused in res:
         assert calls == sum(([("paint", c), ("build", c, 0, 2 + c), ("feb", c)] for c in mine), [])
+        assert fused == sum(([("fused", c, 0, 2 + c), ("feb", c)] for c in mine), [])
 
 
 def test_dist_command_line_parses():

@@ -46,7 +46,8 @@ def compare_dirs(a, b):
 
 @pytest.mark.ref
 @pytest.mark.skipif(not rlutil.have_ref(), reason="oracle/_ref not built (no /root/reference)")
-@pytest.mark.parametrize("N,L,memory,extra", [(6, 50000, "0.0005", []), (8, 3000, "0.0002", ["--transversion"])])
+@pytest.mark.parametrize("N,L,memory,extra", [(6, 50000, "0.0005", []), (8, 3000, "0.0002", ["--transversion"]),
+                                              (8, 3000, "0.00020001", []), (10, 4000, "0.0003333", [])])
 def test_makechunks_matches_reference(tmp_path, N, L, memory, extra):
     work = str(tmp_path)
     write_synth_haps(work, N, L, seed=N)
@@ -63,7 +64,8 @@ def test_makechunks_matches_reference(tmp_path, N, L, memory, extra):
     assert p.returncode != 0 and b"already exists" in p.stderr
 
 
-@pytest.mark.parametrize("tag,memory,extra", [("a", "0.0005", []), ("b", "0.0002", ["--transversion"])])
+@pytest.mark.parametrize("tag,memory,extra", [("a", "0.0005", []), ("b", "0.0002", ["--transversion"]),
+                                              ("c", "0.00020001", [])])
 def test_makechunks_matches_committed_reference_outputs(tmp_path, tag, memory, extra):
     """runs anywhere: inputs regenerated from the seed (md5-checked), outputs against tests/golden/makechunks.npz --
     the md5 of every file the reference's MakeChunks wrote for them (tools/make_golden.py makechunks), the

@@ -251,7 +251,9 @@ def makechunks_fixture():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from test_makechunks import write_synth_haps
     data = {}
-    for tag, N, L, memory, extra in (("a", 6, 50000, "0.0005", []), ("b", 8, 3000, "0.0002", ["--transversion"])):
+    # (c: an allowance whose window budget, memory * 1e9 / 4 floats, is not a whole number)
+    for tag, N, L, memory, extra in (("a", 6, 50000, "0.0005", []), ("b", 8, 3000, "0.0002", ["--transversion"]),
+                                     ("c", 8, 3000, "0.00020001", [])):
         with tempfile.TemporaryDirectory() as work:
             write_synth_haps(work, N, L, seed=N)
             for fn in ("s.haps", "s.sample", "s.map"):
