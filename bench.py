@@ -85,7 +85,26 @@ def cpu_baseline(N, L, bits, r, rpos, wb, seconds_target=12.0):
     return out
 
 
-def chunk_wallclock_sample(sections=8):
+def chunk_wallclock_full():
+    """The metric's other half MEASURED: the whole C3 chunk -- Paint + BuildTopology of all 267 sections, files in ->
+    .anc / .mut files out -- through `Relate --mode PaintBuildTopology` in a child process (tools/chunk_c3_fused.py).
+    Minutes; before this process touches the GPU."""
+    import subprocess
+    tool = os.path.join(ROOT, "tools", "chunk_c3_fused.py")
+    try:
+        p = subprocess.run([sys.executable, tool, "267"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500,
+                           env=dict(os.environ, C3_NO_TIMING="1"))
+        d = json.loads(p.stdout.decode().strip().split("\n")[-1])
+        return {"workload": "the C3 chunk, synthetic N=5000 x L=500000, %d windows: Relate --mode PaintBuildTopology, "
+                            "Paint + BuildTopology of all %d sections in one process on one GPU, chunk files in, "
+                            ".anc/.mut files out (no paint files)" % (d["windows"], d["sections"]),
+                "measured": True, "wall_s": d["wall_s"], "sections": d["sections"], "trees": d["trees_built"],
+                "trees_per_s": d["trees_per_s"], "anc_GB": d["anc_GB"], "stage_lines": d.get("stage_lines", [])[:4]}
+    except Exception as e:  # never a reason to lose the bench line
+        return {"error": str(e)[:200]}
+
+
+def chunk_wallclock_sample(sections=8, host_builder=False):
     """The other half of BASELINE.json's metric, "chunk wall-clock, N=5000": a bounded sample through the drop-in
     CLI, files in -> files out, in a child process (tools/chunk_wallclock_big.py): the Paint stage of an N=5000 x
     L=20000 chunk and BuildTopology of its first `sections` sections in ONE call, as the reference's scripts hand
@@ -94,8 +113,11 @@ def chunk_wallclock_sample(sections=8):
     import subprocess
     tool = os.path.join(ROOT, "tools", "chunk_wallclock_big.py")
     try:
+        # host_builder: the same sections with the trees built by the host's MinMatch (threaded, pinned to L3 groups)
+        # instead of the device workers -- the CPU figure beside the chunk wall-clock
+        env = dict(os.environ, RELATE_AMD_GPU_BUILD="0") if host_builder else dict(os.environ)
         p = subprocess.run([sys.executable, tool, "5000", "20000", "20", str(sections)], stdout=subprocess.PIPE,
-                           stderr=subprocess.PIPE, timeout=900)
+                           stderr=subprocess.PIPE, timeout=900, env=env)
         d = json.loads(p.stdout.decode().strip().split("\n")[-1])
         return {"workload": "synthetic N=5000 x L=20000 chunk (%d windows) through Relate --mode Paint (whole chunk) "
                             "and --mode BuildTopology (sections 0-%d in one call), chunk files in, paint/.anc/.mut "
@@ -127,6 +149,10 @@ def main():
     ap.add_argument("--skip-k23", dest="skip_k23", action="store_true", help="skip the RePaint / matrix measurement")
     ap.add_argument("--skip-chunk", dest="skip_chunk", action="store_true",
                     help="skip the chunk wall-clock sample through the CLI (N=5000 runs on one GPU only)")
+    ap.add_argument("--skip-full-chunk", dest="skip_full", action="store_true",
+                    help="skip the whole-C3-chunk wall-clock (Paint + all 267 sections, ~3 minutes)")
+    ap.add_argument("--skip-host-builder", dest="skip_host", action="store_true",
+                    help="skip the host-builder run of the chunk sample (the CPU figure beside it, ~2 minutes)")
     ap.add_argument("--workload", default="c3", choices=["c3", "c4"],
                     help="c3 (default; the configuration BASELINE.json's metric is quoted on): one chunk of N=5000 x "
                          "L=500k per GPU.  c4 (BASELINE.json config #4): N=2000 x 5M SNPs cut into ~50 chunks of "
@@ -159,9 +185,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     # the chunk wall-clock sample runs in child processes BEFORE this process touches the GPU: the tree builder's
     # long-running workgroups are time-sliced against every other process that holds hardware queues on the device
-    chunk_sample = None
+    chunk_sample = chunk_full = chunk_host = None
     if world == 1 and args.n == 5000 and args.workload == "c3" and not args.skip_chunk:
         chunk_sample = chunk_wallclock_sample()
+        if not args.skip_host:
+            chunk_host = chunk_wallclock_sample(host_builder=True)
+        if not args.skip_full:
+            chunk_full = chunk_wallclock_full()
     import torch
     dist = None
     if "RANK" in os.environ:  # launched by torch.distributed.run: one rank per GPU, RCCL for the bookkeeping
@@ -360,14 +390,14 @@ def main():
             out["cpu_baseline"] = cpu_baseline(N, L, bits, r, rpos, wb)
         if chunk_sample is not None:
             out["config"]["chunk_wallclock_sample"] = chunk_sample
-            try:  # the whole C3 chunk through the fused stage: a 5-minute run (tools/chunk_c3_fused.py 267), quoted
-                  # from its committed record, NOT measured in this run
-                full = json.load(open(os.path.join(ROOT, "profiles", "r02_c3_fused_all_267_sections.json")))
-                out["config"]["chunk_wallclock_c3_static"] = {
-                    "from": "profiles/r02_c3_fused_all_267_sections.json", "wall_s": full["wall_s"],
-                    "sections": full["sections"], "trees": full["trees_built"], "trees_per_s": full["trees_per_s"]}
-            except Exception:
-                pass
+            if chunk_full is not None:
+                out["config"]["chunk_wallclock_c3"] = chunk_full
+            if chunk_host is not None and "cpu_baseline" in out:
+                # the same 8 sections with the trees built on the host's cores (this library's threaded MinMatch;
+                # the reference binary builds section 0 alone in 1211 s)
+                out["cpu_baseline"]["chunk_wallclock_sample_host_builder"] = {
+                    k: chunk_host.get(k) for k in ("build_topology_s", "sections", "trees", "trees_per_s", "host_threads",
+                                                   "error") if k in chunk_host}
         print(json.dumps(out), flush=True)
     for cx in ctxs:
         cx.close()

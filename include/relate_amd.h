@@ -294,6 +294,11 @@ int rl_stage_set_sample_ages(const char *file);
  * N = 5000) is written or read; the float / run-length quantisation the file
  * would apply (src/collapsed_matrix.hpp:228-296) is applied on the device.  Same
  * .anc / .mut as rl_stage_paint followed by rl_stage_build_topology. */
+/* (between rl_paint and the windows of a context, for chunks whose stones would not leave room for the sections'
+ * windows) moves the painted stepping stones to pinned host memory and frees their HBM; a window opened without a
+ * paint file afterwards takes its slice back.  What the fused stage does under RELATE_AMD_PARK_STONES=1. */
+int rl_park_stones(rl_ctx *ctx);
+
 int rl_stage_paint_build_topology(const char *out_dir, int chunk_index,
                             int first_section, int last_section,
                             int use_painting, double theta, double rho,

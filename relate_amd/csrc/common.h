@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "device_types.h"
@@ -42,6 +43,18 @@ inline hipError_t make_stream(hipStream_t *s, bool tree_builder) {
   return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
 }
 
+// Device and pinned-host memory of the library go through a cache: a released block is kept and handed to the next
+// request of (about) its size instead of going back to the driver.  hipFree / hipHostFree wait until the device
+// is idle -- with the tree builder's resident workers (minmatch_gpu.hip) that is "until no section has a tree in
+// flight", i.e. a window closing in the middle of a stage would stall its thread until all the others stall too.
+// Windows of a stage ask for the same sizes over and over, so the cache also saves ~25 driver calls per window.
+// device_cache_trim() gives everything back (end of a stage; when an allocation fails).
+void *device_cache_alloc(size_t bytes, size_t *got);  // nullptr: out of memory (after a trim)
+void device_cache_release(void *p, size_t bytes);
+void *pinned_cache_alloc(size_t bytes, size_t *got);
+void pinned_cache_release(void *p, size_t bytes);
+void device_cache_trim();
+
 // owning device buffer
 struct DevBuf {
   void *p = nullptr;
@@ -50,8 +63,12 @@ struct DevBuf {
   DevBuf() = default;
   DevBuf(const DevBuf &) = delete;
   DevBuf &operator=(const DevBuf &) = delete;
+  void swap(DevBuf &o) {
+    std::swap(p, o.p);
+    std::swap(bytes, o.bytes);
+  }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p) device_cache_release(p, bytes);
     p = nullptr;
     bytes = 0;
   }
@@ -59,13 +76,13 @@ struct DevBuf {
     if (n <= bytes && p) return RL_OK;
     release();
     if (n == 0) n = 16;
-    hipError_t e = hipMalloc(&p, n);
-    if (e != hipSuccess) {
-      p = nullptr;
-      set_error("hipMalloc(%zu bytes) failed: %s", n, hipGetErrorString(e));
+    size_t got = 0;
+    p = device_cache_alloc(n, &got);
+    if (!p) {
+      set_error("hipMalloc(%zu bytes) failed", n);
       return RL_ENOMEM;
     }
-    bytes = n;
+    bytes = got;
     return RL_OK;
   }
   template <typename T>
@@ -120,11 +137,17 @@ struct rl_ctx {
   float *h_alpha = nullptr, *h_beta = nullptr;
   rl::DevBuf d_k2_scratch;  // RePaint's checkpoint rows and side records of one launch, shared by the context's
                             // windows (window.cpp)
+  // The fused Paint + BuildTopology stage owns the stones and nobody reads them after the windows: a window
+  // quantises ITS slice where it lies (once: stone_quantised[w]) and re-paints from there, instead of keeping a
+  // 2 N^2-float copy per open section.
+  bool stones_disposable = false;
+  std::vector<char> stone_quantised;  // [W], under repaint_mutex
   bool have_chunk = false, plan_on_device = false, painted = false;
   int paint_mode = -1;
   // RePaint launches of the context's windows share the forward strips, the target counter and stream s0: one at a
   // time (the windows' other work -- distance matrices -- runs on their own streams, side by side)
   std::mutex repaint_mutex;
+  long long repaint_launches = 0;  // (under repaint_mutex) RePaint launches of the context's windows
   float ms_fwd = 0.f, ms_bwd = 0.f, ms_paint = 0.f;
   int paint_split = 0;  // rl_set_paint_split: one launch per direction instead of one for both
 };
@@ -141,5 +164,3 @@ size_t decode_stone(const unsigned char *in, size_t avail, int N, float *v, int 
 float fast_log_host(float v);
 }  // namespace rl
 
-// (context.cpp) the stepping stones of a painted chunk to pinned host memory, their device buffers released
-extern "C" int rl_park_stones(rl_ctx *ctx);

@@ -18,6 +18,8 @@
 
 #include <sched.h>
 
+#include <map>
+
 #include "common.h"
 
 namespace rl {
@@ -48,6 +50,81 @@ int local_rank() {
 }
 
 // host threads of this process: RELATE_AMD_THREADS, else this rank's share of the cores the process may run on
+// ---- the memory cache (common.h)
+namespace {
+struct BlockCache {
+  std::mutex m;
+  std::multimap<std::pair<int, size_t>, void *> free_blocks;  // (device, bytes) -> block
+  size_t held = 0;
+};
+BlockCache g_dev_cache, g_pin_cache;
+
+template <typename AllocFn>
+void *cache_alloc(BlockCache &c, size_t bytes, size_t *got, AllocFn raw_alloc) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  {
+    std::lock_guard<std::mutex> lk(c.m);
+    auto it = c.free_blocks.lower_bound({dev, bytes});
+    // (a block up to an eighth larger will do: the rows a window keeps differ a little from window to window)
+    if (it != c.free_blocks.end() && it->first.first == dev && it->first.second <= bytes + bytes / 8 + 4096) {
+      void *p = it->second;
+      *got = it->first.second;
+      c.held -= it->first.second;
+      c.free_blocks.erase(it);
+      return p;
+    }
+  }
+  void *p = raw_alloc(bytes);
+  if (!p) {  // give the cached blocks back and try once more
+    device_cache_trim();
+    p = raw_alloc(bytes);
+  }
+  *got = bytes;
+  return p;
+}
+void cache_release(BlockCache &c, void *p, size_t bytes) {
+  int dev = 0;
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, p) == hipSuccess) dev = attr.device;
+  std::lock_guard<std::mutex> lk(c.m);
+  c.free_blocks.emplace(std::make_pair(dev, bytes), p);
+  c.held += bytes;
+}
+}  // namespace
+
+void *device_cache_alloc(size_t bytes, size_t *got) {
+  return cache_alloc(g_dev_cache, bytes, got, [](size_t n) -> void * {
+    void *p = nullptr;
+    return hipMalloc(&p, n) == hipSuccess ? p : nullptr;
+  });
+}
+void device_cache_release(void *p, size_t bytes) { cache_release(g_dev_cache, p, bytes); }
+void *pinned_cache_alloc(size_t bytes, size_t *got) {
+  return cache_alloc(g_pin_cache, bytes, got, [](size_t n) -> void * {
+    void *p = nullptr;
+    return hipHostMalloc(&p, n, 0) == hipSuccess ? p : nullptr;
+  });
+}
+void pinned_cache_release(void *p, size_t bytes) { cache_release(g_pin_cache, p, bytes); }
+void device_cache_trim() {
+  std::vector<void *> dev_blocks, pin_blocks;
+  {
+    std::lock_guard<std::mutex> lk(g_dev_cache.m);
+    for (auto &b : g_dev_cache.free_blocks) dev_blocks.push_back(b.second);
+    g_dev_cache.free_blocks.clear();
+    g_dev_cache.held = 0;
+  }
+  {
+    std::lock_guard<std::mutex> lk(g_pin_cache.m);
+    for (auto &b : g_pin_cache.free_blocks) pin_blocks.push_back(b.second);
+    g_pin_cache.free_blocks.clear();
+    g_pin_cache.held = 0;
+  }
+  for (void *p : dev_blocks) (void)hipFree(p);
+  for (void *p : pin_blocks) (void)hipHostFree(p);
+}
+
 int host_threads() {
   const char *e = getenv("RELATE_AMD_THREADS");
   int n = 0;
@@ -441,6 +518,7 @@ void rl_destroy(rl_ctx *ctx) {
   if (ctx->h_alpha) (void)hipHostFree(ctx->h_alpha);
   if (ctx->h_beta) (void)hipHostFree(ctx->h_beta);
   delete ctx;
+  rl::device_cache_trim();  // (the context's buffers went to the cache: back to the driver)
 }
 
 // The stones of a painted chunk move to pinned host memory and their device buffers are released (C3: 2 x 26.7 GB,
@@ -570,6 +648,31 @@ int rl_load_chunk(rl_ctx *ctx, const char *dir, int chunk_index) {
   }
   std::vector<int> wb(nw);
   memcpy(wb.data(), pbuf.data() + 12, (size_t)nw * 4);
+  std::vector<double> r, rpos;
+  if ((rc = read_vec(d + "/chunk_" + c + ".r", r))) return rc;
+  if ((rc = read_vec(d + "/chunk_" + c + ".rpos", rpos))) return rc;
+  if ((int)r.size() != L || (int)rpos.size() != L + 1) {
+    set_error(".r/.rpos sizes disagree with L=%d", L);
+    return RL_EFORMAT;
+  }
+  // chunk_<c>.bits: the panel bit-packed, written by this library's MakeChunks next to the reference's files
+  // (makechunks.cpp) -- an eighth of the .hap file, and already in the layout the device works on
+  {
+    FILE *fp = fopen((d + "/chunk_" + c + ".bits").c_str(), "rb");
+    if (fp) {
+      uint32_t head[4] = {0, 0, 0, 0};
+      std::vector<uint32_t> words;
+      bool ok = fread(head, 4, 4, fp) == 4 && head[0] == 0x31424c52u && (int)head[1] == N && (int)head[2] == L &&
+                head[3] >= (uint32_t)((N + 31) / 32) && head[3] <= (uint32_t)((N + 31) / 32) + 64;
+      if (ok) {
+        words.resize((size_t)L * head[3]);
+        ok = fread(words.data(), 4, words.size(), fp) == words.size();
+      }
+      fclose(fp);
+      if (ok) return rl_set_chunk_bits(ctx, N, L, words.data(), (int)head[3], r.data(), rpos.data(), wb.data(), nw - 1);
+      // (a stale or foreign file: the reference's own input decides)
+    }
+  }
   // chunk_<c>.hap: u64 L, u64 N, L*N chars (collapsed_matrix.hpp:204-225)
   std::vector<unsigned char> hap;
   rc = read_all(d + "/chunk_" + c + ".hap", hap);
@@ -584,13 +687,6 @@ int rl_load_chunk(rl_ctx *ctx, const char *dir, int chunk_index) {
   if ((int)hL != L || (int)hN != N || hap.size() < 16 + (size_t)L * N) {
     set_error(".hap dimensions (%llu x %llu) disagree with parameters (%d x %d)",
               (unsigned long long)hL, (unsigned long long)hN, L, N);
-    return RL_EFORMAT;
-  }
-  std::vector<double> r, rpos;
-  if ((rc = read_vec(d + "/chunk_" + c + ".r", r))) return rc;
-  if ((rc = read_vec(d + "/chunk_" + c + ".rpos", rpos))) return rc;
-  if ((int)r.size() != L || (int)rpos.size() != L + 1) {
-    set_error(".r/.rpos sizes disagree with L=%d", L);
     return RL_EFORMAT;
   }
   return rl_set_chunk(ctx, N, L, hap.data() + 16, r.data(), rpos.data(), wb.data(), nw - 1);

@@ -293,34 +293,69 @@ extern "C" int rl_make_chunks(const char *haps_fn, const char *sample_fn, const 
       set_error("Failed to open file %s", haps_fn);
       return RL_EIO;
     }
+    // Next to chunk_<i>.hap (one char per allele: 2.5 GB at N = 5000 x L = 500k) the same panel BIT-PACKED,
+    // chunk_<i>.bits -- what the device path works on (rl_set_chunk_bits: bit n of row s = haplotype n derived at
+    // SNP s): rl_load_chunk prefers it and never touches the 8 x larger char file.  Header: "RLB1", N, L,
+    // row_words (u32 each); then L rows of row_words u32.  RELATE_AMD_CHUNK_BITS=0: the reference's files only.
+    const bool with_bits = !(getenv("RELATE_AMD_CHUNK_BITS") && atoi(getenv("RELATE_AMD_CHUNK_BITS")) == 0);
+    const uint32_t rw = (uint32_t)((N + 31) / 32);
+    auto pack_row = [&](const char *chars, uint32_t *words) {
+      for (uint32_t w = 0; w < rw; w++) words[w] = 0u;
+      for (int n = 0; n < N; n++) words[n >> 5] |= (uint32_t)(chars[n] == '1') << (n & 31);
+    };
     std::vector<char> ring(num_chunks > 1 ? (size_t)overlap * N : 0), row(N);
-    FILE *fh = nullptr;
+    std::vector<uint32_t> words(rw);
+    FILE *fh = nullptr, *fb = nullptr;
     int ci = -1;
     int rc = RL_OK;
     for (int s = 0; s < L && rc == RL_OK; s++) {
       if (ci + 1 < num_chunks && s == plan[ci + 1].begin) {
         if (fh) fclose(fh);
+        if (fb) fclose(fb);
+        fb = nullptr;
         ci++;
         fh = fopen((file_out + "/chunk_" + std::to_string(ci) + ".hap").c_str(), "wb");
-        if (!fh) {
+        if (with_bits) fb = fopen((file_out + "/chunk_" + std::to_string(ci) + ".bits").c_str(), "wb");
+        if (!fh || (with_bits && !fb)) {
           set_error("cannot write chunk files under %s", out_dir);
           rc = RL_EIO;
           break;
         }
         const uint64_t dims[2] = {(uint64_t)(plan[ci].end - plan[ci].first_snp), (uint64_t)N};
         fwrite(dims, 8, 2, fh);
-        for (int t = plan[ci].first_snp; t < s; t++) fwrite(&ring[(size_t)(t % overlap) * N], 1, (size_t)N, fh);
+        if (fb) {
+          const uint32_t head[4] = {0x31424c52u /* "RLB1" */, (uint32_t)N, (uint32_t)dims[0], rw};
+          fwrite(head, 4, 4, fb);
+        }
+        for (int t = plan[ci].first_snp; t < s; t++) {
+          const char *kept = &ring[(size_t)(t % overlap) * N];
+          fwrite(kept, 1, (size_t)N, fh);
+          if (fb) {
+            pack_row(kept, words.data());
+            fwrite(words.data(), 4, rw, fb);
+          }
+        }
       }
       if (read_snp(haps.fp, s, row.data(), false) < 0) {
         rc = RL_EFORMAT;
         break;
       }
       fwrite(row.data(), 1, (size_t)N, fh);
+      if (fb) {
+        pack_row(row.data(), words.data());
+        fwrite(words.data(), 4, rw, fb);
+      }
       if (!ring.empty()) memcpy(&ring[(size_t)(s % overlap) * N], row.data(), (size_t)N);
     }
-    if (fh) fclose(fh);
+    bool bad = false;
+    if (fh) bad |= ferror(fh) != 0 || fclose(fh) != 0;
+    if (fb) bad |= ferror(fb) != 0 || fclose(fb) != 0;
     haps.close();
     if (rc) return rc;
+    if (bad) {
+      set_error("writing the chunk files under %s failed", out_dir);
+      return RL_EIO;
+    }
   }
 
   std::cerr << std::setprecision(2) << "Paint files will take at least "

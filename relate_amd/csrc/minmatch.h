@@ -214,6 +214,8 @@ class DeviceMinMatch {
   DeviceMinMatch(const DeviceMinMatch &) = delete;
   DeviceMinMatch &operator=(const DeviceMinMatch &) = delete;
   int build(MinMatch &tb, const float *d, const float *prior, HostTree &tree);
+  // the buffers a build keeps for itself (the woven matrix, 16 N^2 B, and small ones), allocated now: 0 or < 0
+  int reserve();
   // The same without the matrices crossing PCIe: the caller has the distance matrix written into
   // device_matrix() (K3, rl_window_matrix_rows_device), the carrier penalty and the clade prior of the previous
   // tree are applied on the device (anc_builder.cpp:563-606), build_resident builds from what is there.
@@ -227,5 +229,12 @@ class DeviceMinMatch {
   struct Impl;
   Impl *impl;
 };
+
+// HBM of the pools the device builders of one GPU share (row-major staging matrices, symmetric matrices of the
+// fallback), and the pools allocated now rather than at the first tree (the stage's admission counts on them)
+double device_builder_shared_bytes(int N);
+int device_builder_reserve_shared(int device, int N);
+// how many builders of trees of N leaves will ask the device's workers at the same time (0: unknown)
+int device_builder_expect(int device, int N, int builders);
 
 }  // namespace rl

@@ -22,6 +22,7 @@
 #include <cmath>
 #include <condition_variable>
 #include <cstdint>
+#include <cstring>
 #include <memory>
 #include <mutex>
 #include <random>
@@ -53,43 +54,79 @@ __host__ __device__ inline unsigned mm_index(unsigned a, unsigned b, unsigned N)
 __host__ __device__ inline size_t mm_elements(size_t N) { return ((N + MM_PANEL - 1) / MM_PANEL) * N * MM_PANEL; }
 constexpr int MM_MAXN = 10240;    // one thread holds up to 20 clusters of a merge in registers
 
+// A tree's parameters.  The matrices of a build, woven: M[a][b] = (d(a,b), d(b,a), cf(a,b), cf(b,a)).  A merge needs,
+// per cluster k, the entries (i,k), (k,i), (j,k), (k,j) of both matrices: two 16-byte loads along the rows of i and j
+// instead of four loads along rows and four down columns (a scattered 4-byte access costs one CU ~3.5 cycles:
+// measured 3.7 us per column of 2500 clusters, six of them per merge in the plain layout); what stays scattered is
+// ONE 16-byte store per cluster, M[k][j], which waits for nobody.  Packed from the distance matrix (K3 + carrier
+// penalty) and the clade prior by pack_kernel; row minima of both by rowmin_kernel.
+//
+// One field list, two structs of the same layout: MMParams (plain pointers: what the host fills in) and MMParamsDev
+// (GLOBAL pointers: what the build kernel works with).  A worker reads its parameters from a queue, not from
+// kernel arguments, and a pointer of unknown address space compiles to flat_load / flat_store, which count against
+// the LDS counter too and turn every wait for an LDS read into a wait for the loads in flight -- the phases of a
+// merge overlap exactly these two.
+#define MM_PARAM_FIELDS(PTR)                                                                                         \
+  int N;                                                                                                             \
+  int lds_state; /* the per-cluster state lives in LDS for the build (it fits: N <= ~5200) */                        \
+  float threshold, threshold_CF;                                                                                     \
+  PTR(MM_F4) M; /* [N*N] destroyed */                                                                                \
+  int has_prior; /* the cf halves of M are in use */                                                                 \
+  int debug;     /* experiments (RELATE_AMD_MM_DEBUG): 1 = never the one-pass form of B */                           \
+  PTR(const float) rowmin_D; /* [N] minimum of each row off the diagonal */                                          \
+  PTR(const float) rowmin_CF;                                                                                        \
+  /* the mutually close pairs (a, b > a) of the untouched matrix, row by row in order, from pairscan_kernel */       \
+  PTR(const int) hit_cnt;    /* [N] (more than MM_HITS: not all kept) */                                             \
+  PTR(const unsigned) hit_b; /* [N][MM_HITS] */                                                                      \
+  PTR(const float) hit_sym;  /* [N][MM_HITS] symmetric distance of the pair (0: the prior makes it a certain pair) */ \
+  /* room for the symmetric matrix of the fallback (rare): a pool of the device, `sym_slots` matrices of N*N floats \
+     at SYM, taken with a compare-and-swap on sym_locks[slot] when a tree first needs one and given back when it    \
+     is out; none free (or no pool): the tree is the host's */                                                       \
+  PTR(float) SYM;                                                                                                    \
+  PTR(int) sym_locks;                                                                                                \
+  int sym_slots;                                                                                                     \
+  PTR(float) min_values_sym;                                                                                         \
+  PTR(float) mcs_dist;                                                                                               \
+  PTR(int) mcs_lin1;                                                                                                 \
+  PTR(int) mcs_lin2;                                                                                                 \
+  PTR(float) min_values; /* min_values_CF, mc_lin1, mc_lin2: carried from tree to tree (in and out) */               \
+  PTR(float) min_values_CF;                                                                                          \
+  PTR(float) mc_dist;                                                                                                \
+  PTR(float) mc_dist2;                                                                                               \
+  PTR(int) mc_lin1;                                                                                                  \
+  PTR(int) mc_lin2;                                                                                                  \
+  PTR(int) cluster_index;                                                                                            \
+  PTR(int) cluster_size;                                                                                             \
+  PTR(unsigned char) kflag;                                                                                          \
+  PTR(int) upd_pos;     /* [N] scratch of the symmetric path */                                                      \
+  PTR(unsigned) pair_g; /* [6 * pair_cap] feasible pairs of a merge beyond MM_PAIRS_LDS: key, x<<16|y, sym */        \
+  PTR(int) rowlist;     /* [MM_WAVES][N] pair-scan survivors per wave */                                             \
+  PTR(int) merge_i;     /* [N-1] the merges as (cluster i, cluster j) in order: the host names the nodes from them */ \
+  PTR(int) merge_j;                                                                                                  \
+  PTR(int) status;                                                                                                   \
+  /* (pinned host memory) the status again, stored when everything else of the tree is out and flushed: the         \
+     builder's host thread watches it and takes its tree while the other workers still build theirs */              \
+  PTR(volatile int) host_done;                                                                                       \
+  long long pair_cap;                                                                                                \
+  PTR(long long) timers; /* optional: 100 MHz ticks per phase (RELATE_AMD_TIMING) */                                 \
+  PTR(unsigned) trace;   /* optional (RELATE_AMD_MM_TRACE): [0] merge, [1] phase the workgroup has reached */
+#define MM_HOST_PTR(T) T *
+#define MM_GLOBAL_PTR(T) __attribute__((address_space(1))) T *
+// (a class type -- HIP's float4 -- has no member functions outside the generic address space: the device struct
+//  takes the elements of M as native vectors)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define MM_F4 float4
 struct MMParams {
-  int N;
-  int lds_state;  // the per-cluster state lives in LDS for the build (it fits: N <= ~5200)
-  float threshold, threshold_CF;
-  // The matrices of a build, woven: M[a][b] = (d(a,b), d(b,a), cf(a,b), cf(b,a)).  A merge needs, per cluster k,
-  // the entries (i,k), (k,i), (j,k), (k,j) of both matrices: two 16-byte loads along the rows of i and j instead of
-  // four loads along rows and four down columns (a scattered 4-byte access costs one CU ~3.5 cycles: measured
-  // 3.7 us per column of 2500 clusters, six of them per merge in the plain layout); what stays scattered is ONE
-  // 16-byte store per cluster, M[k][j], which waits for nobody.  Packed from the distance matrix (K3 + carrier
-  // penalty) and the clade prior by pack_kernel; row minima of both by rowmin_kernel.
-  float4 *M;          // [N*N] destroyed
-  int has_prior;      // the cf halves of M are in use
-  int debug;          // experiments (RELATE_AMD_MM_DEBUG): 1 = never the one-pass form of B
-  const float *rowmin_D, *rowmin_CF;  // [N] minimum of each row off the diagonal
-  // the mutually close pairs (a, b > a) of the untouched matrix, row by row in order, from pairscan_kernel
-  const int *hit_cnt;        // [N] (more than MM_HITS: not all kept)
-  const unsigned *hit_b;     // [N][MM_HITS]
-  const float *hit_sym;      // [N][MM_HITS] symmetric distance of the pair (0 if the prior makes it a certain pair)
-  float *SYM;  // [N*N] room for the symmetric matrix
-  float *min_values_sym, *mcs_dist;
-  int *mcs_lin1, *mcs_lin2;
-  float *min_values, *min_values_CF;  // min_values_CF, mc_lin1, mc_lin2: carried from tree to tree (in and out)
-  float *mc_dist, *mc_dist2;
-  int *mc_lin1, *mc_lin2;
-  int *cluster_index, *cluster_size;
-  unsigned char *kflag;
-  int *upd_pos;         // [N] scratch of the symmetric path
-  unsigned *pair_g;     // [6 * pair_cap] feasible pairs of a merge beyond MM_PAIRS_LDS: key, x<<16|y, sym; unsorted, sorted
-  int *rowlist;         // [MM_WAVES][N] pair-scan survivors per wave
-  int *merge_i, *merge_j;  // [N-1] the merges as (cluster i, cluster j) in order; the host names the tree's nodes from them
-  int *status;
-  // (pinned host memory, or null) the status again, stored when everything else of the tree is out and flushed: the
-  // builder's host thread watches it and takes its tree while the launch's other workgroups still build theirs
-  volatile int *host_done;
-  long long pair_cap;
-  long long *timers;  // optional: 100 MHz ticks per phase (RELATE_AMD_TIMING)
+  MM_PARAM_FIELDS(MM_HOST_PTR)
 };
+#undef MM_F4
+#define MM_F4 f32x4
+struct MMParamsDev {
+  MM_PARAM_FIELDS(MM_GLOBAL_PTR)
+};
+#undef MM_F4
+static_assert(sizeof(MMParams) == sizeof(MMParamsDev), "one layout");
 
 struct Rng {  // std::mt19937
   uint32_t mt[624];
@@ -158,7 +195,11 @@ struct Best {
   int lin1, lin2;
 };
 
+constexpr int MM_PARAM_WORDS = 80;  // sizeof(MMParams) / 4 rounded up (static_assert below)
 struct Shared {
+  unsigned praw[MM_PARAM_WORDS];  // the tree's parameters as the worker read them from the queue
+  unsigned ticket;
+  int sym_slot;
   long long tacc[12], tmark;
   Rng rng;
   Best best, best_sym;
@@ -190,11 +231,13 @@ struct Shared {
 template <bool LDS>
 struct State {
   typedef typename std::conditional<LDS, short, int>::type idx_t;
-  float *mv, *mvcf, *mcd, *mcd2;   // min_values, min_values_CF, candidate (dist, dist2)
-  idx_t *lin1, *lin2;              // candidate pair (stale indices are part of the carried state)
-  idx_t *ci;                       // the live clusters in order
-  idx_t *csz;                      // cluster sizes (floats in the reference: exact integers)
-  unsigned char *flag;             // rebuilt in this merge
+  template <typename T>
+  using ptr = typename std::conditional<LDS, T *, __attribute__((address_space(1))) T *>::type;  // (LDS: inferred)
+  ptr<float> mv, mvcf, mcd, mcd2;  // min_values, min_values_CF, candidate (dist, dist2)
+  ptr<idx_t> lin1, lin2;           // candidate pair (stale indices are part of the carried state)
+  ptr<idx_t> ci;                   // the live clusters in order
+  ptr<idx_t> csz;                  // cluster sizes (floats in the reference: exact integers)
+  ptr<unsigned char> flag;         // rebuilt in this merge
 };
 
 // Wave reductions on the DPP crossbar (quad swaps, half-row and row mirrors, the two row broadcasts: the total
@@ -307,8 +350,8 @@ __device__ inline void block_min3(float &f, int &a, int &b, float *bf, int *ba, 
 
 // (32-bit element offsets from a scalar base -- N <= 10240: one address register per load instead of two)
 #define MM(a, b) p.M[mm_index((unsigned)(a), (unsigned)(b), (unsigned)N)]
-#define MM2(a, b) (reinterpret_cast<const float2 *>(p.M + mm_index((unsigned)(a), (unsigned)(b), (unsigned)N))[0])  // (d(a,b), d(b,a))
-#define SS(a, b) p.SYM[(unsigned)(a) * (unsigned)N + (unsigned)(b)]
+#define MM2(a, b) (((MM_GLOBAL_PTR(const f32x2))(p.M + mm_index((unsigned)(a), (unsigned)(b), (unsigned)N)))[0])  // (d(a,b), d(b,a))
+#define SS(a, b) symm[(unsigned)(a) * (unsigned)N + (unsigned)(b)]
 
 // One workgroup per tree: workgroup b builds the tree of params[b].
 //
@@ -332,13 +375,9 @@ __device__ inline void block_min3(float &f, int &a, int &b, float *bf, int *ba, 
 //   E. the merged-away cluster leaves the list.
 // Three dependent memory round trips and eight workgroup barriers per merge; everything else is LDS.
 template <bool LDS, int MAXQ>
-__global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *__restrict__ params) {
+__device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, unsigned char *dyn) {
   typedef typename State<LDS>::idx_t idx_t;
   constexpr int ROWS = MAXQ > 10 ? 2 : MM_ROWS;  // rows of rebuilt clusters per pass (ROWS * MAXQ <= 64 bits of survivors)
-  const MMParams p = params[blockIdx.x];
-  if ((p.lds_state != 0) != LDS) return;  // (the launch carries trees of one kind)
-  __shared__ Shared sh;
-  extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
   const int N = p.N;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float INF = INFINITY;
@@ -378,7 +417,28 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
     const long long tn = wall_clock64(); \
     sh.tacc[x] += tn - sh.tmark;         \
     sh.tmark = tn;                       \
+  }                                      \
+  if (p.trace && tid == 0) {             \
+    p.trace[0] = (unsigned)sh.n;         \
+    p.trace[1] = (unsigned)(x);          \
   }
+
+  // The tree leaves the workgroup -- built (0) or handed to the host (1: no room for the symmetric matrix, 2: more
+  // tied candidates than the lists hold): thread 0, at a point all threads have reached.  The symmetric matrix goes
+  // back to the pool; status, the tree and the carried state reach memory BEFORE the host hears of them in pinned
+  // memory -- the builder's host thread takes its tree while the other workgroups still build theirs, no
+  // end-of-kernel write-back in between.
+  auto leave = [&](int code) {
+    if (tid == 0) {
+      *p.status = code;
+      __threadfence_system();
+      if (sh.sym_slot >= 0) __hip_atomic_store(&p.sym_locks[sh.sym_slot], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      *p.host_done = code;
+      __threadfence_system();
+    }
+  };
+  MM_GLOBAL_PTR(float) symm = nullptr;  // the symmetric matrix of the fallback, once one is taken from the pool
+  if (tid == 0) sh.sym_slot = -1;
 
   // ---- QuickBuild set-up (:1061-1100)
   for (int c = tid; c < N; c += MM_BLOCK) {
@@ -494,7 +554,7 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
         const float mva = st.mv[ar];
         for (int b0 = ar + 1; b0 < N; b0 += MM_BLOCK) {
           const int b = b0 + tid;
-          float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+          f32x4 e = {0.f, 0.f, 0.f, 0.f};
           bool hit = false;
           if (b < N) {
             e = MM(ar, b);
@@ -538,19 +598,34 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
   LAP(1);
 
   // ---- the merges
+  // A tree the lists cannot hold is handed to the host (bail >= 0: the code).  ONE way out of the function, through
+  // wave-uniform branches the compiler can see are uniform (readfirstlane): the workgroup goes on to its next tree
+  // behind this call, and an exit the compiler takes for divergent -- it hangs on values read from LDS -- is laid
+  // out as a loop in which a wave passes the caller's barriers once per group of lanes.
+  int bail = -1;
   for (int num_nodes = N; num_nodes < 2 * N - 1; num_nodes++) {
     const int n = sh.n;
     if (sh.best.dist == INF && !sh.use_sym) {
       // no mutually closest pair: from here on the symmetric matrix picks the pair when there is none
       // (initialize_sym, tree_builder.cpp:255-293): s(a,l) = d(a,l) + d(l,a) over the live clusters, row minima
       // with the first cluster that reaches them, the smallest of those (first row, first cluster)
-      if (!p.SYM) {  // (the caller gave no room for it)
-        if (tid == 0) {
-          *p.status = 1;
-          if (p.host_done) *p.host_done = 1;
+      if (tid == 0) {  // a matrix of the device's pool
+        int got = -1;
+        for (int sl = 0; sl < p.sym_slots && got < 0; sl++) {
+          int expected = 0;
+          if (__hip_atomic_compare_exchange_strong(&p.sym_locks[sl], &expected, 1, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT))
+            got = sl;
         }
-        return;
+        sh.sym_slot = got;
       }
+      __syncthreads();
+      const int slot = __builtin_amdgcn_readfirstlane(sh.sym_slot);
+      if (slot < 0) {  // (none free, or no pool)
+        bail = 1;
+        break;
+      }
+      symm = p.SYM + (size_t)slot * N * N;
       float bs = INF;
       int bs_pos = n;
       for (int ia = wave; ia < n; ia += MM_WAVES) {
@@ -560,7 +635,7 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
         for (int il = lane; il < n; il += 64) {
           const int l = st.ci[il];
           if (l == a) continue;
-          const float2 e = MM2(a, l);
+          const f32x2 e = MM2(a, l);
           const float v = e.x + e.y;
           SS(a, l) = v;
           if (v < mv) {  // (ascending per lane: the first one stays)
@@ -616,6 +691,9 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
       const float q = (float)((double)a * rc_added);
       return fabsf(q) >= 1e-30f || a == 0.0f ? q : a / added;
     };
+    // (the live list shrinks from N to 2: the register slots past it are skipped by wave-uniform branches, not by
+    //  predication -- half of all slots over a build)
+    const int nq = (n + MM_BLOCK - 1) / MM_BLOCK;
     int a_k[MAXQ];
     float mv_cf = INF, mvj = INF, bd = INF, bd2 = INF;
     int bpos = n;
@@ -623,14 +701,13 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
     for (int q = 0; q < MAXQ; q++) {
       const int ik = q * MM_BLOCK + tid;
       a_k[q] = ik < n ? (int)st.ci[ik] : -1;
-
     }
     constexpr int QC = 5;  // clusters per pass (ten at once cost more in spilled registers than the second round trip)
 #pragma unroll
     for (int q0 = 0; q0 < MAXQ; q0 += QC) {
       if (q0 * MM_BLOCK >= n) break;
       // every load of the pass first: the two rows from memory, then -- under their latency -- the clusters' state
-      float4 ei[QC], ej[QC];
+      f32x4 ei[QC], ej[QC];
 #pragma unroll
       for (int qq = 0; qq < QC; qq++) {
         const int k = a_k[q0 + qq];
@@ -673,8 +750,8 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
         if (dik != djk) njk = over_added(csi * dik + csj * djk);
         if (dki != dkj) nkj = over_added(csi * dki + csj * dkj);
         // (written whether changed or not: the same bits where the reference leaves the entry alone)
-        MM(j, k) = make_float4(njk, nkj, ncjk, nckj);
-        if (!(p.debug & 2)) MM(k, j) = make_float4(nkj, njk, nckj, ncjk);  // (2: timing experiment, wrong trees)
+        MM(j, k) = f32x4{njk, nkj, ncjk, nckj};
+        if (!(p.debug & 2)) MM(k, j) = f32x4{nkj, njk, nckj, ncjk};  // (2: timing experiment, wrong trees)
         if (njk < mvj) mvj = njk;
         bool rescan = false;
         if (dkj != dki) {
@@ -722,13 +799,10 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
     }
     min_value_j += threshold;
     mvcf_j += threshold_CF;
-    const int nupd = sh.nupd;
+    const int nupd = __builtin_amdgcn_readfirstlane(sh.nupd);
     if (nupd > MM_UPD_MAX) {  // (degenerate matrices: this tree is the host's)
-      if (tid == 0) {
-        *p.status = 2;
-        if (p.host_done) *p.host_done = 2;
-      }
-      return;
+      bail = 2;
+      break;
     }
 
     // -- B: rows of the rebuilt clusters: (d(k,l), d(l,k)) along row k of M, ROWS rows per pass.  The row-minimum
@@ -736,11 +810,12 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
     // any smaller entry, else the row's minimum", three reductions finished by one wave per row --, then the
     // candidate tests of every pair a rebuilt cluster is part of (:1893-1911 for the clusters before it, :1913-2018
     // for the ones behind it), on the same registers when the merge has no more than ROWS rebuilt clusters.
-    float2 cj[MAXQ];  // row j of M as this thread wrote it in A, (d(j,k), d(k,j)): asked for now, used in C
+    f32x2 cj[MAXQ];  // row j of M as this thread wrote it in A, (d(j,k), d(k,j)): asked for now, used in C
 #pragma unroll
     for (int q = 0; q < MAXQ; q++) {
+      if (q >= nq) break;
       const int k = a_k[q];
-      cj[q] = (k >= 0 && k != i && k != j) ? MM2(j, k) : make_float2(INF, INF);
+      cj[q] = (k >= 0 && k != i && k != j) ? MM2(j, k) : f32x2{INF, INF};
     }
     float v[ROWS][MAXQ], w[ROWS][MAXQ];
     auto load_rows = [&](const int (&ks)[ROWS]) {
@@ -749,7 +824,8 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
         if (ks[r] < 0) continue;
 #pragma unroll
         for (int q = 0; q < MAXQ; q++) {
-          const float2 e = a_k[q] >= 0 ? MM2(ks[r], a_k[q]) : make_float2(INF, INF);
+          if (q >= nq) break;
+          const f32x2 e = a_k[q] >= 0 ? MM2(ks[r], a_k[q]) : f32x2{INF, INF};
           v[r][q] = e.x;
           w[r][q] = e.y;
         }
@@ -766,6 +842,7 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
         int pos_old = n, pos_less = n;
 #pragma unroll
         for (int q = 0; q < MAXQ; q++) {
+          if (q >= nq) break;
           const int l = a_k[q];
           if (l < 0 || l == i || l == k) continue;
           const float x = l == j ? patch[r] : v[r][q];
@@ -809,7 +886,7 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
         sh.pk[0][slot] = key;
         sh.pxy[0][slot] = ((unsigned)x << 16) | (unsigned)y;
       } else if (slot - MM_PAIRS_LDS < p.pair_cap) {
-        unsigned *g = p.pair_g + (size_t)(slot - MM_PAIRS_LDS) * 3;
+        auto g = p.pair_g + (size_t)(slot - MM_PAIRS_LDS) * 3;
         g[0] = key;
         g[1] = ((unsigned)x << 16) | (unsigned)y;
       }
@@ -825,6 +902,7 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
         const float mvk = st.mv[ku];
 #pragma unroll
         for (int q = 0; q < MAXQ; q++) {
+          if (q >= nq) break;
           const int l = a_k[q];
           bool ok = l >= 0 && l != i && l != j && l != ku && v[r][q] <= mvk;
           if (ok) {
@@ -904,6 +982,7 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
       unsigned cand = 0;
 #pragma unroll
       for (int q = 0; q < MAXQ; q++) {
+        if (q >= nq) break;
         const int k = a_k[q];
         const bool ok = k >= 0 && k != i && k != j && cj[q].x <= min_value_j && cj[q].y <= st.mv[k];
         cand |= ok ? 1u << q : 0u;
@@ -918,13 +997,10 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
     __syncthreads();
     LAP(4);
     // -- D: the pairs in the reference's order
-    const int m = sh.npairs;
+    const int m = __builtin_amdgcn_readfirstlane(sh.npairs);
     if (m - MM_PAIRS_LDS > p.pair_cap) {
-      if (tid == 0) {
-        *p.status = 2;
-        if (p.host_done) *p.host_done = 2;
-      }
-      return;
+      bail = 2;
+      break;
     }
     auto pair_at = [&](int side, int e, unsigned &key, unsigned &xy, float &sym) {
       if (e < MM_PAIRS_LDS) {
@@ -932,7 +1008,7 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
         xy = sh.pxy[side][e];
         sym = sh.psym[side][e];
       } else {
-        const unsigned *g = p.pair_g + ((size_t)side * p.pair_cap + (size_t)(e - MM_PAIRS_LDS)) * 3;
+        auto g = p.pair_g + ((size_t)side * p.pair_cap + (size_t)(e - MM_PAIRS_LDS)) * 3;
         key = g[0];
         xy = g[1];
         sym = __uint_as_float(g[2]);
@@ -948,7 +1024,7 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
         float sym;
         pair_at(0, e, key, xy, sym);
         const int x = (int)(xy >> 16), y = (int)(xy & 0xffffu);
-        const float4 f = MM(x, y);  // (d(x,y), d(y,x), cf(x,y), cf(y,x))
+        const f32x4 f = MM(x, y);  // (d(x,y), d(y,x), cf(x,y), cf(y,x))
         int rank = 0;
         const int ml = min(m, MM_PAIRS_LDS);
         for (int g = 0; g < ml; g++) rank += sh.pk[0][g] < key ? 1 : 0;
@@ -960,7 +1036,7 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
           sh.pxy[1][rank] = xy;
           sh.psym[1][rank] = sym;
         } else {
-          unsigned *g = p.pair_g + ((size_t)p.pair_cap + (size_t)(rank - MM_PAIRS_LDS)) * 3;
+          auto g = p.pair_g + ((size_t)p.pair_cap + (size_t)(rank - MM_PAIRS_LDS)) * 3;
           g[0] = key;
           g[1] = xy;
           g[2] = __float_as_uint(sym);
@@ -979,6 +1055,8 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
       const int ipos = sh.ipos;
 #pragma unroll
       for (int q = 0; q < MAXQ; q++) {
+        nxt[q] = -1;
+        if (q >= nq) continue;
         const int ik = q * MM_BLOCK + tid;
         nxt[q] = (ik >= ipos && ik + 1 < n) ? (int)st.ci[ik + 1] : -1;
       }
@@ -1120,7 +1198,7 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
       for (int r = 0; r < nres_s; r++) {
         const int k = st.ci[p.upd_pos[r]];
         const float old = p.min_values_sym[k];
-        const float *row = p.SYM + (size_t)k * N;
+        auto row = symm + (size_t)k * N;
         float fm = INF, fm2 = 0.0f;
         int fpos = n, pos_old = n, pos_less = n;
         for (int il = tid; il < n; il += MM_BLOCK) {
@@ -1153,7 +1231,7 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
       __syncthreads();
       float b1 = INF, b2 = 0.0f, mj = INF, mj2 = 0.0f;
       int bp = n, mjp = n;
-      const float *srowj = p.SYM + (size_t)j * N;
+      auto srowj = symm + (size_t)j * N;
       for (int ik = tid; ik < n; ik += MM_BLOCK) {
         const int k = st.ci[ik];
         if (k == j || k == i) continue;
@@ -1203,27 +1281,135 @@ __global__ void __launch_bounds__(MM_BLOCK, 1) minmatch_kernel(const MMParams *_
     __syncthreads();
     LAP(8);
   }
-  if constexpr (LDS) {  // the carried state goes out
-    for (int c = tid; c < N; c += MM_BLOCK) {
-      p.mc_lin1[c] = (int)st.lin1[c];
-      p.mc_lin2[c] = (int)st.lin2[c];
-      p.min_values_CF[c] = st.mvcf[c];
+  if (bail < 0) {
+    if constexpr (LDS) {  // the carried state goes out
+      for (int c = tid; c < N; c += MM_BLOCK) {
+        p.mc_lin1[c] = (int)st.lin1[c];
+        p.mc_lin2[c] = (int)st.lin2[c];
+        p.min_values_CF[c] = st.mvcf[c];
+      }
     }
-  }
-  if (tid == 0) {
-    *p.status = 0;
-    if (p.timers) {
+    if (tid == 0 && p.timers) {
       sh.tacc[11] = (clock64() - cstart) * 100 / (wall_clock64() - tstart + 1);  // shader clock, MHz
       for (int x = 0; x < 12; x++) p.timers[x] = sh.tacc[x];
     }
+    bail = 0;
   }
-  if (p.host_done) {  // the tree, the carried state and the status reach memory before the host hears of them
-    __threadfence_system();
-    __syncthreads();
+  __threadfence_system();  // every wave's part of the tree and of the carried state
+  __syncthreads();
+  leave(bail);
+#undef LAP
+}
+
+// A tree's parameters as a worker reads them from the queue: one 32-bit word per thread, uncached; from LDS every
+// word goes through readfirstlane, so the builder keeps them in scalar registers as it did when they were kernel
+// arguments.
+__device__ inline void params_from_words(MMParamsDev &p, const unsigned *w) {
+  unsigned *out = reinterpret_cast<unsigned *>(&p);
+#pragma unroll
+  for (int x = 0; x < (int)(sizeof(MMParams) / 4); x++) out[x] = __builtin_amdgcn_readfirstlane(w[x]);
+}
+
+// The builders' requests of one device and tree size, in pinned host memory: the host writes a request's words, then
+// `tail`; workers claim tickets from `head` (device memory) and read the words of their ticket.
+constexpr int MM_QUEUE_CAP = 1024;  // requests in flight <= builders alive (a section has one tree in flight)
+constexpr int MM_LAUNCHES = 4;      // worker launches alive at once (a stream, i.e. a hardware queue, each)
+struct WorkQueue {
+  unsigned tail;
+  unsigned pad[15];
+  unsigned words[MM_QUEUE_CAP][MM_PARAM_WORDS];
+};
+// device memory: the ticket counter, and per launch how many of its workers are building and when one last was
+struct WorkerState {
+  unsigned head;
+  unsigned pad[15];
+  struct {
+    int busy;           // workers of the launch that are building
+    unsigned activity;  // counts its claims and finished trees
+    long long pad2[7];
+  } launch[MM_LAUNCHES];
+};
+static_assert(sizeof(MMParams) % 4 == 0 && sizeof(MMParams) / 4 <= MM_PARAM_WORDS, "MM_PARAM_WORDS");
+
+// One workgroup = one WORKER: it takes the next tree of the queue, builds it, says so in the request's own word of
+// pinned memory and takes the next -- a tree starts the moment a worker is free instead of waiting for a launch to
+// gather, and no launch lasts as long as its slowest tree.  The workers of a launch leave TOGETHER, when none of
+// them has had a tree for `idle_ticks` (100 MHz): a launch holds its stream -- one of a few hardware queues -- until
+// its last workgroup is gone, so workers that trickled away one by one would leave streams occupied by a few
+// stragglers and no way to bring the others back.  Nothing a worker waits for can fail to arrive: the only loop
+// without a tree in it is the idle one, bounded by the clock.
+template <bool LDS, int MAXQ>
+__global__ void __launch_bounds__(MM_BLOCK, 1)
+    minmatch_worker(WorkQueue *q, WorkerState *ws, int launch, long long idle_ticks) {
+  __shared__ Shared sh;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+  const int tid = threadIdx.x;
+  auto &mine = ws->launch[launch];
+  // (progress marks for RELATE_AMD_MM_TRACE, in the queue's spare words: workers started / tickets claimed / trees
+  //  left / workers gone)
+  auto mark = [&](int which) {
+    if (tid == 0) __hip_atomic_fetch_add(&q->pad[which], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  };
+  mark(0);
+  // (one divergent block per turn -- thread 0 settles the accounts of the tree just built and claims the next --,
+  //  then barriers and wave-uniform branches only: what follows an `if (tid == 0)` behind the build is laid out by
+  //  the compiler as a loop over groups of lanes, and a barrier inside it is passed twice by thread 0's wave)
+  bool had_tree = false;
+  for (;;) {
     if (tid == 0) {
-      *p.host_done = 0;
-      __threadfence_system();
+      if (had_tree) {
+        __hip_atomic_fetch_add(&q->pad[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_fetch_add(&mine.activity, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&mine.busy, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      unsigned ticket = ~0u;
+      // (idle time is measured on this workgroup's own clock, from the last change of the launch's activity count it
+      //  has seen: the counters of different XCDs are not one clock)
+      unsigned seen = __hip_atomic_load(&mine.activity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      long long since = wall_clock64();
+      for (;;) {
+        const unsigned h = __hip_atomic_load(&ws->head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned t = __hip_atomic_load(&q->tail, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((int)(t - h) > 0) {
+          unsigned expected = h;
+          if (__hip_atomic_compare_exchange_strong(&ws->head, &expected, h + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT)) {
+            ticket = h;
+            __hip_atomic_fetch_add(&mine.busy, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(&mine.activity, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(&q->pad[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+          }
+          continue;
+        }
+        const unsigned act = __hip_atomic_load(&mine.activity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long long now = wall_clock64();
+        if (act != seen) {
+          seen = act;
+          since = now;
+        } else if (now - since > idle_ticks &&
+                   __hip_atomic_load(&mine.busy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+          break;
+        }
+        __builtin_amdgcn_s_sleep(127);  // (~3 us: the queue is read across PCIe)
+      }
+      if (ticket == ~0u) __hip_atomic_fetch_add(&q->pad[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      sh.ticket = ticket;
     }
+    __syncthreads();
+    const unsigned ticket = __builtin_amdgcn_readfirstlane(sh.ticket);
+    if (ticket == ~0u) break;
+    if (tid < MM_PARAM_WORDS)
+      sh.praw[tid] = __hip_atomic_load(&q->words[ticket % MM_QUEUE_CAP][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // what the tree's inputs were written with -- kernels of the builder's stream, finished before the request was
+    // published -- may sit in other XCDs' L2 or stale in this one's: acquire at system scope, every wave
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    __syncthreads();
+    MMParamsDev p;
+    params_from_words(p, sh.praw);
+    build_tree<LDS, MAXQ>(p, sh, dyn);
+    __syncthreads();  // (sh is the next tree's)
+    had_tree = true;
   }
 }
 
@@ -1367,191 +1553,416 @@ int rng_restatement_mismatches(unsigned seed, int n) {
 static size_t lds_state_bytes(int N) { return (((size_t)25 * N) + 255) & ~(size_t)255; }
 // ... and whether it fits next to the kernel's static LDS (160 KB per workgroup on gfx950)
 static bool lds_state_fits(int N) {
-  static size_t fixed = 0;
-  if (!fixed) {
+  static std::atomic<size_t> fixed{0};  // (a property of the code object, the same on every device)
+  size_t f = fixed.load();
+  if (!f) {
     hipFuncAttributes a;
-    if (hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&minmatch_kernel<true, 10>)) != hipSuccess) return false;
-    fixed = a.sharedSizeBytes;
+    if (hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&minmatch_worker<true, 10>)) != hipSuccess) return false;
+    fixed.store(f = a.sharedSizeBytes);
   }
-  return N <= 10 * MM_BLOCK && fixed + lds_state_bytes(N) <= (size_t)160 * 1024;
+  return N <= 10 * MM_BLOCK && f + lds_state_bytes(N) <= (size_t)160 * 1024;
 }
 
-// Trees of different sections are built at the same time, but a process has a handful of hardware queues (4 by
-// default): 40 builders with a stream and a one-workgroup launch each run 4 at a time.  So builders hand their
-// request to a dispatcher of the device, which puts all that are waiting into one launch -- a workgroup each --
-// and keeps up to three launches in flight.
-class BuildDispatcher {
+static int env_int(const char *name, int fallback, int lo, int hi) {
+  const char *e = getenv(name);
+  return e ? std::max(lo, std::min(hi, atoi(e))) : fallback;
+}
+
+// What the builders of one device share.
+//
+// * Staging: the row-major distance matrix (K3 writes it, the carrier penalty edits it) and clade prior of a tree
+//   are needed from K3 until the weave (pack_kernel) -- a few ms of a tree's ~0.2 s.  A builder takes a pair from
+//   a small pool for that time instead of owning 8 N^2 bytes for life (200 MB of the 725 MB a section used to pin
+//   at N = 5000: why 91 sections were all that fitted).
+// * The symmetric matrix of the fallback (tree_builder.cpp:255-293): a pool of `sym_slots` matrices the build
+//   kernels take and give back themselves (MMParams::sym_locks).
+class DeviceShare {
  public:
-  struct Request {
-    MMParams p;
-    std::atomic<bool> done{false};  // the launch that carried it is over
-    int rc = 0;
+  struct Staging {
+    DevBuf D, CF;
   };
-  static BuildDispatcher &of(int device) {
+  static DeviceShare &of(int device) {
     static std::mutex gm;
-    static std::vector<BuildDispatcher *> all;
+    static std::vector<DeviceShare *> all;
     std::lock_guard<std::mutex> lk(gm);
     if ((int)all.size() <= device) all.resize(device + 1, nullptr);
-    if (!all[device]) all[device] = new BuildDispatcher(device);  // lives as long as the process
+    if (!all[device]) all[device] = new DeviceShare();  // lives as long as the process
     return *all[device];
   }
-  void enroll(int delta) {
-    std::lock_guard<std::mutex> lk(m_);
-    builders_ += delta;
+  // a staging pair with room for N x N floats each (blocks while all are out); nullptr: no memory
+  Staging *take(int N) {
+    std::unique_lock<std::mutex> lk(m_);
+    for (;;) {
+      if (!free_.empty()) {
+        Staging *s = free_.back();
+        free_.pop_back();
+        lk.unlock();
+        if (s->D.alloc((size_t)N * N * 4) || s->CF.alloc((size_t)N * N * 4)) {
+          give(s);
+          return nullptr;
+        }
+        return s;
+      }
+      if (made_ < cap_) {
+        made_++;
+        lk.unlock();
+        Staging *s = new Staging();
+        if (s->D.alloc((size_t)N * N * 4) || s->CF.alloc((size_t)N * N * 4)) {
+          delete s;
+          lk.lock();
+          made_--;
+          if (made_ == 0) return nullptr;  // not even one: out of memory
+          cap_ = made_;                    // what there is has to do
+          continue;
+        }
+        return s;
+      }
+      cv_.wait(lk);
+    }
   }
-  // Hands the tree to the next launch and returns when ITS workgroup is through -- it says so in pinned host memory
-  // (p.host_done, -1 until then) -- not when the launch is: a launch lasts as long as its slowest tree.
-  int run(const std::shared_ptr<Request> &r) {
+  void give(Staging *s) {
     {
       std::lock_guard<std::mutex> lk(m_);
-      pending_.push_back(r);
-      waiting_++;
+      free_.push_back(s);
     }
-    cv_work_.notify_one();
+    cv_.notify_one();
+  }
+  // a pair that is free or can still be made; nullptr rather than waiting
+  Staging *take_if_any(int N) {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      if (free_.empty() && made_ >= cap_) return nullptr;
+    }
+    return take(N);
+  }
+  // the pool of symmetric matrices for trees of N leaves (grown on demand, never shrunk); *slots = 0: none
+  void sym_pool(int N, float **base, int **locks, int *slots) {
+    std::lock_guard<std::mutex> lk(m_);
+    if (sym_n_ < N) {
+      int want = env_int("RELATE_AMD_BUILD_SYM_SLOTS", 8, 0, 64);
+      DevBuf nb, nl;
+      while (want > 0 && nb.alloc((size_t)want * N * N * 4)) want /= 2;
+      if (want > 0 && !nl.alloc(64 * 4) && hipMemset(nl.p, 0, 64 * 4) == hipSuccess) {
+        // (builds in flight hold pointers into the old pool: it is kept, not freed)
+        retired_.emplace_back(new DevBuf());
+        retired_.back()->swap(sym_);
+        retired_.emplace_back(new DevBuf());
+        retired_.back()->swap(sym_locks_);
+        sym_.swap(nb);
+        sym_locks_.swap(nl);
+        sym_n_ = N;
+        sym_slots_ = want;
+      }
+    }
+    *base = sym_n_ >= N ? sym_.as<float>() : nullptr;
+    *locks = sym_locks_.as<int>();
+    *slots = sym_n_ >= N ? sym_slots_ : 0;
+  }
+  // every staging pair and the symmetric pool now (the stage admits its sections against what is free after this)
+  int prefill(int N) {
+    std::vector<Staging *> got;
+    for (int x = 0; x < cap_; x++) {
+      Staging *s = take_if_any(N);
+      if (!s) break;
+      got.push_back(s);
+    }
+    const bool any = !got.empty();
+    for (Staging *s : got) give(s);
+    float *b;
+    int *l, n;
+    sym_pool(N, &b, &l, &n);
+    return any ? 0 : -1;
+  }
+  // bytes of HBM the shared pools take for trees of N leaves (the stage's admission counts them once)
+  static double bytes(int N) {
+    return (double)env_int("RELATE_AMD_BUILD_STAGING", 12, 1, 64) * 8.0 * N * N +
+           (double)env_int("RELATE_AMD_BUILD_SYM_SLOTS", 8, 0, 64) * 4.0 * N * N;
+  }
+
+ private:
+  DeviceShare() : cap_(env_int("RELATE_AMD_BUILD_STAGING", 12, 1, 64)) {}
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::vector<Staging *> free_;
+  int made_ = 0, cap_;
+  DevBuf sym_, sym_locks_;
+  std::vector<std::unique_ptr<DevBuf>> retired_;
+  int sym_n_ = 0, sym_slots_ = 0;
+};
+double device_builder_shared_bytes(int N) { return DeviceShare::bytes(N); }
+int device_builder_reserve_shared(int device, int N) {
+  if (hipSetDevice(device) != hipSuccess) return -1;
+  return DeviceShare::of(device).prefill(N);
+}
+
+// The builders of one device and one tree size hand their trees to WORKERS -- resident workgroups that pull
+// requests from a queue in pinned host memory (minmatch_worker).  Why not a launch per tree, or per batch of
+// trees: a process has a dozen hardware queues and kernels of one queue run one after the other, so 150 sections
+// with a stream each build a dozen trees at a time; batched launches (round 2) waited 10 ms to gather, lasted as
+// long as their slowest tree and kept at most 4 x ~15 trees in flight on 256 CUs.
+// The launcher thread adds workers when trees wait: up to MM_LAUNCHES launches alive (a lowest-priority stream
+// each; more hardware queues than ~16 in all and the device time-slices them), sized as a ladder -- an eighth, an
+// eighth, a quarter, half of the workers the job can use (the CUs less an eighth, or the builders the stage
+// announced, expect()) -- so that a few trees do not sit on 200 CUs and 200 trees get theirs in four launches.
+class BuildQueue {
+ public:
+  static BuildQueue *of(int device, int N) {
+    // (the queues live as long as the process and are never destroyed: their launcher threads wait on them)
+    static std::mutex gm;
+    static std::vector<BuildQueue *> *all = new std::vector<BuildQueue *>();
+    std::lock_guard<std::mutex> lk(gm);
+    const bool lds = lds_state_fits(N);
+    for (BuildQueue *q : *all)
+      if (q->device_ == device && q->N_ == N) return q;
+    BuildQueue *q = new BuildQueue(device, N, lds);
+    if (!q->ok_) return nullptr;
+    all->push_back(q);
+    return q;
+  }
+  // builders that will ask at the same time (the stage: its section threads); 0: unknown
+  void expect(int builders) {
+    std::lock_guard<std::mutex> lk(m_);
+    expected_ = builders;
+  }
+  // Publishes the tree and returns when ITS worker says it is out (p.host_done, -1 until then): 0, or RL_EHIP.
+  int run(const MMParams &p) {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      const unsigned t = published_++;
+      MMParams pp = p;
+      pp.trace = getenv("RELATE_AMD_MM_TRACE") ? &q_->pad[8] : nullptr;
+      memcpy(q_->words[t % MM_QUEUE_CAP], &pp, sizeof(MMParams));
+      __atomic_store_n(&q_->tail, published_, __ATOMIC_RELEASE);
+      outstanding_++;
+    }
+    cv_.notify_one();
     int rc = 0;
-    for (;;) {
-      if (r->p.host_done && *r->p.host_done != -1) break;
-      if (r->done.load(std::memory_order_acquire)) {
-        rc = r->rc;
+    const auto t0 = std::chrono::steady_clock::now();
+    static const bool trace = getenv("RELATE_AMD_MM_TRACE") != nullptr;
+    auto last_trace = t0;
+    for (unsigned spins = 0;; spins++) {
+      if (__atomic_load_n(p.host_done, __ATOMIC_ACQUIRE) != -1) break;
+      if (trace && std::chrono::steady_clock::now() - last_trace > std::chrono::seconds(1)) {
+        last_trace = std::chrono::steady_clock::now();
+        fprintf(stderr, "[mm trace] N=%d waiting %.0f s: published %u, workers started %u, tickets claimed %u, trees left %u, "
+                "workers gone %u, outstanding %d; last mark: %u clusters left, phase %u\n", N_,
+                std::chrono::duration<double>(last_trace - t0).count(),
+                __atomic_load_n(&q_->tail, __ATOMIC_ACQUIRE), __atomic_load_n(&q_->pad[0], __ATOMIC_ACQUIRE),
+                __atomic_load_n(&q_->pad[1], __ATOMIC_ACQUIRE), __atomic_load_n(&q_->pad[2], __ATOMIC_ACQUIRE),
+                __atomic_load_n(&q_->pad[3], __ATOMIC_ACQUIRE), outstanding_, __atomic_load_n(&q_->pad[8], __ATOMIC_ACQUIRE),
+                __atomic_load_n(&q_->pad[9], __ATOMIC_ACQUIRE));
+        fflush(stderr);
+      }
+      if (failed_.load()) {
+        rc = RL_EHIP;
         break;
       }
-      std::this_thread::sleep_for(std::chrono::microseconds(100));
+      std::this_thread::sleep_for(std::chrono::microseconds(spins < 50 ? 100 : 250));
+      if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(600)) {
+        set_error("tree builder: the tree was not built within 10 minutes");
+        rc = RL_EHIP;
+        break;
+      }
     }
     std::lock_guard<std::mutex> lk(m_);
-    waiting_--;
+    outstanding_--;
     return rc;
   }
 
  private:
-  explicit BuildDispatcher(int device) : device_(device) {
-    // launches in flight at once (each on a stream of its own) and how long a launch waits for more trees
-    int launchers = 4;
-    if (const char *e = getenv("RELATE_AMD_BUILD_LAUNCHERS")) launchers = std::max(1, std::min(16, atoi(e)));
-    if (const char *e = getenv("RELATE_AMD_BUILD_GATHER_MS")) gather_ms_ = std::max(0, atoi(e));
-    for (int t = 0; t < launchers; t++) workers_.emplace_back([this] { worker(); });
-    for (auto &w : workers_) w.detach();
+  BuildQueue(int device, int N, bool lds) : device_(device), N_(N), lds_(lds) {
+    if (hipSetDevice(device) != hipSuccess) return;
+    if (hipHostMalloc(reinterpret_cast<void **>(&q_), sizeof(WorkQueue), hipHostMallocCoherent) != hipSuccess) return;
+    memset(q_, 0, sizeof(WorkQueue));
+    if (d_state_.alloc(sizeof(WorkerState)) || hipMemset(d_state_.p, 0, sizeof(WorkerState)) != hipSuccess) return;
+    int cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    // a worker has a CU to itself (150 KB of LDS, 8 waves of 256 registers); an eighth of the chip stays free for
+    // the stage's short kernels (RePaint, distance matrices, weave)
+    cap_ = env_int("RELATE_AMD_BUILD_WORKERS", cus - cus / 8, 1, 1024);
+    idle_ms_ = env_int("RELATE_AMD_BUILD_IDLE_MS", 50, 1, 10000);
+    ok_ = true;
+    std::thread([this] { launcher(); }).detach();
   }
-  void worker() {
+  void launcher() {
     (void)hipSetDevice(device_);
-    // A build kernel runs for ~0.1 s; the short kernels of the stage (distance matrices, penalty, prior, the weave of
-    // the next tree) must not queue up behind one in a hardware queue they happen to share: the builds go to the
-    // lowest-priority streams, which the runtime maps to hardware queues of their own.
-    hipStream_t stream = nullptr;
-    (void)make_stream(&stream, true);
-    {  // the per-cluster state of a build in LDS: more than the default 64 KB of dynamic LDS
+    // The workers run for as long as there are trees; the short kernels of the stage must not queue up behind a
+    // launch in a hardware queue they happen to share: lowest-priority streams, which the runtime maps to hardware
+    // queues of their own.
+    hipStream_t streams[MM_LAUNCHES];
+    int size[MM_LAUNCHES] = {0, 0, 0, 0};
+    for (auto &st : streams)
+      if (make_stream(&st, true) != hipSuccess) {
+        failed_.store(true);
+        return;
+      }
+    size_t dyn = 0;
+    if (lds_) {  // the per-cluster state of a build in LDS: more than the default 64 KB of dynamic LDS
+      const void *fn = reinterpret_cast<const void *>(&minmatch_worker<true, 10>);
       hipFuncAttributes a;
-      if (hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&minmatch_kernel<true, 10>)) == hipSuccess)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&minmatch_kernel<true, 10>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)a.sharedSizeBytes);
+      if (hipFuncGetAttributes(&a, fn) != hipSuccess ||
+          hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)a.sharedSizeBytes) != hipSuccess) {
+        failed_.store(true);
+        return;
+      }
+      dyn = lds_state_bytes(N_);
     }
-    DevBuf d_params;
-    std::vector<std::shared_ptr<Request>> batch;
-    std::vector<MMParams> params;
+    const bool verbose = getenv("RELATE_AMD_TIMING") != nullptr;
     for (;;) {
+      int demand = 0, goal = 0;
       {
         std::unique_lock<std::mutex> lk(m_);
-        cv_work_.wait(lk, [&] { return !pending_.empty(); });
-        // The builders whose tree is not being built right now are about to ask too (their hosts are preparing the
-        // next matrices): wait for them a little -- concurrent launches are few (hardware queues), so a launch
-        // should carry what there is.
-        const auto until = std::chrono::steady_clock::now() + std::chrono::milliseconds(gather_ms_);
-        while ((int)pending_.size() < builders_ - (waiting_ - (int)pending_.size()) &&
-               std::chrono::steady_clock::now() < until) {
-          lk.unlock();
-          std::this_thread::sleep_for(std::chrono::milliseconds(1));
-          lk.lock();
+        static const bool trace = getenv("RELATE_AMD_MM_TRACE") != nullptr;
+        while (trace && !cv_.wait_for(lk, std::chrono::milliseconds(500), [&] { return outstanding_ > 0; })) {
+          fprintf(stderr, "[mm trace] N=%d idle: published %u, workers started %u, tickets claimed %u, trees left %u, workers "
+                  "gone %u; streams busy:", N_, __atomic_load_n(&q_->tail, __ATOMIC_ACQUIRE),
+                  __atomic_load_n(&q_->pad[0], __ATOMIC_ACQUIRE), __atomic_load_n(&q_->pad[1], __ATOMIC_ACQUIRE),
+                  __atomic_load_n(&q_->pad[2], __ATOMIC_ACQUIRE), __atomic_load_n(&q_->pad[3], __ATOMIC_ACQUIRE));
+          for (int l = 0; l < MM_LAUNCHES; l++) fprintf(stderr, " %d", hipStreamQuery(streams[l]) == hipSuccess ? 0 : size[l]);
+          fprintf(stderr, "\n");
+          fflush(stderr);
         }
-        batch.swap(pending_);
+        cv_.wait(lk, [&] { return outstanding_ > 0; });
+        demand = outstanding_;
+        goal = std::min(cap_, expected_ > 0 ? std::max(expected_, demand) : cap_);
       }
-      if (batch.empty()) continue;
-      params.clear();
-      for (const auto &r : batch) params.push_back(r->p);
-      int rc = d_params.alloc(params.size() * sizeof(MMParams));
-      if (!rc && hipMemcpyAsync(d_params.p, params.data(), params.size() * sizeof(MMParams), hipMemcpyHostToDevice,
-                                stream) != hipSuccess)
-        rc = RL_EHIP;
-      if (!rc) {
-        const auto t0 = std::chrono::steady_clock::now();
-        // the trees whose per-cluster state fits in LDS and the larger ones: one launch per kind, each kernel
-        // leaves the other kind's workgroups at once
-        size_t dyn = 0;
-        bool any_lds = false, any_glob = false;
-        for (const MMParams &q : params) {
-          if (q.lds_state) {
-            any_lds = true;
-            dyn = std::max(dyn, lds_state_bytes(q.N));
-          } else {
-            any_glob = true;
-          }
+      int alive = 0, free_stream = -1, busy_launches = 0;
+      for (int l = 0; l < MM_LAUNCHES; l++) {
+        if (size[l] > 0 && hipStreamQuery(streams[l]) == hipSuccess) size[l] = 0;  // its last worker has left
+        alive += size[l];
+        busy_launches += size[l] > 0;
+        if (size[l] == 0 && free_stream < 0) free_stream = l;
+      }
+      if (demand > alive && alive < goal && free_stream >= 0) {
+        // the ladder: 1/8, 1/8, 1/4, 1/2 of the goal -- and never fewer than the trees that wait
+        static const int eighths[MM_LAUNCHES] = {1, 1, 2, 4};
+        int n = std::max((goal * eighths[busy_launches] + 7) / 8, demand - alive);
+        n = std::max(1, std::min(n, goal - alive));
+        const int l = free_stream;
+        const long long idle = (long long)idle_ms_ * 100000LL;
+        if (lds_)
+          hipLaunchKernelGGL((minmatch_worker<true, 10>), dim3((unsigned)n), dim3(MM_BLOCK), dyn, streams[l], q_,
+                             d_state_.as<WorkerState>(), l, idle);
+        else
+          hipLaunchKernelGGL((minmatch_worker<false, 20>), dim3((unsigned)n), dim3(MM_BLOCK), 0, streams[l], q_,
+                             d_state_.as<WorkerState>(), l, idle);
+        if (hipGetLastError() != hipSuccess) {
+          failed_.store(true);
+          return;
         }
-        if (any_lds)
-          hipLaunchKernelGGL((minmatch_kernel<true, 10>), dim3((unsigned)batch.size()), dim3(MM_BLOCK), dyn, stream,
-                             d_params.as<MMParams>());
-        if (any_glob && !rc)
-          hipLaunchKernelGGL((minmatch_kernel<false, 20>), dim3((unsigned)batch.size()), dim3(MM_BLOCK), 0, stream,
-                             d_params.as<MMParams>());
-        if (rc || hipGetLastError() != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) rc = RL_EHIP;
-        if (getenv("RELATE_AMD_TIMING"))
-          fprintf(stderr, "[tree builder launch] %zu trees, %.1f ms\n", batch.size(),
-                  1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+        size[l] = n;
+        if (verbose) {
+          fprintf(stderr, "[tree builder workers] +%d on stream %d: %d alive, %d trees waiting or being built, goal %d\n", n,
+                  l, alive + n, demand, goal);
+          fflush(stderr);
+        }
       }
-      for (const auto &r : batch) {
-        r->rc = rc;
-        r->done.store(true, std::memory_order_release);
-      }
-      batch.clear();
+      std::this_thread::sleep_for(std::chrono::microseconds(300));
     }
   }
-  int device_;
-  int gather_ms_ = 10;
-  int builders_ = 0, waiting_ = 0;  // builders alive on this device; builders waiting for a tree (asked or being built)
+  int device_, N_;
+  bool lds_, ok_ = false;
+  WorkQueue *q_ = nullptr;
+  DevBuf d_state_;
+  int cap_ = 224, idle_ms_ = 50;
   std::mutex m_;
-  std::condition_variable cv_work_;
-  std::vector<std::shared_ptr<Request>> pending_;
-  std::vector<std::thread> workers_;
+  std::condition_variable cv_;
+  unsigned published_ = 0;
+  int outstanding_ = 0, expected_ = 0;
+  std::atomic<bool> failed_{false};
 };
+int device_builder_expect(int device, int N, int builders) {
+  if (hipSetDevice(device) != hipSuccess) return -1;
+  BuildQueue *q = BuildQueue::of(device, N);
+  if (!q) return -1;
+  q->expect(builders);
+  return 0;
+}
+
+// the word of coherent pinned memory a worker tells its builder "this tree is out" in: taken from / given back to a
+// list (give != nullptr), never freed
+static int *done_word(int *give) {
+  static std::mutex m;
+  static std::vector<int *> spare;
+  std::lock_guard<std::mutex> lk(m);
+  if (give) {
+    spare.push_back(give);
+    return nullptr;
+  }
+  if (!spare.empty()) {
+    int *w = spare.back();
+    spare.pop_back();
+    return w;
+  }
+  int *w = nullptr;
+  return hipHostMalloc(reinterpret_cast<void **>(&w), 64, hipHostMallocCoherent) == hipSuccess ? w : nullptr;
+}
 
 struct DeviceMinMatch::Impl {
   int N = 0, device = 0;
   hipStream_t stream = nullptr;
-  DevBuf d_D, d_CF, d_M, d_SYM, d_hits, d_f, d_i, d_feas, d_rowlist, d_status, d_flags, d_member, d_tab, d_acc;
+  DeviceShare::Staging *staging = nullptr;  // held from device_matrix() / the upload until the matrices are woven
+  DevBuf d_M, d_hits, d_f, d_i, d_feas, d_rowlist, d_status, d_flags, d_member, d_tab, d_acc;
   long long builds = 0;
   double t_prep = 0, t_wait = 0, t_out = 0;  // RELATE_AMD_TIMING: uploads + weave, submit -> tree done, copy-out (s)
   long long n_timed = 0;
-  int *h_done = nullptr;  // pinned: the build kernel's "this tree is out" (BuildDispatcher::run)
+  int *h_done = nullptr;  // pinned: the worker's "this tree is out"
+  // pinned: what goes in and comes out per tree (candidate indices 2N, min_values_CF N, the merges 2N) -- from
+  // pageable memory every one of these small copies is staged and synchronised by the runtime, milliseconds each
+  // with a hundred sections copying at once
+  int *h_io = nullptr;
+  size_t h_io_bytes = 0, h_tab_bytes = 0;
+  int *h_tab = nullptr;   // pinned: the previous tree's tables for prior_kernel (6T + N ints), then N carrier flags
+  float acc_val = 0.0f;   // d_acc holds acc[c] = val added c times for this val
+  bool acc_valid = false;
+  void drop_staging() {
+    if (staging) DeviceShare::of(device).give(staging);
+    staging = nullptr;
+  }
 };
 
 DeviceMinMatch::DeviceMinMatch(int N, int device) : impl(new Impl()) {
   impl->N = N;
   impl->device = device;
-  BuildDispatcher::of(device).enroll(1);
 }
 DeviceMinMatch::~DeviceMinMatch() {
-  BuildDispatcher::of(impl->device).enroll(-1);
+  impl->drop_staging();
   if (getenv("RELATE_AMD_TIMING") && impl->n_timed)
     fprintf(stderr, "[gpu tree builder] %lld trees, host ms per tree: uploads + weave %.2f, submit -> done %.2f, "
                     "copy-out %.2f\n", impl->n_timed, 1e3 * impl->t_prep / impl->n_timed,
             1e3 * impl->t_wait / impl->n_timed, 1e3 * impl->t_out / impl->n_timed);
   if (impl->stream) (void)hipStreamDestroy(impl->stream);
-  if (impl->h_done) (void)hipHostFree(impl->h_done);
+  // (nothing goes back to the driver here: hipFree / hipHostFree would wait for the workers of the other builders)
+  if (impl->h_done) done_word(impl->h_done);
+  if (impl->h_io) pinned_cache_release(impl->h_io, impl->h_io_bytes);
+  if (impl->h_tab) pinned_cache_release(impl->h_tab, impl->h_tab_bytes);
   delete impl;
 }
 
 float *DeviceMinMatch::device_matrix() {
   Impl &m = *impl;
   if (hipSetDevice(m.device) != hipSuccess) return nullptr;
-  if (m.d_D.alloc((size_t)m.N * m.N * 4)) return nullptr;
-  return m.d_D.as<float>();
+  if (!m.staging) m.staging = DeviceShare::of(m.device).take(m.N);
+  return m.staging ? m.staging->D.as<float>() : nullptr;
 }
 
 int DeviceMinMatch::apply_penalty(const char *member, float val) {
   Impl &m = *impl;
   const int N = m.N;
+  if (!m.staging) return -1;
   RL_HIP(hipSetDevice(m.device));
   if (!m.stream) RL_HIP(make_stream(&m.stream, false));
   if (m.d_member.alloc((size_t)N)) return -1;
-  RL_HIP(hipMemcpyAsync(m.d_member.p, member, (size_t)N, hipMemcpyHostToDevice, m.stream));
-  hipLaunchKernelGGL(penalty_kernel, dim3(N), dim3(256), 0, m.stream, m.d_D.as<float>(), N,
+  const size_t tab_ints = (size_t)6 * (2 * N - 1) + N;
+  if (!m.h_tab && !(m.h_tab = static_cast<int *>(pinned_cache_alloc(tab_ints * 4 + (size_t)N, &m.h_tab_bytes)))) {
+    set_error("tree builder: no pinned host memory for the prior's tables");
+    return -1;
+  }
+  char *flags = reinterpret_cast<char *>(m.h_tab + tab_ints);
+  memcpy(flags, member, (size_t)N);
+  RL_HIP(hipMemcpyAsync(m.d_member.p, flags, (size_t)N, hipMemcpyHostToDevice, m.stream));
+  hipLaunchKernelGGL(penalty_kernel, dim3(N), dim3(256), 0, m.stream, m.staging->D.as<float>(), N,
                      m.d_member.as<unsigned char>(), val);
   RL_HIP(hipGetLastError());
   return 0;
@@ -1560,11 +1971,17 @@ int DeviceMinMatch::apply_penalty(const char *member, float val) {
 int DeviceMinMatch::apply_prior(const HostTree &t, float val) {
   Impl &m = *impl;
   const int N = m.N, T = 2 * N - 1;
+  if (!m.staging) return -1;
   RL_HIP(hipSetDevice(m.device));
   if (!m.stream) RL_HIP(make_stream(&m.stream, false));
-  // the same tables as the host's clade_prior (treeseq.cpp)
-  std::vector<int> tab((size_t)6 * T + N);
-  int *parent = tab.data(), *cl = parent + T, *cr = cl + T, *depth = cr + T, *lo = depth + T, *size = lo + T,
+  // the same tables as the host's clade_prior (treeseq.cpp), in pinned memory: nothing here waits for the copy
+  // (the next tree of this builder -- the next writer of the block -- comes after this one is built)
+  const size_t tab_ints = (size_t)6 * T + N;
+  if (!m.h_tab && !(m.h_tab = static_cast<int *>(pinned_cache_alloc(tab_ints * 4 + (size_t)N, &m.h_tab_bytes)))) {
+    set_error("tree builder: no pinned host memory for the prior's tables");
+    return -1;
+  }
+  int *parent = m.h_tab, *cl = parent + T, *cr = cl + T, *depth = cr + T, *lo = depth + T, *size = lo + T,
       *order = size + T;
   for (int v = 0; v < T; v++) {
     parent[v] = t.parent[v];
@@ -1581,28 +1998,51 @@ int DeviceMinMatch::apply_prior(const HostTree &t, float val) {
     lo[cr[v]] = lo[v] + size[cl[v]];
   }
   for (int i = 0; i < N; i++) order[lo[i]] = i;
-  std::vector<float> acc((size_t)N + 1, 0.0f);
-  for (int c = 1; c <= N; c++) acc[c] = acc[c - 1] + val;
-  int rc = m.d_tab.alloc(tab.size() * 4);
-  rc = rc ? rc : m.d_acc.alloc(acc.size() * 4);
-  rc = rc ? rc : m.d_CF.alloc((size_t)N * N * 4);
+  int rc = m.d_tab.alloc(tab_ints * 4);
+  rc = rc ? rc : m.d_acc.alloc(((size_t)N + 1) * 4);
   if (rc) return -1;
-  RL_HIP(hipMemcpyAsync(m.d_tab.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, m.stream));
-  RL_HIP(hipMemcpyAsync(m.d_acc.p, acc.data(), acc.size() * 4, hipMemcpyHostToDevice, m.stream));
+  if (!m.acc_valid || m.acc_val != val) {  // (one val per section: once)
+    std::vector<float> acc((size_t)N + 1, 0.0f);
+    for (int c = 1; c <= N; c++) acc[c] = acc[c - 1] + val;
+    RL_HIP(hipMemcpy(m.d_acc.p, acc.data(), acc.size() * 4, hipMemcpyHostToDevice));
+    m.acc_val = val;
+    m.acc_valid = true;
+  }
+  RL_HIP(hipMemcpyAsync(m.d_tab.p, m.h_tab, tab_ints * 4, hipMemcpyHostToDevice, m.stream));
   const int *q = m.d_tab.as<int>();
-  hipLaunchKernelGGL(prior_kernel, dim3(N), dim3(256), 0, m.stream, m.d_CF.as<float>(), N, q, q + T, q + 2 * (size_t)T,
-                     q + 3 * (size_t)T, q + 4 * (size_t)T, q + 5 * (size_t)T, q + 6 * (size_t)T, m.d_acc.as<float>());
+  hipLaunchKernelGGL(prior_kernel, dim3(N), dim3(256), 0, m.stream, m.staging->CF.as<float>(), N, q, q + T,
+                     q + 2 * (size_t)T, q + 3 * (size_t)T, q + 4 * (size_t)T, q + 5 * (size_t)T, q + 6 * (size_t)T,
+                     m.d_acc.as<float>());
   RL_HIP(hipGetLastError());
-  RL_HIP(hipStreamSynchronize(m.stream));  // (tab and acc are locals)
   return 0;
 }
 
+int DeviceMinMatch::reserve() {
+  Impl &m = *impl;
+  const int N = m.N;
+  if (hipSetDevice(m.device) != hipSuccess) return -1;
+  const long long pair_cap = (long long)8 * N;
+  int rc = m.d_M.alloc(mm_elements(N) * 16);
+  rc = rc ? rc : m.d_hits.alloc(((size_t)N + (size_t)2 * N * MM_HITS) * 4);
+  rc = rc ? rc : m.d_f.alloc((size_t)8 * N * 4);  // min_values, min_values_CF, mc_dist, mc_dist2, 2 of the symmetric path, 2 row minima
+  rc = rc ? rc : m.d_i.alloc(((size_t)12 * N + 8) * 4);  // ints, see build_impl
+  rc = rc ? rc : m.d_feas.alloc((size_t)pair_cap * 6 * 4);
+  rc = rc ? rc : m.d_rowlist.alloc((size_t)MM_WAVES * N * 4);
+  rc = rc ? rc : m.d_status.alloc(16 + 12 * 8);
+  rc = rc ? rc : m.d_flags.alloc((size_t)N);
+  return rc ? -1 : 0;
+}
+
 int DeviceMinMatch::build_resident(MinMatch &tb, bool with_prior, HostTree &tree) {
-  return build_impl(tb, nullptr, nullptr, true, with_prior, tree);
+  const int rc = build_impl(tb, nullptr, nullptr, true, with_prior, tree);
+  impl->drop_staging();
+  return rc;
 }
 
 int DeviceMinMatch::build(MinMatch &tb, const float *d, const float *prior, HostTree &tree) {
-  return build_impl(tb, d, prior, false, prior != nullptr, tree);
+  const int rc = build_impl(tb, d, prior, false, prior != nullptr, tree);
+  impl->drop_staging();
+  return rc;
 }
 
 int DeviceMinMatch::build_impl(MinMatch &tb, const float *d, const float *prior_host, bool resident, bool with_prior,
@@ -1616,23 +2056,26 @@ int DeviceMinMatch::build_impl(MinMatch &tb, const float *d, const float *prior_
   }
   RL_HIP(hipSetDevice(m.device));
   if (!m.stream) RL_HIP(make_stream(&m.stream, false));
+  BuildQueue *queue = BuildQueue::of(m.device, N);
+  if (!queue) {
+    set_error("tree builder: no queue on device %d (pinned host memory)", m.device);
+    return -1;
+  }
+  if (!m.staging) {
+    if (resident) {
+      set_error("tree builder: build_resident without device_matrix()");
+      return -1;
+    }
+    m.staging = DeviceShare::of(m.device).take(N);
+    if (!m.staging) return -1;
+  }
   const bool prior = with_prior;
   const size_t NN = (size_t)N * N;
   const auto tb0 = std::chrono::steady_clock::now();
   const long long pair_cap = (long long)8 * N;
-  int rc = m.d_D.alloc(NN * 4);
-  rc = rc ? rc : (prior ? m.d_CF.alloc(NN * 4) : 0);
-  rc = rc ? rc : m.d_M.alloc(mm_elements(N) * 16);
-  rc = rc ? rc : m.d_hits.alloc(((size_t)N + (size_t)2 * N * MM_HITS) * 4);
-  rc = rc ? rc : m.d_SYM.alloc(NN * 4);
-  rc = rc ? rc : m.d_f.alloc((size_t)8 * N * 4);  // min_values, min_values_CF, mc_dist, mc_dist2, 2 of the symmetric path, 2 row minima
-  rc = rc ? rc : m.d_i.alloc(((size_t)12 * N + 8) * 4);  // ints, see below
-  rc = rc ? rc : m.d_feas.alloc((size_t)pair_cap * 6 * 4);
-  rc = rc ? rc : m.d_rowlist.alloc((size_t)MM_WAVES * N * 4);
-  rc = rc ? rc : m.d_status.alloc(16 + 12 * 8);
-  rc = rc ? rc : m.d_flags.alloc((size_t)N);
-  if (rc) return -1;
+  if (reserve()) return -1;
   MMParams p;
+  memset(&p, 0, sizeof(p));
   p.N = N;
   p.lds_state = lds_state_fits(N) ? 1 : 0;
   p.threshold = tb.threshold;
@@ -1653,7 +2096,7 @@ int DeviceMinMatch::build_impl(MinMatch &tb, const float *d, const float *prior_
   p.mc_dist2 = f + 3 * (size_t)N;
   p.min_values_sym = f + 4 * (size_t)N;
   p.mcs_dist = f + 5 * (size_t)N;
-  p.SYM = m.d_SYM.as<float>();
+  DeviceShare::of(m.device).sym_pool(N, &p.SYM, &p.sym_locks, &p.sym_slots);
   int *q = m.d_i.as<int>();
   p.mc_lin1 = q;
   p.mc_lin2 = q + N;
@@ -1669,28 +2112,36 @@ int DeviceMinMatch::build_impl(MinMatch &tb, const float *d, const float *prior_
   p.pair_cap = pair_cap;
   p.rowlist = m.d_rowlist.as<int>();
   p.status = m.d_status.as<int>();
-  if (!m.h_done && hipHostMalloc(reinterpret_cast<void **>(&m.h_done), 64, hipHostMallocCoherent) != hipSuccess)
-    m.h_done = nullptr;  // (without it the builder waits for the whole launch)
+  if (!m.h_done && !(m.h_done = done_word(nullptr))) {
+    set_error("tree builder: no pinned host memory for the completion word");
+    return -1;
+  }
   p.host_done = m.h_done;
   const bool timing = getenv("RELATE_AMD_TIMING") != nullptr;
   p.timers = timing ? reinterpret_cast<long long *>(m.d_status.as<char>() + 16) : nullptr;
 
   // state the builders carry from tree to tree: in
-  std::vector<int> lin((size_t)2 * N);
+  if (!m.h_io && !(m.h_io = static_cast<int *>(pinned_cache_alloc((size_t)5 * N * 4, &m.h_io_bytes)))) {
+    set_error("tree builder: no pinned host memory for the per-tree copies");
+    return -1;
+  }
+  int *lin = m.h_io, *tr = m.h_io + 3 * (size_t)N;
+  float *mvcf = reinterpret_cast<float *>(m.h_io + 2 * (size_t)N);
   for (int c = 0; c < N; c++) {
     lin[c] = tb.mc[c].lin1;
     lin[(size_t)N + c] = tb.mc[c].lin2;
+    mvcf[c] = tb.min_values_CF[c];
   }
-  RL_HIP(hipMemcpyAsync(p.mc_lin1, lin.data(), (size_t)2 * N * 4, hipMemcpyHostToDevice, m.stream));
-  RL_HIP(hipMemcpyAsync(p.min_values_CF, tb.min_values_CF.data(), (size_t)N * 4, hipMemcpyHostToDevice, m.stream));
+  RL_HIP(hipMemcpyAsync(p.mc_lin1, lin, (size_t)2 * N * 4, hipMemcpyHostToDevice, m.stream));
+  RL_HIP(hipMemcpyAsync(p.min_values_CF, mvcf, (size_t)N * 4, hipMemcpyHostToDevice, m.stream));
+  float *dD = m.staging->D.as<float>(), *dCF = prior ? m.staging->CF.as<float>() : nullptr;
   if (!resident) {
-    RL_HIP(hipMemcpyAsync(m.d_D.p, d, NN * 4, hipMemcpyHostToDevice, m.stream));
-    if (prior) RL_HIP(hipMemcpyAsync(m.d_CF.p, prior_host, NN * 4, hipMemcpyHostToDevice, m.stream));
+    RL_HIP(hipMemcpyAsync(dD, d, NN * 4, hipMemcpyHostToDevice, m.stream));
+    if (prior) RL_HIP(hipMemcpyAsync(dCF, prior_host, NN * 4, hipMemcpyHostToDevice, m.stream));
   }
   {
     // the woven matrix and the row minima, on the whole chip; the build itself is one workgroup
     const dim3 grid((N + 31) / 32, (N + 31) / 32);
-    const float *dD = m.d_D.as<float>(), *dCF = prior ? m.d_CF.as<float>() : nullptr;
     hipLaunchKernelGGL(pack_kernel, grid, dim3(256), 0, m.stream, dD, dCF, p.M, N);
     hipLaunchKernelGGL(rowmin_kernel, dim3(N), dim3(256), 0, m.stream, dD, f + 6 * (size_t)N, N);
     if (prior) hipLaunchKernelGGL(rowmin_kernel, dim3(N), dim3(256), 0, m.stream, dCF, f + 7 * (size_t)N, N);
@@ -1699,23 +2150,23 @@ int DeviceMinMatch::build_impl(MinMatch &tb, const float *d, const float *prior_
                        reinterpret_cast<float *>(hits + N + (size_t)N * MM_HITS));
     RL_HIP(hipGetLastError());
   }
-  const int minus1 = -1;
-  RL_HIP(hipMemcpyAsync(p.status, &minus1, 4, hipMemcpyHostToDevice, m.stream));
+  RL_HIP(hipMemsetAsync(p.status, 0xff, 4, m.stream));  // (-1)
+  static const bool trace = getenv("RELATE_AMD_MM_TRACE") != nullptr;
+  if (trace) fprintf(stderr, "[mm trace] N=%d inputs submitted\n", N), fflush(stderr);
   RL_HIP(hipStreamSynchronize(m.stream));  // inputs in place
+  if (trace) fprintf(stderr, "[mm trace] N=%d inputs in place\n", N), fflush(stderr);
+  m.drop_staging();                        // (woven: the row-major matrices go back to the pool)
   const auto tb1 = std::chrono::steady_clock::now();
-  {
-    if (m.h_done) *m.h_done = -1;
-    auto req = std::make_shared<BuildDispatcher::Request>();
-    req->p = p;
-    if (BuildDispatcher::of(m.device).run(req)) {
-      set_error("tree builder launch failed");
-      return -1;
-    }
+  __atomic_store_n(m.h_done, -1, __ATOMIC_RELEASE);
+  if (queue->run(p)) {
+    set_error("tree builder: the workers of device %d failed", m.device);
+    return -1;
   }
   const auto tb2 = std::chrono::steady_clock::now();
-  int status = -1;
-  RL_HIP(hipMemcpyAsync(&status, p.status, 4, hipMemcpyDeviceToHost, m.stream));
-  RL_HIP(hipStreamSynchronize(m.stream));
+  // (the worker stores the code where it stores "done", behind a system-scope fence: no copy of p.status, which
+  //  could still sit in the worker's L2 for a copy engine)
+  const int status = __atomic_load_n(m.h_done, __ATOMIC_ACQUIRE);
+  if (trace) fprintf(stderr, "[mm trace] N=%d tree out, status %d\n", N, status), fflush(stderr);
   if (status != 0) return status > 0 ? status : -1;
   if (timing) {
     long long tk[12];
@@ -1727,11 +2178,12 @@ int DeviceMinMatch::build_impl(MinMatch &tb, const float *d, const float *prior_
     fprintf(stderr, " shader_MHz %lld\n", tk[11]);
   }
   // out: the tree and the carried state
-  std::vector<int> tr((size_t)2 * N);  // merge_i [N), merge_j [N) lie back to back
-  RL_HIP(hipMemcpyAsync(tr.data(), p.merge_i, ((size_t)2 * N - 1) * 4, hipMemcpyDeviceToHost, m.stream));
-  RL_HIP(hipMemcpyAsync(lin.data(), p.mc_lin1, (size_t)2 * N * 4, hipMemcpyDeviceToHost, m.stream));
-  RL_HIP(hipMemcpyAsync(tb.min_values_CF.data(), p.min_values_CF, (size_t)N * 4, hipMemcpyDeviceToHost, m.stream));
+  // (merge_i [N), merge_j [N) lie back to back)
+  RL_HIP(hipMemcpyAsync(tr, p.merge_i, ((size_t)2 * N - 1) * 4, hipMemcpyDeviceToHost, m.stream));
+  RL_HIP(hipMemcpyAsync(lin, p.mc_lin1, (size_t)2 * N * 4, hipMemcpyDeviceToHost, m.stream));
+  RL_HIP(hipMemcpyAsync(mvcf, p.min_values_CF, (size_t)N * 4, hipMemcpyDeviceToHost, m.stream));
   RL_HIP(hipStreamSynchronize(m.stream));
+  for (int c = 0; c < N; c++) tb.min_values_CF[c] = mvcf[c];
   tree.reset(N);
   {  // the nodes of the tree from the merges (tree_builder.cpp:2437-2460, 2631-2636): cluster j lives on as the new node
     std::vector<int> node(N);

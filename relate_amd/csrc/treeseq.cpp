@@ -59,11 +59,16 @@ struct rl_treeseq {
   rl_matrix_dev_fn matrix_dev = nullptr;  // with it the distance matrices never leave the device
   long long gpu_trees = 0, host_trees = 0;
   std::vector<double> sample_ages;  // N values (--sample_ages) or empty
+  // the device builder's buffers (16 N^2 B of woven matrix) outlive a section: the next one of this object reuses them
+  rl::DeviceMinMatch *dev_builder = nullptr;
+  ~rl_treeseq() { delete dev_builder; }
 
   bool derived(int snp, int n) const { return (bits[(size_t)snp * row_words + (n >> 5)] >> (n & 31)) & 1u; }
 };
 
 namespace rl {
+
+double device_builder_shared_bytes(int N);  // (minmatch_gpu.hip) HBM of the pools the device builders share
 
 // ---- Where a SNP sits on a tree (anc_builder.cpp:1064-1413: MapMutation, ForceMapMutation and their two
 // recursions PropagateMutationGlobal / PropagateMutationLocal).
@@ -369,8 +374,11 @@ int rl_treeseq_build(rl_treeseq *ts, int start, int end, rl_matrix_fn matrix, rl
   // with sample ages (ancient samples) the candidates carry a third key and a clock: its own builder, on the host
   std::unique_ptr<MinMatchAges> tb_ages;
   if ((int)ts->sample_ages.size() == N) tb_ages.reset(new MinMatchAges(N, ts->theta));
-  std::unique_ptr<DeviceMinMatch> dev;
-  if (ts->build_device >= 0 && N <= 10240 && !tb_ages) dev.reset(new DeviceMinMatch(N, ts->build_device));  // (its registers per thread)
+  DeviceMinMatch *dev = nullptr;
+  if (ts->build_device >= 0 && N <= 10240 && !tb_ages) {  // (its registers per thread)
+    if (!ts->dev_builder) ts->dev_builder = new DeviceMinMatch(N, ts->build_device);
+    dev = ts->dev_builder;
+  }
   int build_rc = 0;
   auto build_tree = [&](float *dm, const float *prior, HostTree &t) {
     if (tb_ages) {
@@ -551,6 +559,10 @@ int rl_treeseq_set_sample_ages(rl_treeseq *ts, const double *ages, int n) {
 
 int rl_treeseq_set_build_device(rl_treeseq *ts, int device) {
   if (!ts) return RL_EINVAL;
+  if (ts->dev_builder && device != ts->build_device) {
+    delete ts->dev_builder;
+    ts->dev_builder = nullptr;
+  }
   ts->build_device = device;
   return RL_OK;
 }
@@ -789,11 +801,19 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
   // sections run side by side (40 sections: 98 s against 331 s).  RELATE_AMD_GPU_BUILD=0 / 1 decides otherwise.
   const bool gpu_build = getenv("RELATE_AMD_GPU_BUILD") ? atoi(getenv("RELATE_AMD_GPU_BUILD")) != 0
                                                         : last_section > first_section;
-  // stones + matrix + cursors next to the rows; RePaint's strips are one buffer of the context (reserved below);
-  // a tree builder on the device keeps the distance matrix, the prior, the symmetric matrix and the woven float4
-  // matrix of the build (minmatch_gpu.hip): 7 N^2 floats and change
-  const double fixed_bytes = 3.0 * 4.0 * ctx->N * ctx->nloc + 4.0 * max_rows + 64e6 +
-                             (gpu_build ? 29.0 * ctx->N * (ctx->N + 64.0) : 0.0);
+  // Next to its rows a window holds cursors and small per-target arrays, a stage from paint files also the decoded
+  // stones (2 N^2 floats; the fused stage re-paints from the context's own); a tree builder on the device keeps the
+  // woven float4 matrix of the build (16 N^2 B, minmatch_gpu.hip) -- the row-major matrices of a tree and the
+  // symmetric matrix of the fallback come from pools of the device, counted once.  RePaint's strips are one buffer
+  // of the context (reserved below).
+  const double NN = (double)ctx->N * (ctx->N + 64.0);
+  const double builder_bytes = gpu_build ? 17.0 * NN : 0.0;  // (allocated once per section thread, kept)
+  const double fixed_bytes = 4.0 * max_rows + 48e6 + (from_files || ctx->h_alpha ? 8.0 * ctx->N * ctx->nloc : 0.0) +
+                             (gpu_build && ctx->nloc == ctx->N ? 0.0 : 4.0 * ctx->N * ctx->nloc);
+  if (gpu_build && device_builder_reserve_shared(device, ctx->N)) {  // the pools now: the admission sees what is left
+    rl_destroy(ctx);
+    return RL_ENOMEM;
+  }
   auto window_bytes = [&](int w) {
     const double kept = cap_rows > 0 ? std::min(rows_of[w], (double)cap_rows) : rows_of[w];
     return kept * row_bytes + fixed_bytes;
@@ -811,19 +831,27 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
     }
     size_t free_b = 0, total_b = 0;
     const bool known = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
+    const double room = known ? 0.9 * (double)free_b : 0.0;
     if (const char *e = getenv("RELATE_AMD_WINDOW_ROWS")) {
       cap_rows = std::max(0LL, atoll(e));
     } else if (known) {
-      const double budget = 0.85 * (double)free_b / nthreads - fixed_bytes;
-      if (max_rows * row_bytes > budget)  // not below a sixteenth of a window: RePaint runs again for every part
-        cap_rows = (long long)std::max({budget / row_bytes, max_rows / 16.0, 3.0 * ctx->nloc + 64.0});
+      // Every section the host could work on should be open: the trees of different sections are what fills the
+      // chip (a workgroup per tree).  A window that keeps 1/P of its rows runs RePaint P times -- about half a
+      // window's 14 ms each time at C3, where the builders leave it half the chip: not below a P-th of the largest
+      // window, P <= RELATE_AMD_WINDOW_PARTS (24: 148 sections open at C3; DESIGN.md 5 has the trade)
+      int parts_max = 24;
+      if (const char *pe = getenv("RELATE_AMD_WINDOW_PARTS")) parts_max = std::max(1, atoi(pe));
+      int parts = 1;
+      while (parts < parts_max && room / (max_rows / parts * row_bytes + fixed_bytes + builder_bytes) < nthreads) parts++;
+      if (parts > 1) cap_rows = (long long)std::max({max_rows / parts, 3.0 * ctx->nloc + 64.0});
     }
     if (known) {
-      const double per_window = window_bytes((first_section + last_section) / 2);
-      concurrent = std::max(1, std::min(nthreads, (int)(0.9 * (double)free_b / std::max(per_window, 1.0))));
+      const double per_window = window_bytes((first_section + last_section) / 2) + builder_bytes;
+      concurrent = std::max(1, std::min(nthreads, (int)(room / std::max(per_window, 1.0))));
       nthreads = std::min(nthreads, concurrent + 2);  // a couple more wait for room instead of idling a slot
     }
   }
+  if (gpu_build && sample_ages.empty()) (void)device_builder_expect(device, ctx->N, nthreads);  // (sizes the workers' launches)
   // Host threads left over by the sections help inside each tree build (minmatch.h BuildThreads).  Helpers are the
   // less efficient use of a core (a merge is split 8 ways for a 2.5x shorter build) and a helper that loses its
   // core stalls every merge, so they get a quarter of the physical cores at most: measured on 2 x 64 cores with 8
@@ -877,7 +905,9 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
       if (end >= L) end = L - 1;
       const std::string pf = od + "/chunk_" + c + "/paint/relate_" + std::to_string(section) + ".bin";
       rl_window *win = nullptr;
-      const double need = window_bytes(section);
+      // (this thread's builder keeps its buffers from section to section: only the first one asks for them)
+      const bool builder_new = gpu_build && sample_ages.empty() && !ts->dev_builder;
+      const double need = window_bytes(section) + (builder_new ? builder_bytes : 0.0);
       for (;;) {  // admission: wait until the window fits next to the ones that are open or being opened
         bool admitted = false;
         {
@@ -892,6 +922,13 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
         if (admitted) {  // (reading and decoding the paint file, the uploads and RePaint: outside the lock)
           win = rl_window_open_bounded(ctx, section, from_files ? pf.c_str() : nullptr, start, sum_mode, cap_rows,
                                        nullptr);
+          if (win && builder_new) {  // (while the reservation stands)
+            ts->dev_builder = new DeviceMinMatch(ctx->N, device);
+            if (ts->dev_builder->reserve()) {
+              rl_window_close(win);
+              win = nullptr;
+            }
+          }
           std::lock_guard<std::mutex> lk(g_gpu_mutex);
           reserved_bytes -= need;
           if (win) most_open = std::max(most_open, ++open_sections);
@@ -928,12 +965,14 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
     for (int t = 0; t < nthreads; t++) th.emplace_back(worker);
     for (auto &x : th) x.join();
   }
+  if (gpu_build && sample_ages.empty()) (void)device_builder_expect(device, ctx->N, 0);
   rc = first_error.load();
   if (rc) set_error("%s", first_message.c_str());
   if (getenv("RELATE_AMD_TIMING"))
     fprintf(stderr, "[stage] sections %d..%d on %d threads, up to %d open at once, %lld of at most %.0f posterior rows "
-            "resident per window, %s tree builder, %.1f s\n", first_section, last_section, nthreads, most_open,
-            cap_rows > 0 ? cap_rows : (long long)max_rows, max_rows, gpu_build ? "GPU" : "host",
+            "resident per window, %lld RePaint launches, %s tree builder, %.1f s\n", first_section, last_section,
+            nthreads, most_open, cap_rows > 0 ? cap_rows : (long long)max_rows, max_rows, ctx->repaint_launches,
+            gpu_build ? "GPU" : "host",
             std::chrono::duration<double>(std::chrono::steady_clock::now() - stage_t0).count());
   rl_destroy(ctx);
   if (!rc) {
@@ -985,6 +1024,7 @@ int rl_stage_paint_build_topology(const char *out_dir, int chunk_index, int firs
   // would not fit otherwise; at C3 (53 GB of stones) it opens 112 sections instead of 91 and the chunk takes 330 s
   // instead of 291 s: past ~90 trees in flight the build kernels slow each other down
   if (!rc && getenv("RELATE_AMD_PARK_STONES") && atoi(getenv("RELATE_AMD_PARK_STONES")) != 0) rc = rl_park_stones(ctx);
+  if (!rc) ctx->stones_disposable = true;  // (nobody writes paint files from this context: the windows may edit them)
   if (!rc) {  // (the Paint stage makes this directory for its files; the trees go there)
     const std::string cdir = std::string(out_dir) + "/chunk_" + std::to_string(chunk_index);
     if (mkdir(cdir.c_str(), 0777) != 0 && errno != EEXIST) {

@@ -29,6 +29,8 @@ struct rl_window {
   // What RePaint needs to run again (a bounded window keeps part of its posterior rows and recomputes as the
   // tree builder moves on): the decoded stones, the plan slices, the last-interval coefficients.
   DevBuf d_ab, d_be, d_la, d_lb, d_ib, d_ie, d_cfl, d_nxl, d_order, d_ck_off;
+  // the window's stones: its own decoded copy (d_ab ..), or the context's slice quantised in place (fused stage)
+  const float *ab = nullptr, *be = nullptr, *la = nullptr, *lb = nullptr;
   DevBuf d_slab_off, d_row_lo, d_row_hi, d_slab_base;
   std::vector<int64_t> slab_off, slab_base;  // [nloc]
   std::vector<int32_t> row_lo, row_hi;       // [nloc] resident posterior rows [lo, hi) of each target
@@ -39,12 +41,13 @@ struct rl_window {
   hipStream_t stream = nullptr;
   hipEvent_t e0 = nullptr, e2 = nullptr;
   unsigned char *h_stage = nullptr;  // pinned: the per-target arguments of one matrix, sent in one copy
+  size_t h_stage_bytes = 0;
   DevBuf d_stage;
   ~rl_window() {
     if (stream) (void)hipStreamDestroy(stream);
     if (e0) (void)hipEventDestroy(e0);
     if (e2) (void)hipEventDestroy(e2);
-    if (h_stage) (void)hipHostFree(h_stage);
+    if (h_stage) pinned_cache_release(h_stage, h_stage_bytes);
   }
 };
 
@@ -77,10 +80,10 @@ static int repaint_rows(rl_window *win, float *kernel_ms) {
   p.ie = win->d_ie.as<int32_t>();
   p.cf_last = win->d_cfl.as<double>();
   p.nxt_last = win->d_nxl.as<double>();
-  p.alpha_begin = win->d_ab.as<float>();
-  p.beta_end = win->d_be.as<float>();
-  p.ls_alpha = win->d_la.as<float>();
-  p.ls_beta = win->d_lb.as<float>();
+  p.alpha_begin = win->ab;
+  p.beta_end = win->be;
+  p.ls_alpha = win->la;
+  p.ls_beta = win->lb;
   p.top_off = win->d_top_off.as<int64_t>();
   p.slab_off = win->d_slab_off.as<int64_t>();
   p.row_lo = win->d_row_lo.as<int32_t>();
@@ -105,6 +108,7 @@ static int repaint_rows(rl_window *win, float *kernel_ms) {
     return RL_EHIP;
   }
   if (kernel_ms) (void)hipEventElapsedTime(kernel_ms, ctx->ev0, ctx->ev2);
+  ctx->repaint_launches++;
   one_at_a_time.unlock();
   win->repaints++;
   if (!win->have_logscales) {  // (every launch writes all of them, with the same values)
@@ -315,9 +319,28 @@ rl_window *rl_window_open_bounded(rl_ctx *ctx, int w, const char *paint_file, in
     rc = rc ? rc : win->d_be.upload(be);
     rc = rc ? rc : win->d_la.upload(la);
     rc = rc ? rc : win->d_lb.upload(lb);
-  } else {
+  } else if (ctx->stones_disposable && !ctx->h_alpha) {
     // decode(encode(x)): the paint file's round trip is part of the numerics -- floats, and runs of
-    // nearly equal values replaced by their first (collapsed_matrix.hpp:228-296) -- applied where the stones are
+    // nearly equal values replaced by their first (collapsed_matrix.hpp:228-296) -- applied to the context's slice
+    // where it lies, once
+    const size_t sn = (size_t)nloc * N;
+    float *ca = ctx->d_alpha.as<float>() + (size_t)w * sn, *cb = ctx->d_beta.as<float>() + (size_t)w * sn;
+    std::lock_guard<std::mutex> s0_is_mine(ctx->repaint_mutex);
+    if (ctx->stone_quantised.size() != (size_t)W) ctx->stone_quantised.assign((size_t)W, 0);
+    if (!ctx->stone_quantised[w]) {
+      if (launch_quantise(ca, nloc, N, ctx->s0) != hipSuccess || launch_quantise(cb, nloc, N, ctx->s0) != hipSuccess ||
+          hipStreamSynchronize(ctx->s0) != hipSuccess) {
+        set_error("stone quantisation on the device failed");
+        rc = RL_EHIP;
+      }
+      ctx->stone_quantised[w] = 1;
+    }
+    win->ab = ca;
+    win->be = cb;
+    win->la = ctx->d_lsa.as<float>() + (size_t)w * nloc;
+    win->lb = ctx->d_lsb.as<float>() + (size_t)w * nloc;
+  } else {
+    // the same on a copy: the context's stones stay as painted (rl_write_paint_files may still want them)
     const size_t sn = (size_t)nloc * N;
     rc = rc ? rc : win->d_ab.alloc(sn * 4);
     rc = rc ? rc : win->d_be.alloc(sn * 4);
@@ -346,6 +369,12 @@ rl_window *rl_window_open_bounded(rl_ctx *ctx, int w, const char *paint_file, in
       rc = RL_EHIP;
     }
   }
+  if (!win->ab) {
+    win->ab = win->d_ab.as<float>();
+    win->be = win->d_be.as<float>();
+    win->la = win->d_la.as<float>();
+    win->lb = win->d_lb.as<float>();
+  }
   rc = rc ? rc : win->d_ib.upload(ib);
   rc = rc ? rc : win->d_ie.upload(ie);
   rc = rc ? rc : win->d_cfl.upload(cf_last);
@@ -355,8 +384,7 @@ rl_window *rl_window_open_bounded(rl_ctx *ctx, int w, const char *paint_file, in
   rc = rc ? rc : win->d_ck_off.upload(win->ck_off);
   rc = rc ? rc : win->d_top.alloc((size_t)std::min(rows, win->cap_rows) * S * 64 * waves * sizeof(float));
   rc = rc ? rc : win->d_ls.alloc((size_t)rows * sizeof(float));
-  rc = rc ? rc : win->d_matrix.alloc((size_t)nloc * N * sizeof(float));
-  if (rc) {
+  if (rc) {  // (d_matrix: when a matrix is first asked for into host memory)
     delete win;
     return nullptr;
   }
@@ -506,7 +534,7 @@ static int window_matrix(rl_window *win, int snp, float *d_host, void *d_dev, fl
   if (!win->stream) {
     if (make_stream(&win->stream, false) != hipSuccess ||
         hipEventCreate(&win->e0) != hipSuccess || hipEventCreate(&win->e2) != hipSuccess ||
-        hipHostMalloc(reinterpret_cast<void **>(&win->h_stage), ((stage_bytes + 7) & ~(size_t)7) + 8, 0) != hipSuccess) {
+        !(win->h_stage = static_cast<unsigned char *>(pinned_cache_alloc(((stage_bytes + 7) & ~(size_t)7) + 8, &win->h_stage_bytes)))) {
       set_error("rl_window_matrix: stream / staging buffer creation failed");
       return RL_EHIP;
     }
@@ -535,6 +563,7 @@ static int window_matrix(rl_window *win, int snp, float *d_host, void *d_dev, fl
   p.wr = reinterpret_cast<const double *>(ds + o_wr);
   p.e_pn = reinterpret_cast<const float *>(ds + o_epn);
   p.e_np = reinterpret_cast<const float *>(ds + o_enp);
+  if (!d_dev && (rc = win->d_matrix.alloc((size_t)nloc * N * sizeof(float)))) return rc;
   p.matrix = d_dev ? static_cast<float *>(d_dev) : win->d_matrix.as<float>();
   RL_HIP(hipEventRecord(win->e0, win->stream));
   RL_HIP(launch_matrix(p, ctx->lay, ctx->S, ctx->waves, win->stream));

@@ -139,3 +139,53 @@ def test_large_trees_state_in_lds_and_in_global_memory(N):
     rng = np.random.RandomState(N)
     prior = (np.floor(rng.rand(N, N) * 3) * 6.9).astype(np.float32)
     run_sequence(N, [(split_tree_matrix(rng, N), None), (split_tree_matrix(rng, N), prior)])
+
+
+def test_builders_side_by_side_with_hand_overs_and_the_symmetric_pool(monkeypatch):
+    """Several builders at once, as the sections of a stage: workers pull their trees from one queue.  One builder's
+    flat matrix is handed to the host (status 2) WHILE the others' workgroups are building -- the status word
+    must be out before the host hears of the tree, no end-of-launch write-back helps --, two builders
+    need the symmetric matrix at the same time with ONE in the device's pool: one takes it, the other's tree goes to
+    the host (status 1).  Every tree equals the host builder's."""
+    import threading
+    monkeypatch.setenv("RELATE_AMD_BUILD_SYM_SLOTS", "1")
+    N = 1300
+    rng = np.random.RandomState(11)
+    flat = np.full((N, N), 2.5, np.float32)
+    np.fill_diagonal(flat, 0)
+    idx = np.arange(N)
+    circ = (((idx[None, :] - idx[:, None]) % N) * 10.0).astype(np.float32)
+    plans = [[(coalescent_matrix(rng, N), None), (flat, None), (coalescent_matrix(rng, N), None)],
+             [(circ, None), (circ + rng.rand(N, N).astype(np.float32), None)],
+             [(circ, None), (coalescent_matrix(rng, N), None)],
+             [(coalescent_matrix(rng, N), None), (coalescent_matrix(rng, N), flat * 2), (flat, None)]]
+    want = []
+    for mats in plans:
+        host = api.Builder(N)
+        want.append([host.build(d, p) for d, p in mats])
+        host.close()
+    devs = [api.Builder(N, device=0) for _ in plans]
+    got = [None] * len(plans)
+    on_gpu = [0] * len(plans)
+
+    def work(b):
+        out = []
+        for d, p in plans[b]:
+            out.append(devs[b].build(d, p))
+            on_gpu[b] += devs[b].last_on_gpu
+        got[b] = out
+
+    threads = [threading.Thread(target=work, args=(b,)) for b in range(len(plans))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for b in range(len(plans)):
+        assert got[b] is not None
+        for t, (ref, g) in enumerate(zip(want[b], got[b])):
+            for a, c in zip(ref, g):
+                assert np.array_equal(a, c), (b, t)
+    for d in devs:
+        d.close()
+    assert on_gpu[0] == 2 and on_gpu[3] == 2  # the flat matrices went to the host, the others stayed
+    assert 2 <= on_gpu[1] + on_gpu[2] <= 4    # with one symmetric matrix in the pool a circulant tree may be the host's

@@ -37,8 +37,11 @@ def write_synth_haps(work, N, L, seed):
 
 
 def compare_dirs(a, b):
-    fa, fb = sorted(os.listdir(a)), sorted(os.listdir(b))
+    """a: the reference's directory, b: ours -- which holds, next to the reference's files, the bit-packed panel
+    chunk_<i>.bits of every chunk (checked against the .hap file by test_bits_file_is_the_hap_file_bit_packed)"""
+    fa, fb = sorted(os.listdir(a)), sorted(f for f in os.listdir(b) if not f.endswith(".bits"))
     assert fa == fb
+    assert sorted(f for f in os.listdir(b) if f.endswith(".bits")) == sorted(f[:-4] + ".bits" for f in fb if f.endswith(".hap"))
     for fn in fa:
         assert open(os.path.join(a, fn), "rb").read() == open(os.path.join(b, fn), "rb").read(), fn
     return fa
@@ -81,7 +84,7 @@ def test_makechunks_matches_committed_reference_outputs(tmp_path, tag, memory, e
                         "--memory", memory] + extra + ["-o", "ours"], cwd=work, stderr=subprocess.PIPE)
     assert p.returncode == 0, p.stderr.decode()
     want = sorted(k.split("/", 2)[2] for k in z.files if k.startswith(tag + "/md5/"))
-    assert sorted(os.listdir(os.path.join(work, "ours"))) == want
+    assert sorted(f for f in os.listdir(os.path.join(work, "ours")) if not f.endswith(".bits")) == want
     for fn in want:
         b = open(os.path.join(work, "ours", fn), "rb").read()
         if "%s/file/%s" % (tag, fn) in z.files:
@@ -142,3 +145,34 @@ def test_makechunks_gz_example_matches_reference(tmp_path):
     args[-1] = "0.0005"
     p = subprocess.run([CLI] + args + ["-o", "small"], cwd=work, stderr=subprocess.PIPE)
     assert p.returncode != 0 and p.stderr
+
+
+def test_bits_file_is_the_hap_file_bit_packed(tmp_path):
+    """chunk_<i>.bits (this library's side output of MakeChunks, the layout rl_set_chunk_bits takes) against
+    chunk_<i>.hap, the reference's char panel, for every chunk of a multi-chunk job (rows carried over the
+    20000-SNP overlap included); RELATE_AMD_CHUNK_BITS=0 leaves the reference's files alone"""
+    work = str(tmp_path)
+    N, L = 70, 26000
+    write_synth_haps(work, N, L, seed=3)
+    args = ["--mode", "MakeChunks", "--haps", "s.haps", "--sample", "s.sample", "--map", "s.map", "--memory", "0.0064"]
+    p = subprocess.run([CLI] + args + ["-o", "ours"], cwd=work, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr.decode()
+    chunks = sorted(f for f in os.listdir(os.path.join(work, "ours")) if f.endswith(".hap"))
+    assert len(chunks) >= 2
+    for f in chunks:
+        hap = open(os.path.join(work, "ours", f), "rb").read()
+        hl, hn = np.frombuffer(hap, np.uint64, 2)
+        seq = np.frombuffer(hap, np.uint8, int(hl * hn), 16).reshape(int(hl), int(hn))
+        bits = open(os.path.join(work, "ours", f[:-4] + ".bits"), "rb").read()
+        magic, bn, bl, rw = np.frombuffer(bits, np.uint32, 4)
+        assert (magic, bn, bl, rw) == (0x31424c52, hn, hl, (hn + 31) // 32)
+        words = np.frombuffer(bits, np.uint32, int(bl) * int(rw), 16).reshape(int(bl), int(rw))
+        want = np.zeros((int(hl), int(rw) * 32), np.uint8)
+        want[:, :int(hn)] = seq == ord("1")
+        assert np.array_equal(np.packbits(want, axis=1, bitorder="little").view(np.uint32), words), f
+    p = subprocess.run([CLI] + args + ["-o", "plain"], cwd=work, stderr=subprocess.PIPE,
+                       env=dict(os.environ, RELATE_AMD_CHUNK_BITS="0"))
+    assert p.returncode == 0, p.stderr.decode()
+    assert not [f for f in os.listdir(os.path.join(work, "plain")) if f.endswith(".bits")]
+    assert sorted(os.listdir(os.path.join(work, "plain"))) == sorted(
+        f for f in os.listdir(os.path.join(work, "ours")) if not f.endswith(".bits"))

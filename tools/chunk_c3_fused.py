@@ -49,15 +49,21 @@ try:
         m = re.search(r"(\d+) trees kept of (\d+) built", l)
         if m:
             trees += int(m.group(2))
-    out["trees_built"] = trees
-    out["trees_per_s"] = trees / out["wall_s"]
+    # trees kept: the count in every .anc header (byte has_ages, u32 N, u32 trees)
+    import struct
+    kept = 0
+    for f in os.listdir(os.path.join(d, "chunk_0")):
+        if f.endswith(".anc"):
+            with open(os.path.join(d, "chunk_0", f), "rb") as fh:
+                kept += struct.unpack("<I", fh.read(9)[5:9])[0]
+    out["trees_kept"] = kept
+    out["trees_built"] = trees if trees else kept  # (built, incl. the rejected ones, only with the timing lines)
+    out["trees_per_s"] = out["trees_built"] / out["wall_s"]
     out["anc_GB"] = sum(os.path.getsize(os.path.join(d, "chunk_0", f)) for f in os.listdir(os.path.join(d, "chunk_0"))
                         if f.endswith(".anc")) / 1e9
     out["stage_lines"] = [l.strip() for l in err.split("\n") if l.startswith("[") and "tree sequence" not in l
-                          and "[tree builder launch]" not in l and "[gpu tree builder]" not in l][:12]
-    sizes = [int(re.search(r"launch\] (\d+) trees", l).group(1)) for l in err.split("\n") if "[tree builder launch]" in l]
-    if sizes:
-        out["builder_launches"] = {"launches": len(sizes), "mean_trees_per_launch": sum(sizes) / len(sizes), "max": max(sizes)}
+                          and "[tree builder workers]" not in l and "[gpu tree builder]" not in l][:12]
+    out["builder_worker_launches"] = [l.strip() for l in err.split("\n") if "[tree builder workers]" in l][:24]
     out["builder_host_side"] = [l.strip() for l in err.split("\n") if "host ms per tree" in l][:6]
     acc, ntr = {}, 0
     for l in err.split("\n"):

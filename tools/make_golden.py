@@ -215,6 +215,101 @@ def n5000_fixture(N=5000, L=1200, mem=10.0):
           "%.1f KB" % (os.path.getsize(os.path.join(GOLD, "n5000.npz")) / 1e3))
 
 
+def n5000_matrix_fixture(N=5000, L=1200, mem=10.0, rows=(0, 1, 2, 1250, 2500, 3750, 4998, 4999)):
+    """GetMatrix of the reference at the headline tile (the chunk of n5000_fixture): window 0's distance matrix at its
+    first SNP and at two later ones -- `rows` of each in full (a 5000 x 5000 matrix is 100 MB), the md5 of the whole
+    matrix, and the largest |logscale| of the window's posterior rows (the scale of the tolerance SURVEY.md 7 H1
+    derives for re-associated sums)."""
+    import ctypes as C
+    import hashlib
+    from relate_amd import api
+    lib = api.lib()
+    seq = np.zeros((L, N), dtype=np.uint8)
+    bp = np.zeros(L, dtype=np.int32)
+    r = np.zeros(L); rpos = np.zeros(L + 1)
+    assert lib.rl_synth_panel(N, L, C.c_uint64(1), 100, 1, seq.ctypes.data_as(C.c_void_p), None, 0,
+                              bp.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p),
+                              rpos.ctypes.data_as(C.c_void_p)) == 0
+    budget = mem * 1e9 / 4.0 - (2.0 * N * N + 3.0 * N)
+    wb = np.zeros(L + 2, dtype=np.int32)
+    W = lib.rl_synth_windows(N, L, seq.ctypes.data_as(C.c_void_p), C.c_double(budget), wb.ctypes.data_as(C.c_void_p), 499)
+    assert W >= 2, W
+    s0, s1 = int(wb[0]), int(wb[1]) - 1
+    snps = [s0 + (s1 - s0) // 3, s1 - 1]
+    data = {"meta": np.array([N, L, W, 1], dtype=np.int64), "mem": np.array([mem]), "rows": np.array(rows, dtype=np.int32),
+            "snps": np.array([s0] + snps, dtype=np.int32)}
+    with tempfile.TemporaryDirectory() as work:
+        d = os.path.join(work, "out")
+        os.makedirs(d)
+        lib.rl_write_chunk_files.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int]
+        assert lib.rl_write_chunk_files(d.encode(), 0, N, L, seq.ctypes.data_as(C.c_void_p),
+                                        bp.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p),
+                                        rpos.ctypes.data_as(C.c_void_p), wb.ctypes.data_as(C.c_void_p), W) == 0
+        run([rlutil.REF_RELATE, "--mode", "Paint", "--chunk_index", "0", "-o", "out"], work)
+        run([rlutil.REF_HARNESS, "matrix", "out", "0", "0", "mx.bin"] + [str(s) for s in snps], work)
+        buf = open(os.path.join(work, "mx.bin"), "rb").read()
+        assert np.frombuffer(buf, np.int32, 1, 0)[0] == N
+        pos = 4
+        for i in range(3):
+            s = int(np.frombuffer(buf, np.int32, 1, pos)[0]); pos += 4
+            assert s == data["snps"][i]
+            m = np.frombuffer(buf, np.float32, N * N, pos).reshape(N, N); pos += 4 * N * N
+            data["matrix_rows/%d" % i] = m[list(rows)].copy()
+            data["matrix_md5/%d" % i] = np.frombuffer(hashlib.md5(m.tobytes()).digest(), dtype=np.uint8)
+        # the window's logscales: RePaintSection dump of a few targets (each D x N floats) is enough for the scale
+        run([rlutil.REF_HARNESS, "repaint", "out", "0", "0", "rp.bin"], work)
+        rb = open(os.path.join(work, "rp.bin"), "rb")
+        assert np.frombuffer(rb.read(4), np.int32)[0] == N
+        scale = 0.0
+        for n in range(N):
+            D = int(np.frombuffer(rb.read(4), np.int32)[0])
+            ls = np.frombuffer(rb.read(4 * D), np.float32)
+            scale = max(scale, float(np.abs(ls).max()))
+            rb.seek(4 * D * N, 1)
+        data["logscale_max"] = np.array([scale])
+    np.savez_compressed(os.path.join(GOLD, "n5000_matrix.npz"), **data)
+    print("n5000_matrix snps", data["snps"], "max |logscale| %.1f" % scale,
+          "%.1f KB" % (os.path.getsize(os.path.join(GOLD, "n5000_matrix.npz")) / 1e3))
+
+
+def pipeline_fixture(N=6, L=50000, memory="0.0005"):
+    """The many-chunks route end to end (BASELINE.json config #4's shape, scripts/RelateParallel/RelateParallel.sh:216-262)
+    on the synthetic .haps of tests/test_makechunks.py: the reference's MakeChunks (3 overlapping chunks), then per
+    chunk Paint, BuildTopology of all sections and FindEquivalentBranches.  The fixture keeps the md5 of every paint
+    file and of every .anc / .mut as FindEquivalentBranches leaves them; the test regenerates the inputs from the seed."""
+    import hashlib
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_makechunks import write_synth_haps
+    md5 = lambda b: np.frombuffer(hashlib.md5(b).digest(), dtype=np.uint8)
+    data = {"args": np.array([N, L], dtype=np.int64), "memory": np.array([float(memory)])}
+    with tempfile.TemporaryDirectory() as work:
+        write_synth_haps(work, N, L, seed=N)
+        for fn in ("s.haps", "s.sample", "s.map"):
+            data["in_md5/" + fn] = md5(open(os.path.join(work, fn), "rb").read())
+        run([rlutil.REF_RELATE, "--mode", "MakeChunks", "--haps", "s.haps", "--sample", "s.sample", "--map", "s.map",
+             "--memory", memory, "-o", "job"], work)
+        C = int(np.fromfile(os.path.join(work, "job", "parameters.bin"), dtype=np.int32, count=3)[2])
+        data["num_chunks"] = np.array([C], dtype=np.int64)
+        total = 0
+        for c in range(C):
+            W = int(np.fromfile(os.path.join(work, "job", "parameters_c%d.bin" % c), dtype=np.int32, count=3)[2]) - 1
+            run([rlutil.REF_RELATE, "--mode", "Paint", "--chunk_index", str(c), "-o", "job"], work)
+            for w in range(W):
+                data["c%d/paint/relate_%d.bin" % (c, w)] = md5(
+                    open(os.path.join(work, "job", "chunk_%d" % c, "paint", "relate_%d.bin" % w), "rb").read())
+            run([rlutil.REF_RELATE, "--mode", "BuildTopology", "--chunk_index", str(c), "--first_section", "0",
+                 "--last_section", str(W - 1), "-o", "job"], work)
+            run([rlutil.REF_RELATE, "--mode", "FindEquivalentBranches", "--chunk_index", str(c), "-o", "job"], work)
+            for w in range(W):
+                for ext in ("anc", "mut"):
+                    data["c%d/job_%d.%s" % (c, w, ext)] = md5(
+                        open(os.path.join(work, "job", "chunk_%d" % c, "job_%d.%s" % (w, ext)), "rb").read())
+            data["c%d/sections" % c] = np.array([W], dtype=np.int64)
+            total += W
+    np.savez_compressed(os.path.join(GOLD, "pipeline6.npz"), **data)
+    print("pipeline6: %d chunks, %d sections, %.1f KB" % (C, total, os.path.getsize(os.path.join(GOLD, "pipeline6.npz")) / 1e3))
+
+
 def ages_fixture(name="synth24_ages", N=24, L=900, seed=21, budget=4000):
     """BuildTopology --sample_ages (ancient samples) of the synth24 chunk: the ages file and the reference's .anc / .mut
     of every section, with the default consistency prior and with --no_consistency"""
@@ -277,11 +372,17 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "ages":
         ages_fixture()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "pipeline":
+        pipeline_fixture()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "noisy":
         noisy_fixture()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "makechunks":
         makechunks_fixture()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "n5000_matrix":  # a few minutes, ~30 GB of scratch files
+        n5000_matrix_fixture()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "n5000":  # ~15 minutes of the single-threaded reference
         n5000_fixture()
