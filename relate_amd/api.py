@@ -31,7 +31,8 @@ def lib():
             raise RelateError(
                 "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(make -C relate_amd/csrc)" % LIB_PATH)
-        L = C.CDLL(LIB_PATH)
+        # (RELATE_AMD_LIB: another build of the library, tools/bench_builder_variants.py)
+        L = C.CDLL(os.environ.get("RELATE_AMD_LIB") or LIB_PATH)
         L.rl_last_error.restype = C.c_char_p
         L.rl_version.restype = C.c_char_p
         L.rl_create.restype = C.c_void_p

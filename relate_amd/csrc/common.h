@@ -30,16 +30,16 @@ void set_error(const char *fmt, ...);
 
 // Streams of the stage: the tree builder's long-running workgroups go to lowest-priority streams, which the runtime
 // maps to hardware queues of their own -- the short kernels of the stage (distance matrices, penalty, prior, the weave
-// of the next tree) must not queue up behind one.  (Tried: CU masks that keep the other kernels off the builder's
+// of the next tree) must not queue up behind one.  The context's stream (Paint; RePaint of the stage's windows,
+// tens of milliseconds per launch when the workers hold most of the chip) is a highest-priority stream for the
+// same reason: a hardware queue of its own instead of one shared with the streams of two dozen sections.  (Tried: CU masks that keep the other kernels off the builder's
 // CUs, hipExtStreamCreateWithCUMask with 3 or 4 of every 8 CUs for the trees -- the 80-section stage did not finish
 // in four times its usual time.)
-inline hipError_t make_stream(hipStream_t *s, bool tree_builder) {
-  if (tree_builder) {
-    int least = 0, greatest = 0;
-    if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess &&
-        hipStreamCreateWithPriority(s, hipStreamNonBlocking, least) == hipSuccess)
-      return hipSuccess;
-  }
+inline hipError_t make_stream(hipStream_t *s, bool tree_builder, bool repaint = false) {
+  int least = 0, greatest = 0;
+  if ((tree_builder || repaint) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess &&
+      hipStreamCreateWithPriority(s, hipStreamNonBlocking, tree_builder ? least : greatest) == hipSuccess)
+    return hipSuccess;
   return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
 }
 
@@ -148,6 +148,7 @@ struct rl_ctx {
   // time (the windows' other work -- distance matrices -- runs on their own streams, side by side)
   std::mutex repaint_mutex;
   long long repaint_launches = 0;  // (under repaint_mutex) RePaint launches of the context's windows
+  double repaint_ms = 0.0;         // ... and their time on the device (HIP events)
   float ms_fwd = 0.f, ms_bwd = 0.f, ms_paint = 0.f;
   int paint_split = 0;  // rl_set_paint_split: one launch per direction instead of one for both
 };

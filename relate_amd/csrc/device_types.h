@@ -95,6 +95,13 @@ struct RepaintParams {
   int sum_mode;
   int partial;                // the logscales of every row are in place (an earlier launch of this window wrote them):
                               // the forward pass may stop below row_hi, the backward pass at row_lo
+  // A bounded window keeps ONE state of the backward pass per target -- beta (doubles, register-major like a
+  // checkpoint row), the step's factor and the running logscale as they stand before row r is done -- so that a
+  // later launch, whose rows lie below r, starts there instead of at the window's last row.  save_row[t] >= 0: this
+  // launch leaves the state at that row; start_row[t] >= 0: it starts from the state kept there (window.cpp).
+  double *bstate;             // [nloc][waves][S*64], or null
+  double *bscal;              // [nloc][2]
+  const int32_t *start_row, *save_row;  // [nloc]
 };
 
 struct MatrixParams {

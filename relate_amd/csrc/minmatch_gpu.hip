@@ -16,6 +16,7 @@
 // carry from tree to tree (min_values_CF and the stale candidate indices, minmatch.h) is copied in before and
 // out after every build, so host and device builders can alternate on a section.
 #include <hip/hip_runtime.h>
+#include <unistd.h>
 
 #include <atomic>
 #include <chrono>
@@ -37,9 +38,15 @@ namespace rl {
 
 namespace {
 
-constexpr int MM_BLOCK = 512;   // (8 waves: 256 registers per lane -- a thread keeps ~10 clusters of a merge in registers)
+#ifndef MM_BLOCK_N
+#define MM_BLOCK_N 512
+#endif
+constexpr int MM_BLOCK = MM_BLOCK_N;   // (8 waves: 256 registers per lane -- a thread keeps ~10 clusters of a merge in registers)
 constexpr int MM_WAVES = MM_BLOCK / 64;
-constexpr int MM_ROWS = 3;        // rows of rebuilt clusters scanned per pass of a merge (2 once a thread holds > 10 clusters)
+#ifndef MM_ROWS_N
+#define MM_ROWS_N 2  // (3: 119 ms per N = 5000 tree, 2: 110, 4: 134 -- registers)
+#endif
+constexpr int MM_ROWS = MM_ROWS_N;  // rows of rebuilt clusters scanned per pass of a merge (2 once a thread holds > 10 clusters)
 constexpr int MM_HITS = 64;       // mutually close pairs per row pairscan_kernel keeps; more: the host builds the tree
 constexpr int MM_UPD_MAX = 512;   // rebuilt clusters of one merge (list in LDS); more: the host builds the tree
 constexpr int MM_PAIRS_LDS = 768; // feasible pairs of one merge kept in LDS; more go through global scratch
@@ -53,6 +60,7 @@ __host__ __device__ inline unsigned mm_index(unsigned a, unsigned b, unsigned N)
 }
 __host__ __device__ inline size_t mm_elements(size_t N) { return ((N + MM_PANEL - 1) / MM_PANEL) * N * MM_PANEL; }
 constexpr int MM_MAXN = 10240;    // one thread holds up to 20 clusters of a merge in registers
+constexpr int MM_Q_LDS = 5120 / MM_BLOCK, MM_Q_GLOB = MM_MAXN / MM_BLOCK;  // register slots per thread: state in LDS / global
 
 // A tree's parameters.  The matrices of a build, woven: M[a][b] = (d(a,b), d(b,a), cf(a,b), cf(b,a)).  A merge needs,
 // per cluster k, the entries (i,k), (k,i), (j,k), (k,j) of both matrices: two 16-byte loads along the rows of i and j
@@ -111,7 +119,11 @@ constexpr int MM_MAXN = 10240;    // one thread holds up to 20 clusters of a mer
   PTR(long long) timers; /* optional: 100 MHz ticks per phase (RELATE_AMD_TIMING) */                                 \
   PTR(unsigned) trace;   /* optional (RELATE_AMD_MM_TRACE): [0] merge, [1] phase the workgroup has reached */
 #define MM_HOST_PTR(T) T *
+#ifdef MM_FLAT  // (experiment: pointers of unknown address space, as before round 3)
+#define MM_GLOBAL_PTR(T) T *
+#else
 #define MM_GLOBAL_PTR(T) __attribute__((address_space(1))) T *
+#endif
 // (a class type -- HIP's float4 -- has no member functions outside the generic address space: the device struct
 //  takes the elements of M as native vectors)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -200,7 +212,8 @@ struct Shared {
   unsigned praw[MM_PARAM_WORDS];  // the tree's parameters as the worker read them from the queue
   unsigned ticket;
   int sym_slot;
-  long long tacc[12], tmark;
+  long long tacc[16], tmark;
+  int cnt_rescan_only;  // (statistics, RELATE_AMD_TIMING) rebuilt clusters of the merge whose candidate does not touch i or j
   Rng rng;
   Best best, best_sym;
   int use_sym;
@@ -232,7 +245,7 @@ template <bool LDS>
 struct State {
   typedef typename std::conditional<LDS, short, int>::type idx_t;
   template <typename T>
-  using ptr = typename std::conditional<LDS, T *, __attribute__((address_space(1))) T *>::type;  // (LDS: inferred)
+  using ptr = typename std::conditional<LDS, T *, MM_GLOBAL_PTR(T)>::type;  // (LDS: inferred)
   ptr<float> mv, mvcf, mcd, mcd2;  // min_values, min_values_CF, candidate (dist, dist2)
   ptr<idx_t> lin1, lin2;           // candidate pair (stale indices are part of the carried state)
   ptr<idx_t> ci;                   // the live clusters in order
@@ -377,7 +390,7 @@ __device__ inline void block_min3(float &f, int &a, int &b, float *bf, int *ba, 
 template <bool LDS, int MAXQ>
 __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, unsigned char *dyn) {
   typedef typename State<LDS>::idx_t idx_t;
-  constexpr int ROWS = MAXQ > 10 ? 2 : MM_ROWS;  // rows of rebuilt clusters per pass (ROWS * MAXQ <= 64 bits of survivors)
+  constexpr int ROWS = MAXQ * MM_ROWS > 64 ? 64 / MAXQ : MM_ROWS;  // rows of rebuilt clusters per pass (ROWS * MAXQ <= 64 bits of survivors)
   const int N = p.N;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float INF = INFINITY;
@@ -408,7 +421,8 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
   }
   // (timing: thread 0 only, accumulators in LDS -- twelve 64-bit counters per thread would cost the kernel its registers)
   if (tid == 0) {
-    for (int x = 0; x < 12; x++) sh.tacc[x] = 0;
+    for (int x = 0; x < 16; x++) sh.tacc[x] = 0;
+    sh.cnt_rescan_only = 0;
     sh.tmark = wall_clock64();
   }
   const long long tstart = wall_clock64(), cstart = clock64();
@@ -482,28 +496,45 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
   // lane 0 does the writes; the lanes matter when the generator's state is renewed (624 words, 64 at a time).
   // Per pair the LDS reads -- two words of the generator, both clusters' candidates, the next pair's record -- are
   // independent and go out together: one LDS latency per pair.
-  int ridx = 624;  // (wave 0: position in the generator's state)
-  auto next_word = [&]() -> uint32_t {
-    if (ridx >= 624) {
-      rng_renew_wave(sh.rng, lane);
-      ridx = 0;
+  // The draws come 64 at a time: lane l tempers words ridx + 2l, ridx + 2l + 1 of the state and forms the
+  // (l + 1)-th uniform float from now -- std::uniform_real_distribution<double>(0,1) of libstdc++ (rng_unif),
+  // narrowed to float (tree_builder.hpp:60) --; a pair then takes its number with one readlane instead of two LDS
+  // reads and thirty dependent instructions on the ordered path.  (624 is even: a draw never straddles a renewal.)
+  int ridx = 624;       // (wave 0: position in the generator's state)
+  float rnd_lane = 0.f; // lane l: draw number l of the batch
+  int rnd_have = 0, rnd_at = 0;
+  auto next_rnd = [&]() -> float {
+    if (rnd_at >= rnd_have) {
+      if (ridx >= 624) {
+        rng_renew_wave(sh.rng, lane);
+        ridx = 0;
+      }
+      rnd_have = min(64, (624 - ridx) / 2);
+      const int i0 = lane < rnd_have ? ridx + 2 * lane : 0;
+      uint32_t y1 = sh.rng.mt[i0], y2 = sh.rng.mt[i0 + 1];
+      y1 ^= y1 >> 11;
+      y2 ^= y2 >> 11;
+      y1 ^= (y1 << 7) & 0x9d2c5680u;
+      y2 ^= (y2 << 7) & 0x9d2c5680u;
+      y1 ^= (y1 << 15) & 0xefc60000u;
+      y2 ^= (y2 << 15) & 0xefc60000u;
+      y1 ^= y1 >> 18;
+      y2 ^= y2 >> 18;
+      const double sum = (double)y1 + (double)y2 * 4294967296.0;
+      double ret = sum / 18446744073709551616.0;
+      if (ret >= 1.0) ret = 0.99999999999999988897769753748434595763683319091796875;
+      rnd_lane = (float)ret;
+      ridx += 2 * rnd_have;
+      rnd_at = 0;
     }
-    uint32_t y = sh.rng.mt[ridx++];
-    y ^= y >> 11;
-    y ^= (y << 7) & 0x9d2c5680u;
-    y ^= (y << 15) & 0xefc60000u;
-    y ^= y >> 18;
-    return y;
+    const int at = __builtin_amdgcn_readfirstlane(rnd_at);
+    rnd_at++;
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rnd_lane), at));
   };
   // one feasible pair in the reference's order: one draw, both clusters' best candidate (:1704-1716); -> the draw
   auto apply = [&](int x, int y, float sym) -> float {
-    const uint32_t w1 = next_word(), w2 = next_word();
+    const float rnd = next_rnd();
     const float ad = st.mcd[x], ad2 = st.mcd2[x], bdd = st.mcd[y], bdd2 = st.mcd2[y];
-    // std::uniform_real_distribution<double>(0,1) of libstdc++ (rng_unif), narrowed to float (tree_builder.hpp:60)
-    const double sum = (double)w1 + (double)w2 * 4294967296.0;
-    double ret = sum / 18446744073709551616.0;
-    if (ret >= 1.0) ret = 0.99999999999999988897769753748434595763683319091796875;
-    const float rnd = (float)ret;
     if (lane == 0) {
       if (ad > sym || (ad == sym && ad2 > rnd)) {
         st.lin1[x] = (idx_t)x;
@@ -693,7 +724,11 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
     };
     // (the live list shrinks from N to 2: the register slots past it are skipped by wave-uniform branches, not by
     //  predication -- half of all slots over a build)
+#ifdef MM_NO_SKIP
+    const int nq = MAXQ;
+#else
     const int nq = (n + MM_BLOCK - 1) / MM_BLOCK;
+#endif
     int a_k[MAXQ];
     float mv_cf = INF, mvj = INF, bd = INF, bd2 = INF;
     int bpos = n;
@@ -702,7 +737,10 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
       const int ik = q * MM_BLOCK + tid;
       a_k[q] = ik < n ? (int)st.ci[ik] : -1;
     }
-    constexpr int QC = 5;  // clusters per pass (ten at once cost more in spilled registers than the second round trip)
+#ifndef MM_QC
+#define MM_QC 5
+#endif
+    constexpr int QC = MM_QC;  // clusters per pass (ten at once cost more in spilled registers than the second round trip)
 #pragma unroll
     for (int q0 = 0; q0 < MAXQ; q0 += QC) {
       if (q0 * MM_BLOCK >= n) break;
@@ -751,7 +789,11 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
         if (dki != dkj) nkj = over_added(csi * dki + csj * dkj);
         // (written whether changed or not: the same bits where the reference leaves the entry alone)
         MM(j, k) = f32x4{njk, nkj, ncjk, nckj};
+#ifdef MM_NT_COLUMN  // (experiment: the scattered store past the caches)
+        if (!(p.debug & 2)) __builtin_nontemporal_store(f32x4{nkj, njk, nckj, ncjk}, &MM(k, j));
+#else
         if (!(p.debug & 2)) MM(k, j) = f32x4{nkj, njk, nckj, ncjk};  // (2: timing experiment, wrong trees)
+#endif
         if (njk < mvj) mvj = njk;
         bool rescan = false;
         if (dkj != dki) {
@@ -760,6 +802,7 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
         }
         const int l1 = s_l1[qq], l2 = s_l2[qq];
         const bool touches = l1 == j || l2 == j || l1 == i || l2 == i;
+        if (p.timers && rescan && !touches) atomicAdd(&sh.cnt_rescan_only, 1);
         if (rescan || touches) {  // k rebuilds its candidates (:1893-1911)
           st.flag[k] = 1;
           st.mcd[k] = INF;
@@ -803,6 +846,13 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
     if (nupd > MM_UPD_MAX) {  // (degenerate matrices: this tree is the host's)
       bail = 2;
       break;
+    }
+    if (p.timers && tid == 0) {
+      sh.tacc[12] += nupd * 100;
+      sh.tacc[13] += sh.cnt_rescan_only * 100;
+      sh.tacc[14] += nupd == 0 ? 100 : 0;
+      sh.tacc[15] += sh.cnt_rescan_only > 0 ? 100 : 0;
+      sh.cnt_rescan_only = 0;
     }
 
     // -- B: rows of the rebuilt clusters: (d(k,l), d(l,k)) along row k of M, ROWS rows per pass.  The row-minimum
@@ -1088,6 +1138,7 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
       __syncthreads();
       erase_write();
     }
+    if (p.timers && tid == 0) sh.tacc[10] += wall_clock64() - sh.tmark;  // (of "ordered": before the first draw)
     if (wave == 0) {
       // the clusters whose candidates change, at their turn: after their own pairs
       float sd = INF, sd2 = INF;
@@ -1291,7 +1342,7 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
     }
     if (tid == 0 && p.timers) {
       sh.tacc[11] = (clock64() - cstart) * 100 / (wall_clock64() - tstart + 1);  // shader clock, MHz
-      for (int x = 0; x < 12; x++) p.timers[x] = sh.tacc[x];
+      for (int x = 0; x < 16; x++) p.timers[x] = sh.tacc[x];
     }
     bail = 0;
   }
@@ -1557,10 +1608,10 @@ static bool lds_state_fits(int N) {
   size_t f = fixed.load();
   if (!f) {
     hipFuncAttributes a;
-    if (hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&minmatch_worker<true, 10>)) != hipSuccess) return false;
+    if (hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&minmatch_worker<true, MM_Q_LDS>)) != hipSuccess) return false;
     fixed.store(f = a.sharedSizeBytes);
   }
-  return N <= 10 * MM_BLOCK && f + lds_state_bytes(N) <= (size_t)160 * 1024;
+  return N <= MM_Q_LDS * MM_BLOCK && f + lds_state_bytes(N) <= (size_t)160 * 1024;
 }
 
 static int env_int(const char *name, int fallback, int lo, int hi) {
@@ -1799,7 +1850,7 @@ class BuildQueue {
       }
     size_t dyn = 0;
     if (lds_) {  // the per-cluster state of a build in LDS: more than the default 64 KB of dynamic LDS
-      const void *fn = reinterpret_cast<const void *>(&minmatch_worker<true, 10>);
+      const void *fn = reinterpret_cast<const void *>(&minmatch_worker<true, MM_Q_LDS>);
       hipFuncAttributes a;
       if (hipFuncGetAttributes(&a, fn) != hipSuccess ||
           hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)a.sharedSizeBytes) != hipSuccess) {
@@ -1842,10 +1893,10 @@ class BuildQueue {
         const int l = free_stream;
         const long long idle = (long long)idle_ms_ * 100000LL;
         if (lds_)
-          hipLaunchKernelGGL((minmatch_worker<true, 10>), dim3((unsigned)n), dim3(MM_BLOCK), dyn, streams[l], q_,
+          hipLaunchKernelGGL((minmatch_worker<true, MM_Q_LDS>), dim3((unsigned)n), dim3(MM_BLOCK), dyn, streams[l], q_,
                              d_state_.as<WorkerState>(), l, idle);
         else
-          hipLaunchKernelGGL((minmatch_worker<false, 20>), dim3((unsigned)n), dim3(MM_BLOCK), 0, streams[l], q_,
+          hipLaunchKernelGGL((minmatch_worker<false, MM_Q_GLOB>), dim3((unsigned)n), dim3(MM_BLOCK), 0, streams[l], q_,
                              d_state_.as<WorkerState>(), l, idle);
         if (hipGetLastError() != hipSuccess) {
           failed_.store(true);
@@ -1904,7 +1955,7 @@ struct DeviceMinMatch::Impl {
   hipStream_t stream = nullptr;
   DeviceShare::Staging *staging = nullptr;  // held from device_matrix() / the upload until the matrices are woven
   DevBuf d_M, d_hits, d_f, d_i, d_feas, d_rowlist, d_status, d_flags, d_member, d_tab, d_acc;
-  long long builds = 0;
+  long long builds = 0, n_built = 0;
   double t_prep = 0, t_wait = 0, t_out = 0;  // RELATE_AMD_TIMING: uploads + weave, submit -> tree done, copy-out (s)
   long long n_timed = 0;
   int *h_done = nullptr;  // pinned: the worker's "this tree is out"
@@ -2028,7 +2079,7 @@ int DeviceMinMatch::reserve() {
   rc = rc ? rc : m.d_i.alloc(((size_t)12 * N + 8) * 4);  // ints, see build_impl
   rc = rc ? rc : m.d_feas.alloc((size_t)pair_cap * 6 * 4);
   rc = rc ? rc : m.d_rowlist.alloc((size_t)MM_WAVES * N * 4);
-  rc = rc ? rc : m.d_status.alloc(16 + 12 * 8);
+  rc = rc ? rc : m.d_status.alloc(16 + 16 * 8);
   rc = rc ? rc : m.d_flags.alloc((size_t)N);
   return rc ? -1 : 0;
 }
@@ -2132,8 +2183,22 @@ int DeviceMinMatch::build_impl(MinMatch &tb, const float *d, const float *prior_
     lin[(size_t)N + c] = tb.mc[c].lin2;
     mvcf[c] = tb.min_values_CF[c];
   }
-  RL_HIP(hipMemcpyAsync(p.mc_lin1, lin, (size_t)2 * N * 4, hipMemcpyHostToDevice, m.stream));
+  // (min_values_CF as carried over is also what pairscan_kernel tests the prior with: that copy goes to the device)
+  const float *mvcf_dev = p.min_values_CF;
   RL_HIP(hipMemcpyAsync(p.min_values_CF, mvcf, (size_t)N * 4, hipMemcpyHostToDevice, m.stream));
+  if (p.lds_state) {
+    // The worker reads the carried state from the pinned block and leaves it there again together with the merges:
+    // 100 KB across PCIe per tree instead of three copies and a stream synchronisation behind the build (16 ms per
+    // tree with a hundred sections sharing the hardware queues).  The system-scope fences around a tree in the worker
+    // order them with the request and with "done".
+    p.mc_lin1 = lin;
+    p.mc_lin2 = lin + N;
+    p.min_values_CF = mvcf;
+    p.merge_i = tr;
+    p.merge_j = tr + N;
+  } else {  // (the state lives in these arrays throughout the build: device memory)
+    RL_HIP(hipMemcpyAsync(p.mc_lin1, lin, (size_t)2 * N * 4, hipMemcpyHostToDevice, m.stream));
+  }
   float *dD = m.staging->D.as<float>(), *dCF = prior ? m.staging->CF.as<float>() : nullptr;
   if (!resident) {
     RL_HIP(hipMemcpyAsync(dD, d, NN * 4, hipMemcpyHostToDevice, m.stream));
@@ -2145,7 +2210,7 @@ int DeviceMinMatch::build_impl(MinMatch &tb, const float *d, const float *prior_
     hipLaunchKernelGGL(pack_kernel, grid, dim3(256), 0, m.stream, dD, dCF, p.M, N);
     hipLaunchKernelGGL(rowmin_kernel, dim3(N), dim3(256), 0, m.stream, dD, f + 6 * (size_t)N, N);
     if (prior) hipLaunchKernelGGL(rowmin_kernel, dim3(N), dim3(256), 0, m.stream, dCF, f + 7 * (size_t)N, N);
-    hipLaunchKernelGGL(pairscan_kernel, dim3(N), dim3(256), 0, m.stream, p.M, p.rowmin_D, p.rowmin_CF, p.min_values_CF,
+    hipLaunchKernelGGL(pairscan_kernel, dim3(N), dim3(256), 0, m.stream, p.M, p.rowmin_D, p.rowmin_CF, mvcf_dev,
                        p.has_prior, p.threshold, p.threshold_CF, N, hits, reinterpret_cast<unsigned *>(hits + N),
                        reinterpret_cast<float *>(hits + N + (size_t)N * MM_HITS));
     RL_HIP(hipGetLastError());
@@ -2155,6 +2220,26 @@ int DeviceMinMatch::build_impl(MinMatch &tb, const float *d, const float *prior_
   if (trace) fprintf(stderr, "[mm trace] N=%d inputs submitted\n", N), fflush(stderr);
   RL_HIP(hipStreamSynchronize(m.stream));  // inputs in place
   if (trace) fprintf(stderr, "[mm trace] N=%d inputs in place\n", N), fflush(stderr);
+  if (const char *dump = getenv("RELATE_AMD_MM_DUMP")) {
+    // (tools/bench_builder_variants.py) the matrices of builds first..last of this builder, as the kernel gets them:
+    // "<dir>:<first>:<last>"; the process ends behind the last one
+    char dir[512];
+    int first = 0, last = 0;
+    if (sscanf(dump, "%511[^:]:%d:%d", dir, &first, &last) == 3 && m.n_built >= first && m.n_built <= last) {
+      std::vector<float> host(NN);
+      for (int which = 0; which < (prior ? 2 : 1); which++) {
+        RL_HIP(hipMemcpy(host.data(), which ? (const void *)dCF : (const void *)dD, NN * 4, hipMemcpyDeviceToHost));
+        const std::string fn = std::string(dir) + (which ? "/cf_" : "/d_") + std::to_string(m.n_built) + ".bin";
+        FILE *fp = fopen(fn.c_str(), "wb");
+        if (fp) {
+          fwrite(host.data(), 4, NN, fp);
+          fclose(fp);
+        }
+      }
+      if (m.n_built == last) _exit(0);
+    }
+  }
+  m.n_built++;
   m.drop_staging();                        // (woven: the row-major matrices go back to the pool)
   const auto tb1 = std::chrono::steady_clock::now();
   __atomic_store_n(m.h_done, -1, __ATOMIC_RELEASE);
@@ -2169,20 +2254,24 @@ int DeviceMinMatch::build_impl(MinMatch &tb, const float *d, const float *prior_
   if (trace) fprintf(stderr, "[mm trace] N=%d tree out, status %d\n", N, status), fflush(stderr);
   if (status != 0) return status > 0 ? status : -1;
   if (timing) {
-    long long tk[12];
+    long long tk[16];
     RL_HIP(hipMemcpy(tk, p.timers, sizeof(tk), hipMemcpyDeviceToHost));
     fprintf(stderr, "[gpu tree builder] N=%d, us:", N);
-    static const char *names[12] = {"row minima", "pair scan", "updates", "rescans", "pair tests", "pair order",
-                                    "ordered", "symmetric", "erase", "pairs_x100", "", ""};
-    for (int x = 0; x < 10; x++) fprintf(stderr, " %s %.0f", names[x], tk[x] / 100.0);
+    static const char *names[16] = {"row minima", "pair scan", "updates", "rescans", "pair tests", "pair order",
+                                    "ordered", "symmetric", "erase", "pairs_x100", "before_draws", "", "rebuilt_x100",
+                                    "rescan_only_x100", "merges_none_rebuilt_x100", "merges_with_rescan_only_x100"};
+    for (int x = 0; x < 11; x++) fprintf(stderr, " %s %.0f", names[x], tk[x] / 100.0);
+    for (int x = 12; x < 16; x++) fprintf(stderr, " %s %.0f", names[x], tk[x] / 100.0);
     fprintf(stderr, " shader_MHz %lld\n", tk[11]);
   }
   // out: the tree and the carried state
   // (merge_i [N), merge_j [N) lie back to back)
-  RL_HIP(hipMemcpyAsync(tr, p.merge_i, ((size_t)2 * N - 1) * 4, hipMemcpyDeviceToHost, m.stream));
-  RL_HIP(hipMemcpyAsync(lin, p.mc_lin1, (size_t)2 * N * 4, hipMemcpyDeviceToHost, m.stream));
-  RL_HIP(hipMemcpyAsync(mvcf, p.min_values_CF, (size_t)N * 4, hipMemcpyDeviceToHost, m.stream));
-  RL_HIP(hipStreamSynchronize(m.stream));
+  if (!p.lds_state) {
+    RL_HIP(hipMemcpyAsync(tr, p.merge_i, ((size_t)2 * N - 1) * 4, hipMemcpyDeviceToHost, m.stream));
+    RL_HIP(hipMemcpyAsync(lin, p.mc_lin1, (size_t)2 * N * 4, hipMemcpyDeviceToHost, m.stream));
+    RL_HIP(hipMemcpyAsync(mvcf, p.min_values_CF, (size_t)N * 4, hipMemcpyDeviceToHost, m.stream));
+    RL_HIP(hipStreamSynchronize(m.stream));
+  }
   for (int c = 0; c < N; c++) tb.min_values_CF[c] = mvcf[c];
   tree.reset(N);
   {  // the nodes of the tree from the merges (tree_builder.cpp:2437-2460, 2631-2636): cluster j lives on as the new node

@@ -119,6 +119,7 @@ RL_DEV void repaint_forward(const RepaintParams &p, int n, float *stage, WaveLin
   Chunk first = load_masks<CH>(row, 0);
   // (a later launch of a bounded window: rows from row_hi on are of no use to the backward pass)
   const int Dfwd = p.partial ? min(D, max(1, (int)p.row_hi[t])) : D;
+  const int ck_from = p.partial ? (int)p.row_lo[t] : 0;
   for (int i = 1; i < Dfwd; i++) {
     retire_touch(touched);
     if (i + 1 < D) touched = touch_row(p.masks, S, s2, pl.lane, WAVES, wv);
@@ -163,7 +164,8 @@ RL_DEV void repaint_forward(const RepaintParams &p, int n, float *stage, WaveLin
       cfac = 1.0;
     }
     cfac *= cf_i;
-    if (i % CK == 0) store_row<S>(ckrows + (int64_t)(i / CK) * ROW, a);  // checkpoint row
+    // checkpoint row (a later launch of a bounded window: only the blocks the backward pass rebuilds rows from)
+    if (i % CK == 0 && (!p.partial || i + CK > ck_from)) store_row<S>(ckrows + (int64_t)(i / CK) * ROW, a);
     if (scribe) {  // what the backward pass needs to redo this step from the previous row
       side[(size_t)i * REPAINT_SIDE + 0] = cfac_used;
       side[(size_t)i * REPAINT_SIDE + 1] = divisor;
@@ -314,19 +316,34 @@ RL_DEV void repaint_backward(const RepaintParams &p, int n, float *stage, double
   block_records(cpb, rec, sit);
   block_records(cpb - CK, rec_next, sit_next);
   double b[S];
-  float lsf = (float)lane_value(rec, (D - 1 - cpb) * REPAINT_SIDE + 2);  // the forward pass's last logscale
-  lsf = lsf + p.ls_beta[t];  // float += float (:895)
-  {
+  // (a later launch of a bounded window may start from the state an earlier one left at row jstart: nothing above it
+  //  is asked for -- the rows kept lie below -- and the pass goes on exactly as it would have)
+  const int jstart = (p.bstate && p.partial) ? __builtin_amdgcn_readfirstlane(p.start_row[t]) : -1;
+  const int jsave = p.bstate ? __builtin_amdgcn_readfirstlane(p.save_row[t]) : -1;
+  double *__restrict__ bst = p.bstate ? p.bstate + ((size_t)t * WAVES + wv) * (S * 64) + pl.lane : nullptr;
+  float lsf = 0.0f;
+  if (jstart < 0) {
+    lsf = (float)lane_value(rec, (D - 1 - cpb) * REPAINT_SIDE + 2);  // the forward pass's last logscale
+    lsf = lsf + p.ls_beta[t];  // float += float (:895)
     const ColdRepaint cp = cold_params<RepaintParams>();
     load_stone<S>(pl, cp->beta_end + (size_t)t * cp->lay.N, b, stage);
+    set_slot<S>(b, pl.jk, pl.kbit, 0.0);  // the target's own slot of beta is +0.0 (fast_painting.cpp: b[k] = 0)
+  } else {
+    load_row<S>(bst, b);
+    cpb = (jstart + 1) - (jstart + 1) % CK;  // the block of the row above: the loop steps down from there
+    block_records(cpb, rec, sit);
+    block_records(cpb - CK, rec_next, sit_next);
   }
-  set_slot<S>(b, pl.jk, pl.kbit, 0.0);  // the target's own slot of beta is +0.0 (fast_painting.cpp: b[k] = 0)
   HeldRow<S> ck;  // (the strip shares its LDS with `stage`, which is done with by now)
   ck.lds = strip;
 #pragma unroll
   for (int i = 0; i < (HeldRow<S>::VREG > 0 ? HeldRow<S>::VREG : 1); i++) ck.v[i] = 0.0;
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-  if (block_kept(cpb)) ck.request(ckrows + (int64_t)(cpb / CK) * ROW - pl.lane, pl.lane);
+  {  // the checkpoint row of the block the first row to be done belongs to
+    const int first_row = jstart < 0 ? D - 1 : jstart;
+    const int blk = first_row - first_row % CK;
+    if (block_kept(blk)) ck.request(ckrows + (int64_t)(blk / CK) * ROW - pl.lane, pl.lane);
+  }
   MaskRow rows[CK];
   double cfs[CK], dvs[CK];
   auto open_block = [&]() {
@@ -366,24 +383,38 @@ RL_DEV void repaint_backward(const RepaintParams &p, int n, float *stage, double
       default: if constexpr (CK > 7) product_steps<S, 7, false>(ck, pl.lane, b, trow, rows, cfs, dvs, r, K1); break;
     }
   };
-  int s0 = st[D - 1], s1 = D > 1 ? st[D - 2] : 0, s2 = D > 2 ? st[D - 3] : 0;
-  MaskRow rown = site_row(p.masks, S, p.L, s0, WAVES, wv);
-  double bsum;
-  {  // the window's last row: beta is the stone (:930)
-    const MaskTerm<S> term{rown, b, theta, ntheta};
-    bsum = wave_sum<MODE, S, WAVES>(term, local_sum<S>(term), lk);
-  }
-  product_row(D - 1, true);
   // (a later launch of a bounded window: the logscales are in place, the forward pass stopped below row_hi -- its
   //  records above are not there -- and nothing below row_lo is asked for)
   const int jstop = p.partial ? max(0, row_lo) : 0, jls = p.partial ? row_hi : D;
-  if (pl.lane == 0 && wv == 0 && D - 1 < jls) lsout[D - 1] = lsf;
-  double cfac = cf_last * bsum;
-  double prev_ls = (double)p.ls_beta[t];  // :951
+  const int jtop = jstart < 0 ? D - 2 : jstart;  // the first row the loop does
+  // at the top of row j: s0 = site j + 1, s1 = site j, s2 = site j - 1
+  int s0 = st[jtop + 1], s1 = jtop >= 0 ? st[jtop] : 0, s2 = jtop >= 1 ? st[jtop - 1] : 0;
+  MaskRow rown = site_row(p.masks, S, p.L, s0, WAVES, wv);
+  double bsum, cfac, prev_ls;
+  if (jstart < 0) {
+    {  // the window's last row: beta is the stone (:930)
+      const MaskTerm<S> term{rown, b, theta, ntheta};
+      bsum = wave_sum<MODE, S, WAVES>(term, local_sum<S>(term), lk);
+    }
+    product_row(D - 1, true);
+    if (pl.lane == 0 && wv == 0 && D - 1 < jls) lsout[D - 1] = lsf;
+    cfac = cf_last * bsum;
+    prev_ls = (double)p.ls_beta[t];  // :951
+  } else {
+    cfac = p.bscal[(size_t)t * 2];
+    prev_ls = p.bscal[(size_t)t * 2 + 1];
+  }
   MaskRow rowh = site_row(p.masks, S, p.L, s1, WAVES, wv);
   u64x4 firstn = load_masks<4>(rown, 0), firsth = load_masks<4>(rowh, 0);
   uint32_t touched = 0;
-  for (int j = D - 2; j >= jstop; j--) {
+  for (int j = jtop; j >= jstop; j--) {
+    if (j == jsave) {  // the state before row j, for the launches to come (window.cpp: place_rows)
+      store_row<S>(bst, b);
+      if (pl.lane == 0 && wv == 0) {
+        p.bscal[(size_t)t * 2] = cfac;
+        p.bscal[(size_t)t * 2 + 1] = prev_ls;
+      }
+    }
     if (j < cpb) {  // the pass enters the block below: its records were requested a block ago
       cpb -= CK;
       rec = rec_next;

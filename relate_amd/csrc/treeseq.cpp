@@ -814,9 +814,11 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
     rl_destroy(ctx);
     return RL_ENOMEM;
   }
+  // (a bounded window also keeps one state of RePaint's backward pass per target, doubles: window.cpp)
+  const double bstate_bytes = 2.0 * row_bytes * ctx->nloc + 16.0 * ctx->nloc;
   auto window_bytes = [&](int w) {
     const double kept = cap_rows > 0 ? std::min(rows_of[w], (double)cap_rows) : rows_of[w];
-    return kept * row_bytes + fixed_bytes;
+    return kept * row_bytes + fixed_bytes + (cap_rows > 0 && cap_rows < rows_of[w] ? bstate_bytes : 0.0);
   };
   // (section threads of device builds mostly wait for their tree: as many as there are CUs to build on)
   int nthreads = gpu_build ? 256 : std::max(1, std::min(host_threads() / 2, 64));  // (host_threads: this rank's share)
@@ -835,20 +837,30 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
     if (const char *e = getenv("RELATE_AMD_WINDOW_ROWS")) {
       cap_rows = std::max(0LL, atoll(e));
     } else if (known) {
-      // Every section the host could work on should be open: the trees of different sections are what fills the
-      // chip (a workgroup per tree).  A window that keeps 1/P of its rows runs RePaint P times -- about half a
-      // window's 14 ms each time at C3, where the builders leave it half the chip: not below a P-th of the largest
-      // window, P <= RELATE_AMD_WINDOW_PARTS (24: 148 sections open at C3; DESIGN.md 5 has the trade)
-      int parts_max = 24;
+      // The trees of different sections are what fills the chip (a workgroup per tree), so as many sections as HBM
+      // holds should be open -- but a window that keeps 1/P of its rows runs RePaint P times, about half a window's
+      // pass each time, on the CUs the builders leave free: not below a P-th of the largest window,
+      // P <= RELATE_AMD_WINDOW_PARTS (28).  And the sections go in WAVES of whatever is open at once: 267 sections
+      // 112 at a time are three waves, the last one a third full; 134 at a time are two full ones.  So: the fewest
+      // waves the memory allows at P_max, the sections spread evenly over them, and the smallest P that opens
+      // that many (C3: 2 waves of 134, P = 20: 234 s -> see DESIGN.md 6).
+      int parts_max = 28;
       if (const char *pe = getenv("RELATE_AMD_WINDOW_PARTS")) parts_max = std::max(1, atoi(pe));
+      auto fits = [&](int parts) {
+        return (int)(room / (max_rows / parts * row_bytes + fixed_bytes + builder_bytes + (parts > 1 ? bstate_bytes : 0.0)));
+      };
+      const int nsec = last_section - first_section + 1;
+      const int most = std::max(1, std::min(nthreads, fits(parts_max)));
+      const int waves = (nsec + most - 1) / most;
+      nthreads = std::min(nthreads, (nsec + waves - 1) / waves);
       int parts = 1;
-      while (parts < parts_max && room / (max_rows / parts * row_bytes + fixed_bytes + builder_bytes) < nthreads) parts++;
+      while (parts < parts_max && fits(parts) < nthreads) parts++;
       if (parts > 1) cap_rows = (long long)std::max({max_rows / parts, 3.0 * ctx->nloc + 64.0});
     }
     if (known) {
       const double per_window = window_bytes((first_section + last_section) / 2) + builder_bytes;
       concurrent = std::max(1, std::min(nthreads, (int)(room / std::max(per_window, 1.0))));
-      nthreads = std::min(nthreads, concurrent + 2);  // a couple more wait for room instead of idling a slot
+      nthreads = std::min(nthreads, concurrent);
     }
   }
   if (gpu_build && sample_ages.empty()) (void)device_builder_expect(device, ctx->N, nthreads);  // (sizes the workers' launches)
@@ -970,9 +982,9 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
   if (rc) set_error("%s", first_message.c_str());
   if (getenv("RELATE_AMD_TIMING"))
     fprintf(stderr, "[stage] sections %d..%d on %d threads, up to %d open at once, %lld of at most %.0f posterior rows "
-            "resident per window, %lld RePaint launches, %s tree builder, %.1f s\n", first_section, last_section,
-            nthreads, most_open, cap_rows > 0 ? cap_rows : (long long)max_rows, max_rows, ctx->repaint_launches,
-            gpu_build ? "GPU" : "host",
+            "resident per window, %lld RePaint launches (%.1f s on the device), %s tree builder, %.1f s\n", first_section,
+            last_section, nthreads, most_open, cap_rows > 0 ? cap_rows : (long long)max_rows, max_rows,
+            ctx->repaint_launches, 1e-3 * ctx->repaint_ms, gpu_build ? "GPU" : "host",
             std::chrono::duration<double>(std::chrono::steady_clock::now() - stage_t0).count());
   rl_destroy(ctx);
   if (!rc) {

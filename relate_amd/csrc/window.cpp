@@ -32,6 +32,10 @@ struct rl_window {
   // the window's stones: its own decoded copy (d_ab ..), or the context's slice quantised in place (fused stage)
   const float *ab = nullptr, *be = nullptr, *la = nullptr, *lb = nullptr;
   DevBuf d_slab_off, d_row_lo, d_row_hi, d_slab_base;
+  // a bounded window's ONE kept state of the backward pass per target (repaint_kernels.hip): the row it stands
+  // before (-1: none), and what the next launch does with it
+  DevBuf d_bstate, d_bscal, d_start_row, d_save_row;
+  std::vector<int32_t> b_row, start_row, save_row;  // [nloc]
   std::vector<int64_t> slab_off, slab_base;  // [nloc]
   std::vector<int32_t> row_lo, row_hi;       // [nloc] resident posterior rows [lo, hi) of each target
   int64_t cap_rows = 0;                      // rows d_top holds; >= all rows: the whole window is resident
@@ -96,6 +100,10 @@ static int repaint_rows(rl_window *win, float *kernel_ms) {
   p.order = win->d_order.as<int32_t>();
   p.sum_mode = win->sum_mode;
   p.partial = win->have_logscales ? 1 : 0;
+  p.bstate = win->d_bstate.as<double>();
+  p.bscal = win->d_bscal.as<double>();
+  p.start_row = win->d_start_row.as<int32_t>();
+  p.save_row = win->d_save_row.as<int32_t>();
   (void)N;
   bool ok = hipEventRecord(ctx->ev0, ctx->s0) == hipSuccess;
   hipError_t le = ok ? launch_repaint(p, S, waves, ctx->s0) : hipErrorUnknown;
@@ -107,10 +115,15 @@ static int repaint_rows(rl_window *win, float *kernel_ms) {
     set_error("repaint launch failed: %s / %s", hipGetErrorString(le), hipGetErrorString(se));
     return RL_EHIP;
   }
-  if (kernel_ms) (void)hipEventElapsedTime(kernel_ms, ctx->ev0, ctx->ev2);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev2);
+  if (kernel_ms) *kernel_ms = ms;
+  ctx->repaint_ms += ms;
   ctx->repaint_launches++;
   one_at_a_time.unlock();
   win->repaints++;
+  for (size_t t = 0; t < win->save_row.size(); t++)
+    if (win->save_row[t] >= 0) win->b_row[t] = win->save_row[t];
   if (!win->have_logscales) {  // (every launch writes all of them, with the same values)
     const int64_t rows = win->top_off[nloc];
     win->logscales.resize((size_t)rows);
@@ -169,6 +182,30 @@ static int place_rows(rl_window *win, int snp, float *kernel_ms) {
   rc = rc ? rc : win->d_slab_base.upload(win->slab_base);
   rc = rc ? rc : win->d_row_lo.upload(win->row_lo);
   rc = rc ? rc : win->d_row_hi.upload(win->row_hi);
+  if (!rc && win->cap_rows < all_rows && !(getenv("RELATE_AMD_WINDOW_BSTATE") && atoi(getenv("RELATE_AMD_WINDOW_BSTATE")) == 0)) {
+    // The backward pass of a launch runs from the window's last row down to the part's first: half a window on
+    // average, however small the part.  One kept state per target cuts that: a launch that has to come down from
+    // the last row leaves its state halfway between there and the top of its part, and the launches whose rows
+    // lie below that start from it (24 parts: 132 part-lengths of descent instead of 300).
+    const size_t row_doubles = (size_t)ctx->S * 64 * ctx->waves;
+    rc = win->d_bstate.alloc((size_t)nloc * row_doubles * sizeof(double));
+    rc = rc ? rc : win->d_bscal.alloc((size_t)nloc * 2 * sizeof(double));
+    if (win->b_row.empty()) win->b_row.assign(nloc, -1);
+    win->start_row.assign(nloc, -1);
+    win->save_row.assign(nloc, -1);
+    for (int t = 0; t < nloc; t++) {
+      const int D = (int)(win->top_off[t + 1] - win->top_off[t]);
+      const bool from_state = win->have_logscales && win->b_row[t] >= 0 && win->b_row[t] >= win->row_hi[t] - 1 &&
+                              win->b_row[t] <= D - 2;
+      if (from_state) {
+        win->start_row[t] = win->b_row[t];
+      } else if (D - 2 - win->row_hi[t] >= 12) {
+        win->save_row[t] = win->row_hi[t] + (D - 2 - win->row_hi[t]) / 2;
+      }
+    }
+    rc = rc ? rc : win->d_start_row.upload(win->start_row);
+    rc = rc ? rc : win->d_save_row.upload(win->save_row);
+  }
   return rc ? rc : repaint_rows(win, kernel_ms);
 }
 

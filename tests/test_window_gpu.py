@@ -41,7 +41,7 @@ def run_case(tmp_path, N, L, budget, seed, theta=0.001, rho=1.0, windows=None, v
     for w in (windows if windows is not None else sorted(set([0, W // 2, W - 1]))):
         pf = os.path.join(pdir, "relate_%d.bin" % w)
         s0, s1 = int(ch.wb[w]), int(ch.wb[w + 1]) - 1
-        ow = o.ro_window_open(C.byref(d), pf.encode(), s0, 4)
+        ow = o.ro_window_open(C.byref(d), pf.encode(), s0, 4) if o else None
         assert ow
         win = ctx.open_window(w, pf, s0, api.RL_SUM_EXACT)
         assert (win.start, win.end) == (o.ro_window_start(C.c_void_p(ow)), o.ro_window_end(C.c_void_p(ow)))
@@ -144,11 +144,13 @@ def test_repaint_lanes_order_matches_oracle(tmp_path, N, L, wb):
 
 
 @pytest.mark.parametrize("N,L,budget,seed,cap", [(96, 1400, 60000, 9, 0.08), (200, 1500, 400000, 7, 0.3),
-                                                 (64, 1500, 30000, 1, 0.0)])
+                                                 (64, 1500, 30000, 1, 0.0), (5300, 500, 3.0e8, 3, 0.2)])
 def test_bounded_window_same_matrices(tmp_path, N, L, budget, seed, cap):
     """rl_window_open_bounded: a window that keeps part of its posterior rows resident and repaints as the tree
-    builder moves on gives, SNP by SNP, the matrices of the window that keeps everything (and of the oracle)"""
-    o = rlutil.oracle()
+    builder moves on gives, SNP by SNP, the matrices of the window that keeps everything (and of the oracle; the
+    two-wavefront layout, N = 5300, against the full window only).  Later launches of a bounded window start their
+    backward pass from the state an earlier one kept (repaint_kernels.hip)."""
+    o = rlutil.oracle() if N <= 5120 else None
     ch = rlutil.synth_chunk(N, L, seed=seed, budget=budget)
     ctx = api.Context()
     ctx.set_chunk(ch.seq, ch.r, ch.rpos, ch.wb)
@@ -162,7 +164,7 @@ def test_bounded_window_same_matrices(tmp_path, N, L, budget, seed, cap):
         full = ctx.open_window(w, pf, s0, api.RL_SUM_EXACT)
         rows = sum(full.rows(n) for n in range(N))
         part = ctx.open_window(w, pf, s0, api.RL_SUM_EXACT, max_rows=max(1, int(cap * rows)))
-        ow = o.ro_window_open(C.byref(d), pf.encode(), s0, 4)
+        ow = o.ro_window_open(C.byref(d), pf.encode(), s0, 4) if o else None
         with pytest.raises(api.RelateError):
             part.topology(int(np.argmax([full.rows(n) for n in range(N)])))  # not all of its rows are there
         step = max(1, (s1 - s0) // 40)
@@ -170,17 +172,20 @@ def test_bounded_window_same_matrices(tmp_path, N, L, budget, seed, cap):
             if s > s0:
                 full.advance(s)
                 part.advance(s)
-                o.ro_window_advance(C.c_void_p(ow), s)
+                if o:
+                    o.ro_window_advance(C.c_void_p(ow), s)
             if (s - s0) % step == 0 or s == s1:
                 A, B = full.matrix(s), part.matrix(s)
-                o.ro_window_matrix(C.c_void_p(ow), s, M.ctypes.data_as(C.c_void_p))
                 assert np.array_equal(u32(A), u32(B)), (w, s)
-                assert np.array_equal(u32(A), u32(M)), (w, s)
+                if o:
+                    o.ro_window_matrix(C.c_void_p(ow), s, M.ctypes.data_as(C.c_void_p))
+                    assert np.array_equal(u32(A), u32(M)), (w, s)
         assert full.repaints == 1
         assert part.repaints >= 2, part.repaints  # it did move through the window in parts
         part.close()
         full.close()
-        o.ro_window_free(C.c_void_p(ow))
+        if o:
+            o.ro_window_free(C.c_void_p(ow))
     ctx.close()
 
 
