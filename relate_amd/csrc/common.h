@@ -28,16 +28,18 @@ void set_error(const char *fmt, ...);
     }                                                                             \
   } while (0)
 
-// Streams of the stage: the tree builder's long-running workgroups go to lowest-priority streams, which the runtime
-// maps to hardware queues of their own -- the short kernels of the stage (distance matrices, penalty, prior, the weave
-// of the next tree) must not queue up behind one.  The context's stream (Paint; RePaint of the stage's windows,
-// tens of milliseconds per launch when the workers hold most of the chip) is a highest-priority stream for the
-// same reason: a hardware queue of its own instead of one shared with the streams of two dozen sections.  (Tried: CU masks that keep the other kernels off the builder's
-// CUs, hipExtStreamCreateWithCUMask with 3 or 4 of every 8 CUs for the trees -- the 80-section stage did not finish
-// in four times its usual time.)
-inline hipError_t make_stream(hipStream_t *s, bool tree_builder, bool repaint = false) {
+// Streams of the stage, three priorities.  LOWEST: the tree builder's resident workers -- the runtime maps the
+// priorities to hardware queues of their own, so nothing queues up behind a launch that lasts for seconds.  HIGHEST:
+// the streams of the sections (a window's distance matrices; a builder's penalty, prior, weave and pair scan) -- a
+// dozen kernels of a fraction of a millisecond per tree, on the section's critical path.  NORMAL: the context's
+// stream (Paint; RePaint of the stage's windows, ~13 ms per launch on the CUs the workers leave free and busy 40 %
+// of the time): with RePaint above them the sections' kernels waited for a whole launch to drain (2.4 ms each,
+// 20-40 ms per tree), below them they take the CUs its workgroups free one by one.
+// (Tried: CU masks that keep the other kernels off the builder's CUs, hipExtStreamCreateWithCUMask with 3 or 4 of
+// every 8 CUs for the trees -- the 80-section stage did not finish in four times its usual time.)
+inline hipError_t make_stream(hipStream_t *s, bool tree_builder, bool section = false) {
   int least = 0, greatest = 0;
-  if ((tree_builder || repaint) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess &&
+  if ((tree_builder || section) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess &&
       hipStreamCreateWithPriority(s, hipStreamNonBlocking, tree_builder ? least : greatest) == hipSuccess)
     return hipSuccess;
   return hipStreamCreateWithFlags(s, hipStreamNonBlocking);

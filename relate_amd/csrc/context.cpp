@@ -497,7 +497,7 @@ rl_ctx *rl_create(int device) {
   }
   rl_ctx *ctx = new rl_ctx();
   ctx->device = device;
-  if (make_stream(&ctx->s0, false, true) != hipSuccess || make_stream(&ctx->s1, false) != hipSuccess ||
+  if (make_stream(&ctx->s0, false) != hipSuccess || make_stream(&ctx->s1, false) != hipSuccess ||
       hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
       hipEventCreate(&ctx->ev2) != hipSuccess) {
     set_error("stream/event creation failed");

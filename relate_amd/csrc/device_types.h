@@ -102,6 +102,12 @@ struct RepaintParams {
   double *bstate;             // [nloc][waves][S*64], or null
   double *bscal;              // [nloc][2]
   const int32_t *start_row, *save_row;  // [nloc]
+  // ... and ONE of the forward pass: alpha, the step's factor and the logscales as they stand behind row r, a
+  // multiple of the checkpoint interval -- where the rows of the next part begin, so that its launch starts there
+  // instead of at the window's first row.  fsave_row / fstart_row as above.
+  double *fstate;             // [nloc][waves][S*64], or null
+  double *fscal;              // [nloc][4]: cfac, prev_ls, lsf
+  const int32_t *fstart_row, *fsave_row;  // [nloc]
 };
 
 struct MatrixParams {

@@ -1364,7 +1364,7 @@ __device__ inline void params_from_words(MMParamsDev &p, const unsigned *w) {
 // The builders' requests of one device and tree size, in pinned host memory: the host writes a request's words, then
 // `tail`; workers claim tickets from `head` (device memory) and read the words of their ticket.
 constexpr int MM_QUEUE_CAP = 1024;  // requests in flight <= builders alive (a section has one tree in flight)
-constexpr int MM_LAUNCHES = 4;      // worker launches alive at once (a stream, i.e. a hardware queue, each)
+constexpr int MM_LAUNCHES = 6;      // worker launches alive at once (a stream, i.e. a hardware queue, each)
 struct WorkQueue {
   unsigned tail;
   unsigned pad[15];
@@ -1491,9 +1491,16 @@ __global__ void __launch_bounds__(256) pack_kernel(const float *__restrict__ D, 
 }
 
 // out[a] = min over l != a of in[a][l]: the row minima of tree_builder.cpp:1659-1666, a workgroup per row
-__global__ void __launch_bounds__(256) rowmin_kernel(const float *__restrict__ in, float *__restrict__ out, int N) {
+// (blocks N .. 2N-1: the same for the second matrix, the clade prior)
+__global__ void __launch_bounds__(256) rowmin_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                    const float *__restrict__ in2, float *__restrict__ out2, int N) {
   __shared__ float part[4];
-  const int a = blockIdx.x;
+  int a = blockIdx.x;
+  if (a >= N) {
+    a -= N;
+    in = in2;
+    out = out2;
+  }
   const float *row = in + (size_t)a * N;
   float mv = INFINITY;
   for (int l = threadIdx.x; l < N; l += 256)
@@ -1622,7 +1629,8 @@ static int env_int(const char *name, int fallback, int lo, int hi) {
 // What the builders of one device share.
 //
 // * Staging: the row-major distance matrix (K3 writes it, the carrier penalty edits it) and clade prior of a tree
-//   are needed from K3 until the weave (pack_kernel) -- a few ms of a tree's ~0.2 s.  A builder takes a pair from
+//   are needed from K3 until the weave (pack_kernel) -- ~30 ms of a tree's ~0.2 s with a hundred sections sharing
+//   the hardware queues: 32 pairs (12 were a queue of their own at 134 sections: 11 s of every section's 60).  A builder takes a pair from
 //   a small pool for that time instead of owning 8 N^2 bytes for life (200 MB of the 725 MB a section used to pin
 //   at N = 5000: why 91 sections were all that fitted).
 // * The symmetric matrix of the fallback (tree_builder.cpp:255-293): a pool of `sym_slots` matrices the build
@@ -1726,12 +1734,12 @@ class DeviceShare {
   }
   // bytes of HBM the shared pools take for trees of N leaves (the stage's admission counts them once)
   static double bytes(int N) {
-    return (double)env_int("RELATE_AMD_BUILD_STAGING", 12, 1, 64) * 8.0 * N * N +
+    return (double)env_int("RELATE_AMD_BUILD_STAGING", 32, 1, 128) * 8.0 * N * N +
            (double)env_int("RELATE_AMD_BUILD_SYM_SLOTS", 8, 0, 64) * 4.0 * N * N;
   }
 
  private:
-  DeviceShare() : cap_(env_int("RELATE_AMD_BUILD_STAGING", 12, 1, 64)) {}
+  DeviceShare() : cap_(env_int("RELATE_AMD_BUILD_STAGING", 32, 1, 128)) {}
   std::mutex m_;
   std::condition_variable cv_;
   std::vector<Staging *> free_;
@@ -1752,9 +1760,9 @@ int device_builder_reserve_shared(int device, int N) {
 // with a stream each build a dozen trees at a time; batched launches (round 2) waited 10 ms to gather, lasted as
 // long as their slowest tree and kept at most 4 x ~15 trees in flight on 256 CUs.
 // The launcher thread adds workers when trees wait: up to MM_LAUNCHES launches alive (a lowest-priority stream
-// each; more hardware queues than ~16 in all and the device time-slices them), sized as a ladder -- an eighth, an
-// eighth, a quarter, half of the workers the job can use (the CUs less an eighth, or the builders the stage
-// announced, expect()) -- so that a few trees do not sit on 200 CUs and 200 trees get theirs in four launches.
+// each; more than ~20 hardware queues in all and the device time-slices them), each at least half as large as
+// what is alive -- 16, 16, 16, 24, 36, 54 ... -- up to the workers the job can use (the CUs less an eighth, or the
+// builders the stage announced, expect()).
 class BuildQueue {
  public:
   static BuildQueue *of(int device, int N) {
@@ -1842,7 +1850,7 @@ class BuildQueue {
     // launch in a hardware queue they happen to share: lowest-priority streams, which the runtime maps to hardware
     // queues of their own.
     hipStream_t streams[MM_LAUNCHES];
-    int size[MM_LAUNCHES] = {0, 0, 0, 0};
+    int size[MM_LAUNCHES] = {};
     for (auto &st : streams)
       if (make_stream(&st, true) != hipSuccess) {
         failed_.store(true);
@@ -1885,10 +1893,13 @@ class BuildQueue {
         busy_launches += size[l] > 0;
         if (size[l] == 0 && free_stream < 0) free_stream = l;
       }
-      if (demand > alive && alive < goal && free_stream >= 0) {
-        // the ladder: 1/8, 1/8, 1/4, 1/2 of the goal -- and never fewer than the trees that wait
-        static const int eighths[MM_LAUNCHES] = {1, 1, 2, 4};
-        int n = std::max((goal * eighths[busy_launches] + 7) / 8, demand - alive);
+      // Workers follow the trees that are waiting or being built, not the sections that exist: a section spends half
+      // of its time outside the build (distance matrix, RePaint, mapping), and a worker without a tree still holds
+      // its CU -- with one per section RePaint had 122 CUs of 256 and was the stage's bottleneck (82 % busy, 0.7 s of
+      // queue per launch).  A launch adds what is missing plus a margin, at least half of what is alive (the
+      // launches are few: MM_LAUNCHES streams), never past the goal.
+      if (demand + 4 > alive && alive < goal && free_stream >= 0) {
+        int n = std::max({demand + 8 - alive, alive / 2, 16});
         n = std::max(1, std::min(n, goal - alive));
         const int l = free_stream;
         const long long idle = (long long)idle_ms_ * 100000LL;
@@ -2003,7 +2014,7 @@ int DeviceMinMatch::apply_penalty(const char *member, float val) {
   const int N = m.N;
   if (!m.staging) return -1;
   RL_HIP(hipSetDevice(m.device));
-  if (!m.stream) RL_HIP(make_stream(&m.stream, false));
+  if (!m.stream) RL_HIP(make_stream(&m.stream, false, true));
   if (m.d_member.alloc((size_t)N)) return -1;
   const size_t tab_ints = (size_t)6 * (2 * N - 1) + N;
   if (!m.h_tab && !(m.h_tab = static_cast<int *>(pinned_cache_alloc(tab_ints * 4 + (size_t)N, &m.h_tab_bytes)))) {
@@ -2024,7 +2035,7 @@ int DeviceMinMatch::apply_prior(const HostTree &t, float val) {
   const int N = m.N, T = 2 * N - 1;
   if (!m.staging) return -1;
   RL_HIP(hipSetDevice(m.device));
-  if (!m.stream) RL_HIP(make_stream(&m.stream, false));
+  if (!m.stream) RL_HIP(make_stream(&m.stream, false, true));
   // the same tables as the host's clade_prior (treeseq.cpp), in pinned memory: nothing here waits for the copy
   // (the next tree of this builder -- the next writer of the block -- comes after this one is built)
   const size_t tab_ints = (size_t)6 * T + N;
@@ -2106,7 +2117,7 @@ int DeviceMinMatch::build_impl(MinMatch &tb, const float *d, const float *prior_
     if (every > 0 && ++m.builds % every == 0) return 2;
   }
   RL_HIP(hipSetDevice(m.device));
-  if (!m.stream) RL_HIP(make_stream(&m.stream, false));
+  if (!m.stream) RL_HIP(make_stream(&m.stream, false, true));
   BuildQueue *queue = BuildQueue::of(m.device, N);
   if (!queue) {
     set_error("tree builder: no queue on device %d (pinned host memory)", m.device);
@@ -2169,14 +2180,16 @@ int DeviceMinMatch::build_impl(MinMatch &tb, const float *d, const float *prior_
   }
   p.host_done = m.h_done;
   const bool timing = getenv("RELATE_AMD_TIMING") != nullptr;
-  p.timers = timing ? reinterpret_cast<long long *>(m.d_status.as<char>() + 16) : nullptr;
+  p.timers = nullptr;  // (set below: a corner of the pinned block, read when the tree is out -- no copy)
 
   // state the builders carry from tree to tree: in
-  if (!m.h_io && !(m.h_io = static_cast<int *>(pinned_cache_alloc((size_t)5 * N * 4, &m.h_io_bytes)))) {
+  if (!m.h_io && !(m.h_io = static_cast<int *>(pinned_cache_alloc((size_t)5 * N * 4 + 16 * 8 + 8, &m.h_io_bytes)))) {
     set_error("tree builder: no pinned host memory for the per-tree copies");
     return -1;
   }
   int *lin = m.h_io, *tr = m.h_io + 3 * (size_t)N;
+  long long *h_timers = reinterpret_cast<long long *>((reinterpret_cast<uintptr_t>(m.h_io + 5 * (size_t)N) + 7) & ~(uintptr_t)7);
+  if (timing) p.timers = h_timers;
   float *mvcf = reinterpret_cast<float *>(m.h_io + 2 * (size_t)N);
   for (int c = 0; c < N; c++) {
     lin[c] = tb.mc[c].lin1;
@@ -2208,14 +2221,13 @@ int DeviceMinMatch::build_impl(MinMatch &tb, const float *d, const float *prior_
     // the woven matrix and the row minima, on the whole chip; the build itself is one workgroup
     const dim3 grid((N + 31) / 32, (N + 31) / 32);
     hipLaunchKernelGGL(pack_kernel, grid, dim3(256), 0, m.stream, dD, dCF, p.M, N);
-    hipLaunchKernelGGL(rowmin_kernel, dim3(N), dim3(256), 0, m.stream, dD, f + 6 * (size_t)N, N);
-    if (prior) hipLaunchKernelGGL(rowmin_kernel, dim3(N), dim3(256), 0, m.stream, dCF, f + 7 * (size_t)N, N);
+    hipLaunchKernelGGL(rowmin_kernel, dim3(prior ? 2 * N : N), dim3(256), 0, m.stream, dD, f + 6 * (size_t)N, dCF,
+                       f + 7 * (size_t)N, N);
     hipLaunchKernelGGL(pairscan_kernel, dim3(N), dim3(256), 0, m.stream, p.M, p.rowmin_D, p.rowmin_CF, mvcf_dev,
                        p.has_prior, p.threshold, p.threshold_CF, N, hits, reinterpret_cast<unsigned *>(hits + N),
                        reinterpret_cast<float *>(hits + N + (size_t)N * MM_HITS));
     RL_HIP(hipGetLastError());
   }
-  RL_HIP(hipMemsetAsync(p.status, 0xff, 4, m.stream));  // (-1)
   static const bool trace = getenv("RELATE_AMD_MM_TRACE") != nullptr;
   if (trace) fprintf(stderr, "[mm trace] N=%d inputs submitted\n", N), fflush(stderr);
   RL_HIP(hipStreamSynchronize(m.stream));  // inputs in place
@@ -2254,8 +2266,7 @@ int DeviceMinMatch::build_impl(MinMatch &tb, const float *d, const float *prior_
   if (trace) fprintf(stderr, "[mm trace] N=%d tree out, status %d\n", N, status), fflush(stderr);
   if (status != 0) return status > 0 ? status : -1;
   if (timing) {
-    long long tk[16];
-    RL_HIP(hipMemcpy(tk, p.timers, sizeof(tk), hipMemcpyDeviceToHost));
+    const long long *tk = h_timers;
     fprintf(stderr, "[gpu tree builder] N=%d, us:", N);
     static const char *names[16] = {"row minima", "pair scan", "updates", "rescans", "pair tests", "pair order",
                                     "ordered", "symmetric", "erase", "pairs_x100", "before_draws", "", "rebuilt_x100",

@@ -98,29 +98,41 @@ RL_DEV void repaint_forward(const RepaintParams &p, int n, float *stage, WaveLin
   const double K1 = in_vgpr(c.K1);
 
   double a[S];
-  {
+  // (a later launch of a bounded window starts from the state an earlier one left behind row f0, a checkpoint row)
+  const int f0 = (p.fstate && p.partial) ? max(0, __builtin_amdgcn_readfirstlane(p.fstart_row[t])) : 0;
+  const int fsave = p.fstate ? __builtin_amdgcn_readfirstlane(p.fsave_row[t]) : -1;
+  double *__restrict__ fst = p.fstate ? p.fstate + ((size_t)t * WAVES + wv) * (S * 64) + pl.lane : nullptr;
+  double ssum, cfac, prev_ls;
+  float lsf;
+  if (f0 == 0) {
     const ColdRepaint cp = cold_params<RepaintParams>();
     load_stone<S>(pl, cp->alpha_begin + (size_t)t * cp->lay.N, a, stage);
+    set_slot<S>(a, pl.jk, pl.kbit, 0.0);  // alpha[n] = 0 for the target itself (:781)
+    ssum = wave_sum<MODE, S, WAVES>(RegTerm<S>{a}, local_sum<S>(RegTerm<S>{a}), lk);
+    lsf = p.ls_alpha[t];
+    prev_ls = (double)lsf;
+    cfac = (D == 1 ? cf_last : cfp[0]) * ssum;
+  } else {
+    load_row<S>(fst, a);
+    cfac = p.fscal[(size_t)t * 4];
+    prev_ls = p.fscal[(size_t)t * 4 + 1];
+    lsf = (float)p.fscal[(size_t)t * 4 + 2];
+    ssum = 0.0;
   }
-  set_slot<S>(a, pl.jk, pl.kbit, 0.0);  // alpha[n] = 0 for the target itself (:781)
-  double ssum = wave_sum<MODE, S, WAVES>(RegTerm<S>{a}, local_sum<S>(RegTerm<S>{a}), lk);
-  float lsf = p.ls_alpha[t];
-  double prev_ls = (double)lsf;
-  store_row<S>(ckrows, a);  // row 0 is a checkpoint
+  store_row<S>(ckrows + (int64_t)(f0 / CK) * ROW, a);  // the row the pass starts from is a checkpoint (row 0 always is)
   if (scribe) {
-    side[0] = 0.0;
-    side[1] = 0.0;
-    side[2] = (double)lsf;
+    side[(size_t)f0 * REPAINT_SIDE + 0] = 0.0;
+    side[(size_t)f0 * REPAINT_SIDE + 1] = 0.0;
+    side[(size_t)f0 * REPAINT_SIDE + 2] = (double)lsf;
   }
-  double cfac = (D == 1 ? cf_last : cfp[0]) * ssum;
-  int s1 = D > 1 ? st[1] : 0, s2 = D > 2 ? st[2] : 0;  // row pipeline as in paint_forward
+  int s1 = D > f0 + 1 ? st[f0 + 1] : 0, s2 = D > f0 + 2 ? st[f0 + 2] : 0;  // row pipeline as in paint_forward
   uint32_t touched = 0;
   MaskRow row = site_row(p.masks, S, p.L, s1, WAVES, wv);
   Chunk first = load_masks<CH>(row, 0);
   // (a later launch of a bounded window: rows from row_hi on are of no use to the backward pass)
   const int Dfwd = p.partial ? min(D, max(1, (int)p.row_hi[t])) : D;
   const int ck_from = p.partial ? (int)p.row_lo[t] : 0;
-  for (int i = 1; i < Dfwd; i++) {
+  for (int i = f0 + 1; i < Dfwd; i++) {
     retire_touch(touched);
     if (i + 1 < D) touched = touch_row(p.masks, S, s2, pl.lane, WAVES, wv);
     s1 = s2;
@@ -170,6 +182,14 @@ RL_DEV void repaint_forward(const RepaintParams &p, int n, float *stage, WaveLin
       side[(size_t)i * REPAINT_SIDE + 0] = cfac_used;
       side[(size_t)i * REPAINT_SIDE + 1] = divisor;
       side[(size_t)i * REPAINT_SIDE + 2] = (double)lsf;
+    }
+    if (i == fsave) {  // the state behind row i, for the launch of the next part (window.cpp: place_rows)
+      store_row<S>(fst, a);
+      if (scribe) {
+        p.fscal[(size_t)t * 4] = cfac;
+        p.fscal[(size_t)t * 4 + 1] = prev_ls;
+        p.fscal[(size_t)t * 4 + 2] = (double)lsf;
+      }
     }
   }
   retire_touch(touched);

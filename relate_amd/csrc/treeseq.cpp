@@ -815,7 +815,7 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
     return RL_ENOMEM;
   }
   // (a bounded window also keeps one state of RePaint's backward pass per target, doubles: window.cpp)
-  const double bstate_bytes = 2.0 * row_bytes * ctx->nloc + 16.0 * ctx->nloc;
+  const double bstate_bytes = 2.0 * (2.0 * row_bytes * ctx->nloc + 24.0 * ctx->nloc);  // (one of each pass)
   auto window_bytes = [&](int w) {
     const double kept = cap_rows > 0 ? std::min(rows_of[w], (double)cap_rows) : rows_of[w];
     return kept * row_bytes + fixed_bytes + (cap_rows > 0 && cap_rows < rows_of[w] ? bstate_bytes : 0.0);
@@ -840,11 +840,11 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
       // The trees of different sections are what fills the chip (a workgroup per tree), so as many sections as HBM
       // holds should be open -- but a window that keeps 1/P of its rows runs RePaint P times, about half a window's
       // pass each time, on the CUs the builders leave free: not below a P-th of the largest window,
-      // P <= RELATE_AMD_WINDOW_PARTS (28).  And the sections go in WAVES of whatever is open at once: 267 sections
+      // P <= RELATE_AMD_WINDOW_PARTS (32).  And the sections go in WAVES of whatever is open at once: 267 sections
       // 112 at a time are three waves, the last one a third full; 134 at a time are two full ones.  So: the fewest
       // waves the memory allows at P_max, the sections spread evenly over them, and the smallest P that opens
       // that many (C3: 2 waves of 134, P = 20: 234 s -> see DESIGN.md 6).
-      int parts_max = 28;
+      int parts_max = 32;
       if (const char *pe = getenv("RELATE_AMD_WINDOW_PARTS")) parts_max = std::max(1, atoi(pe));
       auto fits = [&](int parts) {
         return (int)(room / (max_rows / parts * row_bytes + fixed_bytes + builder_bytes + (parts > 1 ? bstate_bytes : 0.0)));

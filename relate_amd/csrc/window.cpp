@@ -6,6 +6,7 @@
 //                       (anc_builder.cpp:487-495)
 //   rl_window_matrix  = GetMatrix                (anc_builder.cpp:109-207)
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <numeric>
@@ -31,11 +32,21 @@ struct rl_window {
   DevBuf d_ab, d_be, d_la, d_lb, d_ib, d_ie, d_cfl, d_nxl, d_order, d_ck_off;
   // the window's stones: its own decoded copy (d_ab ..), or the context's slice quantised in place (fused stage)
   const float *ab = nullptr, *be = nullptr, *la = nullptr, *lb = nullptr;
-  DevBuf d_slab_off, d_row_lo, d_row_hi, d_slab_base;
   // a bounded window's ONE kept state of the backward pass per target (repaint_kernels.hip): the row it stands
   // before (-1: none), and what the next launch does with it
-  DevBuf d_bstate, d_bscal, d_start_row, d_save_row;
+  DevBuf d_bstate, d_bscal, d_fstate, d_fscal;
+  std::vector<int32_t> f_row, fstart_row, fsave_row;  // the forward pass's kept state likewise
+  // the per-launch arrays (slab_off, slab_base: int64; row_lo, row_hi, start_row, save_row: int32; [nloc] each) go to
+  // the device in ONE copy from a pinned block, on RePaint's stream and in its turn: six blocking copies from
+  // pageable memory took 50-180 ms per launch with a hundred sections copying
+  DevBuf d_place;
+  unsigned char *h_place = nullptr;
+  size_t h_place_bytes = 0;
   std::vector<int32_t> b_row, start_row, save_row;  // [nloc]
+  // RELATE_AMD_TIMING: where the window's wall-clock goes (seconds): choosing rows + uploads, waiting for the context's
+  // RePaint turn, the launch until it is through, the matrices' own part (arguments, kernel, wait)
+  double t_place = 0, t_turn = 0, t_launch = 0, t_matrix = 0;
+  long long n_matrices = 0;
   std::vector<int64_t> slab_off, slab_base;  // [nloc]
   std::vector<int32_t> row_lo, row_hi;       // [nloc] resident posterior rows [lo, hi) of each target
   int64_t cap_rows = 0;                      // rows d_top holds; >= all rows: the whole window is resident
@@ -48,10 +59,14 @@ struct rl_window {
   size_t h_stage_bytes = 0;
   DevBuf d_stage;
   ~rl_window() {
+    if (getenv("RELATE_AMD_TIMING") && n_matrices > 0)
+      fprintf(stderr, "[window %d] %lld matrices, %d RePaint launches; s: rows + uploads %.2f, waiting for RePaint's turn %.2f, "
+              "RePaint launches %.2f, matrices %.2f\n", w, n_matrices, repaints, t_place, t_turn, t_launch, t_matrix);
     if (stream) (void)hipStreamDestroy(stream);
     if (e0) (void)hipEventDestroy(e0);
     if (e2) (void)hipEventDestroy(e2);
     if (h_stage) pinned_cache_release(h_stage, h_stage_bytes);
+    if (h_place) pinned_cache_release(h_place, h_place_bytes);
   }
 };
 
@@ -66,7 +81,10 @@ static int repaint_rows(rl_window *win, float *kernel_ms) {
   // the checkpoint rows and side records of the forward kernel are scratch of the launch: one buffer per context,
   // launches are serialised
   const int64_t ck_doubles = win->ck_off[nloc] * (int64_t)S * 64 * waves;
+  const auto t_ask = std::chrono::steady_clock::now();
   std::unique_lock<std::mutex> one_at_a_time(ctx->repaint_mutex);
+  const auto t_got = std::chrono::steady_clock::now();
+  win->t_turn += std::chrono::duration<double>(t_got - t_ask).count();
   int rc = ctx->d_k2_scratch.alloc(repaint_scratch_bytes(win->top_off[nloc], nloc, S, waves));
   if (rc) return rc;
   RepaintParams p;
@@ -89,9 +107,16 @@ static int repaint_rows(rl_window *win, float *kernel_ms) {
   p.ls_alpha = win->la;
   p.ls_beta = win->lb;
   p.top_off = win->d_top_off.as<int64_t>();
-  p.slab_off = win->d_slab_off.as<int64_t>();
-  p.row_lo = win->d_row_lo.as<int32_t>();
-  p.row_hi = win->d_row_hi.as<int32_t>();
+  {
+    const unsigned char *dp = win->d_place.as<unsigned char>();
+    p.slab_off = reinterpret_cast<const int64_t *>(dp);
+    p.row_lo = reinterpret_cast<const int32_t *>(dp + (size_t)nloc * 16);
+    p.row_hi = reinterpret_cast<const int32_t *>(dp + (size_t)nloc * 20);
+    p.start_row = reinterpret_cast<const int32_t *>(dp + (size_t)nloc * 24);
+    p.save_row = reinterpret_cast<const int32_t *>(dp + (size_t)nloc * 28);
+    p.fstart_row = reinterpret_cast<const int32_t *>(dp + (size_t)nloc * 32);
+    p.fsave_row = reinterpret_cast<const int32_t *>(dp + (size_t)nloc * 36);
+  }
   p.topology = win->d_top.as<float>();
   p.logscales = win->d_ls.as<float>();
   p.scratch = ctx->d_k2_scratch.as<double>();
@@ -102,10 +127,11 @@ static int repaint_rows(rl_window *win, float *kernel_ms) {
   p.partial = win->have_logscales ? 1 : 0;
   p.bstate = win->d_bstate.as<double>();
   p.bscal = win->d_bscal.as<double>();
-  p.start_row = win->d_start_row.as<int32_t>();
-  p.save_row = win->d_save_row.as<int32_t>();
+  p.fstate = win->d_fstate.as<double>();
+  p.fscal = win->d_fscal.as<double>();
   (void)N;
-  bool ok = hipEventRecord(ctx->ev0, ctx->s0) == hipSuccess;
+  bool ok = hipMemcpyAsync(win->d_place.p, win->h_place, (size_t)nloc * 40, hipMemcpyHostToDevice, ctx->s0) == hipSuccess;
+  ok = ok && hipEventRecord(ctx->ev0, ctx->s0) == hipSuccess;
   hipError_t le = ok ? launch_repaint(p, S, waves, ctx->s0) : hipErrorUnknown;
   ok = ok && le == hipSuccess;
   ok = ok && hipEventRecord(ctx->ev2, ctx->s0) == hipSuccess;
@@ -121,9 +147,12 @@ static int repaint_rows(rl_window *win, float *kernel_ms) {
   ctx->repaint_ms += ms;
   ctx->repaint_launches++;
   one_at_a_time.unlock();
+  win->t_launch += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_got).count();
   win->repaints++;
-  for (size_t t = 0; t < win->save_row.size(); t++)
+  for (size_t t = 0; t < win->save_row.size(); t++) {
     if (win->save_row[t] >= 0) win->b_row[t] = win->save_row[t];
+    if (win->fsave_row[t] >= 0) win->f_row[t] = win->fsave_row[t];
+  }
   if (!win->have_logscales) {  // (every launch writes all of them, with the same values)
     const int64_t rows = win->top_off[nloc];
     win->logscales.resize((size_t)rows);
@@ -143,6 +172,7 @@ static int repaint_rows(rl_window *win, float *kernel_ms) {
 // which is taken as far as the capacity allows.
 static int place_rows(rl_window *win, int snp, float *kernel_ms) {
   rl_ctx *ctx = win->ctx;
+  const auto t_in = std::chrono::steady_clock::now();
   const int nloc = win->nloc, k0 = win->k0, L = ctx->L;
   const int64_t all_rows = win->top_off[nloc];
   if (win->cap_rows >= all_rows) {
@@ -154,10 +184,18 @@ static int place_rows(rl_window *win, int snp, float *kernel_ms) {
     std::vector<int32_t> extra(nloc, 0);
     int64_t used = 2 * (int64_t)nloc;
     const int last_wanted = std::min(L - 1, win->end + 1);
+    // The sections of a stage open together and would come back for their next part together, every one of them
+    // waiting for a hundred RePaint launches ahead of it: the FIRST part of window w is cut short by a fraction that
+    // differs from window to window (golden-ratio sequence), which spreads the later requests over the period.
+    int64_t cap_now = win->cap_rows;
+    if (!win->have_logscales) {
+      const double frac = std::fmod(0.6180339887498949 * (win->w + 1), 1.0);
+      cap_now = std::max<int64_t>(3 * (int64_t)nloc + 64, (int64_t)((0.15 + 0.85 * frac) * (double)win->cap_rows));
+    }
     for (int s0 = std::max(snp, 0); s0 <= last_wanted; s0++) {
       int64_t pop = 0;
       for (int t = 0; t < nloc; t++) pop += derived(ctx, s0, k0 + t);
-      if (used + pop > win->cap_rows && s0 > snp) break;
+      if (used + pop > cap_now && s0 > snp) break;
       used += pop;
       for (int t = 0; t < nloc; t++) extra[t] += derived(ctx, s0, k0 + t);
     }
@@ -178,11 +216,20 @@ static int place_rows(rl_window *win, int snp, float *kernel_ms) {
               (long long)win->cap_rows);
     return RL_ENOMEM;
   }
-  int rc = win->d_slab_off.upload(win->slab_off);
-  rc = rc ? rc : win->d_slab_base.upload(win->slab_base);
-  rc = rc ? rc : win->d_row_lo.upload(win->row_lo);
-  rc = rc ? rc : win->d_row_hi.upload(win->row_hi);
-  if (!rc && win->cap_rows < all_rows && !(getenv("RELATE_AMD_WINDOW_BSTATE") && atoi(getenv("RELATE_AMD_WINDOW_BSTATE")) == 0)) {
+  int rc = win->d_place.alloc((size_t)nloc * 40);
+  if (!rc && !win->h_place && !(win->h_place = static_cast<unsigned char *>(pinned_cache_alloc((size_t)nloc * 40, &win->h_place_bytes)))) {
+    set_error("window %d: no pinned host memory for the launch arguments", win->w);
+    rc = RL_ENOMEM;
+  }
+  if (rc) return rc;
+  const bool keep_state = win->cap_rows < all_rows &&
+                          !(getenv("RELATE_AMD_WINDOW_BSTATE") && atoi(getenv("RELATE_AMD_WINDOW_BSTATE")) == 0);
+  win->start_row.assign(nloc, -1);
+  win->save_row.assign(nloc, -1);
+  win->fstart_row.assign(nloc, -1);
+  win->fsave_row.assign(nloc, -1);
+  if (win->f_row.empty()) win->f_row.assign(nloc, -1);
+  if (keep_state) {
     // The backward pass of a launch runs from the window's last row down to the part's first: half a window on
     // average, however small the part.  One kept state per target cuts that: a launch that has to come down from
     // the last row leaves its state halfway between there and the top of its part, and the launches whose rows
@@ -190,9 +237,8 @@ static int place_rows(rl_window *win, int snp, float *kernel_ms) {
     const size_t row_doubles = (size_t)ctx->S * 64 * ctx->waves;
     rc = win->d_bstate.alloc((size_t)nloc * row_doubles * sizeof(double));
     rc = rc ? rc : win->d_bscal.alloc((size_t)nloc * 2 * sizeof(double));
+    if (rc) return rc;
     if (win->b_row.empty()) win->b_row.assign(nloc, -1);
-    win->start_row.assign(nloc, -1);
-    win->save_row.assign(nloc, -1);
     for (int t = 0; t < nloc; t++) {
       const int D = (int)(win->top_off[t + 1] - win->top_off[t]);
       const bool from_state = win->have_logscales && win->b_row[t] >= 0 && win->b_row[t] >= win->row_hi[t] - 1 &&
@@ -203,9 +249,33 @@ static int place_rows(rl_window *win, int snp, float *kernel_ms) {
         win->save_row[t] = win->row_hi[t] + (D - 2 - win->row_hi[t]) / 2;
       }
     }
-    rc = rc ? rc : win->d_start_row.upload(win->start_row);
-    rc = rc ? rc : win->d_save_row.upload(win->save_row);
+    // The forward pass likewise ran from the window's first row up to the part's last, every time: the state behind
+    // the checkpoint row in whose block the NEXT part begins (its first row is this part's last but one) is kept, and
+    // the next launch starts from it -- a part's own rows instead of half a window (half of RePaint's work with the
+    // backward state in place).
+    constexpr int CK = REPAINT_CHECKPOINT;
+    rc = win->d_fstate.alloc((size_t)nloc * row_doubles * sizeof(double));
+    rc = rc ? rc : win->d_fscal.alloc((size_t)nloc * 4 * sizeof(double));
+    if (rc) return rc;
+    for (int t = 0; t < nloc; t++) {
+      const int lo_blk = win->row_lo[t] - win->row_lo[t] % CK;
+      if (win->have_logscales && win->f_row[t] > 0 && win->f_row[t] <= lo_blk) win->fstart_row[t] = win->f_row[t];
+      const int next_lo = std::max(0, win->row_hi[t] - 2), f = next_lo - next_lo % CK;
+      if (f > std::max(0, win->fstart_row[t])) win->fsave_row[t] = f;
+    }
   }
+  {  // (the block is rewritten only after the launch that read it is through: repaint_rows waits for its launch)
+    unsigned char *hp = win->h_place;
+    memcpy(hp, win->slab_off.data(), (size_t)nloc * 8);
+    memcpy(hp + (size_t)nloc * 8, win->slab_base.data(), (size_t)nloc * 8);
+    memcpy(hp + (size_t)nloc * 16, win->row_lo.data(), (size_t)nloc * 4);
+    memcpy(hp + (size_t)nloc * 20, win->row_hi.data(), (size_t)nloc * 4);
+    memcpy(hp + (size_t)nloc * 24, win->start_row.data(), (size_t)nloc * 4);
+    memcpy(hp + (size_t)nloc * 28, win->save_row.data(), (size_t)nloc * 4);
+    memcpy(hp + (size_t)nloc * 32, win->fstart_row.data(), (size_t)nloc * 4);
+    memcpy(hp + (size_t)nloc * 36, win->fsave_row.data(), (size_t)nloc * 4);
+  }
+  win->t_place += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_in).count();
   return rc ? rc : repaint_rows(win, kernel_ms);
 }
 
@@ -565,11 +635,12 @@ static int window_matrix(rl_window *win, int snp, float *d_host, void *d_dev, fl
     const int prc = place_rows(win, snp, nullptr);
     if (prc) return prc;
   }
+  const auto t_mx = std::chrono::steady_clock::now();
   // the per-target arguments in one pinned block, one copy, on the window's stream
   const size_t o_wl = 0, o_wr = o_wl + (size_t)nloc * 8, o_vsp = o_wr + (size_t)nloc * 8, o_epn = o_vsp + (size_t)nloc * 4,
                o_enp = o_epn + (size_t)nloc * 4, o_dir = o_enp + (size_t)nloc * 4, stage_bytes = o_dir + (size_t)nloc;
   if (!win->stream) {
-    if (make_stream(&win->stream, false) != hipSuccess ||
+    if (make_stream(&win->stream, false, true) != hipSuccess ||
         hipEventCreate(&win->e0) != hipSuccess || hipEventCreate(&win->e2) != hipSuccess ||
         !(win->h_stage = static_cast<unsigned char *>(pinned_cache_alloc(((stage_bytes + 7) & ~(size_t)7) + 8, &win->h_stage_bytes)))) {
       set_error("rl_window_matrix: stream / staging buffer creation failed");
@@ -593,7 +664,7 @@ static int window_matrix(rl_window *win, int snp, float *d_host, void *d_dev, fl
   p.topology = win->d_top.as<float>();
   p.logscales = win->d_ls.as<float>();
   p.top_off = win->d_top_off.as<int64_t>();
-  p.slab_base = win->d_slab_base.as<int64_t>();
+  p.slab_base = reinterpret_cast<const int64_t *>(win->d_place.as<unsigned char>() + (size_t)nloc * 8);
   p.v_snp_prev = reinterpret_cast<const int32_t *>(ds + o_vsp);
   p.direct = ds + o_dir;
   p.wl = reinterpret_cast<const double *>(ds + o_wl);
@@ -609,6 +680,8 @@ static int window_matrix(rl_window *win, int snp, float *d_host, void *d_dev, fl
     RL_HIP(hipMemcpyAsync(d_host, p.matrix, (size_t)nloc * N * sizeof(float), hipMemcpyDeviceToHost, win->stream));
   RL_HIP(hipStreamSynchronize(win->stream));
   if (kernel_ms) RL_HIP(hipEventElapsedTime(kernel_ms, win->e0, win->e2));
+  win->t_matrix += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_mx).count();
+  win->n_matrices++;
   return RL_OK;
 }
 

@@ -73,6 +73,8 @@ try:
                 acc[m.group(1).strip()] = acc.get(m.group(1).strip(), 0) + int(m.group(2))
     if ntr:
         out["gpu_builder_ms_per_tree"] = {k: round(v / ntr / 1000.0, 2) for k, v in acc.items()}
+    wl = [l.strip() for l in err.split("\n") if l.startswith("[window ")]
+    out["window_lines"] = wl[:3] + wl[len(wl) // 2: len(wl) // 2 + 3]
     out["one_section"] = [l.strip() for l in err.split("\n") if "[tree sequence]" in l][:1]
 finally:
     shutil.rmtree(work, ignore_errors=True)
