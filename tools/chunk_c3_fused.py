@@ -61,7 +61,7 @@ try:
     out["trees_per_s"] = out["trees_built"] / out["wall_s"]
     out["anc_GB"] = sum(os.path.getsize(os.path.join(d, "chunk_0", f)) for f in os.listdir(os.path.join(d, "chunk_0"))
                         if f.endswith(".anc")) / 1e9
-    out["stage_lines"] = [l.strip() for l in err.split("\n") if l.startswith("[") and "tree sequence" not in l
+    out["stage_lines"] = [l.strip() for l in err.split("\n") if l.startswith("[") and "\r" not in l and "[window " not in l and "tree sequence" not in l
                           and "[tree builder workers]" not in l and "[gpu tree builder]" not in l][:12]
     out["builder_worker_launches"] = [l.strip() for l in err.split("\n") if "[tree builder workers]" in l][:24]
     out["builder_host_side"] = [l.strip() for l in err.split("\n") if "host ms per tree" in l][:6]
