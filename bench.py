@@ -292,12 +292,17 @@ def main():
     extra = None
     roofline_k2 = None
     pmc = None
-    try:  # HBM bytes per launch: separate rocprofv3 --pmc runs (tools/gpu_profile_r02.sh), committed summary
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_c3.json")))
-        if pmc["N"] != N or pmc["L"] != L or by_target or args.workload != "c3":
+    pmc_file = None
+    for cand in ("r03_pmc_c3.json", "r02_pmc_c3.json"):  # HBM bytes per launch: separate rocprofv3 --pmc runs
+        try:                                              # (tools/gpu_profile_r03.sh), committed summary
+            pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))
+            if pmc["N"] != N or pmc["L"] != L or by_target or args.workload != "c3":
+                pmc = None
+            else:
+                pmc_file = "profiles/" + cand
+                break
+        except Exception:
             pmc = None
-    except Exception:
-        pmc = None
     if rank == 0 and not args.skip_k23 and not by_target:
         try:
             w = (len(wb) - 1) // 2
@@ -313,7 +318,7 @@ def main():
             roofline_k2 = {"bound": "hbm", "kernel": "repaint_fwd_kernel + repaint_bwd_kernel (one window, all targets)",
                            "achieved": k2_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k2_gbs / HBM_PEAK_GBS,
                            "traffic": pmc["kernels"]["repaint"]["hbm_bytes_per_launch"] if pmc else None,
-                           "traffic_static_from": "profiles/r02_pmc_c3.json" if pmc else None,
+                           "traffic_static_from": pmc_file if pmc else None,
                            "algorithmic_bytes": k2_bytes, "window": w, "target_site_rows": rows, "ms": win.repaint_ms}
             extra = {"window": w,
                      "k2_repaint_ms": win.repaint_ms,
@@ -337,7 +342,7 @@ def main():
         # HBM bytes per launch: PMC passes (FETCH_SIZE + WRITE_SIZE) are separate rocprofv3 runs
         # (tools/gpu_profile_r02.sh); the committed summary is read here, NOT measured in this run
         traffic = pmc["kernels"][args.mode]["hbm_bytes_per_launch"] if pmc and args.mode in pmc["kernels"] else None
-        traffic_from = "profiles/r02_pmc_c3.json" if traffic is not None else None
+        traffic_from = pmc_file if traffic is not None else None
         # SURVEY.md 8d caveat H5: at 1 bit per update the FP64 vector pipe, not HBM, is the resource that binds.
         # USEFUL f64 instructions per pair of directional updates (one donor at one visited site, both passes):
         # 3 forward (add, masked mul, add into the sum) + 6 backward (masked add, add, masked mul, two for the

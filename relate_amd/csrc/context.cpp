@@ -497,7 +497,8 @@ rl_ctx *rl_create(int device) {
   }
   rl_ctx *ctx = new rl_ctx();
   ctx->device = device;
-  if (make_stream(&ctx->s0, false) != hipSuccess || make_stream(&ctx->s1, false) != hipSuccess ||
+  if (make_stream(&ctx->s0, false, getenv("RELATE_AMD_K2_HIGH") && atoi(getenv("RELATE_AMD_K2_HIGH")) != 0) != hipSuccess ||
+      make_stream(&ctx->s1, false) != hipSuccess ||
       hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
       hipEventCreate(&ctx->ev2) != hipSuccess) {
     set_error("stream/event creation failed");
@@ -545,6 +546,7 @@ int rl_park_stones(rl_ctx *ctx) {
   ctx->h_beta = b;
   ctx->d_alpha.release();
   ctx->d_beta.release();
+  rl::device_cache_trim();  // (released blocks wait in the cache: these are to be someone else's memory)
   return RL_OK;
 }
 

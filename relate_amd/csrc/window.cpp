@@ -43,6 +43,7 @@ struct rl_window {
   unsigned char *h_place = nullptr;
   size_t h_place_bytes = 0;
   std::vector<int32_t> b_row, start_row, save_row;  // [nloc]
+  int anchor_snp = -1;  // the SNP the kept backward states stand above (the same for all targets), -1: none
   // RELATE_AMD_TIMING: where the window's wall-clock goes (seconds): choosing rows + uploads, waiting for the context's
   // RePaint turn, the launch until it is through, the matrices' own part (arguments, kernel, wait)
   double t_place = 0, t_turn = 0, t_launch = 0, t_matrix = 0;
@@ -175,6 +176,8 @@ static int place_rows(rl_window *win, int snp, float *kernel_ms) {
   const auto t_in = std::chrono::steady_clock::now();
   const int nloc = win->nloc, k0 = win->k0, L = ctx->L;
   const int64_t all_rows = win->top_off[nloc];
+  int part_last = L - 1;            // the last SNP whose trees the part serves
+  std::vector<int32_t> part_extra;  // derived sites of each target in [snp, part_last]
   if (win->cap_rows >= all_rows) {
     for (int t = 0; t < nloc; t++) {
       win->row_lo[t] = 0;
@@ -182,6 +185,7 @@ static int place_rows(rl_window *win, int snp, float *kernel_ms) {
     }
   } else {
     std::vector<int32_t> extra(nloc, 0);
+    part_last = std::max(snp, 0);
     int64_t used = 2 * (int64_t)nloc;
     const int last_wanted = std::min(L - 1, win->end + 1);
     // The sections of a stage open together and would come back for their next part together, every one of them
@@ -197,8 +201,10 @@ static int place_rows(rl_window *win, int snp, float *kernel_ms) {
       for (int t = 0; t < nloc; t++) pop += derived(ctx, s0, k0 + t);
       if (used + pop > cap_now && s0 > snp) break;
       used += pop;
+      part_last = s0;
       for (int t = 0; t < nloc; t++) extra[t] += derived(ctx, s0, k0 + t);
     }
+    part_extra = extra;
     for (int t = 0; t < nloc; t++) {
       const int D = (int)(win->top_off[t + 1] - win->top_off[t]);
       win->row_lo[t] = std::min(std::max(win->v_snp_prev[t], 0), D);
@@ -232,22 +238,38 @@ static int place_rows(rl_window *win, int snp, float *kernel_ms) {
   if (keep_state) {
     // The backward pass of a launch runs from the window's last row down to the part's first: half a window on
     // average, however small the part.  One kept state per target cuts that: a launch that has to come down from
-    // the last row leaves its state halfway between there and the top of its part, and the launches whose rows
-    // lie below that start from it (24 parts: 132 part-lengths of descent instead of 300).
+    // the last row leaves the states above an ANCHOR SNP halfway between the end of its part and the end of the
+    // window, and the launches of the parts that end at or before the anchor start from them.  The anchor is a SNP,
+    // not a row, so that ALL targets switch in the same launches (a target's state stands before the row its part
+    // would end at if the part ended at the anchor): a launch is as long as its longest descent, and with a midpoint
+    // per target a few targets came down from the last row in most launches.  24 parts: 132 part-lengths of
+    // descent instead of 300, and four or five long launches per window instead of a dozen.
     const size_t row_doubles = (size_t)ctx->S * 64 * ctx->waves;
     rc = win->d_bstate.alloc((size_t)nloc * row_doubles * sizeof(double));
     rc = rc ? rc : win->d_bscal.alloc((size_t)nloc * 2 * sizeof(double));
     if (rc) return rc;
     if (win->b_row.empty()) win->b_row.assign(nloc, -1);
-    for (int t = 0; t < nloc; t++) {
-      const int D = (int)(win->top_off[t + 1] - win->top_off[t]);
-      const bool from_state = win->have_logscales && win->b_row[t] >= 0 && win->b_row[t] >= win->row_hi[t] - 1 &&
-                              win->b_row[t] <= D - 2;
-      if (from_state) {
-        win->start_row[t] = win->b_row[t];
-      } else if (D - 2 - win->row_hi[t] >= 12) {
-        win->save_row[t] = win->row_hi[t] + (D - 2 - win->row_hi[t]) / 2;
+    const int last_snp = std::min(L - 1, win->end + 1);
+    if (win->have_logscales && win->anchor_snp >= part_last) {
+      for (int t = 0; t < nloc; t++) {
+        const int D = (int)(win->top_off[t + 1] - win->top_off[t]);
+        if (win->b_row[t] >= 0 && win->b_row[t] >= win->row_hi[t] - 1 && win->b_row[t] <= D - 2)
+          win->start_row[t] = win->b_row[t];  // (else: this target from the stone)
       }
+    } else if (last_snp - part_last >= 24) {
+      const int anchor = part_last + (last_snp - part_last) / 2;
+      std::vector<int32_t> more(nloc, 0);
+      for (int s0 = part_last + 1; s0 <= anchor; s0++)
+        for (int t = 0; t < nloc; t++) more[t] += derived(ctx, s0, k0 + t);
+      for (int t = 0; t < nloc; t++) {
+        const int D = (int)(win->top_off[t + 1] - win->top_off[t]);
+        // the row a part from here to the anchor would end at, and one more (a later part counts its first SNP twice)
+        const int r = win->row_lo[t] + part_extra[t] + more[t] + 3;
+        if (r <= D - 2 && r > win->row_hi[t]) win->save_row[t] = r;
+      }
+      win->anchor_snp = anchor;
+      for (int t = 0; t < nloc; t++)
+        if (win->save_row[t] < 0) win->b_row[t] = -1;  // (no state for this target under the new anchor)
     }
     // The forward pass likewise ran from the window's first row up to the part's last, every time: the state behind
     // the checkpoint row in whose block the NEXT part begins (its first row is this part's last but one) is kept, and
