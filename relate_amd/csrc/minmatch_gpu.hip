@@ -1778,7 +1778,8 @@ class BuildQueue {
     all->push_back(q);
     return q;
   }
-  // builders that will ask at the same time (the stage: its section threads); 0: unknown
+  // the most workers the caller wants alive (the stage: its section threads, fewer when RePaint needs the chip); 0: no
+  // word
   void expect(int builders) {
     std::lock_guard<std::mutex> lk(m_);
     expected_ = builders;
@@ -1840,6 +1841,7 @@ class BuildQueue {
     // a worker has a CU to itself (150 KB of LDS, 8 waves of 256 registers); an eighth of the chip stays free for
     // the stage's short kernels (RePaint, distance matrices, weave)
     cap_ = env_int("RELATE_AMD_BUILD_WORKERS", cus - cus / 8, 1, 1024);
+    cap_from_env_ = getenv("RELATE_AMD_BUILD_WORKERS") != nullptr;
     idle_ms_ = env_int("RELATE_AMD_BUILD_IDLE_MS", 50, 1, 10000);
     ok_ = true;
     std::thread([this] { launcher(); }).detach();
@@ -1884,7 +1886,9 @@ class BuildQueue {
         }
         cv_.wait(lk, [&] { return outstanding_ > 0; });
         demand = outstanding_;
-        goal = std::min(cap_, expected_ > 0 ? std::max(expected_, demand) : cap_);
+        // (the stage's word, expect(), is a limit -- it knows what RePaint needs of the chip; RELATE_AMD_BUILD_WORKERS
+        //  overrides it)
+        goal = (expected_ > 0 && !cap_from_env_) ? std::min(cap_, expected_) : cap_;
       }
       int alive = 0, free_stream = -1, busy_launches = 0;
       for (int l = 0; l < MM_LAUNCHES; l++) {
@@ -1928,6 +1932,7 @@ class BuildQueue {
   WorkQueue *q_ = nullptr;
   DevBuf d_state_;
   int cap_ = 224, idle_ms_ = 50;
+  bool cap_from_env_ = false;
   std::mutex m_;
   std::condition_variable cv_;
   unsigned published_ = 0;

@@ -863,7 +863,18 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
       nthreads = std::min(nthreads, concurrent);
     }
   }
-  if (gpu_build && sample_ages.empty()) (void)device_builder_expect(device, ctx->N, nthreads);  // (sizes the workers' launches)
+  if (gpu_build && sample_ages.empty()) {
+    // One worker per open section -- unless the windows are bounded: then RePaint runs all through the stage, on the
+    // CUs the workers do not hold (a worker has a CU to itself), and it is the queue every section waits in.  At C3
+    // (134 sections, 37 launches per window): 110 workers 207 s, 100 workers 177 s, 90 workers 190 s (RePaint 168 /
+    // 100 / 92 s busy; trees waiting 5 / 36 / 55 ms for a worker): the workers get 3/8 of the CUs.
+    int workers = nthreads, cus = 256;
+    if (cap_rows > 0) {
+      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 8) cus = 256;
+      workers = std::min(nthreads, 3 * cus / 8);
+    }
+    (void)device_builder_expect(device, ctx->N, workers);
+  }
   // Host threads left over by the sections help inside each tree build (minmatch.h BuildThreads).  Helpers are the
   // less efficient use of a core (a merge is split 8 ways for a 2.5x shorter build) and a helper that loses its
   // core stalls every merge, so they get a quarter of the physical cores at most: measured on 2 x 64 cores with 8
