@@ -16,6 +16,16 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* EXPERIMENT (tools/exp_fp32_state.py): -DRO_FP32_STATE builds a variant in which the per-donor
+ * state of the Li-Stephens passes (alpha, beta) is rounded to float after every update -- what a kernel with packed
+ * FP32 state would hold -- while sums, factors and logscales stay double.  The default build is the restatement. */
+#ifdef RO_FP32_STATE
+#define RO_STATE(v) ((double)(float)(v))
+#else
+#define RO_STATE(v) (v)
+#endif
+
+
 /* ------------------------------------------------------------------ */
 /* fast_log.hpp:6-21 : exponent extraction + quadratic on the mantissa */
 float ro_fast_log(float val) {
@@ -265,14 +275,14 @@ static int paint_target(const ro_data *d, const paint_consts *c, const int *wb,
       double v = a[n] + cfac;
       double derived = (double)(seq_k > row[n]);
       v *= derived * c->theta_ratio + 1.0;
-      a[n] = v;
+      a[n] = RO_STATE(v);
     }
     a[k] = 0.0;
     S = sum_alpha(a, N, k, order, paint_lanes(N));
     cfac = S;
     if (cfac < c->lower || cfac > c->upper) { /* :334-347 */
       const double tmp = cfac;
-      for (int n = 0; n < N; n++) a[n] /= tmp;
+      for (int n = 0; n < N; n++) a[n] = RO_STATE(a[n] / tmp);
       ls += log(tmp);
       cfac = 1.0;
     }
@@ -322,7 +332,7 @@ static int paint_target(const ro_data *d, const paint_consts *c, const int *wb,
       double derived = (double)(seqk_next > row_next[n]);
       double v = b[n] + derived * bt + b1;
       v *= derived * c->theta_ratio + 1.0;
-      b[n] = v;
+      b[n] = RO_STATE(v);
     }
     b[k] = 0.0;
     const char *row = seq + (size_t)snp * N;
@@ -330,7 +340,7 @@ static int paint_target(const ro_data *d, const paint_consts *c, const int *wb,
     cfac = B;
     if (cfac < c->lower || cfac > c->upper) { /* :538-551 */
       const double tmp = cfac;
-      for (int n = 0; n < N; n++) b[n] /= tmp;
+      for (int n = 0; n < N; n++) b[n] = RO_STATE(b[n] / tmp);
       ls += ro_fast_log((float)tmp); /* float fast_log here (:548) */
       cfac = 1.0;
     }
@@ -618,14 +628,14 @@ int ro_repaint_section(const ro_data *d, const float *alpha_begin,
       double v = ap[n] + cfac;
       double derived = (double)(seq_k > row[n]);
       v *= derived * c->theta_ratio + 1.0;
-      a[n] = v;
+      a[n] = RO_STATE(v);
     }
     a[k] = 0.0;
     S = sum_alpha(a, N, k, order, paint_lanes(N));
     cfac = S;
     if (cfac < c->lower || cfac > c->upper) { /* :865-877 */
       const double tmp = cfac;
-      for (int n = 0; n < N; n++) a[n] /= tmp;
+      for (int n = 0; n < N; n++) a[n] = RO_STATE(a[n] / tmp);
       prev_logscale += log(tmp);
       logscales[i] = (float)(logscales[i] + log(tmp));
       cfac = 1.0;
@@ -657,7 +667,7 @@ int ro_repaint_section(const ro_data *d, const float *alpha_begin,
       double derived = (double)(seqk_next > row_next[n]);
       double v = b[n] + derived * bt + b1;
       v *= derived * c->theta_ratio + 1.0;
-      b[n] = v;
+      b[n] = RO_STATE(v);
     }
     b[k] = 0.0;
     const char *row = seq + (size_t)site[j] * N;
@@ -668,7 +678,7 @@ int ro_repaint_section(const ro_data *d, const float *alpha_begin,
     for (int n = 0; n < N; n++) t[n] = (float)(a[n] * b[n]); /* :1039 */
     if (cfac < c->lower || cfac > c->upper) { /* :1047-1061 */
       const double tmp = cfac;
-      for (int n = 0; n < N; n++) b[n] /= tmp;
+      for (int n = 0; n < N; n++) b[n] = RO_STATE(b[n] / tmp);
       prev_logscale += log(tmp);
       logscales[j] = (float)(logscales[j] + log(tmp));
       cfac = 1.0;

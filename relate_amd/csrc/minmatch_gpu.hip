@@ -1391,7 +1391,7 @@ static_assert(sizeof(MMParams) % 4 == 0 && sizeof(MMParams) / 4 <= MM_PARAM_WORD
 // without a tree in it is the idle one, bounded by the clock.
 template <bool LDS, int MAXQ>
 __global__ void __launch_bounds__(MM_BLOCK, 1)
-    minmatch_worker(WorkQueue *q, WorkerState *ws, int launch, long long idle_ticks) {
+    minmatch_worker(WorkQueue *q, WorkerState *ws, int launch, long long idle_ticks, int trace) {
   __shared__ Shared sh;
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
   const int tid = threadIdx.x;
@@ -1399,7 +1399,7 @@ __global__ void __launch_bounds__(MM_BLOCK, 1)
   // (progress marks for RELATE_AMD_MM_TRACE, in the queue's spare words: workers started / tickets claimed / trees
   //  left / workers gone)
   auto mark = [&](int which) {
-    if (tid == 0) __hip_atomic_fetch_add(&q->pad[which], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (trace && tid == 0) __hip_atomic_fetch_add(&q->pad[which], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   };
   mark(0);
   // (one divergent block per turn -- thread 0 settles the accounts of the tree just built and claims the next --,
@@ -1409,7 +1409,7 @@ __global__ void __launch_bounds__(MM_BLOCK, 1)
   for (;;) {
     if (tid == 0) {
       if (had_tree) {
-        __hip_atomic_fetch_add(&q->pad[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (trace) __hip_atomic_fetch_add(&q->pad[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_fetch_add(&mine.activity, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(&mine.busy, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -1428,7 +1428,7 @@ __global__ void __launch_bounds__(MM_BLOCK, 1)
             ticket = h;
             __hip_atomic_fetch_add(&mine.busy, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_fetch_add(&mine.activity, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(&q->pad[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (trace) __hip_atomic_fetch_add(&q->pad[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             break;
           }
           continue;
@@ -1444,7 +1444,7 @@ __global__ void __launch_bounds__(MM_BLOCK, 1)
         }
         __builtin_amdgcn_s_sleep(127);  // (~3 us: the queue is read across PCIe)
       }
-      if (ticket == ~0u) __hip_atomic_fetch_add(&q->pad[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (trace && ticket == ~0u) __hip_atomic_fetch_add(&q->pad[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       sh.ticket = ticket;
     }
     __syncthreads();
@@ -1907,12 +1907,13 @@ class BuildQueue {
         n = std::max(1, std::min(n, goal - alive));
         const int l = free_stream;
         const long long idle = (long long)idle_ms_ * 100000LL;
+        const int trace_flag = getenv("RELATE_AMD_MM_TRACE") ? 1 : 0;
         if (lds_)
           hipLaunchKernelGGL((minmatch_worker<true, MM_Q_LDS>), dim3((unsigned)n), dim3(MM_BLOCK), dyn, streams[l], q_,
-                             d_state_.as<WorkerState>(), l, idle);
+                             d_state_.as<WorkerState>(), l, idle, trace_flag);
         else
           hipLaunchKernelGGL((minmatch_worker<false, MM_Q_GLOB>), dim3((unsigned)n), dim3(MM_BLOCK), 0, streams[l], q_,
-                             d_state_.as<WorkerState>(), l, idle);
+                             d_state_.as<WorkerState>(), l, idle, trace_flag);
         if (hipGetLastError() != hipSuccess) {
           failed_.store(true);
           return;
