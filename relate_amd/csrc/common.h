@@ -3,6 +3,7 @@
 #include <cstdlib>
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -56,6 +57,8 @@ void device_cache_release(void *p, size_t bytes);
 void *pinned_cache_alloc(size_t bytes, size_t *got);
 void pinned_cache_release(void *p, size_t bytes);
 void device_cache_trim();
+// set while tree-builder workers may hold the device (minmatch_gpu.hip): a failed allocation does not trim then
+extern std::atomic<bool> g_workers_may_be_resident;
 
 // owning device buffer
 struct DevBuf {

@@ -58,6 +58,9 @@ struct BlockCache {
   size_t held = 0;
 };
 BlockCache g_dev_cache, g_pin_cache;
+}  // namespace
+std::atomic<bool> g_workers_may_be_resident{false};
+namespace {
 
 template <typename AllocFn>
 void *cache_alloc(BlockCache &c, size_t bytes, size_t *got, AllocFn raw_alloc) {
@@ -76,7 +79,10 @@ void *cache_alloc(BlockCache &c, size_t bytes, size_t *got, AllocFn raw_alloc) {
     }
   }
   void *p = raw_alloc(bytes);
-  if (!p) {  // give the cached blocks back and try once more
+  // Out of memory: give the cached blocks back and try once more -- unless the tree builder's workers may be
+  // resident (hipFree would wait for them, i.e. for as long as any section has a tree in flight): then the caller
+  // gets its error, as it would have without a cache.
+  if (!p && !g_workers_may_be_resident.load()) {
     device_cache_trim();
     p = raw_alloc(bytes);
   }

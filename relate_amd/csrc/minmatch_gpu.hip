@@ -1844,6 +1844,7 @@ class BuildQueue {
     cap_from_env_ = getenv("RELATE_AMD_BUILD_WORKERS") != nullptr;
     idle_ms_ = env_int("RELATE_AMD_BUILD_IDLE_MS", 50, 1, 10000);
     ok_ = true;
+    g_workers_may_be_resident.store(true);
     std::thread([this] { launcher(); }).detach();
   }
   void launcher() {
