@@ -525,7 +525,13 @@ void rl_destroy(rl_ctx *ctx) {
   if (ctx->h_alpha) (void)hipHostFree(ctx->h_alpha);
   if (ctx->h_beta) (void)hipHostFree(ctx->h_beta);
   delete ctx;
-  rl::device_cache_trim();  // (the context's buffers went to the cache: back to the driver)
+  // (the context's buffers went to the cache: back to the driver -- unless the process says it is about to end,
+  //  RELATE_AMD_KEEP_CACHE=1, the command-line tool: the blocks stay reusable, and the exit releases them at once)
+  static const bool keep = getenv("RELATE_AMD_KEEP_CACHE") && atoi(getenv("RELATE_AMD_KEEP_CACHE")) != 0;
+  if (!keep)
+    rl::device_cache_trim();
+  else
+    (void)hipDeviceSynchronize();  // (as the trim's hipFree does: the tree builder's idle workers have left when this returns)
 }
 
 // The stones of a painted chunk move to pinned host memory and their device buffers are released (C3: 2 x 26.7 GB,

@@ -1365,6 +1365,7 @@ __device__ inline void params_from_words(MMParamsDev &p, const unsigned *w) {
 // `tail`; workers claim tickets from `head` (device memory) and read the words of their ticket.
 constexpr int MM_QUEUE_CAP = 1024;  // requests in flight <= builders alive (a section has one tree in flight)
 constexpr int MM_LAUNCHES = 6;      // worker launches alive at once (a stream, i.e. a hardware queue, each)
+constexpr int MM_XCDS = 8;          // a launch's workgroups are dealt to the XCDs in turn
 struct WorkQueue {
   unsigned tail;
   unsigned pad[15];
@@ -1890,6 +1891,8 @@ class BuildQueue {
         // (the stage's word, expect(), is a limit -- it knows what RePaint needs of the chip; RELATE_AMD_BUILD_WORKERS
         //  overrides it)
         goal = (expected_ > 0 && !cap_from_env_) ? std::min(cap_, expected_) : cap_;
+        // whole rounds of the XCDs (below): the goal too
+        if (goal >= MM_XCDS) goal -= goal % MM_XCDS;
       }
       int alive = 0, free_stream = -1, busy_launches = 0;
       for (int l = 0; l < MM_LAUNCHES; l++) {
@@ -1905,6 +1908,11 @@ class BuildQueue {
       // launches are few: MM_LAUNCHES streams), never past the goal.
       if (demand + 4 > alive && alive < goal && free_stream >= 0) {
         int n = std::max({demand + 8 - alive, alive / 2, 16});
+        // Workgroup b of a launch goes to XCD b % 8, every launch starting at XCD 0 again: launches of any size pile
+        // their remainders on the low XCDs (six launches: up to six workers more there than on XCD 7), and a RePaint
+        // launch -- its workgroups dealt to the XCDs in the same round-robin -- lasts as long as the XCD with the
+        // fewest CUs left.  Whole rounds only.
+        n = (n + MM_XCDS - 1) / MM_XCDS * MM_XCDS;
         n = std::max(1, std::min(n, goal - alive));
         const int l = free_stream;
         const long long idle = (long long)idle_ms_ * 100000LL;

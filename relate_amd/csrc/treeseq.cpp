@@ -735,6 +735,7 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
                           int flags, int fb, int sum_mode, int device, bool from_files,
                           const char *sample_ages_file = nullptr) {
   int rc = RL_OK;
+  const auto entry_t0 = std::chrono::steady_clock::now();
   const int W = ctx->W, L = ctx->L;
   if (first_section >= W) {  // BuildTopology.cpp:45
     rl_destroy(ctx);
@@ -883,8 +884,24 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
   std::atomic<int> open_sections(0);
   int most_open = 0;            // (under g_gpu_mutex)
   const auto stage_t0 = std::chrono::steady_clock::now();
+  if (getenv("RELATE_AMD_TIMING"))
+    fprintf(stderr, "[stage] set-up before the section threads (plan, reservations) %.3f s\n",
+            std::chrono::duration<double>(stage_t0 - entry_t0).count());
   double reserved_bytes = 0.0;  // (under g_gpu_mutex) HBM promised to windows that are being opened
-  std::atomic<int> next(first_section);
+  // The sections are dealt to the threads longest first: with about two sections per thread (C3: 267 on 134) and
+  // 228 - 496 trees per section, dealing them in index order left the threads with 500 - 950 trees each, and the
+  // stage ended on a long tail of a few open sections with most of the tree builder's workers idle (the same deal
+  // replayed with the measured tree counts: 214 s in index order, 176 s longest first, 174 s perfectly even).  How
+  // many trees a section needs is not known before its SNPs are mapped; its SNP count is (correlation 0.90).
+  // The files of a section do not depend on when it is built.
+  std::vector<int> deal(last_section - first_section + 1);
+  for (size_t x = 0; x < deal.size(); x++) deal[x] = first_section + (int)x;
+  if (nthreads > 1)
+    std::stable_sort(deal.begin(), deal.end(), [&](int a, int b) {
+      auto snps = [&](int w) { return (w < W - 1 ? ctx->wb[w + 1] : L) - ctx->wb[w]; };
+      return snps(a) > snps(b);
+    });
+  std::atomic<int> next(0);
   std::atomic<int> first_error(0);
   std::mutex err_mutex;
   std::string first_message;  // (rl_last_error is per thread: the failing worker's text is carried to the caller)
@@ -921,8 +938,9 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
       if (ctx->nloc == ctx->N) rl_treeseq_set_device_matrix(ts, win_matrix_dev);
     }
     for (;;) {
-      const int section = next.fetch_add(1);
-      if (section > last_section || first_error.load()) break;
+      const int turn = next.fetch_add(1);
+      if (turn >= (int)deal.size() || first_error.load()) break;
+      const int section = deal[turn];
       const int start = ctx->wb[section];
       int end = (section < W - 1) ? ctx->wb[section + 1] - 1 : L - 1;
       if (end >= L) end = L - 1;
@@ -997,7 +1015,11 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
             last_section, nthreads, most_open, cap_rows > 0 ? cap_rows : (long long)max_rows, max_rows,
             ctx->repaint_launches, 1e-3 * ctx->repaint_ms, gpu_build ? "GPU" : "host",
             std::chrono::duration<double>(std::chrono::steady_clock::now() - stage_t0).count());
+  const auto destroy_t0 = std::chrono::steady_clock::now();
   rl_destroy(ctx);
+  if (getenv("RELATE_AMD_TIMING"))
+    fprintf(stderr, "[stage] context released in %.3f s\n",
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - destroy_t0).count());
   if (!rc) {
     rusage usage;
     getrusage(RUSAGE_SELF, &usage);
@@ -1034,15 +1056,27 @@ int rl_stage_paint_build_topology(const char *out_dir, int chunk_index, int firs
                                   int use_painting, double theta, double rho, int flags, int fb, int sum_mode,
                                   int device) {
   if (!out_dir) return RL_EINVAL;
+  // RELATE_AMD_TIMING=1: wall-clock of what precedes the sections on stderr
+  const bool timing = getenv("RELATE_AMD_TIMING") != nullptr;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t0 = now();
+  auto lap = [&](const char *what) {
+    const double t1 = now();
+    if (timing) fprintf(stderr, "[fused stage] %-36s %8.3f s\n", what, t1 - t0);
+    t0 = t1;
+  };
   rl_ctx *ctx = rl_create(device);
   if (!ctx) return RL_ENODEVICE;
+  lap("device context");
   int rc = rl_load_chunk(ctx, out_dir, chunk_index);
+  lap("read chunk files");
   if (!rc && use_painting) rc = rl_set_painting(ctx, theta, rho);
   if (!rc) {
     std::cerr << "---------------------------------------------------------" << std::endl;
     std::cerr << "Painting sequences (stepping stones stay on the device)..." << std::endl;
     rc = rl_paint(ctx, sum_mode, nullptr);
   }
+  lap("plan + uploads + masks + paint kernels");
   // RELATE_AMD_PARK_STONES=1: the stones to pinned host memory, their HBM to the sections' windows -- for chunks that
   // would not fit otherwise; at C3 (53 GB of stones) it opens 112 sections instead of 91 and the chunk takes 330 s
   // instead of 291 s: past ~90 trees in flight the build kernels slow each other down

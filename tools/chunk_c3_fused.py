@@ -43,6 +43,10 @@ try:
                        env=dict(os.environ) if os.environ.get("C3_NO_TIMING") else dict(os.environ, RELATE_AMD_TIMING="1"))
     out["wall_s"] = time.time() - t0
     err = p.stderr.decode()
+    if os.environ.get("C3_KEEP_STDERR"):  # (everything but the per-tree and per-window lines)
+        with open(os.path.join(ROOT, os.environ["C3_KEEP_STDERR"]), "w") as fh:
+            fh.write("\n".join(l for l in err.replace("\r", "\n").split("\n")
+                               if l.strip() and "[gpu tree builder]" not in l and not re.match(r"^\[\d+/\d+\]$", l.strip())))
     assert p.returncode == 0, err[-600:]
     trees = 0
     for l in err.split("\n"):
