@@ -149,11 +149,21 @@ struct rl_ctx {
   std::vector<char> stone_quantised;  // [W], under repaint_mutex
   bool have_chunk = false, plan_on_device = false, painted = false;
   int paint_mode = -1;
-  // RePaint launches of the context's windows share the forward strips, the target counter and stream s0: one at a
-  // time (the windows' other work -- distance matrices -- runs on their own streams, side by side)
+  // A RePaint launch of one of the context's windows needs the forward strips (d_k2_scratch) and a stream: one at a
+  // time on s0 (the windows' other work -- distance matrices -- runs on their own streams, side by side).
   std::mutex repaint_mutex;
-  long long repaint_launches = 0;  // (under repaint_mutex) RePaint launches of the context's windows
-  double repaint_ms = 0.0;         // ... and their time on the device (HIP events)
+  // A stage may open a SECOND lane (strips, stream, events of its own; RELATE_AMD_REPAINT_LANES=2, treeseq.cpp): a
+  // launch is a forward and a backward kernel of one workgroup per target, each as long as its longest target, on
+  // the CUs the tree builder's workers leave -- two windows' launches side by side fill each other's tails.
+  struct RepaintLane {
+    std::mutex m;
+    hipStream_t s = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    rl::DevBuf scratch;
+  } lane2;
+  bool two_lanes = false;
+  std::atomic<long long> repaint_launches{0};  // RePaint launches of the context's windows
+  std::atomic<long long> repaint_us{0};        // ... and their time on the device (HIP events), microseconds
   float ms_fwd = 0.f, ms_bwd = 0.f, ms_paint = 0.f;
   int paint_split = 0;  // rl_set_paint_split: one launch per direction instead of one for both
 };

@@ -522,6 +522,9 @@ void rl_destroy(rl_ctx *ctx) {
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
+  if (ctx->lane2.s) (void)hipStreamDestroy(ctx->lane2.s);
+  if (ctx->lane2.e0) (void)hipEventDestroy(ctx->lane2.e0);
+  if (ctx->lane2.e1) (void)hipEventDestroy(ctx->lane2.e1);
   if (ctx->h_alpha) (void)hipHostFree(ctx->h_alpha);
   if (ctx->h_beta) (void)hipHostFree(ctx->h_beta);
   delete ctx;

@@ -832,6 +832,21 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
       rl_destroy(ctx);
       return RL_ENOMEM;
     }
+    // RELATE_AMD_REPAINT_LANES=2: a second RePaint lane (common.h).  Not the default: its strips are sized for a
+    // window's first, whole pass like the first lane's (C3: 7 GB), and at C3 that is what lets 134 sections open
+    // instead of 89 -- two lanes and 89 sections in three waves: 183 s (no section waits for RePaint, 71 s busy),
+    // one lane and 134 sections: 173 s.
+    const char *le = getenv("RELATE_AMD_REPAINT_LANES");
+    if (last_section > first_section && le && atoi(le) == 2 && !ctx->two_lanes) {
+      auto &ln = ctx->lane2;
+      if (ln.scratch.alloc(strips) == 0 && make_stream(&ln.s, false) == hipSuccess &&
+          hipEventCreate(&ln.e0) == hipSuccess && hipEventCreate(&ln.e1) == hipSuccess) {
+        ctx->two_lanes = true;
+      } else {
+        (void)hipGetLastError();
+        ln.scratch.release();
+      }
+    }
     size_t free_b = 0, total_b = 0;
     const bool known = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
     const double room = known ? 0.9 * (double)free_b : 0.0;
@@ -1013,7 +1028,7 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
     fprintf(stderr, "[stage] sections %d..%d on %d threads, up to %d open at once, %lld of at most %.0f posterior rows "
             "resident per window, %lld RePaint launches (%.1f s on the device), %s tree builder, %.1f s\n", first_section,
             last_section, nthreads, most_open, cap_rows > 0 ? cap_rows : (long long)max_rows, max_rows,
-            ctx->repaint_launches, 1e-3 * ctx->repaint_ms, gpu_build ? "GPU" : "host",
+            ctx->repaint_launches.load(), 1e-6 * (double)ctx->repaint_us.load(), gpu_build ? "GPU" : "host",
             std::chrono::duration<double>(std::chrono::steady_clock::now() - stage_t0).count());
   const auto destroy_t0 = std::chrono::steady_clock::now();
   rl_destroy(ctx);

@@ -83,10 +83,31 @@ static int repaint_rows(rl_window *win, float *kernel_ms) {
   // launches are serialised
   const int64_t ck_doubles = win->ck_off[nloc] * (int64_t)S * 64 * waves;
   const auto t_ask = std::chrono::steady_clock::now();
-  std::unique_lock<std::mutex> one_at_a_time(ctx->repaint_mutex);
+  // (whichever lane is free; with both taken, the windows queue up behind the two in turn)
+  static std::atomic<unsigned> turn{0};
+  std::unique_lock<std::mutex> one_at_a_time(ctx->repaint_mutex, std::defer_lock);
+  bool second = false;
+  if (!ctx->two_lanes) {
+    one_at_a_time.lock();
+  } else if (!one_at_a_time.try_lock()) {
+    std::unique_lock<std::mutex> other(ctx->lane2.m, std::try_to_lock);
+    if (!other.owns_lock()) {
+      if (turn.fetch_add(1) & 1u)
+        other.lock();
+      else
+        one_at_a_time.lock();
+    }
+    if (other.owns_lock()) {
+      one_at_a_time = std::move(other);
+      second = true;
+    }
+  }
+  hipStream_t stream = second ? ctx->lane2.s : ctx->s0;
+  hipEvent_t e0 = second ? ctx->lane2.e0 : ctx->ev0, e1 = second ? ctx->lane2.e1 : ctx->ev2;
+  rl::DevBuf &scratch = second ? ctx->lane2.scratch : ctx->d_k2_scratch;
   const auto t_got = std::chrono::steady_clock::now();
   win->t_turn += std::chrono::duration<double>(t_got - t_ask).count();
-  int rc = ctx->d_k2_scratch.alloc(repaint_scratch_bytes(win->top_off[nloc], nloc, S, waves));
+  int rc = scratch.alloc(repaint_scratch_bytes(win->top_off[nloc], nloc, S, waves));
   if (rc) return rc;
   RepaintParams p;
   p.lay = ctx->lay;
@@ -120,7 +141,7 @@ static int repaint_rows(rl_window *win, float *kernel_ms) {
   }
   p.topology = win->d_top.as<float>();
   p.logscales = win->d_ls.as<float>();
-  p.scratch = ctx->d_k2_scratch.as<double>();
+  p.scratch = scratch.as<double>();
   p.ck_off = win->d_ck_off.as<int64_t>();
   p.side = p.scratch + ck_doubles;
   p.order = win->d_order.as<int32_t>();
@@ -131,21 +152,21 @@ static int repaint_rows(rl_window *win, float *kernel_ms) {
   p.fstate = win->d_fstate.as<double>();
   p.fscal = win->d_fscal.as<double>();
   (void)N;
-  bool ok = hipMemcpyAsync(win->d_place.p, win->h_place, (size_t)nloc * 40, hipMemcpyHostToDevice, ctx->s0) == hipSuccess;
-  ok = ok && hipEventRecord(ctx->ev0, ctx->s0) == hipSuccess;
-  hipError_t le = ok ? launch_repaint(p, S, waves, ctx->s0) : hipErrorUnknown;
+  bool ok = hipMemcpyAsync(win->d_place.p, win->h_place, (size_t)nloc * 40, hipMemcpyHostToDevice, stream) == hipSuccess;
+  ok = ok && hipEventRecord(e0, stream) == hipSuccess;
+  hipError_t le = ok ? launch_repaint(p, S, waves, stream) : hipErrorUnknown;
   ok = ok && le == hipSuccess;
-  ok = ok && hipEventRecord(ctx->ev2, ctx->s0) == hipSuccess;
-  hipError_t se = hipEventSynchronize(ctx->ev2);
+  ok = ok && hipEventRecord(e1, stream) == hipSuccess;
+  hipError_t se = hipEventSynchronize(e1);
   ok = ok && se == hipSuccess;
   if (!ok) {
     set_error("repaint launch failed: %s / %s", hipGetErrorString(le), hipGetErrorString(se));
     return RL_EHIP;
   }
   float ms = 0.f;
-  (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev2);
+  (void)hipEventElapsedTime(&ms, e0, e1);
   if (kernel_ms) *kernel_ms = ms;
-  ctx->repaint_ms += ms;
+  ctx->repaint_us += (long long)(1e3 * ms);
   ctx->repaint_launches++;
   one_at_a_time.unlock();
   win->t_launch += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_got).count();
