@@ -97,7 +97,7 @@ void BuildThreads::run(const std::function<void(int, int)> &job) {
   while (done_.load(std::memory_order_acquire) != T_ - 1) __builtin_ia32_pause();
 }
 
-MinMatch::MinMatch(int N_, double theta) : N(N_), pool(N_ >= 2 * build_min_clusters() ? build_threads() : 1) {
+MinMatch::MinMatch(int N_, double theta) : N(N_), sym(N_), pool(N_ >= 2 * build_min_clusters() ? build_threads() : 1) {
   kflag.resize(N);
   kmask.resize(N);
   upos.resize(MAX_GATHER);
@@ -114,10 +114,8 @@ MinMatch::MinMatch(int N_, double theta) : N(N_), pool(N_ >= 2 * build_min_clust
   convert_index.resize(N);
   cluster_size.resize(N);
   min_values.resize(N);
-  min_values_sym.resize(N);
   min_values_CF.resize(N);  // zero-initialised and never refilled (:2399-2400)
   mc.resize(N);
-  mc_sym.resize(N);
   updated_cluster.resize(N);
 }
 
@@ -204,30 +202,6 @@ void MinMatch::initialize() {
         }
       }
     }
-}
-
-// tree_builder.cpp:255-293
-void MinMatch::initialize_sym() {
-  sym_d.resize((size_t)N * N);
-  const size_t n = cluster_index.size();
-  for (size_t ia = 0; ia < n; ia++)
-    for (size_t ib = ia + 1; ib < n; ib++) {
-      const int a = cluster_index[ia], b = cluster_index[ib];
-      sym_d[(size_t)a * N + b] = d(a, b) + d(b, a);
-      sym_d[(size_t)b * N + a] = sym_d[(size_t)a * N + b];
-    }
-  for (int a : cluster_index) {
-    float &mv = min_values_sym[a];
-    mc_sym[a].dist = INF;
-    for (int l : cluster_index) {
-      const float v = sym_d[(size_t)a * N + l];
-      if (mv > v && l != a) {
-        mv = v;
-        if (mc_sym[a].dist > mv) { mc_sym[a].lin1 = a; mc_sym[a].lin2 = l; mc_sym[a].dist = mv; }
-        if (best_sym.dist > mc_sym[a].dist) { best_sym.lin1 = a; best_sym.lin2 = l; best_sym.dist = mv; }
-      }
-    }
-  }
 }
 
 // tree_builder.cpp:296-598 (no prior) / :1844-2070 (prior)
@@ -451,56 +425,6 @@ void MinMatch::coalesce(int i, int j) {
   t_phase2 += now_s() - tp1;
 }
 
-// tree_builder.cpp:968-1058
-void MinMatch::coalesce_sym(int i, int j) {
-  const float added = cluster_size[i] + cluster_size[j];
-  float min_value_k, min_value_j = INF;
-  auto s = [&](int a, int b) -> float & { return sym_d[(size_t)a * N + b]; };
-  best_sym.dist = INF;
-  mc_sym[j].dist = INF;
-  const size_t n = cluster_index.size();
-  for (size_t ik = 0; ik < n; ik++) {
-    const int k = cluster_index[ik];
-    if (ik + PREFETCH_AHEAD < n) {
-      const float *nxt = sym_d.data() + (size_t)cluster_index[ik + PREFETCH_AHEAD] * N;
-      pf(nxt + j);
-      pf(nxt + i);
-    }
-    if (k == j || k == i) continue;
-    const float dkj = s(k, j), dki = s(k, i), dik = s(i, k), djk = s(j, k);
-    min_value_k = min_values_sym[k];
-    if (dik != djk) s(j, k) = (cluster_size[i] * dik + cluster_size[j] * djk) / added;
-    if (dki != dkj) s(k, j) = (cluster_size[i] * dki + cluster_size[j] * dkj) / added;
-    if (dkj != dki) {
-      if (std::fabs(min_value_k - dkj) < 1e-6 || std::fabs(min_value_k - dki) < 1e-6) {
-        const float min_value_old = min_value_k;
-        min_value_k = INF;
-        mc_sym[k].dist = INF;
-        for (int l : cluster_index) {
-          if (l != i && l != k) {
-            if (min_value_k > s(k, l)) {
-              min_value_k = s(k, l);
-              if (mc_sym[k].dist > min_value_k) { mc_sym[k].lin1 = k; mc_sym[k].lin2 = l; mc_sym[k].dist = min_value_k; }
-              if (min_value_k == min_value_old) break;
-            }
-          }
-        }
-        min_values_sym[k] = min_value_k;
-      }
-    } else {
-      if (mc_sym[k].lin1 == i) mc_sym[k].lin1 = j;
-      if (mc_sym[k].lin2 == i) mc_sym[k].lin2 = j;
-    }
-    if (best_sym.dist > mc_sym[k].dist) best_sym = mc_sym[k];
-    if (s(j, k) < min_value_j) {
-      min_value_j = s(j, k);
-      if (mc_sym[j].dist > s(j, k)) { mc_sym[j].lin1 = k; mc_sym[j].lin2 = j; mc_sym[j].dist = s(j, k); }
-    }
-  }
-  min_values_sym[j] = min_value_j;
-  if (best_sym.dist > mc_sym[j].dist) best_sym = mc_sym[j];
-}
-
 // merge i into j in the prior matrix and refresh j's row minimum (:2571-2596)
 // tree_builder.cpp:1061-1303 (no prior), :2358-2644 (prior); sample_ages empty
 void MinMatch::quick_build(float *dmat, const float *prior, HostTree &tree) {
@@ -521,10 +445,9 @@ void MinMatch::quick_build(float *dmat, const float *prior, HostTree &tree) {
     cluster_size[c] = 1.0f;
   }
   std::fill(min_values.begin(), min_values.end(), INF);
-  std::fill(min_values_sym.begin(), min_values_sym.end(), INF);
   best.dist = INF;
   best.dist2 = INF;
-  best_sym.dist = INF;
+  sym.reset();
 
   {
     const double t0 = now_s();
@@ -532,16 +455,12 @@ void MinMatch::quick_build(float *dmat, const float *prior, HostTree &tree) {
     t_init += now_s() - t0;
   }
 
-  bool use_sym = false;
   for (int num_nodes = N; num_nodes < 2 * N - 1; num_nodes++) {
     int i, j;
-    if (best.dist == INF) {  // no mutually-closest pair: symmetric fallback
-      if (!use_sym) {
-        initialize_sym();
-        use_sym = true;
-      }
-      i = best_sym.lin1;
-      j = best_sym.lin2;
+    if (best.dist == INF) {  // no mutually closest pair: the smallest symmetric distance, from here on (sym_pairs.h)
+      if (!sym.started()) sym.start(cluster_index, [&](int a, int b) { return d(a, b); });
+      i = sym.closest().first;
+      j = sym.closest().second;
     } else {
       i = best.lin1;
       j = best.lin2;
@@ -554,7 +473,7 @@ void MinMatch::quick_build(float *dmat, const float *prior, HostTree &tree) {
     tree.child_left[num_nodes] = conv_i;
     tree.child_right[num_nodes] = conv_j;
     coalesce(i, j);
-    if (use_sym) coalesce_sym(i, j);
+    if (sym.started()) sym.merge(i, j, cluster_size[i], cluster_size[j], cluster_index);
     cluster_size[j] = cluster_size[i] + cluster_size[j];
     convert_index[j] = num_nodes;
     cluster_index.erase(std::find(cluster_index.begin(), cluster_index.end(), i));

@@ -23,6 +23,8 @@
 #include <random>
 #include <vector>
 
+#include "sym_pairs.h"
+
 namespace rl {
 
 // std::vector allocator for the N x N matrices of the tree builder: 2 MiB-aligned
@@ -128,10 +130,11 @@ class MinMatch {
   std::mt19937 rng;
   std::vector<int> convert_index, cluster_index, updated_cluster;
   std::vector<float> cluster_size;
-  std::vector<Cand> mc, mc_sym;
-  Cand best, best_sym;
-  std::vector<float> min_values, min_values_sym, min_values_CF;
-  MatrixBuf sym_d, d_CF;
+  std::vector<Cand> mc;
+  Cand best;
+  std::vector<float> min_values, min_values_CF;
+  MatrixBuf d_CF;
+  SymPairs sym;  // merges without a mutually closest pair (sym_pairs.h)
   float sym_dist = 0.f, dist_random = 0.f;
 
   float *D = nullptr;         // current asymmetric matrix
@@ -141,9 +144,7 @@ class MinMatch {
   inline float &d(int a, int b) { return D[(size_t)a * N + b]; }
   void consider(int x, int y);  // feasible pair: one draw, update mc[x], mc[y] with (lin1=x, lin2=y)
   void initialize();
-  void initialize_sym();
   void coalesce(int i, int j);
-  void coalesce_sym(int i, int j);
 
   // phase 1 of a merge (parallel) leaves per cluster: 1 = distances or candidate changed, 2 = candidates rebuilt
   std::vector<unsigned char> kflag;
@@ -182,9 +183,7 @@ class MinMatchAges {
   void take_best(const Cand &m);
   float sym_of(int x, int y) const;
   void initialize(const std::vector<double> &ages);
-  void initialize_sym();
   void coalesce(int i, int j, const std::vector<double> &ages);
-  void coalesce_sym(int i, int j);
   inline float &d(int a, int b) { return D[(size_t)a * N + b]; }
 
   int N, Ne;
@@ -193,13 +192,14 @@ class MinMatchAges {
   std::uniform_real_distribution<double> unif{0.0, 1.0};
   std::vector<int> cluster_index, convert_index, updated_cluster;
   std::vector<float> cluster_size;
-  std::vector<Cand> mc, mc_sym;
-  Cand best, best_sym, cand;
+  std::vector<Cand> mc;
+  Cand best, cand;
   double age = 0.0;
   std::vector<double> unique_ages;
   std::vector<int> ages_count;
-  std::vector<float> min_values, min_values_sym, min_values_CF;
-  std::vector<float> sym_d, d_CF;
+  std::vector<float> min_values, min_values_CF;
+  std::vector<float> d_CF;
+  SymPairs sym;  // merges without a mutually closest pair (sym_pairs.h)
   float *D = nullptr;
   const float *CF = nullptr;
 };

@@ -31,17 +31,15 @@ bool MinMatchAges::gt(const Cand &a, const Cand &b) {
   return a.dist > b.dist || (a.dist == b.dist && a.dist2 > b.dist2);
 }
 
-MinMatchAges::MinMatchAges(int N_, double theta) : N(N_) {
+MinMatchAges::MinMatchAges(int N_, double theta) : N(N_), sym(N_) {
   Ne = (int)std::max(17.5f * N, 30000.0f);  // pipeline/BuildTopology.cpp:36 (int Data::Ne)
   threshold = -0.2 * std::log(theta / (1.0 - theta));  // tree_builder.cpp:43-44
   threshold_CF = -0.001 * std::log(theta / (1.0 - theta));
   convert_index.resize(N);
   cluster_size.resize(N);
   min_values.resize(N);
-  min_values_sym.resize(N);
   min_values_CF.resize(N);  // zero-initialised and never refilled (:2399-2400)
   mc.resize(N);
-  mc_sym.resize(N);
   updated_cluster.resize(N);
 }
 
@@ -121,89 +119,6 @@ void MinMatchAges::initialize(const std::vector<double> &ages) {
       }
     }
   }
-}
-
-// tree_builder.cpp:255-293 (as minmatch.cpp: initialize_sym)
-void MinMatchAges::initialize_sym() {
-  sym_d.assign((size_t)N * N, 0.0f);
-  const size_t n = cluster_index.size();
-  for (size_t ia = 0; ia < n; ia++)
-    for (size_t ib = ia + 1; ib < n; ib++) {
-      const int a = cluster_index[ia], b = cluster_index[ib];
-      sym_d[(size_t)a * N + b] = d(a, b) + d(b, a);
-      sym_d[(size_t)b * N + a] = sym_d[(size_t)a * N + b];
-    }
-  for (int a : cluster_index) {
-    float &mv = min_values_sym[a];
-    mc_sym[a].dist = INF;
-    for (int l : cluster_index) {
-      const float v = sym_d[(size_t)a * N + l];
-      if (mv > v && l != a) {
-        mv = v;
-        if (mc_sym[a].dist > mv) {
-          mc_sym[a].lin1 = a;
-          mc_sym[a].lin2 = l;
-          mc_sym[a].dist = mv;
-        }
-        if (best_sym.dist > mc_sym[a].dist) {
-          best_sym.lin1 = a;
-          best_sym.lin2 = l;
-          best_sym.dist = mv;
-        }
-      }
-    }
-  }
-}
-
-// tree_builder.cpp:968-1058 (as minmatch.cpp: coalesce_sym)
-void MinMatchAges::coalesce_sym(int i, int j) {
-  const float added = cluster_size[i] + cluster_size[j];
-  float min_value_k, min_value_j = INF;
-  auto s = [&](int a, int b) -> float & { return sym_d[(size_t)a * N + b]; };
-  best_sym.dist = INF;
-  mc_sym[j].dist = INF;
-  for (int k : cluster_index) {
-    if (k == j || k == i) continue;
-    const float dkj = s(k, j), dki = s(k, i), dik = s(i, k), djk = s(j, k);
-    min_value_k = min_values_sym[k];
-    if (dik != djk) s(j, k) = (cluster_size[i] * dik + cluster_size[j] * djk) / added;
-    if (dki != dkj) s(k, j) = (cluster_size[i] * dki + cluster_size[j] * dkj) / added;
-    if (dkj != dki) {
-      if (std::fabs(min_value_k - dkj) < 1e-6 || std::fabs(min_value_k - dki) < 1e-6) {
-        const float min_value_old = min_value_k;
-        min_value_k = INF;
-        mc_sym[k].dist = INF;
-        for (int l : cluster_index) {
-          if (l != i && l != k) {
-            if (min_value_k > s(k, l)) {
-              min_value_k = s(k, l);
-              if (mc_sym[k].dist > min_value_k) {
-                mc_sym[k].lin1 = k;
-                mc_sym[k].lin2 = l;
-                mc_sym[k].dist = min_value_k;
-              }
-              if (min_value_k == min_value_old) break;
-            }
-          }
-        }
-        min_values_sym[k] = min_value_k;
-      }
-    } else {
-      if (mc_sym[k].lin1 == i) mc_sym[k].lin1 = j;
-      if (mc_sym[k].lin2 == i) mc_sym[k].lin2 = j;
-    }
-    if (best_sym.dist > mc_sym[k].dist) best_sym = mc_sym[k];
-    if (s(j, k) < min_value_j) {
-      min_value_j = s(j, k);
-      if (mc_sym[j].dist > s(j, k)) {
-        mc_sym[j].lin1 = k;
-        mc_sym[j].lin2 = j;
-        mc_sym[j].dist = s(j, k);
-      }
-    }
-  }
-  min_values_sym[j] = min_value_j;
-  if (best_sym.dist > mc_sym[j].dist) best_sym = mc_sym[j];
 }
 
 // tree_builder.cpp:601-965 / :2073-2355
@@ -306,10 +221,9 @@ void MinMatchAges::quick_build(float *dmat, const float *prior, const std::vecto
     cluster_size[c] = 1.0f;
   }
   std::fill(min_values.begin(), min_values.end(), INF);
-  std::fill(min_values_sym.begin(), min_values_sym.end(), INF);
   best.dist = best.dist2 = best.dist3 = INF;
   if (!prior) best.replace = false;  // (:1117 -- the build with a prior leaves the flag as the last build left it)
-  best_sym.dist = INF;
+  sym.reset();
 
   if (unique_ages.empty()) {  // :1125-1152, once per builder
     std::vector<double> sorted = ages;
@@ -339,16 +253,12 @@ void MinMatchAges::quick_build(float *dmat, const float *prior, const std::vecto
 
   initialize(ages);
 
-  bool use_sym = false;
   for (int num_nodes = N; num_nodes < 2 * N - 1; num_nodes++) {
     int i, j;
-    if (best.dist == INF) {
-      if (!use_sym) {
-        initialize_sym();
-        use_sym = true;
-      }
-      i = best_sym.lin1;
-      j = best_sym.lin2;
+    if (best.dist == INF) {  // (sym_pairs.h)
+      if (!sym.started()) sym.start(cluster_index, [&](int a, int b) { return d(a, b); });
+      i = sym.closest().first;
+      j = sym.closest().second;
     } else {
       i = best.lin1;
       j = best.lin2;
@@ -376,7 +286,7 @@ void MinMatchAges::quick_build(float *dmat, const float *prior, const std::vecto
       min_values_CF[j] += threshold_CF;
     }
     coalesce(i, j, ages);
-    if (use_sym) coalesce_sym(i, j);
+    if (sym.started()) sym.merge(i, j, cluster_size[i], cluster_size[j], cluster_index);
 
     ages[j] = std::max(ages[i], ages[j]);
     if (prior) age += 2.0 / ((double)num_lins * (num_lins - 1.0)) * Ne;  // (:2516: before the lineage count drops)

@@ -135,6 +135,22 @@ def test_cli_gpu_build_with_bounded_windows(tmp_path):
         assert open(work / "out" / "chunk_0" / ("out_%d.anc" % w), "rb").read() == fx.z["anc/%d" % w].tobytes(), w
 
 
+def test_fused_stage_with_two_repaint_lanes(tmp_path):
+    """RELATE_AMD_REPAINT_LANES=2: the windows of the sections repaint on two streams with strips of their own, side by
+    side (bounded windows, so that every section comes back for more launches): the same bytes"""
+    work = tmp_path / "work"
+    (work / "out").mkdir(parents=True)
+    fx = Fixture("synth70", work / "out")
+    p = subprocess.run([CLI, "--mode", "PaintBuildTopology", "--chunk_index", "0", "-o", "out"], cwd=str(work),
+                       stderr=subprocess.PIPE,
+                       env=dict(os.environ, RELATE_AMD_REPAINT_LANES="2", RELATE_AMD_WINDOW_ROWS="300",
+                                RELATE_AMD_GPU_BUILD="1"))
+    assert p.returncode == 0, p.stderr.decode()
+    for w in range(fx.W):
+        assert open(work / "out" / "chunk_0" / ("out_%d.mut" % w), "rb").read() == fx.z["mut/%d" % w].tobytes(), w
+        assert open(work / "out" / "chunk_0" / ("out_%d.anc" % w), "rb").read() == fx.z["anc/%d" % w].tobytes(), w
+
+
 @pytest.mark.parametrize("tag,opts", [("nc", ["--no_consistency"]), ("fb", ["--fb", "2500"])])
 def test_cli_gpu_build_options(tmp_path, tag, opts):
     """--no_consistency (no penalty, no prior) and --fb with the trees built on the GPU"""
