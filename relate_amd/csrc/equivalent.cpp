@@ -11,8 +11,15 @@
 // rewrites them with num_events / SNP_begin / SNP_end propagated along
 // equivalent branches.  The reference parks the per-window equivalence tables
 // in equivalent_branches_<w>.bin and deletes them at the end; here they stay in
-// memory.  std::sort is called on the same data in the same way, so unstable
-// tie orders agree with the reference built against the same libstdc++.
+// memory, and the pairs of neighbouring trees are matched on all host threads.
+// Leaf sets: the reference intersects two sorted label lists per correlation;
+// here the leaves of one tree of a pair are numbered depth-first, a clade of it
+// is an interval, and an intersection is two binary searches (below) -- the
+// stage takes half the reference's time on one thread
+// (tools/check_feb_against_reference.py: N = 1000, 128 windows, 4.4 s -> 2.1 s,
+// byte-identical .anc files).  The two std::sort calls of the matching are made
+// on the same data with the same comparisons as the reference's, so that their
+// (unstable) orders of equal keys agree when built against the same libstdc++.
 #include <tgmath.h>
 
 #include <algorithm>
@@ -120,185 +127,199 @@ int write_anc(const std::string &fn, const AncFile &a) {
   return RL_OK;
 }
 
-struct Leaves {
-  std::vector<int> member;  // sorted leaf labels below the node
-  int num_leaves = 0;
-};
+// ---- leaf sets of two neighbouring trees
+// Everything BranchAssociation (src/anc_builder.cpp:1454-1613) asks of the trees is |A n B| for a node A of one tree
+// and a node B of the other (Correlation::Pearson, src/anc.cpp:823-859; the reference intersects two sorted label
+// lists per question, Tree::FindAllLeaves :450-520).  Here the leaves of the REFERENCE tree are numbered in the order
+// a depth-first walk meets them, so the leaves below any of its nodes are one interval of positions; the other tree
+// keeps, per node, the positions of its leaves sorted -- and an intersection is two binary searches.
 
-// Tree::FindLeaves (src/anc.cpp:470-520): post-order merge of the children's sorted lists
-void find_leaves(const AncTree &t, int node, std::vector<Leaves> &lv) {
-  if (t.child_left[node] != -1) {
-    const int c1 = t.child_left[node], c2 = t.child_right[node];
-    find_leaves(t, c1, lv);
-    find_leaves(t, c2, lv);
-    Leaves &out = lv[node];
-    out.member.resize(lv[c1].member.size() + lv[c2].member.size());
-    std::merge(lv[c1].member.begin(), lv[c1].member.end(), lv[c2].member.begin(), lv[c2].member.end(),
-               out.member.begin());
-    out.num_leaves = lv[c1].num_leaves + lv[c2].num_leaves;
-  } else {
-    lv[node].member.assign(1, node);
-    lv[node].num_leaves = 1;
-  }
-}
-// Tree::FindAllLeaves (:450-467)
-void find_all_leaves(const AncTree &t, std::vector<Leaves> &lv) {
+// nodes of a tree, every node after its children
+std::vector<int> children_first(const AncTree &t) {
   const int nodes = (int)t.parent.size(), N = (nodes + 1) / 2;
-  lv.assign(nodes, Leaves());
   int root = nodes - 1;
-  if (t.parent[root] != -1)
+  if (t.parent[root] != -1)  // (as Tree::FindAllLeaves looks for it, :452-461)
     for (int i = N; i < nodes; i++)
       if (t.parent[i] == -1) {
         root = i;
         break;
       }
-  find_leaves(t, root, lv);
+  std::vector<int> order;
+  order.reserve(nodes);
+  std::vector<int> todo(1, root);
+  while (!todo.empty()) {  // parents first, left subtree last to leave the stack ...
+    const int v = todo.back();
+    todo.pop_back();
+    order.push_back(v);
+    if (t.child_left[v] != -1) {
+      todo.push_back(t.child_left[v]);
+      todo.push_back(t.child_right[v]);
+    }
+  }
+  std::reverse(order.begin(), order.end());  // ... reversed: children first
+  return order;
 }
 
-// Correlation::Pearson (src/anc.cpp:823-859): float arithmetic as written there
-struct Correlation {
-  int N;
-  float N_float;
-  explicit Correlation(int n) : N(n), N_float((float)n) {}
-  float pearson(const Leaves &set1, const Leaves &set2) const {
-    if (set1.num_leaves == N || set2.num_leaves == N) {
-      if (set1.num_leaves == set2.num_leaves) return 1;
-      return 0;
-    }
-    float prod = 0.0;
-    auto i1 = set1.member.begin(), i2 = set2.member.begin();
-    const auto e1 = set1.member.end(), e2 = set2.member.end();
-    while (i1 != e1 && i2 != e2) {
-      if (*i1 == *i2) {
-        prod += 1.0;
-        i1++;
-        i2++;
-      } else if (*i1 < *i2) {
-        i1++;
+struct IntervalTree {  // the reference tree of a pair
+  std::vector<int> lo, size;   // per node: its leaves are the positions [lo, lo + size)
+  std::vector<int> position;   // per leaf
+  explicit IntervalTree(const AncTree &t) {
+    const int nodes = (int)t.parent.size();
+    lo.assign(nodes, 0);
+    size.assign(nodes, 0);
+    position.assign((nodes + 1) / 2, 0);
+    const std::vector<int> order = children_first(t);
+    for (int v : order) size[v] = t.child_left[v] == -1 ? 1 : size[t.child_left[v]] + size[t.child_right[v]];
+    for (auto it = order.rbegin(); it != order.rend(); ++it) {  // parents first: hand the interval down
+      const int v = *it;
+      if (t.child_left[v] == -1) {
+        position[v] = lo[v];
       } else {
-        i2++;
+        lo[t.child_left[v]] = lo[v];
+        lo[t.child_right[v]] = lo[v] + size[t.child_left[v]];
       }
     }
-    if (prod == set1.num_leaves && prod == set2.num_leaves) return 1.0;
-    float r = prod - set1.num_leaves * (((float)set2.num_leaves) / N_float);
-    if (r <= 0.0) return 0.0;
-    r /= sqrt(((((float)set1.num_leaves) / N_float) * (N_float - set1.num_leaves)) *
-              ((((float)set2.num_leaves) / N_float) * (N_float - set2.num_leaves)));
-    return r;
   }
 };
 
-struct EquivalentNode {
-  int node1, node2;
+struct PositionSets {  // the other tree of the pair: per node the sorted positions (in the reference tree) of its leaves
+  std::vector<size_t> off;
+  std::vector<int> pos;
+  PositionSets(const AncTree &t, const IntervalTree &ref) {
+    const int nodes = (int)t.parent.size();
+    const std::vector<int> order = children_first(t);
+    std::vector<int> n_below(nodes, 0);
+    for (int v : order) n_below[v] = t.child_left[v] == -1 ? 1 : n_below[t.child_left[v]] + n_below[t.child_right[v]];
+    off.assign((size_t)nodes + 1, 0);
+    for (int v = 0; v < nodes; v++) off[v + 1] = off[v] + (size_t)n_below[v];
+    pos.resize(off[nodes]);
+    for (int v : order) {
+      int *out = pos.data() + off[v];
+      if (t.child_left[v] == -1) {
+        *out = ref.position[v];
+      } else {
+        const int a = t.child_left[v], b = t.child_right[v];
+        std::merge(pos.data() + off[a], pos.data() + off[a + 1], pos.data() + off[b], pos.data() + off[b + 1], out);
+      }
+    }
+  }
+  int size(int v) const { return (int)(off[v + 1] - off[v]); }
+  int shared(int v, int lo, int n) const {  // leaves of v with a position in [lo, lo + n)
+    const int *b = pos.data() + off[v], *e = pos.data() + off[v + 1];
+    return (int)(std::lower_bound(b, e, lo + n) - std::lower_bound(b, e, lo));
+  }
+};
+
+// Correlation::Pearson (src/anc.cpp:823-859) of two leaf sets given their sizes and what they share: float arithmetic
+// in the reference's order of operations (the thresholds 0.9999 / 0.95 are compared against these floats)
+float leaf_set_correlation(int n1, int n2, int both, int N) {
+  if (n1 == N || n2 == N) return n1 == n2 ? 1.0f : 0.0f;
+  const float Nf = (float)N, prod = (float)both;
+  if (prod == n1 && prod == n2) return 1.0f;
+  float r = prod - n1 * (((float)n2) / Nf);
+  if (r <= 0.0) return 0.0f;
+  r /= sqrt(((((float)n1) / Nf) * (Nf - n1)) * ((((float)n2) / Nf) * (Nf - n2)));
+  return r;
+}
+
+struct ScoredPair {
+  int node, ref_node;
   float corr;
-  bool operator>(const EquivalentNode &n) const { return corr > n.corr; }
+  bool operator>(const ScoredPair &o) const { return corr > o.corr; }
 };
 
 struct BranchMatcher {
-  int N, N_total;
-  float threshold_brancheq = 0.95;
-  std::vector<std::vector<int>> potential_branches;
+  int N, nodes;
+  float close_enough = 0.95;  // threshold_brancheq
+  // clade sizes that can correlate >= close_enough with a clade of i leaves, i = 1..N
+  // (PreCalcPotentialBranches, src/anc_builder.cpp:1432-1452: the table and the order of its rows)
+  std::vector<std::vector<int>> sizes_near;
 
-  explicit BranchMatcher(int n) : N(n), N_total(2 * n - 1) {
-    // PreCalcPotentialBranches (src/anc_builder.cpp:1432-1452)
-    potential_branches.resize(N);
-    float threshold_inv = 1 / (threshold_brancheq * threshold_brancheq);
-    float N_float = N;
+  explicit BranchMatcher(int n) : N(n), nodes(2 * n - 1), sizes_near(n) {
+    const float bound = 1 / (close_enough * close_enough), Nf = N;
     for (int i = 1; i <= N; i++) {
-      potential_branches[i - 1].push_back(i);
-      for (int j = i + 1; j <= N; j++) {
-        if (threshold_inv >= j / (N_float - j) * ((N_float - i) / i)) {
-          potential_branches[i - 1].push_back(j);
-          potential_branches[j - 1].push_back(i);
+      sizes_near[i - 1].push_back(i);
+      for (int j = i + 1; j <= N; j++)
+        if (bound >= j / (Nf - j) * ((Nf - i) / i)) {
+          sizes_near[i - 1].push_back(j);
+          sizes_near[j - 1].push_back(i);
         }
-      }
     }
   }
 
-  // BranchAssociation (src/anc_builder.cpp:1454-1613): eq[i] = branch of ref_tree equivalent to branch i of tree
-  void associate(const AncTree &ref_tree, const AncTree &tree, std::vector<int> &eq) const {
-    eq.assign(N_total, -1);
-    std::vector<int> eq_ref(N_total, -1);
-    Correlation cor(N);
-    std::vector<Leaves> tr_leaves, rtr_leaves;
-    find_all_leaves(tree, tr_leaves);
-    find_all_leaves(ref_tree, rtr_leaves);
+  // BranchAssociation (src/anc_builder.cpp:1454-1613): match[i] = the branch of ref_tree equivalent to branch i of
+  // tree, or -1.  Three rounds: leaves; internal branches with a perfect counterpart (the same label first, then the
+  // reference's branches of the same clade size); the rest by descending correlation among counterparts of a
+  // compatible size, greedily.
+  void associate(const AncTree &ref_tree, const AncTree &tree, std::vector<int> &match) const {
+    match.assign(nodes, -1);
+    std::vector<int> taken(nodes, -1);  // per reference branch: who has it
+    const IntervalTree ref(ref_tree);
+    const PositionSets sets(tree, ref);
+    auto corr = [&](int v, int rv) {
+      return leaf_set_correlation(sets.size(v), ref.size[rv], sets.shared(v, ref.lo[rv], ref.size[rv]), N);
+    };
+    auto pair_up = [&](int v, int rv) {
+      match[v] = rv;
+      taken[rv] = v;
+    };
 
-    std::vector<int> sorted_branches(N_total);
-    std::size_t n(0);
-    std::generate(std::begin(sorted_branches), std::end(sorted_branches), [&] { return n++; });
-    std::sort(std::begin(sorted_branches), std::end(sorted_branches),
-              [&](int i1, int i2) { return rtr_leaves[i1].num_leaves < rtr_leaves[i2].num_leaves; });
-    std::vector<int> index_sorted_branches(N, 0);
-    for (auto it = rtr_leaves.begin(); it != std::prev(rtr_leaves.end(), 1); it++) index_sorted_branches[it->num_leaves]++;
-    int cum = 0;
-    for (auto &v : index_sorted_branches) {
-      v += cum;
-      cum = v;
-    }
+    // the reference's branches by clade size.  (std::sort, unstable, on the identity permutation with this
+    // comparison: the order INSIDE a size class is whatever that call leaves, and the greedy round below depends on
+    // it through its own unstable sort -- the same two calls on the same data as anc_builder.cpp:1477-1480, :1603.)
+    std::vector<int> by_size(nodes);
+    for (int v = 0; v < nodes; v++) by_size[v] = v;
+    std::sort(by_size.begin(), by_size.end(), [&](int a, int b) { return ref.size[a] < ref.size[b]; });
+    std::vector<int> class_end(N, 0);  // class_end[s]: branches with <= s leaves (the root, N leaves, is no candidate)
+    for (int v = 0; v < nodes; v++)
+      if (v != nodes - 1 && ref.size[v] < N) class_end[ref.size[v]]++;
+    for (int s = 1; s < N; s++) class_end[s] += class_end[s - 1];
+    auto size_class = [&](int s) {
+      if (s < 1 || s >= N) return std::make_pair(by_size.begin(), by_size.begin());
+      return std::make_pair(by_size.begin() + class_end[s - 1], by_size.begin() + class_end[s]);
+    };
 
-    std::vector<int> unpaired;
-    for (int i = 0; i < N; i++) {  // leaves (:1502-1550)
-      if (eq[i] != -1) continue;
-      const int parent = tree.parent[i], ref_parent = ref_tree.parent[i];
-      const int sibling = tree.child_left[parent] == i ? tree.child_right[parent] : tree.child_left[parent];
-      if (sibling < N) {
-        if (sibling == ref_tree.child_right[ref_parent] || sibling == ref_tree.child_left[ref_parent]) {
-          eq[i] = i;
-          eq_ref[i] = i;
-          eq[sibling] = sibling;
-          eq_ref[sibling] = sibling;
+    for (int leaf = 0; leaf < N; leaf++) {  // :1502-1550
+      if (match[leaf] != -1) continue;
+      const int up = tree.parent[leaf], ref_up = ref_tree.parent[leaf];
+      const int sibling = tree.child_left[up] == leaf ? tree.child_right[up] : tree.child_left[up];
+      if (sibling < N) {  // a cherry: equivalent if it is a cherry of the reference tree too
+        if (sibling == ref_tree.child_right[ref_up] || sibling == ref_tree.child_left[ref_up]) {
+          pair_up(leaf, leaf);
+          pair_up(sibling, sibling);
         }
-      } else {
-        if (cor.pearson(tr_leaves[parent], rtr_leaves[ref_parent]) >= threshold_brancheq) {
-          eq[i] = i;
-          eq_ref[i] = i;
-        }
+      } else if (corr(up, ref_up) >= close_enough) {
+        pair_up(leaf, leaf);
       }
     }
-    for (int i = N; i < N_total - 1; i++) {  // internal branches (:1553-1583)
-      if (cor.pearson(tr_leaves[i], rtr_leaves[i]) >= 0.9999 &&
-          cor.pearson(tr_leaves[tree.parent[i]], rtr_leaves[ref_tree.parent[i]]) >= 0.9999) {
-        eq[i] = i;
-        eq_ref[i] = i;
-      }
-      if (eq[i] == -1) {
-        const int nl = tr_leaves[i].num_leaves;
-        for (auto it = std::next(sorted_branches.begin(), index_sorted_branches[nl - 1]);
-             it != std::next(sorted_branches.begin(), index_sorted_branches[nl]); it++) {
-          if (cor.pearson(tr_leaves[i], rtr_leaves[*it]) >= 0.9999 &&
-              cor.pearson(tr_leaves[tree.parent[i]], rtr_leaves[ref_tree.parent[*it]]) >= 0.9999) {
-            eq[i] = *it;
-            eq_ref[*it] = i;
+    std::vector<int> open;
+    for (int v = N; v < nodes - 1; v++) {  // :1553-1583
+      auto perfect = [&](int rv) { return corr(v, rv) >= 0.9999 && corr(tree.parent[v], ref_tree.parent[rv]) >= 0.9999; };
+      if (perfect(v)) pair_up(v, v);
+      if (match[v] == -1) {
+        const auto cls = size_class(sets.size(v));
+        for (auto it = cls.first; it != cls.second; ++it)
+          if (perfect(*it)) {
+            pair_up(v, *it);
             break;
           }
+      }
+      if (match[v] == -1) open.push_back(v);
+    }
+    std::vector<ScoredPair> candidates;  // :1586-1601
+    for (int v : open)
+      for (int s : sizes_near[sets.size(v) - 1]) {
+        const auto cls = size_class(s);
+        for (auto it = cls.first; it != cls.second; ++it) {
+          if (taken[*it] != -1) continue;
+          const float score = corr(v, *it);
+          if (score >= close_enough && corr(tree.parent[v], ref_tree.parent[*it]) >= close_enough)
+            candidates.push_back(ScoredPair{v, *it, score});
         }
       }
-      if (eq[i] == -1) unpaired.push_back(i);
-    }
-    std::vector<EquivalentNode> possible_pairs;  // approximate matches (:1586-1601)
-    for (int u : unpaired) {
-      const int nl = tr_leaves[u].num_leaves - 1;
-      for (int k : potential_branches[nl]) {
-        for (auto it = std::next(sorted_branches.begin(), index_sorted_branches[k - 1]);
-             it != std::next(sorted_branches.begin(), index_sorted_branches[k]); it++) {
-          if (eq_ref[*it] == -1) {
-            float score = cor.pearson(tr_leaves[u], rtr_leaves[*it]);
-            if (score >= threshold_brancheq &&
-                cor.pearson(tr_leaves[tree.parent[u]], rtr_leaves[ref_tree.parent[*it]]) >= threshold_brancheq) {
-              possible_pairs.push_back(EquivalentNode{u, *it, score});
-            }
-          }
-        }
-      }
-    }
-    std::sort(std::begin(possible_pairs), std::end(possible_pairs), std::greater<EquivalentNode>());
-    for (const EquivalentNode &e : possible_pairs) {
-      if (eq[e.node1] == -1 && eq_ref[e.node2] == -1) {
-        eq[e.node1] = e.node2;
-        eq_ref[e.node2] = e.node1;
-      }
-    }
+    std::sort(candidates.begin(), candidates.end(), std::greater<ScoredPair>());
+    for (const ScoredPair &c : candidates)
+      if (match[c.node] == -1 && taken[c.ref_node] == -1) pair_up(c.node, c.ref_node);
   }
 };
 
