@@ -994,7 +994,12 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
         std::this_thread::sleep_for(std::chrono::milliseconds(50));
       }
       int r = win ? RL_OK : (first_error.load() ? first_error.load() : RL_EIO);
+      const double t_open = std::chrono::duration<double>(std::chrono::steady_clock::now() - stage_t0).count();
       if (!r) r = rl_treeseq_build(ts, start, end, win_matrix, win_advance, win, flags, fb);
+      if (getenv("RELATE_AMD_TIMING"))  // (when the sections start and end: the stage's ramp and tail)
+        fprintf(stderr, "[section %d] turn %d, %d SNPs: window open %.1f s after the stage began, trees built at %.1f s\n",
+                section, turn, end - start + 1, t_open,
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - stage_t0).count());
       if (win) {
         std::lock_guard<std::mutex> lk(g_gpu_mutex);
         rl_window_close(win);

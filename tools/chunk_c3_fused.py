@@ -80,6 +80,15 @@ try:
     wl = [l.strip() for l in err.split("\n") if l.startswith("[window ")]
     out["window_lines"] = wl[:3] + wl[len(wl) // 2: len(wl) // 2 + 3]
     out["one_section"] = [l.strip() for l in err.split("\n") if "[tree sequence]" in l][:1]
+    # when each section's window was open and when its trees were done, seconds after the stage began
+    sec = [(int(m.group(1)), int(m.group(2)), float(m.group(3)), float(m.group(4))) for m in
+           re.finditer(r"\[section (\d+)\] turn (\d+), \d+ SNPs: window open ([\d.]+) s after the stage began, trees built at ([\d.]+) s", err)]
+    if sec:
+        ends = sorted(x[3] for x in sec)
+        out["sections_timeline"] = {"first_window_open_s": min(x[2] for x in sec), "last_first_round_open_s": max(x[2] for x in sec if x[1] < 134),
+                                    "sections_done_by_s": {str(q): ends[min(len(ends) - 1, int(q * len(ends) / 100))] for q in (10, 25, 50, 75, 90, 95, 99)},
+                                    "last_done_s": ends[-1],
+                                    "open_sections_at_s": {str(t): sum(1 for x in sec if x[2] <= t < x[3]) for t in range(0, int(ends[-1]) + 10, 10)}}
 finally:
     shutil.rmtree(work, ignore_errors=True)
 print(json.dumps(out))
