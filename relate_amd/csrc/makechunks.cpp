@@ -6,14 +6,19 @@
 // producer of this path's inputs, so that Paint / BuildTopology no longer need
 // the reference binary upstream.  Every file it writes (parameters.bin,
 // parameters_c<i>.bin, chunk_<i>.{hap,state,bp,dist,rpos,r}, props.bin) is
-// byte-identical to the reference's (tests/test_makechunks.py).
+// byte-identical to the reference's (tests/test_makechunks.py).  The haps text
+// is read once, in blocks parsed on all host threads, into a bit-packed panel
+// that stays in memory (read_haps below); the chunk files are written from it.
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstring>
 #include <iomanip>
 #include <iostream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -63,13 +68,6 @@ int count_newlines(const char *fn, long *lines) {
   return 0;
 }
 
-void put_field(FILE *fp, const std::string &s) {  // 1024 zero-padded bytes (data.cpp:424-436)
-  char dummy[1024];
-  memset(dummy, 0, sizeof dummy);
-  memcpy(dummy, s.c_str(), std::min(s.size(), sizeof(dummy) - 1));
-  fwrite(dummy, 1, 1024, fp);
-}
-
 template <typename T>
 void put_vec(const std::string &fn, unsigned int n, const T *data) {
   FILE *fp = fopen(fn.c_str(), "wb");
@@ -77,6 +75,158 @@ void put_vec(const std::string &fn, unsigned int n, const T *data) {
   fwrite(&n, sizeof(unsigned int), 1, fp);
   fwrite(data, sizeof(T), n, fp);
   fclose(fp);
+}
+
+// ---- the .haps text, read ONCE: blocks of whole lines parsed on all host threads into the bit-packed panel (an
+// allele is one bit here against two characters in the file, so the whole panel stays in memory: N = 2000 x 5M SNPs
+// are 20 GB of text and 1.25 GB of bits) plus what the chunk files repeat of every line.  The reference reads the
+// file twice with fscanf, once for the sizes and once for the rows (haps::ReadSNP, data.cpp:543-573); a line is
+// taken apart as its "%s %s %d %s %s" + fgets would: five fields, then the first N characters that are '0' or '1'.
+struct HapsPanel {
+  uint32_t row_words = 0;
+  std::vector<uint32_t> bits;  // [L][row_words]: bit n of row s = haplotype n carries the second allele at SNP s
+  std::vector<int> bp, derived;
+  std::vector<std::string> rsid, ancestral, alternative;
+};
+
+struct LineFault {  // the first line of a block that does not parse
+  long line = -1;
+  int alleles = -1;  // -1: the five fields; else how many alleles the line holds
+  std::string chr, rs;
+  int bp = 0;
+};
+
+inline bool blank(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f' || c == '\n'; }
+
+// one line [p, e) without its newline -> row `snp` of the panel; false: malformed (fault says how)
+bool parse_haps_line(const char *p, const char *e, int N, HapsPanel &out, size_t snp, LineFault &fault) {
+  auto field = [&](const char *&b, const char *&t) {
+    while (p < e && blank(*p)) p++;
+    b = p;
+    while (p < e && !blank(*p)) p++;
+    t = p;
+    return t > b;
+  };
+  const char *chr_b, *chr_e, *rs_b, *rs_e, *anc_b, *anc_e, *alt_b, *alt_e;
+  if (!field(chr_b, chr_e) || !field(rs_b, rs_e)) return false;
+  while (p < e && blank(*p)) p++;
+  bool negative = false;
+  if (p < e && (*p == '-' || *p == '+')) negative = *p++ == '-';
+  if (p >= e || *p < '0' || *p > '9') return false;
+  long pos = 0;
+  while (p < e && *p >= '0' && *p <= '9') pos = pos * 10 + (*p++ - '0');  // (%d: the digits, wherever they end)
+  if (!field(anc_b, anc_e) || !field(alt_b, alt_e)) return false;
+  uint32_t *row = &out.bits[snp * out.row_words];
+  for (uint32_t w = 0; w < out.row_words; w++) row[w] = 0u;
+  int filled = 0, ones = 0;
+  for (; p < e && filled < N; p++) {
+    const unsigned d = (unsigned)(*p - '0');
+    if (d <= 1u) {
+      row[filled >> 5] |= d << (filled & 31);
+      ones += (int)d;
+      filled++;
+    }
+  }
+  out.bp[snp] = (int)(negative ? -pos : pos);
+  if (filled != N) {
+    fault.alleles = filled;
+    fault.chr.assign(chr_b, chr_e);
+    fault.rs.assign(rs_b, rs_e);
+    fault.bp = out.bp[snp];
+    return false;
+  }
+  out.derived[snp] = ones;
+  out.rsid[snp].assign(rs_b, std::min<size_t>(rs_e - rs_b, 1023));  // (%1023s)
+  out.ancestral[snp].assign(anc_b, std::min<size_t>(anc_e - anc_b, 1023));
+  out.alternative[snp].assign(alt_b, std::min<size_t>(alt_e - alt_b, 1023));
+  return true;
+}
+
+// 0, or an RL_E* code with the error text set.  Lines = newline characters, as the reference counts them: a last
+// line without one is not a SNP.
+int read_haps(const char *fn, int N, HapsPanel &out) {
+  using rl::set_error;
+  InFile f;
+  if (!f.open(fn)) {
+    set_error("Failed to open file %s", fn);
+    return RL_EIO;
+  }
+  out.row_words = (uint32_t)((N + 31) / 32);
+  const size_t block = (size_t)64 << 20;
+  std::vector<char> buf(block + 1);
+  std::vector<size_t> starts;
+  size_t held = 0, L = 0;
+  const int T = std::max(1, rl::host_threads());
+  int rc = RL_OK;
+  for (;;) {
+    if (held == buf.size()) buf.resize(buf.size() * 2);  // (a single line longer than the block)
+    const size_t got = fread(buf.data() + held, 1, buf.size() - held, f.fp);
+    const size_t have = held + got;
+    // whole lines of the block
+    starts.clear();
+    size_t at = 0;
+    while (at < have) {
+      const char *nl = (const char *)memchr(buf.data() + at, '\n', have - at);
+      if (!nl) break;
+      starts.push_back(at);
+      at = (size_t)(nl - buf.data()) + 1;
+    }
+    starts.push_back(at);  // (end of the last whole line)
+    const size_t n = starts.size() - 1;
+    if (n) {
+      out.bits.resize((L + n) * out.row_words);
+      out.bp.resize(L + n);
+      out.derived.resize(L + n);
+      out.rsid.resize(L + n);
+      out.ancestral.resize(L + n);
+      out.alternative.resize(L + n);
+      std::vector<LineFault> faults((size_t)T);
+      auto work = [&](int t) {
+        for (size_t i = n * t / T; i < n * (t + 1) / T; i++)
+          if (!parse_haps_line(buf.data() + starts[i], buf.data() + starts[i + 1] - 1, N, out, L + i, faults[t])) {
+            faults[t].line = (long)(L + i);
+            return;
+          }
+      };
+      std::vector<std::thread> th;
+      for (int t = 1; t < T; t++) th.emplace_back(work, t);
+      work(0);
+      for (auto &x : th) x.join();
+      for (const LineFault &ft : faults)  // (threads hold ascending ranges: the first fault is the lowest line)
+        if (ft.line >= 0) {
+          if (ft.alleles < 0)
+            set_error("%s: malformed line %ld", fn, ft.line + 1);
+          else
+            set_error("%s: SNP %s %s %d has %d alleles, %d expected", fn, ft.chr.c_str(), ft.rs.c_str(), ft.bp, ft.alleles, N);
+          rc = RL_EFORMAT;
+          break;
+        }
+      if (rc) break;
+      L += n;
+    }
+    held = have - at;
+    memmove(buf.data(), buf.data() + at, held);
+    if (got == 0) break;
+  }
+  f.close();
+  return rc;
+}
+
+// a panel row as the characters of chunk_<i>.hap: eight alleles per table entry
+void expand_row(const uint32_t *words, int N, char *chars) {
+  static const struct Table {
+    uint64_t v[256];
+    Table() {
+      for (int b = 0; b < 256; b++) {
+        uint64_t x = 0;
+        for (int k = 0; k < 8; k++) x |= (uint64_t)('0' + ((b >> k) & 1)) << (8 * k);
+        v[b] = x;
+      }
+    }
+  } table;
+  int n = 0;
+  for (; n + 8 <= N; n += 8) memcpy(chars + n, &table.v[(words[n >> 5] >> (n & 31)) & 0xffu], 8);
+  for (; n < N; n++) chars[n] = (char)('0' + ((words[n >> 5] >> (n & 31)) & 1u));
 }
 
 }  // namespace
@@ -108,19 +258,26 @@ extern "C" int rl_make_chunks(const char *haps_fn, const char *sample_fn, const 
     while (fscanf(f.fp, "%1023s %1023s %1023s", id1, id2, dummy) == 3) N += (strcmp(id1, id2) == 0) ? 2 : 1;
     f.close();
   }
-  long Llong = 0;
-  if (count_newlines(haps_fn, &Llong)) {
-    set_error("Failed to open file %s", haps_fn);
-    return RL_EIO;
-  }
-  const int L = (int)Llong;
+  // RELATE_AMD_TIMING=1: wall-clock of the stage's phases on stderr
+  const bool timing = getenv("RELATE_AMD_TIMING") != nullptr;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double lap_t0 = now();
+  auto lap = [&](const char *what) {
+    const double t1 = now();
+    if (timing) fprintf(stderr, "[makechunks] %-44s %8.3f s\n", what, t1 - lap_t0);
+    lap_t0 = t1;
+  };
+  HapsPanel panel;
+  if (int rc = read_haps(haps_fn, N, panel)) return rc;
+  lap("haps text -> bit-packed panel");
+  const int L = (int)panel.bp.size();
   if (N < 2 || L < 2) {
     set_error("MakeChunks: need at least 2 haplotypes and 2 SNPs (N=%d, L=%d)", N, L);
     return RL_EFORMAT;
   }
-
-  std::vector<int> bp_pos((size_t)L + 1);
-  std::vector<std::string> ancestral(L), alternative(L), rsid(L);
+  std::vector<int> &bp_pos = panel.bp;
+  bp_pos.resize((size_t)L + 1);
+  const std::vector<std::string> &ancestral = panel.ancestral, &alternative = panel.alternative, &rsid = panel.rsid;
 
   // The budget of a window (data.cpp:129): `memory_gb` of floats minus the two N x N matrices and three vectors
   // the tree builder holds next to a window's posteriors.
@@ -134,55 +291,11 @@ extern "C" int rl_make_chunks(const char *haps_fn, const char *sample_fn, const 
   int max_chunk_snps = std::min(L + 1, (int)(window_budget / N));
   if (memory_gb >= 100) max_chunk_snps = 2500000;
 
-  // ---- pass 1 over the haps file (haps::ReadSNP, data.cpp:543-573): positions, alleles and, per SNP, what its row
-  // of posteriors will cost a window: (number of derived alleles) * (N + 1) floats (data.cpp:216).  cost[s] is the
-  // running total before SNP s -- integers far below 2^53, so the doubles are exact and a window boundary is a
-  // binary search instead of the reference's accumulate-and-compare over the SNPs.
+  // ---- what a SNP's row of posteriors will cost a window: (number of derived alleles) * (N + 1) floats
+  // (data.cpp:216).  cost[s] is the running total before SNP s -- integers far below 2^53, so the doubles are exact
+  // and a window boundary is a binary search instead of the reference's accumulate-and-compare over the SNPs.
   std::vector<double> cost((size_t)L + 1, 0.0);
-  std::vector<char> line((size_t)2 * N + 10);
-  auto read_snp = [&](FILE *fp, int snp, char *row, bool keep_meta) -> int {
-    char chr[1024], rs[1024], anc[1024], alt[1024];
-    int bp = 0;
-    if (fscanf(fp, "%1023s %1023s %d %1023s %1023s", chr, rs, &bp, anc, alt) != 5 ||
-        !fgets(line.data(), 2 * N + 10, fp)) {
-      set_error("%s: malformed line %d", haps_fn, snp + 1);
-      return -1;
-    }
-    int filled = 0, derived = 0;
-    for (int i = 0; line[i] != '\0' && filled < N; i++)
-      if (line[i] == '0' || line[i] == '1') {
-        derived += line[i] == '1';
-        if (row) row[filled] = line[i];
-        filled++;
-      }
-    if (filled != N) {
-      set_error("%s: SNP %s %s %d has %d alleles, %d expected", haps_fn, chr, rs, bp, filled, N);
-      return -1;
-    }
-    if (keep_meta) {
-      bp_pos[snp] = bp;
-      ancestral[snp] = anc;
-      alternative[snp] = alt;
-      rsid[snp] = rs;
-    }
-    return derived;
-  };
-  {
-    InFile haps;
-    if (!haps.open(haps_fn)) {
-      set_error("Failed to open file %s", haps_fn);
-      return RL_EIO;
-    }
-    for (int s = 0; s < L; s++) {
-      const int derived = read_snp(haps.fp, s, nullptr, true);
-      if (derived < 0) {
-        haps.close();
-        return RL_EFORMAT;
-      }
-      cost[(size_t)s + 1] = cost[s] + (double)derived * (N + 1);
-    }
-    haps.close();
-  }
+  for (int s = 0; s < L; s++) cost[(size_t)s + 1] = cost[s] + (double)panel.derived[s] * (N + 1);
   bp_pos[L] = bp_pos[L - 1] + 1;
 
   // ---- the plan: chunks and their windows from the running cost alone
@@ -285,78 +398,62 @@ extern "C" int rl_make_chunks(const char *haps_fn, const char *sample_fn, const 
     fclose(fs);
   }
 
-  // ---- pass 2: the alleles into chunk_<i>.hap (u64 L, u64 N, L rows of N chars; collapsed_matrix.hpp:204-225).  The
-  // rows stream through; the last `overlap` of them wait in a ring for the next chunk, which starts with them.
-  {
-    InFile haps;
-    if (!haps.open(haps_fn)) {
-      set_error("Failed to open file %s", haps_fn);
-      return RL_EIO;
+  // ---- chunk_<i>.hap (u64 L, u64 N, L rows of N chars; collapsed_matrix.hpp:204-225), the rows of the chunk -- its
+  // own and the `overlap` it repeats from its predecessor -- expanded from the panel in slabs.
+  // Next to it the same rows BIT-PACKED as they lie in memory, chunk_<i>.bits -- what the device path works on
+  // (rl_set_chunk_bits: bit n of row s = haplotype n derived at SNP s): rl_load_chunk prefers it and never touches
+  // the 8 x larger char file (2.5 GB at N = 5000 x L = 500k).  Header: "RLB1", N, L, row_words (u32 each); then L
+  // rows of row_words u32.  RELATE_AMD_CHUNK_BITS=0: the reference's files only.
+  lap("plan, parameters_c*.bin, chunk_*.state");
+  // The chunks are written by a few threads of their own, side by side and next to props.bin below (3 KB per SNP):
+  // the stage is bound by the file system from here on.
+  const bool with_bits = !(getenv("RELATE_AMD_CHUNK_BITS") && atoi(getenv("RELATE_AMD_CHUNK_BITS")) == 0);
+  auto write_chunk = [&](int ci) -> bool {
+    const uint32_t rw = panel.row_words;
+    const int first = plan[ci].first_snp, end = plan[ci].end;
+    FILE *fh = fopen((file_out + "/chunk_" + std::to_string(ci) + ".hap").c_str(), "wb");
+    FILE *fb = with_bits ? fopen((file_out + "/chunk_" + std::to_string(ci) + ".bits").c_str(), "wb") : nullptr;
+    if (!fh || (with_bits && !fb)) {
+      if (fh) fclose(fh);
+      if (fb) fclose(fb);
+      return false;
     }
-    // Next to chunk_<i>.hap (one char per allele: 2.5 GB at N = 5000 x L = 500k) the same panel BIT-PACKED,
-    // chunk_<i>.bits -- what the device path works on (rl_set_chunk_bits: bit n of row s = haplotype n derived at
-    // SNP s): rl_load_chunk prefers it and never touches the 8 x larger char file.  Header: "RLB1", N, L,
-    // row_words (u32 each); then L rows of row_words u32.  RELATE_AMD_CHUNK_BITS=0: the reference's files only.
-    const bool with_bits = !(getenv("RELATE_AMD_CHUNK_BITS") && atoi(getenv("RELATE_AMD_CHUNK_BITS")) == 0);
-    const uint32_t rw = (uint32_t)((N + 31) / 32);
-    auto pack_row = [&](const char *chars, uint32_t *words) {
-      for (uint32_t w = 0; w < rw; w++) words[w] = 0u;
-      for (int n = 0; n < N; n++) words[n >> 5] |= (uint32_t)(chars[n] == '1') << (n & 31);
-    };
-    std::vector<char> ring(num_chunks > 1 ? (size_t)overlap * N : 0), row(N);
-    std::vector<uint32_t> words(rw);
-    FILE *fh = nullptr, *fb = nullptr;
-    int ci = -1;
-    int rc = RL_OK;
-    for (int s = 0; s < L && rc == RL_OK; s++) {
-      if (ci + 1 < num_chunks && s == plan[ci + 1].begin) {
-        if (fh) fclose(fh);
-        if (fb) fclose(fb);
-        fb = nullptr;
-        ci++;
-        fh = fopen((file_out + "/chunk_" + std::to_string(ci) + ".hap").c_str(), "wb");
-        if (with_bits) fb = fopen((file_out + "/chunk_" + std::to_string(ci) + ".bits").c_str(), "wb");
-        if (!fh || (with_bits && !fb)) {
-          set_error("cannot write chunk files under %s", out_dir);
-          rc = RL_EIO;
-          break;
-        }
-        const uint64_t dims[2] = {(uint64_t)(plan[ci].end - plan[ci].first_snp), (uint64_t)N};
-        fwrite(dims, 8, 2, fh);
-        if (fb) {
-          const uint32_t head[4] = {0x31424c52u /* "RLB1" */, (uint32_t)N, (uint32_t)dims[0], rw};
-          fwrite(head, 4, 4, fb);
-        }
-        for (int t = plan[ci].first_snp; t < s; t++) {
-          const char *kept = &ring[(size_t)(t % overlap) * N];
-          fwrite(kept, 1, (size_t)N, fh);
-          if (fb) {
-            pack_row(kept, words.data());
-            fwrite(words.data(), 4, rw, fb);
-          }
-        }
-      }
-      if (read_snp(haps.fp, s, row.data(), false) < 0) {
-        rc = RL_EFORMAT;
-        break;
-      }
-      fwrite(row.data(), 1, (size_t)N, fh);
-      if (fb) {
-        pack_row(row.data(), words.data());
-        fwrite(words.data(), 4, rw, fb);
-      }
-      if (!ring.empty()) memcpy(&ring[(size_t)(s % overlap) * N], row.data(), (size_t)N);
+    const uint64_t dims[2] = {(uint64_t)(end - first), (uint64_t)N};
+    fwrite(dims, 8, 2, fh);
+    const int slab_rows = std::max(1, (int)(((size_t)8 << 20) / (size_t)N));
+    std::vector<char> slab((size_t)slab_rows * N);
+    for (int s0 = first; s0 < end; s0 += slab_rows) {
+      const int n = std::min(slab_rows, end - s0);
+      for (int i = 0; i < n; i++) expand_row(&panel.bits[(size_t)(s0 + i) * rw], N, &slab[(size_t)i * N]);
+      fwrite(slab.data(), 1, (size_t)n * N, fh);
     }
-    bool bad = false;
-    if (fh) bad |= ferror(fh) != 0 || fclose(fh) != 0;
-    if (fb) bad |= ferror(fb) != 0 || fclose(fb) != 0;
-    haps.close();
-    if (rc) return rc;
-    if (bad) {
-      set_error("writing the chunk files under %s failed", out_dir);
-      return RL_EIO;
+    if (fb) {
+      const uint32_t head[4] = {0x31424c52u /* "RLB1" */, (uint32_t)N, (uint32_t)dims[0], rw};
+      fwrite(head, 4, 4, fb);
+      fwrite(&panel.bits[(size_t)first * rw], 4, (size_t)(end - first) * rw, fb);
     }
-  }
+    bool good = ferror(fh) == 0;
+    good &= fclose(fh) == 0;
+    if (fb) {
+      good &= ferror(fb) == 0;
+      good &= fclose(fb) == 0;
+    }
+    return good;
+  };
+  std::atomic<int> next_chunk(0), chunks_failed(0);
+  std::vector<std::thread> chunk_writers;
+  struct JoinAll {  // (whichever way the function is left)
+    std::vector<std::thread> &v;
+    ~JoinAll() {
+      for (auto &t : v)
+        if (t.joinable()) t.join();
+    }
+  } join_chunk_writers{chunk_writers};
+  for (int t = 0; t < std::min({num_chunks, 8, std::max(1, rl::host_threads() / 2)}); t++)
+    chunk_writers.emplace_back([&]() {
+      for (int ci; (ci = next_chunk.fetch_add(1)) < num_chunks;)
+        if (!write_chunk(ci)) chunks_failed++;
+    });
 
   std::cerr << std::setprecision(2) << "Paint files will take at least "
             << 2.0 * (4.0 * N * N * (most_windows + 2.0)) / 1e9 << " GB of disc." << std::endl;
@@ -414,15 +511,34 @@ extern "C" int rl_make_chunks(const char *haps_fn, const char *sample_fn, const 
       set_error("cannot write props.bin");
       return RL_EIO;
     }
-    for (int s = 0; s < L; s++) {
-      fwrite(&s, 4, 1, fp);
-      fwrite(&bp_pos[s], 4, 1, fp);
-      fwrite(&dist[s], 4, 1, fp);
-      put_field(fp, rsid[s]);
-      put_field(fp, ancestral[s]);
-      put_field(fp, alternative[s]);
+    // (3084 bytes per SNP, 15 GB at 5M SNPs: records are laid out in a slab and written with one call each)
+    const size_t rec = 12 + 3 * 1024;
+    const int per_slab = 4096;
+    std::vector<char> slab(rec * per_slab);
+    for (int s0 = 0; s0 < L; s0 += per_slab) {
+      const int n = std::min(per_slab, L - s0);
+      memset(slab.data(), 0, rec * n);
+      for (int i = 0; i < n; i++) {
+        char *q = &slab[rec * i];
+        const int s = s0 + i;
+        memcpy(q, &s, 4);
+        memcpy(q + 4, &bp_pos[s], 4);
+        memcpy(q + 8, &dist[s], 4);
+        auto put = [&](char *dst, const std::string &v) { memcpy(dst, v.data(), std::min<size_t>(v.size(), 1023)); };
+        put(q + 12, rsid[s]);
+        put(q + 12 + 1024, ancestral[s]);
+        put(q + 12 + 2048, alternative[s]);
+      }
+      fwrite(slab.data(), 1, rec * n, fp);
     }
     fclose(fp);
+  }
+  lap("dist, props.bin");
+  for (auto &t : chunk_writers) t.join();
+  lap("waiting for the chunk files' writers");
+  if (chunks_failed.load()) {
+    set_error("writing the chunk files under %s failed", out_dir);
+    return RL_EIO;
   }
 
   // ---- genetic map (data.cpp:593-626) -> rpos, r (data.cpp:441-481)

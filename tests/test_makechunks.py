@@ -176,3 +176,51 @@ def test_bits_file_is_the_hap_file_bit_packed(tmp_path):
     assert not [f for f in os.listdir(os.path.join(work, "plain")) if f.endswith(".bits")]
     assert sorted(os.listdir(os.path.join(work, "plain"))) == sorted(
         f for f in os.listdir(os.path.join(work, "ours")) if not f.endswith(".bits"))
+
+
+@pytest.mark.ref
+@pytest.mark.skipif(not rlutil.have_ref(), reason="oracle/_ref not built (no /root/reference)")
+@pytest.mark.parametrize("variant", ["crlf", "tabs", "no_final_newline", "many_threads"])
+def test_makechunks_line_formats_match_reference(tmp_path, variant):
+    """the .haps text is taken apart by this library's own block reader (whole lines parsed on all host threads)
+    where the reference uses fscanf + fgets: CR LF line ends, tabs and leading blanks, a last line without its
+    newline (not a SNP for either), and more parser threads than lines in a block"""
+    work = str(tmp_path)
+    N, L = 8, 3000
+    ch = write_synth_haps(work, N, L, seed=5)
+    lines = open(os.path.join(work, "s.haps")).read().split("\n")[:-1]
+    if variant == "crlf":
+        text = "\r\n".join(lines) + "\r\n"
+    elif variant == "tabs":
+        text = "".join("  " + l.replace(" ", "\t") + "\n" for l in lines)
+    elif variant == "no_final_newline":
+        text = "\n".join(lines)
+    else:
+        text = "\n".join(lines) + "\n"
+    with open(os.path.join(work, "s.haps"), "w", newline="") as f:
+        f.write(text)
+    args = ["--mode", "MakeChunks", "--haps", "s.haps", "--sample", "s.sample", "--map", "s.map", "--memory", "0.0002"]
+    subprocess.run([rlutil.REF_RELATE] + args + ["-o", "ref"], cwd=work, check=True, stderr=subprocess.PIPE)
+    env = dict(os.environ, RELATE_AMD_THREADS="61") if variant == "many_threads" else dict(os.environ)
+    p = subprocess.run([CLI] + args + ["-o", "ours"], cwd=work, stderr=subprocess.PIPE, env=env)
+    assert p.returncode == 0, p.stderr.decode()
+    compare_dirs(os.path.join(work, "ref"), os.path.join(work, "ours"))
+
+
+@pytest.mark.parametrize("damage,message", [("short", b"alleles"), ("blank", b"malformed line 3"), ("letters", b"malformed line 3")])
+def test_makechunks_reports_the_line_that_does_not_parse(tmp_path, damage, message):
+    work = str(tmp_path)
+    write_synth_haps(work, 8, 200, seed=6)
+    lines = open(os.path.join(work, "s.haps")).read().split("\n")[:-1]
+    if damage == "short":
+        lines[2] = lines[2][:-2]          # one allele missing
+    elif damage == "blank":
+        lines[2] = ""
+    else:
+        f = lines[2].split(" ")
+        f[2] = "x" + f[2]                 # the position is not a number
+        lines[2] = " ".join(f)
+    open(os.path.join(work, "s.haps"), "w").write("\n".join(lines) + "\n")
+    p = subprocess.run([CLI, "--mode", "MakeChunks", "--haps", "s.haps", "--sample", "s.sample", "--map", "s.map",
+                        "--memory", "0.0002", "-o", "ours"], cwd=work, stderr=subprocess.PIPE)
+    assert p.returncode != 0 and message in p.stderr, p.stderr.decode()
