@@ -366,7 +366,36 @@ def makechunks_fixture():
     print("makechunks fixture: %d entries, %.1f KB" % (len(data), os.path.getsize(os.path.join(GOLD, "makechunks.npz")) / 1e3))
 
 
+def builder_fixture():
+    """tests/golden/builder_adversarial.npz: the parent arrays the reference's MinMatch (one object per sequence,
+    oracle/ref_harness quickbuild_seq) gives for the sequences of tests/builder_cases.py"""
+    import builder_cases
+    data = {}
+    for name, make in builder_cases.CASES.items():
+        N, mats = make()
+        work = tempfile.mkdtemp()
+        try:
+            args = [rlutil.REF_HARNESS, "quickbuild_seq", str(N), os.path.join(work, "p.bin")]
+            for t, (d, prior) in enumerate(mats):
+                d.tofile(os.path.join(work, "d%d.bin" % t))
+                args.append(os.path.join(work, "d%d.bin" % t))
+                if prior is None:
+                    args.append("-")
+                else:
+                    prior.tofile(os.path.join(work, "c%d.bin" % t))
+                    args.append(os.path.join(work, "c%d.bin" % t))
+            subprocess.run(args, check=True)
+            data[name] = np.fromfile(os.path.join(work, "p.bin"), dtype=np.int32).reshape(len(mats), 2 * N - 1)
+        finally:
+            shutil.rmtree(work, ignore_errors=True)
+    np.savez_compressed(os.path.join(GOLD, "builder_adversarial.npz"), **data)
+    print("builder_adversarial", {k: v.shape for k, v in data.items()}, "%.1f KB" % (os.path.getsize(os.path.join(GOLD, "builder_adversarial.npz")) / 1e3))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "builder":
+        builder_fixture()
+        sys.exit(0)
     assert rlutil.have_ref(), "run `make -C oracle ref` first (needs /root/reference)"
     os.makedirs(GOLD, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "ages":
