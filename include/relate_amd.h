@@ -304,6 +304,44 @@ int rl_stage_paint_build_topology(const char *out_dir, int chunk_index,
                             int use_painting, double theta, double rho,
                             int flags, int fb, int sum_mode, int device);
 
+/* ------------------------------------- one chunk sharded by target haplotype */
+/* BASELINE.json config #5 (N = 10,000 x L = 200k: 8 N^2 W = 288 GB of stepping stones, more than one GPU holds).
+ * The reference's unit is the section (scripts/RelateParallel/RelateParallel.sh:231-257): each BuildTopology process
+ * decodes the stones of ALL targets of its window, re-paints them and fills whole matrices (src/anc_builder.cpp:49-106,
+ * :109-207).  Here a rank (one process per GPU) is an rl_shard: the chunk loaded with rl_set_target_range(k_begin,
+ * k_end), its own targets painted (from_paint_files = 0: stones stay in HBM, W*(k_end-k_begin)*N floats per
+ * direction) or their records read from the Paint stage's files (from_paint_files = 1).
+ *   rl_shard_rows: rows k_begin..k_end-1 of DistanceMeasure::GetMatrix(snp) of `section` into a device buffer of
+ *     (k_end-k_begin)*N floats.  The first call for a section opens its window (GetTopologyWithRepaint for the
+ *     shard's targets); every call replays the cursor updates of anc_builder.cpp:487-495 from the SNP of the previous
+ *     call up to snp (they are a function of the panel), so SNPs must not decrease within a section.
+ *   rl_shard_release_section: the section's trees are done, its window goes.
+ *   rl_shard_build_section: the tree-sequence loop of ONE section (AncesTreeBuilder::BuildTopology,
+ *     anc_builder.cpp:398-656) on this rank, its OWNER: every matrix comes from `matrix` (N*N floats to the host) or
+ *     -- build_device >= 0 and matrix_dev given -- from `matrix_dev` (N*N floats to a device buffer of that GPU;
+ *     penalty, prior and the build run there), which the caller implements by asking every shard for its rows and
+ *     exchanging them (relate_amd/dist.py run_chunk_by_targets: an RCCL all-gather per matrix).  Writes
+ *     <out>/chunk_<c>/<out>_<section>.anc/.mut like rl_stage_build_topology.
+ *   rl_shard_expect_builders: how many sections this rank will own at once with build_device >= 0 (sizes the device
+ *     tree builder's worker pool); 0 when done.
+ *   rl_shard_set_window_rows: posterior rows a window keeps resident (rl_window_open_bounded's max_rows; 0 = all).
+ *   rl_device_copy: device-to-device copy on `device` (received row blocks into the matrix_dev buffer). */
+typedef struct rl_shard rl_shard;
+rl_shard *rl_shard_open(const char *out_dir, int chunk_index, int k_begin, int k_end,
+                        int use_painting, double theta, double rho, int sum_mode,
+                        int device, int from_paint_files);
+void rl_shard_close(rl_shard *s);
+int rl_shard_dims(const rl_shard *s, int *N, int *L, int *W, int *k_begin, int *k_end);
+int rl_shard_section_bounds(const rl_shard *s, int section, int *start, int *end);
+int rl_shard_set_window_rows(rl_shard *s, long long rows);
+int rl_shard_rows(rl_shard *s, int section, int snp, void *d_rows);
+int rl_shard_release_section(rl_shard *s, int section);
+int rl_shard_expect_builders(rl_shard *s, int builders);
+int rl_shard_build_section(rl_shard *s, int section, int flags, int fb, int build_device,
+                           rl_matrix_fn matrix, rl_matrix_dev_fn matrix_dev, void *user,
+                           int *num_trees);
+int rl_device_copy(void *dst, const void *src, size_t bytes, int device);
+
 /* ------------------------------------------------------------ MakeChunks */
 /* Replaces Data::MakeChunks (src/data.cpp:117-518): parses .haps / .sample
  * (plain or gzip) and the genetic map, decides chunks and windows from the

@@ -301,6 +301,96 @@ class Builder:
         self.close()
 
 
+MATRIX_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p)  # rl_matrix_fn / rl_matrix_dev_fn
+
+
+class Shard:
+    """One rank's share of a chunk sharded by target haplotype (rl_shard, BASELINE.json config #5): the chunk loaded
+    for targets [k_begin, k_end), their stepping stones painted and resident (from_paint_files=False) or read from
+    the Paint stage's files.  rows(): this shard's rows of a section's distance matrix, to a device buffer;
+    build_section(): the tree-sequence loop of a section this rank owns, its matrices supplied by callbacks."""
+
+    def __init__(self, out_dir, chunk_index, k_begin, k_end, painting=None, sum_mode=RL_SUM_EXACT, device=0,
+                 from_paint_files=False):
+        L = lib()
+        L.rl_shard_open.restype = C.c_void_p
+        L.rl_shard_open.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
+                                    C.c_int, C.c_int]
+        L.rl_shard_close.argtypes = [C.c_void_p]
+        L.rl_shard_dims.argtypes = [C.c_void_p] * 6
+        L.rl_shard_section_bounds.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.rl_shard_set_window_rows.argtypes = [C.c_void_p, C.c_longlong]
+        L.rl_shard_rows.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.rl_shard_release_section.argtypes = [C.c_void_p, C.c_int]
+        L.rl_shard_expect_builders.argtypes = [C.c_void_p, C.c_int]
+        L.rl_shard_build_section.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, MATRIX_FN, MATRIX_FN,
+                                             C.c_void_p, C.c_void_p]
+        L.rl_device_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        th, rho = painting if painting else (0.001, 1.0)
+        self.device = device
+        self._h = L.rl_shard_open(out_dir.encode(), chunk_index, k_begin, k_end, 1 if painting else 0, th, rho,
+                                  sum_mode, device, 1 if from_paint_files else 0)
+        if not self._h:
+            raise RelateError(L.rl_last_error().decode())
+        v = [C.c_int() for _ in range(5)]
+        _check(L.rl_shard_dims(C.c_void_p(self._h), *[C.byref(x) for x in v]))
+        self.N, self.L, self.W, self.k_begin, self.k_end = [x.value for x in v]
+
+    def close(self):
+        if self._h:
+            lib().rl_shard_close(C.c_void_p(self._h))
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def section_bounds(self, section):
+        a, b = C.c_int(), C.c_int()
+        _check(lib().rl_shard_section_bounds(C.c_void_p(self._h), section, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def set_window_rows(self, rows):
+        _check(lib().rl_shard_set_window_rows(C.c_void_p(self._h), int(rows)))
+
+    def rows(self, section, snp, device_ptr):
+        """rows k_begin..k_end-1 of the section's distance matrix at snp -> (k_end-k_begin)*N floats at device_ptr"""
+        _check(lib().rl_shard_rows(C.c_void_p(self._h), section, snp, C.c_void_p(device_ptr)))
+
+    def release_section(self, section):
+        _check(lib().rl_shard_release_section(C.c_void_p(self._h), section))
+
+    def expect_builders(self, n):
+        _check(lib().rl_shard_expect_builders(C.c_void_p(self._h), int(n)))
+
+    def copy_on_device(self, dst_ptr, src_ptr, nbytes):
+        _check(lib().rl_device_copy(C.c_void_p(dst_ptr), C.c_void_p(src_ptr), nbytes, self.device))
+
+    def build_section(self, section, matrix, matrix_dev=None, build_device=None, no_consistency=False, fb=0):
+        """matrix(snp, host_ptr) / matrix_dev(snp, device_ptr): fill the N x N float matrix of `snp` (return None or 0;
+        an exception fails the section).  -> number of trees.  Blocks; releases the GIL while the trees are built."""
+        errors = []
+
+        def wrap(fn):
+            def cb(_user, snp, ptr):
+                try:
+                    return int(fn(snp, ptr) or 0)
+                except BaseException as e:  # (must not propagate through the C frames)
+                    errors.append(e)
+                    return -1
+            return MATRIX_FN(cb)
+
+        c_host = wrap(matrix)
+        c_dev = wrap(matrix_dev) if matrix_dev is not None else C.cast(None, MATRIX_FN)
+        n = C.c_int(0)
+        rc = lib().rl_shard_build_section(C.c_void_p(self._h), section, 1 if no_consistency else 0, fb,
+                                          -1 if build_device is None else int(build_device), c_host, c_dev, None,
+                                          C.byref(n))
+        if errors:
+            raise errors[0]
+        _check(rc)
+        return n.value
+
+
 def stage_paint(out_dir, chunk_index=0, painting=None, sum_mode=RL_SUM_EXACT, device=0):
     th, rho = painting if painting else (0.001, 1.0)
     _check(lib().rl_stage_paint(out_dir.encode(), chunk_index, 1 if painting else 0, th, rho, sum_mode, device))

@@ -323,8 +323,9 @@ void rl_treeseq_destroy(rl_treeseq *ts) { delete ts; }
 
 }  // extern "C"
 
-// as rl_treeseq_create, the panel borrowed instead of copied
-static rl_treeseq *treeseq_borrowing(int N, int L, const uint32_t *bits, int row_words, const double *rpos,
+// as rl_treeseq_create, the panel borrowed instead of copied (also used by shard.cpp)
+namespace rl {
+rl_treeseq *treeseq_borrowing(int N, int L, const uint32_t *bits, int row_words, const double *rpos,
                                      const int *bp_pos, const int *state, double theta) {
   rl_treeseq *ts = new rl_treeseq();
   ts->N = N;
@@ -339,6 +340,7 @@ static rl_treeseq *treeseq_borrowing(int N, int L, const uint32_t *bits, int row
   ts->member.assign(N, 0);
   return ts;
 }
+}  // namespace rl
 
 extern "C" {
 

@@ -146,6 +146,281 @@ def run_chunks(out_dir, painting=None, device=None, stages=None, chunks=None, pa
     return mine
 
 
+# ---- one chunk sharded by target haplotype (BASELINE.json config #5) -------------------------------------------
+#
+# Units (include/relate_amd.h "one chunk sharded by target haplotype"; what they mirror in the reference:
+# src/anc_builder.cpp:49-106 -- a section needs the stones of EVERY target -- and RelateParallel.sh:231-257 -- sections
+# are the independent jobs): every rank is an api.Shard for its target_range(); the sections are dealt to the ranks
+# as OWNERS; an owner runs the section's tree-sequence loop and, for every tree, asks all ranks for their rows of the
+# distance matrix at one SNP.  Collectives need one order on all ranks, so requests are exchanged in TICKS:
+#
+#   tick:  every rank publishes its table of <= in_flight requests (section, snp, kind)        -- all_gather, 24 B each
+#          for every request of the tick, in (rank, slot) order:
+#              every rank: shard.rows(section, snp) -> its (maxrows x N) send block             -- K2 (first time) + K3
+#              all ranks:  all_gather of the blocks (N^2 floats in all; RCCL over xGMI)         -- THE exchange
+#              the owner:  the blocks, pads dropped, into the N x N buffer its builder waits for
+#          kind RELEASE: every rank closes its window of that section
+#   the job ends in the tick in which every rank reports that it owns nothing any more.
+#
+# Bytes per tree at N = 10,000 on 8 GPUs: each rank sends 1250 x 10,000 x 4 B = 50 MB and receives 350 MB (2.3 ms at
+# the ~153 GB/s of one xGMI link in a ring; a tree's build is ~0.5 s).  Nothing else of the chunk moves: stones
+# (36 GB per rank), posterior rows (3 GB per window and rank) and cursors stay where they were computed.
+REQ_NONE, REQ_MATRIX, REQ_RELEASE = 0, 1, 2
+
+
+class TorchFabric:
+    """the job's ranks = the ranks of torch.distributed (RCCL on GPUs, gloo on the CPU)"""
+
+    def __init__(self, device=None):
+        self.live = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank() if self.live else 0
+        self.world = dist.get_world_size() if self.live else 1
+        on_gpu = self.live and dist.get_backend() == "nccl"
+        self.device = torch.device("cuda", device if device is not None else local_device()) if (
+            on_gpu or (device is not None and torch.cuda.is_available())) else torch.device("cpu")
+
+    def buffer(self, rows, cols):
+        return torch.zeros((rows, cols), dtype=torch.float32, device=self.device)
+
+    def all_gather_table(self, table):
+        t = torch.as_tensor(table, dtype=torch.int64).to(self.device)
+        if not self.live or self.world == 1:
+            return t.cpu().numpy()[None]
+        out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=torch.int64, device=self.device)
+        dist.all_gather_into_tensor(out, t.contiguous())
+        return out.cpu().numpy().reshape((self.world,) + tuple(t.shape))
+
+    def all_gather_rows(self, send, recv):
+        if not self.live or self.world == 1:
+            recv.copy_(send)
+        else:
+            dist.all_gather_into_tensor(recv, send)
+        if recv.is_cuda:
+            torch.cuda.synchronize(recv.device)
+
+
+class ThreadFabric:
+    """the job's ranks = threads of this process (several target ranges on ONE GPU, or none: tests).  Same protocol,
+    the exchanges through shared lists and a barrier."""
+
+    class Hub:
+        def __init__(self, world):
+            import threading
+            self.world = world
+            self.barrier = threading.Barrier(world)
+            self.slots = [None] * world
+
+    def __init__(self, hub, rank, device=None):
+        self.hub, self.rank, self.world = hub, rank, hub.world
+        self.device = torch.device("cuda", device) if device is not None else torch.device("cpu")
+
+    def buffer(self, rows, cols):
+        return torch.zeros((rows, cols), dtype=torch.float32, device=self.device)
+
+    def _exchange(self, item):
+        self.hub.slots[self.rank] = item
+        self.hub.barrier.wait()
+        items = list(self.hub.slots)
+        self.hub.barrier.wait()
+        return items
+
+    def all_gather_table(self, table):
+        import numpy as np
+        return np.stack(self._exchange(np.array(table, dtype=np.int64)))
+
+    def all_gather_rows(self, send, recv):
+        blocks = self._exchange(send)
+        n = send.shape[0]
+        for r, b in enumerate(blocks):
+            recv[r * n:(r + 1) * n].copy_(b)
+        if recv.is_cuda:
+            torch.cuda.synchronize(recv.device)
+        self.hub.barrier.wait()  # (nobody overwrites its send block while another rank still copies from it)
+
+
+def deal_sections(sections, rank, world):
+    """the sections a rank owns: round-robin in the given order (every rank computes the same deal)"""
+    return [s for i, s in enumerate(sections) if i % world == rank]
+
+
+def run_chunk_by_targets(out_dir, chunk_index=0, painting=None, device=None, sections=None, in_flight=4,
+                         build_on_gpu=True, window_rows=0, sum_mode=0, from_paint_files=False, no_consistency=False,
+                         fb=0, fabric=None, shard=None, num_sections=None, N=None, idle_sleep=0.001):
+    """Paint -> BuildTopology of ONE chunk too large for one GPU, sharded by target haplotype (BASELINE.json config #5):
+    this rank paints target_range(rank, world, N), owns deal_sections(sections) -- at most `in_flight` at a time, a host
+    thread each -- and serves its rows of every matrix any owner asks for (see the protocol above).  Writes
+    <out_dir>/chunk_<c>/<out>_<section>.anc/.mut for the sections it owns, the files rl_stage_build_topology writes.
+    Returns {section: number of trees} for those.
+
+    fabric: TorchFabric (default: the torch.distributed job, one process per GPU) or a ThreadFabric.  shard: an object
+    with api.Shard's methods (default: api.Shard for this rank's range; tests pass stand-ins).  window_rows: posterior
+    rows a window keeps resident (0 = all; a rank holds in_flight x world windows of its share of the targets)."""
+    import ctypes as C
+    import threading
+    import time
+    import numpy as np
+
+    fab = fabric if fabric is not None else TorchFabric(device)
+    rank, world = fab.rank, fab.world
+    dev = device if device is not None else local_device()
+    if shard is None:
+        from relate_amd import api
+        if N is None:
+            N = int(np.fromfile(os.path.join(out_dir, "parameters_c%d.bin" % chunk_index), dtype=np.int32, count=1)[0])
+        k0, k1 = target_range(rank, world, N)
+        shard = api.Shard(out_dir, chunk_index, k0, k1, painting=painting, sum_mode=sum_mode, device=dev,
+                          from_paint_files=from_paint_files)
+        owns_shard = True
+    else:
+        owns_shard = False
+    N = shard.N
+    if (shard.k_begin, shard.k_end) != target_range(rank, world, N):
+        raise ValueError("rank %d of %d holds targets %d..%d, not %s" % (rank, world, shard.k_begin, shard.k_end,
+                                                                          target_range(rank, world, N)))
+    if window_rows:
+        shard.set_window_rows(window_rows)
+    todo = list(range(shard.W if num_sections is None else num_sections)) if sections is None else list(sections)
+    mine = deal_sections(todo, rank, world)
+    Q = max(1, int(in_flight))
+    maxrows = -(-N // world)
+    send = fab.buffer(maxrows, N)
+    recv = fab.buffer(world * maxrows, N)
+    on_device = send.is_cuda
+    gpu_build = bool(build_on_gpu and on_device)
+    if gpu_build:
+        shard.expect_builders(min(Q, max(1, len(mine))))
+
+    lock = threading.Lock()
+    pending = [None] * Q          # slot -> [kind, section, snp, ptr, to_device, event, error]
+    results, failures = {}, []
+    next_mine = [0]
+    active = [0]                  # owner threads still running
+
+    stopped = []                  # the job's error once the tick loop has ended on one
+
+    def post(slot, kind, section, snp=-1, ptr=0, to_device=False):
+        ev = threading.Event()
+        req = [kind, section, snp, ptr, to_device, ev, None]
+        with lock:
+            if stopped:
+                if kind == REQ_RELEASE:
+                    return
+                raise stopped[0]
+            pending[slot] = req
+        ev.wait()
+        if req[6] is not None:
+            raise req[6]
+
+    def owner(slot):
+        try:
+            while True:
+                with lock:
+                    if next_mine[0] >= len(mine) or failures:
+                        return
+                    section = mine[next_mine[0]]
+                    next_mine[0] += 1
+                try:
+                    results[section] = shard.build_section(
+                        section, matrix=lambda snp, ptr: post(slot, REQ_MATRIX, section, snp, ptr, False),
+                        matrix_dev=(lambda snp, ptr: post(slot, REQ_MATRIX, section, snp, ptr, True)) if gpu_build else None,
+                        build_device=dev if gpu_build else None, no_consistency=no_consistency, fb=fb)
+                finally:
+                    post(slot, REQ_RELEASE, section)
+        except BaseException as e:
+            with lock:
+                failures.append(e)
+        finally:
+            with lock:
+                active[0] -= 1
+
+    threads = [threading.Thread(target=owner, args=(q,), daemon=True) for q in range(min(Q, max(1, len(mine))))]
+    active[0] = len(threads)
+    for t in threads:
+        t.start()
+
+    def deliver(req):
+        _, _, _, ptr, to_device, _, _ = req
+        for r in range(world):
+            a, b = target_range(r, world, N)
+            if b == a:
+                continue
+            blk = recv[r * maxrows: r * maxrows + (b - a)]
+            if to_device:
+                shard.copy_on_device(ptr + a * N * 4, blk.data_ptr(), (b - a) * N * 4)
+            else:
+                dst = np.ctypeslib.as_array(C.cast(C.c_void_p(ptr), C.POINTER(C.c_float)), shape=(N, N))
+                dst[a:b] = blk.cpu().numpy()
+
+    served = 0
+    abort = None
+    while True:
+        table = np.zeros((Q + 1, 3), dtype=np.int64)
+        with lock:
+            snapshot = list(pending)
+            idle = active[0] == 0 and all(p is None for p in snapshot)
+            failed = bool(failures) or abort is not None
+        for q, req in enumerate(snapshot):
+            if req is not None:
+                table[q] = (req[0], req[1], req[2])
+        table[Q] = (-1 if failed else (1 if idle else 0), 0, 0)
+        tables = fab.all_gather_table(table)
+        if (tables[:, Q, 0] < 0).any():  # some rank failed: everybody stops in the same tick
+            with lock:
+                err = abort or (failures[0] if failures else RuntimeError("run_chunk_by_targets: another rank failed"))
+                failures.insert(0, err)
+                stopped.append(err)
+                for q, req in enumerate(pending):
+                    if req is not None:
+                        req[6] = err
+                        pending[q] = None
+                        req[5].set()
+            for t in threads:
+                t.join(timeout=60)
+            if owns_shard:
+                shard.close()
+            raise err
+        busy = False
+        for r in range(world):
+            for q in range(Q):
+                kind, section, snp = (int(x) for x in tables[r, q])
+                if kind == REQ_NONE:
+                    continue
+                busy = True
+                if kind == REQ_MATRIX:
+                    try:
+                        if abort is None:
+                            shard.rows(section, snp, send.data_ptr())
+                    except BaseException as e:  # (keep the collectives aligned; the next tick stops the job)
+                        abort = e
+                    fab.all_gather_rows(send, recv)
+                    served += 1
+                elif kind == REQ_RELEASE:
+                    try:
+                        shard.release_section(section)
+                    except BaseException as e:
+                        abort = e
+                if r == rank:
+                    req = snapshot[q]
+                    if kind == REQ_MATRIX and abort is None:
+                        deliver(req)
+                    with lock:
+                        pending[q] = None
+                    req[5].set()
+        if not busy:
+            if (tables[:, Q, 0] == 1).all():
+                break
+            time.sleep(idle_sleep)
+    for t in threads:
+        t.join()
+    if gpu_build:
+        shard.expect_builders(0)
+    if owns_shard:
+        shard.close()
+    if failures:
+        raise failures[0]
+    return results
+
+
 def main(argv=None):
     """`python -m torch.distributed.run --nproc-per-node G -m relate_amd.dist OUT_DIR [--painting theta,rho]`:
     every chunk of OUT_DIR/parameters.bin through Paint, BuildTopology and FindEquivalentBranches, chunk c on rank

@@ -160,8 +160,10 @@ def example_fixture(nsnps=3000):
     print("example8 N", p[0], "L", p[1], "W", W, "%.1f KB" % (os.path.getsize(os.path.join(GOLD, "example8.npz")) / 1e3))
 
 
-def n5000_fixture(N=5000, L=1200, mem=10.0):
-    """The headline tile (BASELINE.json config #3's N = 5000, one wavefront of S = 80 registers per target) against
+def n5000_fixture(N=5000, L=1200, mem=10.0, name="n5000"):
+    """(name = "n10000", N = 10000, L = 600, mem = 12: BASELINE.json config #5's N -- two wavefronts per target in K1 /
+    K2, the device tree builder's global-memory state path -- about an hour of the single-threaded reference.)
+    The headline tile (BASELINE.json config #3's N = 5000, one wavefront of S = 80 registers per target) against
     the reference binary: a short chunk (3 windows), Paint of the whole chunk and BuildTopology of section 0.
     The inputs are regenerated from the seed by the test (their md5s are kept); of the outputs the fixture
     keeps the md5 of every file, the head of window 0's paint file and the parent arrays of the section's trees
@@ -210,9 +212,9 @@ def n5000_fixture(N=5000, L=1200, mem=10.0):
         data["tree_parent_md5"] = np.stack([md5(t[1].astype("<i4").tobytes()) for t in trees])
         for i in sorted(set([0, len(trees) - 2, len(trees) - 1])):
             data["tree_parent/%d" % i] = trees[i][1].astype(np.int32)
-    np.savez_compressed(os.path.join(GOLD, "n5000.npz"), **data)
-    print("n5000 N", N, "L", L, "W", W, "trees", len(trees),
-          "%.1f KB" % (os.path.getsize(os.path.join(GOLD, "n5000.npz")) / 1e3))
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **data)
+    print(name, "N", N, "L", L, "W", W, "trees", len(trees),
+          "%.1f KB" % (os.path.getsize(os.path.join(GOLD, name + ".npz")) / 1e3))
 
 
 def n5000_matrix_fixture(N=5000, L=1200, mem=10.0, rows=(0, 1, 2, 1250, 2500, 3750, 4998, 4999)):
@@ -412,6 +414,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "n5000_matrix":  # a few minutes, ~30 GB of scratch files
         n5000_matrix_fixture()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "n10000":  # ~1 h of the single-threaded reference, ~15 GB of memory
+        n5000_fixture(N=10000, L=600, mem=12.0, name="n10000")
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "n5000":  # ~15 minutes of the single-threaded reference
         n5000_fixture()
