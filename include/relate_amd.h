@@ -47,8 +47,15 @@ enum {
  *   RL_SUM_LANES : per-lane partial sums + wavefront xor-butterfly.  Same
  *                  arithmetic, different association: distances agree to
  *                  ~1e-7 relative before min-subtraction, trees may differ
- *                  where MinMatch breaks float ties.       */
-enum { RL_SUM_EXACT = 0, RL_SUM_LANES = 1, RL_SUM_EXACT_SERIAL = 2 };
+ *                  where MinMatch breaks float ties.
+ *   RL_SUM_LANES32 : the FAST mode.  As RL_SUM_LANES, with the per-donor state of
+ *                  the stepping-stone pass (rl_paint) in packed FP32 instead of
+ *                  double (the stones are floats in the reference too,
+ *                  fast_painting.cpp:241-245); sums, factors, logscales and all of
+ *                  RePaintSection stay double.  Distances within 1e-5 *
+ *                  max(|d|, |logscale|) of the reference's (asserted in the
+ *                  tests); NOT byte-identical files.                           */
+enum { RL_SUM_EXACT = 0, RL_SUM_LANES = 1, RL_SUM_EXACT_SERIAL = 2, RL_SUM_LANES32 = 3 };
 
 typedef struct rl_ctx rl_ctx;
 typedef struct rl_window rl_window;
@@ -133,6 +140,8 @@ int rl_debug_wave_sum(const double *x, int n, int batch, int sum_mode, double *o
 /* Experiment builds only (kernels compiled with -DRL_STATS and
  * RELATE_AMD_STATS set): 16 event counters of the last rl_paint. */
 int rl_debug_stats(rl_ctx *ctx, unsigned long long *out16);
+/* ... and all 32 (16..24: cycles of the forward / backward step by segment, paint_kernels.hip) */
+int rl_debug_stats32(rl_ctx *ctx, unsigned long long *out32);
 
 /* Copy stepping stones of window w to the host: alpha, beta: N*N floats
  * ([target][donor]); ls_alpha, ls_beta: N floats; bsnp_begin/end: N ints.

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "librelate_amd.so")
 RL_SUM_EXACT = 0
 RL_SUM_LANES = 1
 RL_SUM_EXACT_SERIAL = 2
+RL_SUM_LANES32 = 3
 
 _lib = None
 

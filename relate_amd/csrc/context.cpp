@@ -180,6 +180,8 @@ PaintConsts make_consts(int N, double theta) {
   c.log_ntheta = std::log(ntheta);
   c.lower = 1e-10;
   c.upper = 1.0 / c.lower;
+  c.inv_theta = 1.0 / theta;  // (IEEE division: correctly rounded, which div_by_const relies on)
+  c.inv_ntheta = 1.0 / ntheta;
   return c;
 }
 
@@ -797,7 +799,7 @@ int rl_paint(rl_ctx *ctx, int sum_mode, float *kernel_ms) {
     set_error("rl_paint: no chunk loaded");
     return RL_ESTATE;
   }
-  if (sum_mode != RL_SUM_EXACT && sum_mode != RL_SUM_LANES && sum_mode != RL_SUM_EXACT_SERIAL) {
+  if (sum_mode != RL_SUM_EXACT && sum_mode != RL_SUM_LANES && sum_mode != RL_SUM_EXACT_SERIAL && sum_mode != RL_SUM_LANES32) {
     set_error("rl_paint: bad sum_mode");
     return RL_EINVAL;
   }
@@ -841,8 +843,8 @@ int rl_paint(rl_ctx *ctx, int sum_mode, float *kernel_ms) {
   if (const char *e = getenv("RELATE_AMD_PAINT_ORDER")) p.merge_order = atoi(e);  // experiments
   p.stats = nullptr;
   if (getenv("RELATE_AMD_STATS")) {  // experiment builds (-DRL_STATS): 16 counters, see tools/exp_stats.py
-    if ((rc = ctx->d_stats.alloc(16 * sizeof(unsigned long long)))) return rc;
-    RL_HIP(hipMemset(ctx->d_stats.p, 0, 16 * sizeof(unsigned long long)));
+    if ((rc = ctx->d_stats.alloc(32 * sizeof(unsigned long long)))) return rc;
+    RL_HIP(hipMemset(ctx->d_stats.p, 0, 32 * sizeof(unsigned long long)));
     p.stats = ctx->d_stats.as<unsigned long long>();
   }
 
@@ -887,6 +889,12 @@ int rl_paint(rl_ctx *ctx, int sum_mode, float *kernel_ms) {
 int rl_debug_stats(rl_ctx *ctx, unsigned long long *out16) {
   if (!ctx || !ctx->d_stats.p || !out16) return RL_ESTATE;
   RL_HIP(hipMemcpy(out16, ctx->d_stats.p, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return RL_OK;
+}
+
+int rl_debug_stats32(rl_ctx *ctx, unsigned long long *out32) {
+  if (!ctx || !ctx->d_stats.p || !out32) return RL_ESTATE;
+  RL_HIP(hipMemcpy(out32, ctx->d_stats.p, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return RL_OK;
 }
 

@@ -22,6 +22,7 @@ struct PaintConsts {
   double log_Nm1;     // log(N-1)                    (fast_painting.cpp:399)
   double log_ntheta;  // log(1-theta)
   double lower, upper;  // rescaling thresholds 1e-10 / 1e10
+  double inv_theta, inv_ntheta;  // RN(1 / theta), RN(1 / ntheta): div_by_const (paint_device.h)
 };
 
 struct PaintParams {

@@ -42,7 +42,8 @@ hipError_t launch_lane_masks(const uint32_t *bits, int row_words, int L, const L
                              unsigned long long *masks, hipStream_t stream);
 
 // kernel summation modes (template parameter MODE of the kernels)
-//   0 = lanes (RL_SUM_LANES), 1 = exact, parallel (RL_SUM_EXACT), 2 = exact, literal serial (RL_SUM_EXACT_SERIAL)
+//   0 = lanes (RL_SUM_LANES), 1 = exact, parallel (RL_SUM_EXACT), 2 = exact, literal serial (RL_SUM_EXACT_SERIAL),
+//   3 = lanes on a packed-FP32 state (RL_SUM_LANES32; K1 only, paint32_kernels.hip -- K2 then runs its `lanes` kernels)
 // dir: 0 forward pass, 1 backward pass, 2 both in one launch of 2 * nloc workgroups
 template <int MODE>
 hipError_t launch_paint_mode(const PaintParams &p, int S, int waves, int dir, hipStream_t stream);
@@ -51,12 +52,14 @@ hipError_t launch_repaint_mode(const RepaintParams &p, int S, int waves, hipStre
 template <> hipError_t launch_paint_mode<0>(const PaintParams &, int, int, int, hipStream_t);
 template <> hipError_t launch_paint_mode<1>(const PaintParams &, int, int, int, hipStream_t);
 template <> hipError_t launch_paint_mode<2>(const PaintParams &, int, int, int, hipStream_t);
+template <> hipError_t launch_paint_mode<3>(const PaintParams &, int, int, int, hipStream_t);
 template <> hipError_t launch_repaint_mode<0>(const RepaintParams &, int, int, hipStream_t);
 template <> hipError_t launch_repaint_mode<1>(const RepaintParams &, int, int, hipStream_t);
 template <> hipError_t launch_repaint_mode<2>(const RepaintParams &, int, int, hipStream_t);
 
-inline int kernel_mode(int sum_mode) { return sum_mode == 0 ? 1 : (sum_mode == 1 ? 0 : 2); }
+inline int kernel_mode(int sum_mode) { return sum_mode == 0 ? 1 : (sum_mode == 1 || sum_mode == 3 ? 0 : 2); }
 inline hipError_t launch_paint(const PaintParams &p, int S, int waves, int dir, hipStream_t stream) {
+  if (p.sum_mode == 3) return launch_paint_mode<3>(p, S, waves, dir, stream);  // RL_SUM_LANES32
   switch (kernel_mode(p.sum_mode)) {
     case 0: return launch_paint_mode<0>(p, S, waves, dir, stream);
     case 1: return launch_paint_mode<1>(p, S, waves, dir, stream);

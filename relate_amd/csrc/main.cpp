@@ -7,7 +7,7 @@
 // Same options, files and stderr banners as include/pipeline/Relate.cpp:19-115,
 // Paint.cpp, BuildTopology.cpp of the reference; every other --mode is refused
 // (use the reference binary for them).  Extra options: --device n,
-// --sum_mode exact|lanes.
+// --sum_mode exact|lanes|lanes32.
 #include <sys/resource.h>
 
 #include <cstdio>
@@ -127,8 +127,9 @@ int main(int argc, char **argv) {
   int sum_mode = RL_SUM_EXACT;
   if (opt.count("sum_mode")) {
     if (opt["sum_mode"] == "lanes") sum_mode = RL_SUM_LANES;
+    else if (opt["sum_mode"] == "lanes32") sum_mode = RL_SUM_LANES32;
     else if (opt["sum_mode"] != "exact") {
-      std::cerr << "--sum_mode must be exact or lanes" << std::endl;
+      std::cerr << "--sum_mode must be exact, lanes or lanes32" << std::endl;
       return 1;
     }
   }

@@ -57,6 +57,22 @@ RL_DEV float fast_log_dev(float val) {
   return (val + log_2) * 0.69314718f;
 }
 
+// a / b, correctly rounded, for a divisor whose correctly rounded reciprocal y = RN(1 / b) is at hand (theta and
+// 1 - theta: fast_painting.cpp:474-475 divide by them in every backward step).  The compiler's IEEE division is
+// ~16 dependent instructions (v_div_scale x 2, v_rcp, a Newton chain, v_div_fmas, v_div_fixup); with y known:
+//   q0 = RN(a y)                      within 2 ulp of a/b   (y and the product each err by <= 2^-53 relative)
+//   q1 = RN(q0 + RN(a - b q0) y)      faithful              (the residual by FMA)
+//   q2 = RN(q1 + (a - b q1) y)        = RN(a / b)           Markstein's theorem: q faithful, the residual exact (it is,
+//                                                            for a faithful q), y = RN(1/b)  =>  RN(q + r y) = RN(a/b)
+// a is a positive normal number far from the ends of the range here (1e-10 <= sum <= 1e10 times an interval
+// coefficient), so neither the products nor the residuals under- or overflow.  (2.2e9 random a per divisor against
+// the hardware division on the host: no difference, already after q1.)
+RL_DEV double div_by_const(double a, double b, double y) {
+  const double q0 = a * y;
+  const double q1 = __builtin_fma(__builtin_fma(-q0, b, a), y, q0);
+  return __builtin_fma(__builtin_fma(-q1, b, a), y, q1);
+}
+
 // ---- lane-mask panel -------------------------------------------------------
 // The Li-Stephens kernels (K1 stepping stones, K2 RePaint) read the panel in "lane-mask" form: for site s and
 // register j one 64-bit word whose bit l says that the donor lane l holds in

@@ -170,6 +170,10 @@ RL_DEV void paint_forward(const PaintParams &p, int k, float *stage, WaveLink<WA
   }
   retire_touch(touched);
 #ifdef RL_STATS
+  if (MODE != 0 && p.stats && pl.lane == 0 && wv == 0) {  // whole step | chunk loop | sum | rescale test + factor
+    atomicAdd(&p.stats[16], seg1 + seg2 + seg3 + seg4 + seg5);
+    atomicAdd(&p.stats[17], seg3); atomicAdd(&p.stats[18], seg4); atomicAdd(&p.stats[19], seg1 + seg2 + seg5);
+  }
   if (MODE == 0 && p.stats && pl.lane == 0 && wv == 0) {  // wait for prefetch | loads + slot | chunk loop | sum | rescale test
     atomicAdd(&p.stats[0], (unsigned long long)(D - 1));
     atomicAdd(&p.stats[1], seg1); atomicAdd(&p.stats[2], seg2); atomicAdd(&p.stats[3], seg3);
@@ -229,19 +233,23 @@ RL_DEV void paint_backward(const PaintParams &p, int k, float *stage, WaveLink<W
   MaskRow rowh = site_row(p.masks, S, p.L, s1, WAVES, wv);
   u64x4 firstn = load_masks<4>(rown, 0), firsth = load_masks<4>(rowh, 0);
   const double K1 = in_vgpr(c.K1), theta = in_vgpr(c.theta), ntheta = in_vgpr(c.ntheta);
+  unsigned long long bseg1 = 0, bseg2 = 0, bseg3 = 0, bseg4 = 0;
+  (void)bseg1; (void)bseg2; (void)bseg3; (void)bseg4;
   for (int j = D - 2; j >= 0; j--) {
     retire_touch(touched);
     if (j > 0) touched = touch_row(p.masks, S, s2, pl.lane, WAVES, wv);
     s0 = s1;
     s1 = s2;
     if (j > 1) s2 = st[j - 2];
+    RL_TICK(0);
     const double nx_j = nx[j + 1], cf_j = cfp[j];  // used after the sum (see paint_forward)
-    const double b1 = cfac / ntheta;     // :474
-    const double bt = cfac / theta - b1; // :475
+    const double b1 = div_by_const(cfac, ntheta, c.inv_ntheta);     // cfac / ntheta, :474
+    const double bt = div_by_const(cfac, theta, c.inv_theta) - b1;  // cfac / theta - b1, :475
     set_slot<S>(b, pl.jk, pl.kbit, -b1);   // donor k: (-b1) + b1 = +0.0 (never a mismatch with itself)
     double lsum = 0.0;
     MaskRow vrow = (MaskRow)(p.masks + ((size_t)(p.L + 1) * WAVES + wv) * S);
     asm volatile("" : "+s"(vrow));
+    RL_TICK(1);
     for_each_chunk2_tail<S, 4, TAIL>(rown, rowh, vrow, firstn, firsth,
                                      [&](int j0, const u64x4 &mn, const u64x4 &mh, const u64x4 &va) {
       double v[4], x[4];
@@ -257,6 +265,7 @@ RL_DEV void paint_backward(const PaintParams &p, int k, float *stage, WaveLink<W
         lsum += x[jj];  // the lane's share of :495-503
       }
     });
+    RL_TICK(2);
     const MaskTerm<S> term{rowh, b, theta, ntheta, p.stats ? p.stats + 8 : nullptr};
     rown = rowh;
     rowh = site_row(p.masks, S, p.L, s1, WAVES, wv);
@@ -269,6 +278,7 @@ RL_DEV void paint_backward(const PaintParams &p, int k, float *stage, WaveLink<W
       firstn = load_masks<4>(rown, 0);
       firsth = load_masks<4>(rowh, 0);
     }
+    RL_TICK(3);
     ls += nx_j;  // :471-472
     cfac = bsum;
     if (cfac < c.lower || cfac > c.upper) {  // :538-551
@@ -278,12 +288,21 @@ RL_DEV void paint_backward(const PaintParams &p, int k, float *stage, WaveLink<W
       cfac = 1.0;
     }
     cfac *= cf_j;  // :553-556
+    RL_TICK(4);
+    RL_TOCK(bseg1, 0, 1); RL_TOCK(bseg2, 1, 2); RL_TOCK(bseg3, 2, 3); RL_TOCK(bseg4, 3, 4);
     while (next_stone == j) {  // :559-578
       write_stone(0.0f);
       next_stone = stone_index(we);
     }
   }
   retire_touch(touched);
+#ifdef RL_STATS
+  if (p.stats && pl.lane == 0 && wv == 0) {  // whole step | divisions + slot + loads | chunk loop | sum | rescale test + factor
+    atomicAdd(&p.stats[20], bseg1 + bseg2 + bseg3 + bseg4);
+    atomicAdd(&p.stats[21], bseg1); atomicAdd(&p.stats[22], bseg2); atomicAdd(&p.stats[23], bseg3);
+    atomicAdd(&p.stats[24], bseg4);
+  }
+#endif
 }
 
 // S <= 80: hold the kernel to 256 registers so that two waves share a SIMD.
@@ -307,10 +326,26 @@ __global__ void __launch_bounds__(64 * WAVES, 2) paint_kernel(const PaintParams 
     }
   }
   const int k = p.order[b];
+#ifdef RL_STATS
+  // experiment builds: the counters are gathered in LDS (an atomic to global memory per sum and counter made the
+  // kernel 25 x slower and the cycle counts meaningless) and added to the global ones once per workgroup
+  __shared__ unsigned long long lstats[32];
+  if (threadIdx.x < 32) lstats[threadIdx.x] = 0;
+  __syncthreads();
+  PaintParams q = p;
+  if (p.stats) q.stats = lstats;
+  if (backward)
+    paint_backward<S, TAIL, MODE, WAVES>(q, k, stage[lk.w], lk);
+  else
+    paint_forward<S, TAIL, MODE, WAVES>(q, k, stage[lk.w], lk);
+  __syncthreads();
+  if (p.stats && threadIdx.x < 32 && lstats[threadIdx.x]) atomicAdd(&p.stats[threadIdx.x], lstats[threadIdx.x]);
+#else
   if (backward)
     paint_backward<S, TAIL, MODE, WAVES>(p, k, stage[lk.w], lk);
   else
     paint_forward<S, TAIL, MODE, WAVES>(p, k, stage[lk.w], lk);
+#endif
 }
 
 template <int S, int TAIL, int WAVES>

@@ -448,8 +448,8 @@ RL_DEV void repaint_backward(const RepaintParams &p, int n, float *stage, double
     s1 = s2;
     if (j > 1) s2 = st[j - 2];
     const double nx_j = (j + 1 == D - 1 ? nxt_last : nx[j + 1]), cf_j = cfp[j];
-    const double b1 = cfac / ntheta;
-    const double bt = cfac / theta - b1;
+    const double b1 = div_by_const(cfac, ntheta, c.inv_ntheta);     // cfac / ntheta
+    const double bt = div_by_const(cfac, theta, c.inv_theta) - b1;  // cfac / theta - b1
     set_slot<S>(b, pl.jk, pl.kbit, -b1);
     double lsum = 0.0;
     MaskRow vrow = (MaskRow)(p.masks + ((size_t)(p.L + 1) * WAVES + wv) * S);

@@ -250,7 +250,10 @@ int rl_shard_build_section(rl_shard *s, int section, int flags, int fb, int buil
 int rl_device_copy(void *dst, const void *src, size_t bytes, int device) {
   if (!dst || !src) return RL_EINVAL;
   RL_HIP(hipSetDevice(device));
-  RL_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice));
+  // (a device-to-device hipMemcpy may return before the copy has run, and the builder's kernels are on non-blocking
+  //  streams that do not wait for the null stream: the copy is complete when this returns)
+  RL_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, nullptr));
+  RL_HIP(hipStreamSynchronize(nullptr));
   return RL_OK;
 }
 

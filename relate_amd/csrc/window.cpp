@@ -355,7 +355,7 @@ rl_window *rl_window_open_bounded(rl_ctx *ctx, int w, const char *paint_file, in
     set_error("rl_window_open: bad arguments");
     return nullptr;
   }
-  if (sum_mode != RL_SUM_EXACT && sum_mode != RL_SUM_LANES && sum_mode != RL_SUM_EXACT_SERIAL) {
+  if (sum_mode != RL_SUM_EXACT && sum_mode != RL_SUM_LANES && sum_mode != RL_SUM_EXACT_SERIAL && sum_mode != RL_SUM_LANES32) {
     set_error("rl_window_open: bad sum_mode");
     return nullptr;
   }

@@ -52,9 +52,9 @@ def test_two_wavefronts_per_target(N):
     check(ch, modes=("exact", "lanes", "serial"))
 
 
-@pytest.mark.parametrize("N,S", [(2000, 32), (2100, 48), (3500, 64), (5000, 80), (5120, 80)])
+@pytest.mark.parametrize("N,S", [(1000, 16), (2000, 32), (2100, 48), (3500, 64), (5000, 80), (5120, 80)])
 def test_single_wave_large_tiles(N, S):
-    """N = 2000 (BASELINE.json config #4's N, S = 32) and N = 2049..5120: one wavefront per target with the S = 48/64/80 register tiles -- N = 5000 is the tile of
+    """N = 1000 (BASELINE.json config #2's N, S = 16), N = 2000 (config #4's N, S = 32) and N = 2049..5120: one wavefront per target with the S = 48/64/80 register tiles -- N = 5000 is the tile of
     the headline configuration (BASELINE.json config #3); K1 in all three sum orders against the oracle
     (fast_painting.cpp:18-618)"""
     ch = random_chunk(N, 420, 0.13, seed=N, wb=[0, 130, 300, 420], special="flat_targets")

@@ -11,11 +11,15 @@ from relate_amd import api, dist as rdist
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("N,L,budget,parts", [(130, 900, 200000, 2), (70, 700, 40000, 3)])
+@pytest.mark.parametrize("N,L,budget,parts", [(130, 900, 200000, 2), (70, 700, 40000, 3), (5300, 90, None, 3)])
 @pytest.mark.parametrize("mode", ["exact", "lanes"])
 def test_target_ranges_reproduce_the_full_chunk(N, L, budget, parts, mode):
     sm = api.RL_SUM_EXACT if mode == "exact" else api.RL_SUM_LANES
-    ch = rlutil.synth_chunk(N, L, seed=4, budget=budget)
+    if budget is None:  # (N > 5120: two wavefronts per target)
+        from test_edge_gpu import random_chunk
+        ch = random_chunk(N, L, 0.13, seed=N, wb=[0, 30, 60, L])
+    else:
+        ch = rlutil.synth_chunk(N, L, seed=4, budget=budget)
     full = api.Context()
     full.set_chunk(ch.seq, ch.r, ch.rpos, ch.wb)
     full.paint(sm)
@@ -65,3 +69,40 @@ def test_target_ranges_reproduce_the_full_chunk(N, L, budget, parts, mode):
     assert np.array_equal(np.concatenate(rows, 0).view(np.uint32), fd.view(np.uint32))
     fwin.close()
     full.close()
+
+
+@pytest.mark.parametrize("name,parts,build_on_gpu,in_flight,from_files", [
+    ("synth70", 2, True, 2, False), ("synth70", 3, False, 3, False), ("synth24", 4, True, 1, True),
+    ("synth40_noisy", 3, True, 4, False)])
+def test_sharded_route_writes_the_reference_files(tmp_path, name, parts, build_on_gpu, in_flight, from_files):
+    """relate_amd.dist.run_chunk_by_targets (config #5's route) on golden chunks: `parts` ranks (threads on this GPU)
+    paint their target ranges, the sections are dealt to them as owners, every matrix is assembled from all ranks' rows
+    -- every section's .anc / .mut byte-identical to the reference binary's (from_files: the shards read their
+    targets' records from the reference's paint files instead of painting)"""
+    import threading
+    from golden_util import Fixture
+    out = tmp_path / "out"
+    out.mkdir()
+    fx = Fixture(name, out)
+    if from_files:
+        fx.write_paint_files(str(out / "chunk_0" / "paint"))
+    hub = rdist.ThreadFabric.Hub(parts)
+    res, errs = [None] * parts, [None] * parts
+
+    def body(r):
+        try:
+            res[r] = rdist.run_chunk_by_targets(str(out), 0, device=0, in_flight=in_flight, build_on_gpu=build_on_gpu,
+                                                from_paint_files=from_files, fabric=rdist.ThreadFabric(hub, r, device=0))
+        except BaseException as e:
+            errs[r] = e
+
+    th = [threading.Thread(target=body, args=(r,)) for r in range(parts)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert errs == [None] * parts, errs
+    assert sorted(s for r in res for s in r) == list(range(fx.W))
+    for w in range(fx.W):
+        assert open(out / "chunk_0" / ("out_%d.mut" % w), "rb").read() == fx.z["mut/%d" % w].tobytes(), w
+        assert open(out / "chunk_0" / ("out_%d.anc" % w), "rb").read() == fx.z["anc/%d" % w].tobytes(), w

@@ -100,7 +100,7 @@ def test_two_wavefronts_per_target(tmp_path, N):
     run_case(tmp_path, N, 70, None, 5, chunk=ch, via_gpu_paint=True)
 
 
-@pytest.mark.parametrize("N", [2000, 2100, 3500, 5000])
+@pytest.mark.parametrize("N", [1000, 2000, 2100, 3500, 5000])
 def test_single_wave_large_tiles(tmp_path, N):
     """K2 / K3 at the S = 48/64/80 register tiles (N = 5000: the headline configuration's): posterior rows,
     logscales and distance matrices of all three windows against the oracle, paint files by the oracle"""

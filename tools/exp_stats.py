@@ -34,8 +34,8 @@ def main():
         lib.rl_set_paint_split(C.c_void_p(ctx._h), split)
         ms = ctx.paint(api.RL_SUM_EXACT)
         ms = ctx.paint(api.RL_SUM_EXACT)
-        st = np.zeros(16, dtype=np.uint64)
-        rc = lib.rl_debug_stats(C.c_void_p(ctx._h), st.ctypes.data_as(C.c_void_p))
+        st = np.zeros(32, dtype=np.uint64)
+        rc = lib.rl_debug_stats32(C.c_void_p(ctx._h), st.ctypes.data_as(C.c_void_p))
         out[name] = {"kernel_ms": ms, "rc": rc}
         if split:
             f, b = C.c_float(), C.c_float()
@@ -47,6 +47,12 @@ def main():
                             "rerun_lanes_per_sum": float(st[o + 3]) / n, "cycles_scan": float(st[o + 4]) / n,
                             "cycles_chains": float(st[o + 5]) / n, "cycles_classify": float(st[o + 6]) / n,
                             "cycles_walk": float(st[o + 7]) / n}
+        nf, nb = max(1, int(st[0])), max(1, int(st[8]))
+        out[name]["forward_step_cycles"] = {"whole": float(st[16]) / nf, "chunk_loop": float(st[17]) / nf,
+                                            "sum": float(st[18]) / nf, "rest": float(st[19]) / nf}
+        out[name]["backward_step_cycles"] = {"whole": float(st[20]) / nb, "divisions_slot_loads": float(st[21]) / nb,
+                                             "chunk_loop": float(st[22]) / nb, "sum": float(st[23]) / nb,
+                                             "rescale_factor": float(st[24]) / nb}
     print(json.dumps(out, indent=1))
 
 
