@@ -143,7 +143,7 @@ def main():
     ap.add_argument("--haplotypes", dest="n", type=int, default=5000, help="haplotypes")
     ap.add_argument("--snps", dest="l", type=int, default=500000, help="SNPs")
     ap.add_argument("--memory", type=float, default=20.0, help="--memory of MakeChunks (window rule), GB")
-    ap.add_argument("--mode", default="exact", choices=["exact", "lanes"])
+    ap.add_argument("--mode", default="exact", choices=["exact", "lanes", "lanes32"])
     ap.add_argument("--skip-cpu", dest="no_cpu", action="store_true")
     ap.add_argument("--skip-alt", dest="no_alt", action="store_true", help="skip timing the other summation mode")
     ap.add_argument("--skip-k23", dest="skip_k23", action="store_true", help="skip the RePaint / matrix measurement")
@@ -224,7 +224,8 @@ def main():
     ctx = ctxs[0]
     sites = sum(cx.total_sites() for cx in ctxs)
     updates = 2.0 * N * sites
-    mode = api.RL_SUM_EXACT if args.mode == "exact" else api.RL_SUM_LANES
+    MODES = {"exact": api.RL_SUM_EXACT, "lanes": api.RL_SUM_LANES, "lanes32": api.RL_SUM_LANES32}
+    mode = MODES[args.mode]
 
     def barrier():
         torch.cuda.synchronize()
@@ -263,15 +264,29 @@ def main():
     total_updates, dt = rdist.job_stats(updates, dt)  # sum of units, max of seconds over ranks
     fwd_ms, bwd_ms = split_times(mode) if rank == 0 else (0.0, 0.0)
 
-    alt = None
+    # the other summation modes on the same chunk (config.other_modes): `lanes` (re-associated sums, FP64 state) and
+    # `lanes32` (the fast mode: packed-FP32 state, paint32_kernels.hip) next to the bit-exact default.  Useful
+    # instructions per pair of directional updates: 9 FP64 (exact, lanes) / 5 with two donors per packed instruction.
+    alts = {}
+    fast_report = None
+    try:  # what the -m gpu tests measured for the fast modes against the REFERENCE (tests/bigtile.py record)
+        fast_report = json.load(open(os.path.join(ROOT, "profiles", "r04_fast_modes.json")))
+    except Exception:
+        pass
     if not args.no_alt:
-        other = api.RL_SUM_LANES if mode == api.RL_SUM_EXACT else api.RL_SUM_EXACT
-        adt, ak = timed(other, max(1, args.steps), 1 if other == api.RL_SUM_LANES else 0)
-        af, ab = split_times(other) if rank == 0 else (0.0, 0.0)
-        alt = dict(mode="lanes" if other == api.RL_SUM_LANES else "exact",
-                   value=updates * max(1, args.steps) / adt, ms_per_step=1e3 * adt / max(1, args.steps),
-                   kernel_ms=ak, fwd_alone_ms=af, bwd_alone_ms=ab,
-                   roofline_frac=(2.0 * N * sites / 8.0) / (ak * 1e-3) / 1e9 / HBM_PEAK_GBS)
+        for name, other in MODES.items():
+            if other == mode:
+                continue
+            adt, ak = timed(other, max(1, args.steps), 1 if other != api.RL_SUM_EXACT else 0)
+            af, ab = split_times(other) if rank == 0 else (0.0, 0.0)
+            alts[name] = dict(mode=name, value=updates * max(1, args.steps) / adt,
+                              ms_per_step=1e3 * adt / max(1, args.steps), kernel_ms=ak, fwd_alone_ms=af, bwd_alone_ms=ab,
+                              roofline_frac=(2.0 * N * sites / 8.0) / (ak * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              bit_identical_to_reference=(name == "exact"))
+            if fast_report and name in ("lanes", "lanes32"):
+                alts[name]["against_reference_at_N5000"] = {
+                    k[len("n5000_" + name + "_"):]: v for k, v in fast_report.items() if k.startswith("n5000_" + name + "_")}
+    alt = alts.get("lanes") or alts.get("exact")
 
     # secondary kernels of the path on the same chunk (reported under config, not timed steps):
     # K2 RePaintSection of one window for all targets, K3 one N x N distance matrix
@@ -377,6 +392,7 @@ def main():
                 "fwd_alone_ms": fwd_ms,
                 "bwd_alone_ms": bwd_ms,
                 "other_mode": alt,
+                "other_modes": alts,
                 "repaint_and_matrix": extra,
                 "shard": args.shard,
                 "target_shard_matrix": gather,

@@ -290,7 +290,38 @@ int rl_stage_build_topology(const char *out_dir, int chunk_index,
                             int use_painting, double theta, double rho,
                             int flags, int fb, int sum_mode, int device);
 
-/* `--sample_ages <file>` of BuildTopology (pipeline/BuildTopology.cpp:93-108; ancient samples): the file (plain or
+/* Everything a stage call can be told, per call (the positional entry points above and below take the reference's
+ * command-line options only: pipeline/BuildTopology.cpp:20-40).  rl_stage_opts_init fills in the defaults and the
+ * struct's size; a caller built against an older header passes a shorter struct and gets the defaults for the rest.
+ * 0 / -1 = "decide from the chunk and the device" wherever noted.  The RELATE_AMD_* environment variables of the
+ * same names override the struct -- they exist for experiments (tools/, profiles/), not as the interface. */
+typedef struct rl_stage_opts {
+  size_t size;              /* sizeof(rl_stage_opts), set by rl_stage_opts_init                                   */
+  int sum_mode;             /* RL_SUM_*                                                                            */
+  int device;               /* HIP device                                                                          */
+  int use_painting;         /* --painting given: theta, rho (pipeline/Paint.cpp:38-61)                             */
+  double theta, rho;
+  int flags;                /* bit 0: --no_consistency                                                             */
+  int fb;                   /* --fb (0: off)                                                                       */
+  const char *sample_ages_path; /* --sample_ages (NULL: none); replaces rl_stage_set_sample_ages                   */
+  int gpu_build;            /* trees on the device (1), on the host (0); -1: device when several sections are asked for */
+  long long window_rows;    /* posterior rows a window keeps resident; 0: from the HBM that is free; < 0: all      */
+  int window_parts;         /* a window keeps at least 1/window_parts of its rows (0: 32)                          */
+  int section_threads;      /* sections open at once at most (0: from HBM and the device)                          */
+  int workers;              /* tree-builder workgroups on the device (0: one per open section, 3/8 of the CUs when the windows are bounded) */
+  int repaint_lanes;        /* RePaint launches side by side: 1 or 2 (0: 1)                                        */
+  int park_stones;          /* fused stage: stepping stones to pinned host memory after Paint (rl_park_stones)     */
+  int pin_threads;          /* section threads pinned to L3 groups: 1 / 0 (-1: 1)                                  */
+} rl_stage_opts;
+void rl_stage_opts_init(rl_stage_opts *opts);
+int rl_stage_paint_ex(const char *out_dir, int chunk_index, const rl_stage_opts *opts);
+int rl_stage_build_topology_ex(const char *out_dir, int chunk_index, int first_section,
+                               int last_section, const rl_stage_opts *opts);
+int rl_stage_paint_build_topology_ex(const char *out_dir, int chunk_index, int first_section,
+                                     int last_section, const rl_stage_opts *opts);
+
+/* DEPRECATED (process-wide state): use rl_stage_opts.sample_ages_path.
+ * `--sample_ages <file>` of BuildTopology (pipeline/BuildTopology.cpp:93-108; ancient samples): the file (plain or
  * gzip text, one age per haplotype) the FOLLOWING rl_stage_build_topology / rl_stage_paint_build_topology calls of
  * this process read; NULL or "" for none.  With ages the trees are built by the host's sequential restatement of
  * MinMatch's third candidate key and coalescence clock (src/tree_builder.cpp:7-22, 149-252, 601-965, 1123-1233,

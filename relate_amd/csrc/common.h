@@ -57,8 +57,10 @@ void device_cache_release(void *p, size_t bytes);
 void *pinned_cache_alloc(size_t bytes, size_t *got);
 void pinned_cache_release(void *p, size_t bytes);
 void device_cache_trim();
-// set while tree-builder workers may hold the device (minmatch_gpu.hip): a failed allocation does not trim then
-extern std::atomic<bool> g_workers_may_be_resident;
+// launches of tree-builder workers that are alive (minmatch_gpu.hip): while any is, a failed allocation does not
+// trim the cache (hipFree would wait for the workers) -- it takes a larger cached block, or waits for them to leave
+extern std::atomic<int> g_worker_launches;
+size_t device_cache_held();  // bytes of device memory the cache holds for re-use (on any device)
 
 // owning device buffer
 struct DevBuf {

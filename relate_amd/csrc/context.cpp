@@ -59,7 +59,7 @@ struct BlockCache {
 };
 BlockCache g_dev_cache, g_pin_cache;
 }  // namespace
-std::atomic<bool> g_workers_may_be_resident{false};
+std::atomic<int> g_worker_launches{0};
 namespace {
 
 template <typename AllocFn>
@@ -79,12 +79,28 @@ void *cache_alloc(BlockCache &c, size_t bytes, size_t *got, AllocFn raw_alloc) {
     }
   }
   void *p = raw_alloc(bytes);
-  // Out of memory: give the cached blocks back and try once more -- unless the tree builder's workers may be
-  // resident (hipFree would wait for them, i.e. for as long as any section has a tree in flight): then the caller
-  // gets its error, as it would have without a cache.
-  if (!p && !g_workers_may_be_resident.load()) {
-    device_cache_trim();
-    p = raw_alloc(bytes);
+  // Out of memory: give the cached blocks back and try once more.  While the tree builder's workers are resident
+  // hipFree would wait for them (for as long as any section has a tree in flight), so first ANY cached block that is
+  // large enough will do -- the windows of a stage differ by up to 2 x in their rows, more than the eighth above --
+  // and only then the trim, after the workers have left (they do, 50 ms after the last tree; a minute at most here).
+  if (!p) {
+    {
+      std::lock_guard<std::mutex> lk(c.m);
+      auto it = c.free_blocks.lower_bound({dev, bytes});
+      if (it != c.free_blocks.end() && it->first.first == dev) {
+        void *q = it->second;
+        *got = it->first.second;
+        c.held -= it->first.second;
+        c.free_blocks.erase(it);
+        return q;
+      }
+    }
+    for (int waited = 0; g_worker_launches.load() > 0 && waited < 600; waited++)
+      std::this_thread::sleep_for(std::chrono::milliseconds(100));
+    if (g_worker_launches.load() == 0) {
+      device_cache_trim();
+      p = raw_alloc(bytes);
+    }
   }
   *got = bytes;
   return p;
@@ -106,6 +122,10 @@ void *device_cache_alloc(size_t bytes, size_t *got) {
   });
 }
 void device_cache_release(void *p, size_t bytes) { cache_release(g_dev_cache, p, bytes); }
+size_t device_cache_held() {
+  std::lock_guard<std::mutex> lk(g_dev_cache.m);
+  return g_dev_cache.held;
+}
 void *pinned_cache_alloc(size_t bytes, size_t *got) {
   return cache_alloc(g_pin_cache, bytes, got, [](size_t n) -> void * {
     void *p = nullptr;
@@ -674,15 +694,21 @@ int rl_load_chunk(rl_ctx *ctx, const char *dir, int chunk_index) {
     set_error(".r/.rpos sizes disagree with L=%d", L);
     return RL_EFORMAT;
   }
-  // chunk_<c>.bits: the panel bit-packed, written by this library's MakeChunks next to the reference's files
-  // (makechunks.cpp) -- an eighth of the .hap file, and already in the layout the device works on
+  // chunk_<c>.bits: the panel bit-packed, written by this library's MakeChunks (RELATE_AMD_CHUNK_BITS=1) next to the
+  // reference's files (makechunks.cpp) -- an eighth of the .hap file, and already in the layout the device works on.
+  // It names the .hap it belongs to by size and modification time: next to any other .hap it is stale and ignored.
   {
     FILE *fp = fopen((d + "/chunk_" + c + ".bits").c_str(), "rb");
     if (fp) {
       uint32_t head[4] = {0, 0, 0, 0};
+      uint64_t of_hap[2] = {0, 0};
       std::vector<uint32_t> words;
-      bool ok = fread(head, 4, 4, fp) == 4 && head[0] == 0x31424c52u && (int)head[1] == N && (int)head[2] == L &&
-                head[3] >= (uint32_t)((N + 31) / 32) && head[3] <= (uint32_t)((N + 31) / 32) + 64;
+      struct stat st;
+      bool ok = fread(head, 4, 4, fp) == 4 && fread(of_hap, 8, 2, fp) == 2 && head[0] == 0x32424c52u &&
+                (int)head[1] == N && (int)head[2] == L && head[3] >= (uint32_t)((N + 31) / 32) &&
+                head[3] <= (uint32_t)((N + 31) / 32) + 64 && stat((d + "/chunk_" + c + ".hap").c_str(), &st) == 0 &&
+                (uint64_t)st.st_size == of_hap[0] &&
+                (uint64_t)st.st_mtim.tv_sec * 1000000000ull + (uint64_t)st.st_mtim.tv_nsec == of_hap[1];
       if (ok) {
         words.resize((size_t)L * head[3]);
         ok = fread(words.data(), 4, words.size(), fp) == words.size();
@@ -1064,6 +1090,13 @@ int rl_stage_paint(const char *out_dir, int chunk_index, int use_painting, doubl
   lap("stones -> RLE -> paint files");
   rl_destroy(ctx);
   return rc;
+}
+
+int rl_stage_paint_ex(const char *out_dir, int chunk_index, const rl_stage_opts *opts) {
+  rl_stage_opts o;
+  rl_stage_opts_init(&o);
+  if (opts && opts->size >= sizeof(size_t)) memcpy(&o, opts, std::min(opts->size, sizeof(o)));
+  return rl_stage_paint(out_dir, chunk_index, o.use_painting, o.theta, o.rho, o.sum_mode, o.device);
 }
 
 }  // extern "C"

@@ -111,6 +111,13 @@ struct RepaintParams {
   const int32_t *fstart_row, *fsave_row;  // [nloc]
 };
 
+// what one row of a distance matrix is told by the host (anc_builder.cpp:130-168), 32 bytes per target
+struct MatrixArg {
+  double wl, wr;        // interpolation weights
+  float e_pn, e_np;     // expf(ls_prev - ls_next), expf(ls_next - ls_prev): glibc's, for the reference's bits
+  int32_t v_snp_prev;   // the target's cursor
+  int32_t direct;       // 1: no interpolation (the target is derived at the SNP)
+};
 struct MatrixParams {
   int N;
   int k0, nloc;  // rows of targets k0 .. k0+nloc-1; per-row arrays and `matrix` are indexed by t = n - k0
@@ -118,10 +125,9 @@ struct MatrixParams {
   const float *logscales;
   const int64_t *top_off;   // [nloc+1] row offsets into logscales
   const int64_t *slab_base;   // [nloc] posterior row j of target t is topology row slab_base[t] + j
-  const int32_t *v_snp_prev;  // [nloc]
-  const uint8_t *direct;      // [nloc] 1: no interpolation
-  const double *wl, *wr;      // [nloc] interpolation weights
-  const float *e_pn, *e_np;   // [nloc] expf(ls_prev-ls_next), expf(ls_next-ls_prev)
+  const MatrixArg *args;      // [nloc], in PINNED HOST memory: the kernel reads them where the host wrote them (one
+                              // 32-byte scalar load per workgroup over PCIe) -- a copy engine between the host's
+                              // loop and a 0.08 ms kernel cost more than the kernel (0.5 ms per matrix through the ABI)
   float *matrix;              // [nloc][N]
 };
 

@@ -401,5 +401,9 @@ extern "C" int rl_stage_find_equivalent_branches(const char *out_dir, int chunk_
     int rc = write_anc(dir + base + "_" + std::to_string(w) + ".anc", ancs[w]);
     if (rc) return rc;
   }
+  // chunk_<c>.bits (this library's MakeChunks under RELATE_AMD_CHUNK_BITS=1) has been read by the last stage that
+  // wants it: the reference's later stages do not know the file and end on an rmdir of the directory
+  // (Finalize.cpp:290, Clean.cpp:120), which a leftover would fail
+  (void)remove((out + "/chunk_" + std::to_string(chunk_index) + ".bits").c_str());
   return RL_OK;
 }

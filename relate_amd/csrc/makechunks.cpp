@@ -402,22 +402,25 @@ extern "C" int rl_make_chunks(const char *haps_fn, const char *sample_fn, const 
   // own and the `overlap` it repeats from its predecessor -- expanded from the panel in slabs.
   // Next to it the same rows BIT-PACKED as they lie in memory, chunk_<i>.bits -- what the device path works on
   // (rl_set_chunk_bits: bit n of row s = haplotype n derived at SNP s): rl_load_chunk prefers it and never touches
-  // the 8 x larger char file (2.5 GB at N = 5000 x L = 500k).  Header: "RLB1", N, L, row_words (u32 each); then L
-  // rows of row_words u32.  RELATE_AMD_CHUNK_BITS=0: the reference's files only.
+  // the 8 x larger char file (2.5 GB at N = 5000 x L = 500k).  Header: "RLB2", N, L, row_words (u32 each), then the
+  // size and the modification time (ns) of the chunk_<i>.hap it was written next to (u64 each: a .hap regenerated
+  // later -- by the reference's MakeChunks, say -- makes the file stale and rl_load_chunk falls back to the .hap); then
+  // L rows of row_words u32.  OPT-IN (RELATE_AMD_CHUNK_BITS=1): the file is foreign to the reference, whose later
+  // stages delete the files they know and then rmdir the directory (Finalize.cpp:290, Clean.cpp:120; a leftover makes
+  // that fail) -- this library's FindEquivalentBranches removes it, the reference's does not.  Without the option a
+  // chunk_<i>.bits left by an earlier run is removed.
   lap("plan, parameters_c*.bin, chunk_*.state");
   // The chunks are written by a few threads of their own, side by side and next to props.bin below (3 KB per SNP):
   // the stage is bound by the file system from here on.
-  const bool with_bits = !(getenv("RELATE_AMD_CHUNK_BITS") && atoi(getenv("RELATE_AMD_CHUNK_BITS")) == 0);
+  const bool with_bits = getenv("RELATE_AMD_CHUNK_BITS") && atoi(getenv("RELATE_AMD_CHUNK_BITS")) != 0;
   auto write_chunk = [&](int ci) -> bool {
     const uint32_t rw = panel.row_words;
     const int first = plan[ci].first_snp, end = plan[ci].end;
-    FILE *fh = fopen((file_out + "/chunk_" + std::to_string(ci) + ".hap").c_str(), "wb");
-    FILE *fb = with_bits ? fopen((file_out + "/chunk_" + std::to_string(ci) + ".bits").c_str(), "wb") : nullptr;
-    if (!fh || (with_bits && !fb)) {
-      if (fh) fclose(fh);
-      if (fb) fclose(fb);
-      return false;
-    }
+    const std::string hap_name = file_out + "/chunk_" + std::to_string(ci) + ".hap";
+    const std::string bits_name = file_out + "/chunk_" + std::to_string(ci) + ".bits";
+    FILE *fh = fopen(hap_name.c_str(), "wb");
+    if (!with_bits) (void)remove(bits_name.c_str());  // (a stale one would be read instead of this .hap)
+    if (!fh) return false;
     const uint64_t dims[2] = {(uint64_t)(end - first), (uint64_t)N};
     fwrite(dims, 8, 2, fh);
     const int slab_rows = std::max(1, (int)(((size_t)8 << 20) / (size_t)N));
@@ -427,14 +430,18 @@ extern "C" int rl_make_chunks(const char *haps_fn, const char *sample_fn, const 
       for (int i = 0; i < n; i++) expand_row(&panel.bits[(size_t)(s0 + i) * rw], N, &slab[(size_t)i * N]);
       fwrite(slab.data(), 1, (size_t)n * N, fh);
     }
-    if (fb) {
-      const uint32_t head[4] = {0x31424c52u /* "RLB1" */, (uint32_t)N, (uint32_t)dims[0], rw};
-      fwrite(head, 4, 4, fb);
-      fwrite(&panel.bits[(size_t)first * rw], 4, (size_t)(end - first) * rw, fb);
-    }
     bool good = ferror(fh) == 0;
     good &= fclose(fh) == 0;
-    if (fb) {
+    if (good && with_bits) {
+      struct stat st;
+      FILE *fb = stat(hap_name.c_str(), &st) == 0 ? fopen(bits_name.c_str(), "wb") : nullptr;
+      if (!fb) return false;
+      const uint32_t head[4] = {0x32424c52u /* "RLB2" */, (uint32_t)N, (uint32_t)dims[0], rw};
+      const uint64_t of_hap[2] = {(uint64_t)st.st_size,
+                                  (uint64_t)st.st_mtim.tv_sec * 1000000000ull + (uint64_t)st.st_mtim.tv_nsec};
+      fwrite(head, 4, 4, fb);
+      fwrite(of_hap, 8, 2, fb);
+      fwrite(&panel.bits[(size_t)first * rw], 4, (size_t)(end - first) * rw, fb);
       good &= ferror(fb) == 0;
       good &= fclose(fb) == 0;
     }

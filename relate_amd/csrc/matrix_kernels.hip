@@ -18,14 +18,15 @@ __global__ void __launch_bounds__(256) matrix_kernel(const MatrixParams p, const
   const int n = p.k0 + t;     // its target
   const int N = p.N;
   const int64_t stride = (int64_t)S * 64 * waves;
-  const int64_t r0 = p.top_off[t] + p.v_snp_prev[t];
-  const float *__restrict__ tp = p.topology + (p.slab_base[t] + p.v_snp_prev[t]) * stride;
+  const MatrixArg arg = p.args[t];
+  const int64_t r0 = p.top_off[t] + arg.v_snp_prev;
+  const float *__restrict__ tp = p.topology + (p.slab_base[t] + arg.v_snp_prev) * stride;
   const float *__restrict__ tn = tp + stride;
   const float ls_prev = p.logscales[r0];
-  const bool direct = p.direct[t] != 0;
+  const bool direct = arg.direct != 0;
   const float ls_next = direct ? 0.0f : p.logscales[r0 + 1];
-  const double wl = p.wl[t], wr = p.wr[t];
-  const float e_pn = p.e_pn[t], e_np = p.e_np[t];
+  const double wl = arg.wl, wr = arg.wr;
+  const float e_pn = arg.e_pn, e_np = arg.e_np;
   const float scale = -1.0f;
 
   // The posterior rows are read in their own (register-major) order: thread = lane, four registers per pass, every

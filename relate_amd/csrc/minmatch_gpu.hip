@@ -1845,7 +1845,6 @@ class BuildQueue {
     cap_from_env_ = getenv("RELATE_AMD_BUILD_WORKERS") != nullptr;
     idle_ms_ = env_int("RELATE_AMD_BUILD_IDLE_MS", 50, 1, 10000);
     ok_ = true;
-    g_workers_may_be_resident.store(true);
     std::thread([this] { launcher(); }).detach();
   }
   void launcher() {
@@ -1886,7 +1885,23 @@ class BuildQueue {
           fprintf(stderr, "\n");
           fflush(stderr);
         }
-        cv_.wait(lk, [&] { return outstanding_ > 0; });
+        // While a launch of workers is alive the loop keeps polling (its workers leave 50 ms after the last tree):
+        // the library's memory cache may trim -- hipFree waits for the device -- only when none is (g_worker_launches).
+        int launches_alive = 0;
+        for (int l = 0; l < MM_LAUNCHES; l++) launches_alive += size[l] > 0;
+        if (launches_alive > 0) {
+          if (!cv_.wait_for(lk, std::chrono::milliseconds(20), [&] { return outstanding_ > 0; })) {
+            lk.unlock();
+            for (int l = 0; l < MM_LAUNCHES; l++)
+              if (size[l] > 0 && hipStreamQuery(streams[l]) == hipSuccess) {
+                size[l] = 0;
+                g_worker_launches.fetch_sub(1);
+              }
+            continue;
+          }
+        } else {
+          cv_.wait(lk, [&] { return outstanding_ > 0; });
+        }
         demand = outstanding_;
         // (the stage's word, expect(), is a limit -- it knows what RePaint needs of the chip; RELATE_AMD_BUILD_WORKERS
         //  overrides it)
@@ -1896,7 +1911,10 @@ class BuildQueue {
       }
       int alive = 0, free_stream = -1, busy_launches = 0;
       for (int l = 0; l < MM_LAUNCHES; l++) {
-        if (size[l] > 0 && hipStreamQuery(streams[l]) == hipSuccess) size[l] = 0;  // its last worker has left
+        if (size[l] > 0 && hipStreamQuery(streams[l]) == hipSuccess) {  // its last worker has left
+          size[l] = 0;
+          g_worker_launches.fetch_sub(1);
+        }
         alive += size[l];
         busy_launches += size[l] > 0;
         if (size[l] == 0 && free_stream < 0) free_stream = l;
@@ -1928,6 +1946,7 @@ class BuildQueue {
           return;
         }
         size[l] = n;
+        g_worker_launches.fetch_add(1);
         if (verbose) {
           fprintf(stderr, "[tree builder workers] +%d on stream %d: %d alive, %d trees waiting or being built, goal %d\n", n,
                   l, alive + n, demand, goal);

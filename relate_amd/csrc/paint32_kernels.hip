@@ -22,6 +22,17 @@
 #include "exact_sum.h"
 #include "launch.h"
 
+// experiment knobs (tools/build_paint_variant.sh): waves per SIMD the kernel is held to, mask words per chunk
+#ifndef RL32_WAVES_PER_SIMD
+#define RL32_WAVES_PER_SIMD 4
+#endif
+#ifndef RL32_FWD_CH
+#define RL32_FWD_CH 8  // (16: 61.6 ms, 8: 59.7 ms per Paint of the L = 100k cut of C3)
+#endif
+#ifndef RL32_BWD_CH
+#define RL32_BWD_CH 4
+#endif
+
 namespace rl {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -45,6 +56,26 @@ RL_DEV void masked_mul_f32x4(f32x2 &p0, f32x2 &p1, u64 m0, u64 m1, u64 m2, u64 m
   p0 = f32x2{x0, x1};
   p1 = f32x2{x2, x3};
 }
+RL_DEV void masked_mul_f32x8(f32x2 &p0, f32x2 &p1, f32x2 &p2, f32x2 &p3, u64 m0, u64 m1, u64 m2, u64 m3, u64 m4, u64 m5,
+                             u64 m6, u64 m7, float k) {
+  float x0 = p0.x, x1 = p0.y, x2 = p1.x, x3 = p1.y, x4 = p2.x, x5 = p2.y, x6 = p3.x, x7 = p3.y;
+  asm volatile(
+      "s_mov_b64 exec, %8\n\tv_mul_f32 %0, %0, %16\n\t"
+      "s_mov_b64 exec, %9\n\tv_mul_f32 %1, %1, %16\n\t"
+      "s_mov_b64 exec, %10\n\tv_mul_f32 %2, %2, %16\n\t"
+      "s_mov_b64 exec, %11\n\tv_mul_f32 %3, %3, %16\n\t"
+      "s_mov_b64 exec, %12\n\tv_mul_f32 %4, %4, %16\n\t"
+      "s_mov_b64 exec, %13\n\tv_mul_f32 %5, %5, %16\n\t"
+      "s_mov_b64 exec, %14\n\tv_mul_f32 %6, %6, %16\n\t"
+      "s_mov_b64 exec, %15\n\tv_mul_f32 %7, %7, %16\n\t"
+      "s_mov_b64 exec, -1"
+      : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7)
+      : "s"(m0), "s"(m1), "s"(m2), "s"(m3), "s"(m4), "s"(m5), "s"(m6), "s"(m7), "v"(k));
+  p0 = f32x2{x0, x1};
+  p1 = f32x2{x2, x3};
+  p2 = f32x2{x4, x5};
+  p3 = f32x2{x6, x7};
+}
 // x = x * k + a in the lanes of m
 RL_DEV void masked_fma_f32x4(f32x2 &p0, f32x2 &p1, u64 m0, u64 m1, u64 m2, u64 m3, float k, float a) {
   float x0 = p0.x, x1 = p0.y, x2 = p1.x, x3 = p1.y;
@@ -56,6 +87,26 @@ RL_DEV void masked_fma_f32x4(f32x2 &p0, f32x2 &p1, u64 m0, u64 m1, u64 m2, u64 m
       "s_mov_b64 exec, -1"
       : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3)
       : "s"(m0), "s"(m1), "s"(m2), "s"(m3), "v"(k), "v"(a));
+  p0 = f32x2{x0, x1};
+  p1 = f32x2{x2, x3};
+}
+// the two above for one chunk of two pairs under ONE return to exec = -1: p = p * k + a in the lanes of mn, then
+// s0 / s1 += the new halves in the lanes of mh
+RL_DEV void masked_fma_acc_f32x4(f32x2 &p0, f32x2 &p1, float &s0, float &s1, u64 n0, u64 n1, u64 n2, u64 n3, u64 h0,
+                                 u64 h1, u64 h2, u64 h3, float k, float a) {
+  float x0 = p0.x, x1 = p0.y, x2 = p1.x, x3 = p1.y;
+  asm volatile(
+      "s_mov_b64 exec, %6\n\tv_fma_f32 %0, %0, %14, %15\n\t"
+      "s_mov_b64 exec, %7\n\tv_fma_f32 %1, %1, %14, %15\n\t"
+      "s_mov_b64 exec, %8\n\tv_fma_f32 %2, %2, %14, %15\n\t"
+      "s_mov_b64 exec, %9\n\tv_fma_f32 %3, %3, %14, %15\n\t"
+      "s_mov_b64 exec, %10\n\tv_add_f32 %4, %4, %0\n\t"
+      "s_mov_b64 exec, %11\n\tv_add_f32 %5, %5, %1\n\t"
+      "s_mov_b64 exec, %12\n\tv_add_f32 %4, %4, %2\n\t"
+      "s_mov_b64 exec, %13\n\tv_add_f32 %5, %5, %3\n\t"
+      "s_mov_b64 exec, -1"
+      : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(s0), "+v"(s1)
+      : "s"(n0), "s"(n1), "s"(n2), "s"(n3), "s"(h0), "s"(h1), "s"(h2), "s"(h3), "v"(k), "v"(a));
   p0 = f32x2{x0, x1};
   p1 = f32x2{x2, x3};
 }
@@ -218,7 +269,7 @@ RL_DEV void paint32_forward(const PaintParams &p, int k, float *stage, WaveLink<
   uint32_t touched = 0;
   float K1 = (float)c.K1;
   asm volatile("" : "+v"(K1));
-  constexpr int CH = S % 16 == 0 ? 16 : 8;  // mask words (= donors per lane) per chunk
+  constexpr int CH = (S % 16 == 0 && RL32_FWD_CH == 16) ? 16 : 8;  // mask words (= donors per lane) per chunk
   typedef typename MaskChunk<CH>::type Chunk;
   MaskRow row = site_row(p.masks, S, p.L, s1, WAVES, wv);
   Chunk first = load_masks<CH>(row, 0);
@@ -244,8 +295,9 @@ RL_DEV void paint32_forward(const PaintParams &p, int k, float *stage, WaveLink<
         }
       }
 #pragma unroll
-      for (int q = 0; q < CH / 2; q += 2)
-        masked_mul_f32x4(v[q], v[q + 1], m[2 * q], m[2 * q + 1], m[2 * q + 2], m[2 * q + 3], K1);
+      for (int q = 0; q < CH / 2; q += 4)
+        masked_mul_f32x8(v[q], v[q + 1], v[q + 2], v[q + 3], m[2 * q], m[2 * q + 1], m[2 * q + 2], m[2 * q + 3], m[2 * q + 4],
+                         m[2 * q + 5], m[2 * q + 6], m[2 * q + 7], K1);
 #pragma unroll
       for (int q = 0; q < CH / 2; q += 2) {
         a[j0 / 2 + q] = v[q];
@@ -326,7 +378,9 @@ RL_DEV void paint32_backward(const PaintParams &p, int k, float *stage, WaveLink
   uint32_t touched = 0;
   MaskRow rown = site_row(p.masks, S, p.L, s0, WAVES, wv);
   MaskRow rowh = site_row(p.masks, S, p.L, s1, WAVES, wv);
-  u64x4 firstn = load_masks<4>(rown, 0), firsth = load_masks<4>(rowh, 0);
+  constexpr int BCH = (S % 8 == 0 && RL32_BWD_CH == 8 && TAIL % 8 == 0) ? 8 : 4;
+  typedef typename MaskChunk<BCH>::type BChunk;
+  BChunk firstn = load_masks<BCH>(rown, 0), firsth = load_masks<BCH>(rowh, 0);
   float K1 = (float)c.K1;
   asm volatile("" : "+v"(K1));
   const double theta = c.theta, ntheta = c.ntheta;
@@ -346,28 +400,32 @@ RL_DEV void paint32_backward(const PaintParams &p, int k, float *stage, WaveLink
     float smis0 = 0.f, smis1 = 0.f;
     MaskRow vrow = (MaskRow)(p.masks + ((size_t)(p.L + 1) * WAVES + wv) * S);
     asm volatile("" : "+s"(vrow));
-    for_each_chunk2_tail<S, 4, TAIL>(rown, rowh, vrow, firstn, firsth,
-                                     [&](int j0, const u64x4 &mn, const u64x4 &mh, const u64x4 &va) {
-      f32x2 v0 = b[j0 / 2], v1 = b[j0 / 2 + 1];
-      if (j0 + 4 <= S - TAIL) {
-        v0 += b12;
-        v1 += b12;
-      } else {
-        masked_add_f32x2(v0, va[0], va[1], b1);
-        masked_add_f32x2(v1, va[2], va[3], b1);
+    for_each_chunk2_tail<S, BCH, TAIL>(rown, rowh, vrow, firstn, firsth,
+                                       [&](int j0, const BChunk &mn, const BChunk &mh, const BChunk &va) {
+      f32x2 v[BCH / 2];
+#pragma unroll
+      for (int q = 0; q < BCH / 2; q++) {
+        v[q] = b[j0 / 2 + q];
+        if (j0 + 2 * q + 2 <= S - TAIL)
+          v[q] += b12;
+        else
+          masked_add_f32x2(v[q], va[2 * q], va[2 * q + 1], b1);
       }
       // mismatch at the later site: ((b + b1) + bt) K as (b + b1) K + bt K
-      masked_fma_f32x4(v0, v1, mn[0], mn[1], mn[2], mn[3], K1, btK);
-      b[j0 / 2] = v0;
-      b[j0 / 2 + 1] = v1;
-      sall += v0;
-      sall += v1;
-      masked_acc_f32x4(smis0, smis1, v0, v1, mh[0], mh[1], mh[2], mh[3]);  // :495-503
+#pragma unroll
+      for (int q = 0; q < BCH / 2; q += 2)  // ... and the lanes that mismatch at this site into their sum (:495-503)
+        masked_fma_acc_f32x4(v[q], v[q + 1], smis0, smis1, mn[2 * q], mn[2 * q + 1], mn[2 * q + 2], mn[2 * q + 3], mh[2 * q],
+                             mh[2 * q + 1], mh[2 * q + 2], mh[2 * q + 3], K1, btK);
+#pragma unroll
+      for (int q = 0; q < BCH / 2; q++) {
+        b[j0 / 2 + q] = v[q];
+        sall += v[q];
+      }
     });
     rown = rowh;
     rowh = site_row(p.masks, S, p.L, s1, WAVES, wv);
-    firstn = load_masks<4>(rown, 0);
-    firsth = load_masks<4>(rowh, 0);
+    firstn = load_masks<BCH>(rown, 0);
+    firsth = load_masks<BCH>(rowh, 0);
     const double lane_all = (double)sall.x + (double)sall.y, lane_mis = (double)smis0 + (double)smis1;
     bsum = lanes_total<S, WAVES>(ntheta * lane_all + (theta - ntheta) * lane_mis, lk);
     ls += nx_j;  // :471-472
@@ -390,7 +448,7 @@ RL_DEV void paint32_backward(const PaintParams &p, int k, float *stage, WaveLink
 
 // 80 state registers per lane: held to 128 VGPRs, four waves share a SIMD
 template <int S, int TAIL, int WAVES, int DIR>
-__global__ void __launch_bounds__(64 * WAVES, S <= 80 ? (WAVES == 1 ? 4 : 2) : 1) paint32_kernel(const PaintParams p) {
+__global__ void __launch_bounds__(64 * WAVES, WAVES == 1 ? RL32_WAVES_PER_SIMD : RL32_WAVES_PER_SIMD / 2) paint32_kernel(const PaintParams p) {
   __shared__ float stage[WAVES][16 * 64];
   __shared__ WaveLinkStorage link;
   WaveLink<WAVES> lk;

@@ -666,10 +666,16 @@ static int win_advance(void *user, int snp) { return rl_window_advance((rl_windo
 // and the helpers that split a merge, minmatch.h) is kept inside one such group: the helpers hand each other a few
 // cache lines per merge, tens of thousands of times a second, and the matrices are first touched -- so placed on
 // the NUMA node -- by the thread that builds with them.  RELATE_AMD_PIN=0 leaves placement to the scheduler.
-static std::vector<cpu_set_t> cache_groups() {
+// A stage's knobs: the caller's rl_stage_opts (per call), overridden by the RELATE_AMD_* environment variables --
+// those are for experiments (tools/, profiles/): what a consumer of the ABI sets goes through the struct.
+static long long knob(const char *env, long long from_opts, bool opts_set, long long fallback) {
+  if (const char *e = getenv(env)) return atoll(e);
+  return opts_set ? from_opts : fallback;
+}
+
+static std::vector<cpu_set_t> cache_groups(int pin_opt) {
   std::vector<cpu_set_t> groups;
-  if (const char *e = getenv("RELATE_AMD_PIN"))
-    if (atoi(e) == 0) return groups;
+  if (knob("RELATE_AMD_PIN", pin_opt, pin_opt >= 0, 1) == 0) return groups;
   cpu_set_t allowed;
   CPU_ZERO(&allowed);
   if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return groups;
@@ -734,9 +740,10 @@ static std::vector<double> read_sample_ages(const char *fn, int N) {
 }
 
 static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int first_section, int last_section,
-                          int flags, int fb, int sum_mode, int device, bool from_files,
-                          const char *sample_ages_file = nullptr) {
+                          const rl_stage_opts &o, bool from_files) {
   int rc = RL_OK;
+  const int flags = o.flags, fb = o.fb, sum_mode = o.sum_mode, device = o.device;
+  const char *sample_ages_file = (o.sample_ages_path && *o.sample_ages_path) ? o.sample_ages_path : nullptr;
   const auto entry_t0 = std::chrono::steady_clock::now();
   const int W = ctx->W, L = ctx->L;
   if (first_section >= W) {  // BuildTopology.cpp:45
@@ -802,8 +809,7 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
   // The trees themselves are built on the GPU too (minmatch_gpu.hip) when the call covers several sections: a tree
   // takes one workgroup ~115 ms at N = 5000 against ~85 ms on 8 host threads, but the workgroups of different
   // sections run side by side (40 sections: 98 s against 331 s).  RELATE_AMD_GPU_BUILD=0 / 1 decides otherwise.
-  const bool gpu_build = getenv("RELATE_AMD_GPU_BUILD") ? atoi(getenv("RELATE_AMD_GPU_BUILD")) != 0
-                                                        : last_section > first_section;
+  const bool gpu_build = knob("RELATE_AMD_GPU_BUILD", o.gpu_build, o.gpu_build >= 0, last_section > first_section) != 0;
   // Next to its rows a window holds cursors and small per-target arrays, a stage from paint files also the decoded
   // stones (2 N^2 floats; the fused stage re-paints from the context's own); a tree builder on the device keeps the
   // woven float4 matrix of the build (16 N^2 B, minmatch_gpu.hip) -- the row-major matrices of a tree and the
@@ -825,7 +831,7 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
   };
   // (section threads of device builds mostly wait for their tree: as many as there are CUs to build on)
   int nthreads = gpu_build ? 256 : std::max(1, std::min(host_threads() / 2, 64));  // (host_threads: this rank's share)
-  if (const char *e = getenv("RELATE_AMD_SECTION_THREADS")) nthreads = std::max(1, atoi(e));
+  nthreads = std::max(1, (int)knob("RELATE_AMD_SECTION_THREADS", o.section_threads, o.section_threads > 0, nthreads));
   nthreads = std::min(nthreads, last_section - first_section + 1);
   int concurrent = nthreads;
   {
@@ -838,8 +844,8 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
     // window's first, whole pass like the first lane's (C3: 7 GB), and at C3 that is what lets 134 sections open
     // instead of 89 -- two lanes and 89 sections in three waves: 183 s (no section waits for RePaint, 71 s busy),
     // one lane and 134 sections: 173 s.
-    const char *le = getenv("RELATE_AMD_REPAINT_LANES");
-    if (last_section > first_section && le && atoi(le) == 2 && !ctx->two_lanes) {
+    if (last_section > first_section && knob("RELATE_AMD_REPAINT_LANES", o.repaint_lanes, o.repaint_lanes > 0, 1) == 2 &&
+        !ctx->two_lanes) {
       auto &ln = ctx->lane2;
       if (ln.scratch.alloc(strips) == 0 && make_stream(&ln.s, false) == hipSuccess &&
           hipEventCreate(&ln.e0) == hipSuccess && hipEventCreate(&ln.e1) == hipSuccess) {
@@ -852,8 +858,8 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
     size_t free_b = 0, total_b = 0;
     const bool known = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
     const double room = known ? 0.9 * (double)free_b : 0.0;
-    if (const char *e = getenv("RELATE_AMD_WINDOW_ROWS")) {
-      cap_rows = std::max(0LL, atoll(e));
+    if (getenv("RELATE_AMD_WINDOW_ROWS") || o.window_rows != 0) {  // (rows per window by hand; < 0 in the struct: all of them)
+      cap_rows = std::max(0LL, knob("RELATE_AMD_WINDOW_ROWS", o.window_rows, true, 0));
     } else if (known) {
       // The trees of different sections are what fills the chip (a workgroup per tree), so as many sections as HBM
       // holds should be open -- but a window that keeps 1/P of its rows runs RePaint P times, about half a window's
@@ -862,8 +868,7 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
       // 112 at a time are three waves, the last one a third full; 134 at a time are two full ones.  So: the fewest
       // waves the memory allows at P_max, the sections spread evenly over them, and the smallest P that opens
       // that many (C3: 2 waves of 134, P = 20: 234 s -> see DESIGN.md 6).
-      int parts_max = 32;
-      if (const char *pe = getenv("RELATE_AMD_WINDOW_PARTS")) parts_max = std::max(1, atoi(pe));
+      const int parts_max = std::max(1, (int)knob("RELATE_AMD_WINDOW_PARTS", o.window_parts, o.window_parts > 0, 32));
       auto fits = [&](int parts) {
         return (int)(room / (max_rows / parts * row_bytes + fixed_bytes + builder_bytes + (parts > 1 ? bstate_bytes : 0.0)));
       };
@@ -891,6 +896,7 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
       if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 8) cus = 256;
       workers = std::min(nthreads, 3 * cus / 8);
     }
+    if (o.workers > 0) workers = o.workers;  // (RELATE_AMD_BUILD_WORKERS overrides either, minmatch_gpu.hip)
     (void)device_builder_expect(device, ctx->N, workers);
   }
   // Host threads left over by the sections help inside each tree build (minmatch.h BuildThreads).  Helpers are the
@@ -927,7 +933,7 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
     int expected = 0;
     if (first_error.compare_exchange_strong(expected, code)) first_message = rl_last_error();
   };
-  const std::vector<cpu_set_t> groups = cache_groups();
+  const std::vector<cpu_set_t> groups = cache_groups(o.pin_threads);
   std::atomic<int> next_slot(0);
   auto worker = [&]() {
     cpu_set_t before;
@@ -972,7 +978,10 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
           std::lock_guard<std::mutex> lk(g_gpu_mutex);
           size_t free_b = 0, total_b = 0;
           const bool known = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
-          if (!known || (double)free_b - reserved_bytes >= need || (open_sections.load() == 0 && reserved_bytes == 0.0)) {
+          // (closed windows give their blocks to the library's cache, not to the driver: what the cache holds is
+          //  free for the next window too -- cache_alloc takes any cached block that is large enough)
+          if (!known || (double)free_b + (double)device_cache_held() - reserved_bytes >= need ||
+              (open_sections.load() == 0 && reserved_bytes == 0.0)) {
             reserved_bytes += need;
             admitted = true;
           }
@@ -1053,20 +1062,62 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
   return rc;
 }
 
-int rl_stage_build_topology(const char *out_dir, int chunk_index, int first_section, int last_section,
-                            int use_painting, double theta, double rho, int flags, int fb, int sum_mode,
-                            int device) {
+void rl_stage_opts_init(rl_stage_opts *o) {
+  if (!o) return;
+  memset(o, 0, sizeof(*o));
+  o->size = sizeof(*o);
+  o->sum_mode = RL_SUM_EXACT;
+  o->theta = 0.001;
+  o->rho = 1.0;
+  o->gpu_build = -1;
+  o->pin_threads = -1;
+}
+
+// the caller's struct, whatever its age: fields past its `size` keep their defaults
+static rl_stage_opts resolve_opts(const rl_stage_opts *in) {
+  rl_stage_opts o;
+  rl_stage_opts_init(&o);
+  if (in && in->size >= sizeof(size_t)) memcpy(&o, in, std::min(in->size, sizeof(o)));
+  o.size = sizeof(o);
+  return o;
+}
+
+int rl_stage_build_topology_ex(const char *out_dir, int chunk_index, int first_section, int last_section,
+                               const rl_stage_opts *opts) {
   if (!out_dir) return RL_EINVAL;
-  rl_ctx *ctx = rl_create(device);
+  const rl_stage_opts o = resolve_opts(opts);
+  rl_ctx *ctx = rl_create(o.device);
   if (!ctx) return RL_ENODEVICE;
   int rc = rl_load_chunk(ctx, out_dir, chunk_index);
-  if (!rc && use_painting) rc = rl_set_painting(ctx, theta, rho);
+  if (!rc && o.use_painting) rc = rl_set_painting(ctx, o.theta, o.rho);
   if (rc) {
     rl_destroy(ctx);
     return rc;
   }
-  return build_sections(ctx, out_dir, chunk_index, first_section, last_section, flags, fb, sum_mode, device, true,
-                        g_stage_sample_ages.empty() ? nullptr : g_stage_sample_ages.c_str());
+  return build_sections(ctx, out_dir, chunk_index, first_section, last_section, o, true);
+}
+
+// (the positional form; --sample_ages through the deprecated process-wide rl_stage_set_sample_ages)
+static rl_stage_opts positional_opts(int use_painting, double theta, double rho, int flags, int fb, int sum_mode,
+                                     int device) {
+  rl_stage_opts o;
+  rl_stage_opts_init(&o);
+  o.use_painting = use_painting;
+  o.theta = theta;
+  o.rho = rho;
+  o.flags = flags;
+  o.fb = fb;
+  o.sum_mode = sum_mode;
+  o.device = device;
+  o.sample_ages_path = g_stage_sample_ages.empty() ? nullptr : g_stage_sample_ages.c_str();
+  return o;
+}
+
+int rl_stage_build_topology(const char *out_dir, int chunk_index, int first_section, int last_section,
+                            int use_painting, double theta, double rho, int flags, int fb, int sum_mode,
+                            int device) {
+  const rl_stage_opts o = positional_opts(use_painting, theta, rho, flags, fb, sum_mode, device);
+  return rl_stage_build_topology_ex(out_dir, chunk_index, first_section, last_section, &o);
 }
 
 int rl_stage_set_sample_ages(const char *file) {
@@ -1074,10 +1125,12 @@ int rl_stage_set_sample_ages(const char *file) {
   return RL_OK;
 }
 
-int rl_stage_paint_build_topology(const char *out_dir, int chunk_index, int first_section, int last_section,
-                                  int use_painting, double theta, double rho, int flags, int fb, int sum_mode,
-                                  int device) {
+int rl_stage_paint_build_topology_ex(const char *out_dir, int chunk_index, int first_section, int last_section,
+                                     const rl_stage_opts *opts) {
   if (!out_dir) return RL_EINVAL;
+  const rl_stage_opts o = resolve_opts(opts);
+  const int device = o.device, sum_mode = o.sum_mode, use_painting = o.use_painting;
+  const double theta = o.theta, rho = o.rho;
   // RELATE_AMD_TIMING=1: wall-clock of what precedes the sections on stderr
   const bool timing = getenv("RELATE_AMD_TIMING") != nullptr;
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -1102,7 +1155,7 @@ int rl_stage_paint_build_topology(const char *out_dir, int chunk_index, int firs
   // RELATE_AMD_PARK_STONES=1: the stones to pinned host memory, their HBM to the sections' windows -- for chunks that
   // would not fit otherwise; at C3 (53 GB of stones) it opens 112 sections instead of 91 and the chunk takes 330 s
   // instead of 291 s: past ~90 trees in flight the build kernels slow each other down
-  if (!rc && getenv("RELATE_AMD_PARK_STONES") && atoi(getenv("RELATE_AMD_PARK_STONES")) != 0) rc = rl_park_stones(ctx);
+  if (!rc && knob("RELATE_AMD_PARK_STONES", o.park_stones, true, 0) != 0) rc = rl_park_stones(ctx);
   if (!rc) ctx->stones_disposable = true;  // (nobody writes paint files from this context: the windows may edit them)
   if (!rc) {  // (the Paint stage makes this directory for its files; the trees go there)
     const std::string cdir = std::string(out_dir) + "/chunk_" + std::to_string(chunk_index);
@@ -1115,8 +1168,14 @@ int rl_stage_paint_build_topology(const char *out_dir, int chunk_index, int firs
     rl_destroy(ctx);
     return rc;
   }
-  return build_sections(ctx, out_dir, chunk_index, first_section, last_section, flags, fb, sum_mode, device, false,
-                        g_stage_sample_ages.empty() ? nullptr : g_stage_sample_ages.c_str());
+  return build_sections(ctx, out_dir, chunk_index, first_section, last_section, o, false);
+}
+
+int rl_stage_paint_build_topology(const char *out_dir, int chunk_index, int first_section, int last_section,
+                                  int use_painting, double theta, double rho, int flags, int fb, int sum_mode,
+                                  int device) {
+  const rl_stage_opts o = positional_opts(use_painting, theta, rho, flags, fb, sum_mode, device);
+  return rl_stage_paint_build_topology_ex(out_dir, chunk_index, first_section, last_section, &o);
 }
 
 }  // extern "C"

@@ -56,9 +56,11 @@ struct rl_window {
   // a window's distance matrices run on its own stream: the sections of a stage ask for theirs at the same time
   hipStream_t stream = nullptr;
   hipEvent_t e0 = nullptr, e2 = nullptr;
-  unsigned char *h_stage = nullptr;  // pinned: the per-target arguments of one matrix, sent in one copy
-  size_t h_stage_bytes = 0;
-  DevBuf d_stage;
+  unsigned char *h_stage = nullptr;  // pinned: the per-target arguments of one matrix (MatrixArg[nloc]), read by the
+  size_t h_stage_bytes = 0;          // kernel where they lie (d_args: the block's device address)
+  void *d_args = nullptr;
+  std::vector<int32_t> e_cursor;     // [nloc] cursor position e_pn / e_np were computed for
+  std::vector<float> e_pn, e_np;
   ~rl_window() {
     if (getenv("RELATE_AMD_TIMING") && n_matrices > 0)
       fprintf(stderr, "[window %d] %lld matrices, %d RePaint launches; s: rows + uploads %.2f, waiting for RePaint's turn %.2f, "
@@ -637,20 +639,38 @@ static int window_matrix(rl_window *win, int snp, float *d_host, void *d_dev, fl
   rl_ctx *ctx = win->ctx;
   RL_HIP(hipSetDevice(ctx->device));
   const int N = ctx->N, L = ctx->L, k0 = win->k0, nloc = win->nloc;
-  std::vector<uint8_t> direct(nloc);
-  std::vector<double> wl(nloc, 0.5), wr(nloc, 0.5);
-  std::vector<float> epn(nloc, 1.0f), enp(nloc, 1.0f);
+  // the per-target arguments are written where the kernel reads them: a pinned block of the window
+  if (!win->stream) {
+    if (make_stream(&win->stream, false, true) != hipSuccess ||
+        hipEventCreate(&win->e0) != hipSuccess || hipEventCreate(&win->e2) != hipSuccess ||
+        !(win->h_stage = static_cast<unsigned char *>(pinned_cache_alloc((size_t)nloc * sizeof(MatrixArg) + 64, &win->h_stage_bytes))) ||
+        hipHostGetDevicePointer(&win->d_args, win->h_stage, 0) != hipSuccess) {
+      set_error("rl_window_matrix: stream / argument block creation failed");
+      return RL_EHIP;
+    }
+    win->e_cursor.assign((size_t)nloc, -2);
+    win->e_pn.assign((size_t)nloc, 1.0f);
+    win->e_np.assign((size_t)nloc, 1.0f);
+  }
+  MatrixArg *args = reinterpret_cast<MatrixArg *>(win->h_stage);
+  bool covered = true;  // a bounded window: are the rows this tree reads resident?
   for (int t = 0; t < nloc; t++) {
     const int n = k0 + t;
     const int p = win->v_snp_prev[t];
     const int D = (int)(win->top_off[t + 1] - win->top_off[t]);
-    direct[t] = derived(ctx, snp, n) || snp == 0 || snp == L - 1;
-    if (p < 0 || p >= D || (!direct[t] && p + 1 >= D)) {
+    const bool direct = derived(ctx, snp, n) || snp == 0 || snp == L - 1;
+    if (p < 0 || p >= D || (!direct && p + 1 >= D)) {
       set_error("rl_window_matrix: cursor of target %d (%d) outside its %d posterior rows at SNP %d", n, p,
                 D, snp);
       return RL_ESTATE;
     }
-    if (direct[t]) continue;
+    MatrixArg &a = args[t];
+    a.v_snp_prev = p;
+    a.direct = direct ? 1 : 0;
+    a.wl = a.wr = 0.5;
+    a.e_pn = a.e_np = 1.0f;
+    covered = covered && p >= win->row_lo[t] && p + (direct ? 0 : 1) < win->row_hi[t];
+    if (direct) continue;
     if (win->v_rpos_next[t] <= win->v_rpos_prev[t]) {  // anc_builder.cpp:134-141
       for (int l = snp; l < L; l++)
         if (derived(ctx, l, n) || l == L - 1) {
@@ -661,45 +681,24 @@ static int window_matrix(rl_window *win, int snp, float *d_host, void *d_dev, fl
     const double rp = win->v_rpos_prev[t], rn = win->v_rpos_next[t];
     if (rp != rn) {  // :146-153
       const double denom = rn - rp;
-      wl[t] = (rn - ctx->rpos[snp]) / denom;
-      wr[t] = (ctx->rpos[snp] - rp) / denom;
+      a.wl = (rn - ctx->rpos[snp]) / denom;
+      a.wr = (ctx->rpos[snp] - rp) / denom;
     }
-    const float lsp = win->logscales[win->top_off[t] + p], lsn = win->logscales[win->top_off[t] + p + 1];
-    epn[t] = expf(lsp - lsn);  // float expf of a float difference (:167-168), glibc
-    enp[t] = expf(lsn - lsp);
+    if (win->e_cursor[t] != p) {  // (two expf per target and cursor position, not per matrix)
+      const float lsp = win->logscales[win->top_off[t] + p], lsn = win->logscales[win->top_off[t] + p + 1];
+      win->e_pn[t] = expf(lsp - lsn);  // float expf of a float difference (:167-168), glibc
+      win->e_np[t] = expf(lsn - lsp);
+      win->e_cursor[t] = p;
+    }
+    a.e_pn = win->e_pn[t];
+    a.e_np = win->e_np[t];
   }
-  // a bounded window: are the rows this tree reads resident?  If not, move on to the part starting here.
-  bool covered = true;
-  for (int t = 0; t < nloc && covered; t++) {
-    const int p = win->v_snp_prev[t];
-    covered = p >= win->row_lo[t] && p + (direct[t] ? 0 : 1) < win->row_hi[t];
-  }
-  if (!covered) {
+  if (!covered) {  // move on to the part of the window that starts here
     const int prc = place_rows(win, snp, nullptr);
     if (prc) return prc;
   }
   const auto t_mx = std::chrono::steady_clock::now();
-  // the per-target arguments in one pinned block, one copy, on the window's stream
-  const size_t o_wl = 0, o_wr = o_wl + (size_t)nloc * 8, o_vsp = o_wr + (size_t)nloc * 8, o_epn = o_vsp + (size_t)nloc * 4,
-               o_enp = o_epn + (size_t)nloc * 4, o_dir = o_enp + (size_t)nloc * 4, stage_bytes = o_dir + (size_t)nloc;
-  if (!win->stream) {
-    if (make_stream(&win->stream, false, true) != hipSuccess ||
-        hipEventCreate(&win->e0) != hipSuccess || hipEventCreate(&win->e2) != hipSuccess ||
-        !(win->h_stage = static_cast<unsigned char *>(pinned_cache_alloc(((stage_bytes + 7) & ~(size_t)7) + 8, &win->h_stage_bytes)))) {
-      set_error("rl_window_matrix: stream / staging buffer creation failed");
-      return RL_EHIP;
-    }
-  }
-  int rc = win->d_stage.alloc(((stage_bytes + 7) & ~(size_t)7) + 8);
-  if (rc) return rc;
-  memcpy(win->h_stage + o_vsp, win->v_snp_prev.data(), (size_t)nloc * 4);
-  memcpy(win->h_stage + o_wl, wl.data(), (size_t)nloc * 8);
-  memcpy(win->h_stage + o_wr, wr.data(), (size_t)nloc * 8);
-  memcpy(win->h_stage + o_epn, epn.data(), (size_t)nloc * 4);
-  memcpy(win->h_stage + o_enp, enp.data(), (size_t)nloc * 4);
-  memcpy(win->h_stage + o_dir, direct.data(), (size_t)nloc);
-  RL_HIP(hipMemcpyAsync(win->d_stage.p, win->h_stage, stage_bytes, hipMemcpyHostToDevice, win->stream));
-  const unsigned char *ds = win->d_stage.as<unsigned char>();
+  int rc = RL_OK;
   MatrixParams p;
   p.N = N;
   p.k0 = k0;
@@ -708,12 +707,7 @@ static int window_matrix(rl_window *win, int snp, float *d_host, void *d_dev, fl
   p.logscales = win->d_ls.as<float>();
   p.top_off = win->d_top_off.as<int64_t>();
   p.slab_base = reinterpret_cast<const int64_t *>(win->d_place.as<unsigned char>() + (size_t)nloc * 8);
-  p.v_snp_prev = reinterpret_cast<const int32_t *>(ds + o_vsp);
-  p.direct = ds + o_dir;
-  p.wl = reinterpret_cast<const double *>(ds + o_wl);
-  p.wr = reinterpret_cast<const double *>(ds + o_wr);
-  p.e_pn = reinterpret_cast<const float *>(ds + o_epn);
-  p.e_np = reinterpret_cast<const float *>(ds + o_enp);
+  p.args = static_cast<const MatrixArg *>(win->d_args);
   if (!d_dev && (rc = win->d_matrix.alloc((size_t)nloc * N * sizeof(float)))) return rc;
   p.matrix = d_dev ? static_cast<float *>(d_dev) : win->d_matrix.as<float>();
   RL_HIP(hipEventRecord(win->e0, win->stream));

@@ -85,3 +85,18 @@ def run_cli(mode, work, builder, extra_env=None, sections=(0, 0)):
     p = subprocess.run(cmd, cwd=work, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     return p.stderr.decode()
+
+
+def record(key, value):
+    """what a test measured (not only asserted) goes to gpurun_out/test_reports.json -- or $RELATE_AMD_TEST_REPORT -- so
+    that it survives `pytest -q`: tolerances used, identical-entry and identical-tree fractions of the fast modes
+    (bench.py quotes profiles/r04_fast_modes.json, a committed copy)"""
+    import json
+    path = os.environ.get("RELATE_AMD_TEST_REPORT") or os.path.join(ROOT, "gpurun_out", "test_reports.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    try:
+        data = json.load(open(path))
+    except Exception:
+        data = {}
+    data[key] = value
+    json.dump(data, open(path, "w"), indent=1, sort_keys=True)

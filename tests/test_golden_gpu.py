@@ -64,16 +64,18 @@ def test_repaint_and_matrices_bit_identical_to_reference(tmp_path, name, paintin
     ctx.close()
 
 
-def test_lanes_mode_within_tolerance_of_reference(tmp_path):
-    # RL_SUM_LANES re-associates the normalising sums: distances must stay
+@pytest.mark.parametrize("mode", [api.RL_SUM_LANES, api.RL_SUM_LANES32])
+def test_lanes_mode_within_tolerance_of_reference(tmp_path, mode):
+    # RL_SUM_LANES re-associates the normalising sums (RL_SUM_LANES32: and keeps the stepping-stone pass's state in
+    # packed FP32): distances must stay
     # within |d_lanes - d_ref| <= 1e-5 * max(|d|, |logscale|) (SURVEY.md 7 H1:
     # the reference differs from itself by that much under FMA contraction)
     fx = Fixture("synth70", tmp_path)
     ctx = open_ctx(fx)
-    ctx.paint(api.RL_SUM_LANES)
+    ctx.paint(mode)
     for w in fx.dump_windows():
         s0 = int(fx.chunk.wb[w])
-        win = ctx.open_window(w, None, s0, api.RL_SUM_LANES)
+        win = ctx.open_window(w, None, s0, mode)
         scale = max(1.0, max(float(np.abs(ls).max()) for ls, _ in fx.repaint(w)))
         cur = s0
         for s, ref in fx.matrices(w):

@@ -37,11 +37,10 @@ def write_synth_haps(work, N, L, seed):
 
 
 def compare_dirs(a, b):
-    """a: the reference's directory, b: ours -- which holds, next to the reference's files, the bit-packed panel
-    chunk_<i>.bits of every chunk (checked against the .hap file by test_bits_file_is_the_hap_file_bit_packed)"""
-    fa, fb = sorted(os.listdir(a)), sorted(f for f in os.listdir(b) if not f.endswith(".bits"))
+    """a: the reference's directory, b: ours -- the same files, nothing else (the bit-packed panel chunk_<i>.bits is
+    opt-in: test_bits_file_is_the_hap_file_bit_packed)"""
+    fa, fb = sorted(os.listdir(a)), sorted(os.listdir(b))
     assert fa == fb
-    assert sorted(f for f in os.listdir(b) if f.endswith(".bits")) == sorted(f[:-4] + ".bits" for f in fb if f.endswith(".hap"))
     for fn in fa:
         assert open(os.path.join(a, fn), "rb").read() == open(os.path.join(b, fn), "rb").read(), fn
     return fa
@@ -84,7 +83,7 @@ def test_makechunks_matches_committed_reference_outputs(tmp_path, tag, memory, e
                         "--memory", memory] + extra + ["-o", "ours"], cwd=work, stderr=subprocess.PIPE)
     assert p.returncode == 0, p.stderr.decode()
     want = sorted(k.split("/", 2)[2] for k in z.files if k.startswith(tag + "/md5/"))
-    assert sorted(f for f in os.listdir(os.path.join(work, "ours")) if not f.endswith(".bits")) == want
+    assert sorted(os.listdir(os.path.join(work, "ours"))) == want
     for fn in want:
         b = open(os.path.join(work, "ours", fn), "rb").read()
         if "%s/file/%s" % (tag, fn) in z.files:
@@ -148,14 +147,18 @@ def test_makechunks_gz_example_matches_reference(tmp_path):
 
 
 def test_bits_file_is_the_hap_file_bit_packed(tmp_path):
-    """chunk_<i>.bits (this library's side output of MakeChunks, the layout rl_set_chunk_bits takes) against
-    chunk_<i>.hap, the reference's char panel, for every chunk of a multi-chunk job (rows carried over the
-    20000-SNP overlap included); RELATE_AMD_CHUNK_BITS=0 leaves the reference's files alone"""
+    """chunk_<i>.bits (this library's side output of MakeChunks under RELATE_AMD_CHUNK_BITS=1, the layout
+    rl_set_chunk_bits takes) against chunk_<i>.hap, the reference's char panel, for every chunk of a multi-chunk job
+    (rows carried over the 20000-SNP overlap included).  The file names its .hap by size and modification time;
+    without the option MakeChunks writes the reference's files only and REMOVES a .bits an earlier run left (a stale
+    one would be read in place of the new .hap); FindEquivalentBranches removes it too (the reference's Finalize
+    ends on an rmdir of the directory, Finalize.cpp:290)"""
     work = str(tmp_path)
     N, L = 70, 26000
     write_synth_haps(work, N, L, seed=3)
     args = ["--mode", "MakeChunks", "--haps", "s.haps", "--sample", "s.sample", "--map", "s.map", "--memory", "0.0064"]
-    p = subprocess.run([CLI] + args + ["-o", "ours"], cwd=work, stderr=subprocess.PIPE)
+    p = subprocess.run([CLI] + args + ["-o", "ours"], cwd=work, stderr=subprocess.PIPE,
+                       env=dict(os.environ, RELATE_AMD_CHUNK_BITS="1"))
     assert p.returncode == 0, p.stderr.decode()
     chunks = sorted(f for f in os.listdir(os.path.join(work, "ours")) if f.endswith(".hap"))
     assert len(chunks) >= 2
@@ -165,17 +168,34 @@ def test_bits_file_is_the_hap_file_bit_packed(tmp_path):
         seq = np.frombuffer(hap, np.uint8, int(hl * hn), 16).reshape(int(hl), int(hn))
         bits = open(os.path.join(work, "ours", f[:-4] + ".bits"), "rb").read()
         magic, bn, bl, rw = np.frombuffer(bits, np.uint32, 4)
-        assert (magic, bn, bl, rw) == (0x31424c52, hn, hl, (hn + 31) // 32)
-        words = np.frombuffer(bits, np.uint32, int(bl) * int(rw), 16).reshape(int(bl), int(rw))
+        assert (magic, bn, bl, rw) == (0x32424c52, hn, hl, (hn + 31) // 32)
+        st = os.stat(os.path.join(work, "ours", f))
+        assert list(np.frombuffer(bits, np.uint64, 2, 16)) == [st.st_size, st.st_mtime_ns]
+        words = np.frombuffer(bits, np.uint32, int(bl) * int(rw), 32).reshape(int(bl), int(rw))
         want = np.zeros((int(hl), int(rw) * 32), np.uint8)
         want[:, :int(hn)] = seq == ord("1")
         assert np.array_equal(np.packbits(want, axis=1, bitorder="little").view(np.uint32), words), f
-    p = subprocess.run([CLI] + args + ["-o", "plain"], cwd=work, stderr=subprocess.PIPE,
-                       env=dict(os.environ, RELATE_AMD_CHUNK_BITS="0"))
+    p = subprocess.run([CLI] + args + ["-o", "plain"], cwd=work, stderr=subprocess.PIPE)
     assert p.returncode == 0, p.stderr.decode()
     assert not [f for f in os.listdir(os.path.join(work, "plain")) if f.endswith(".bits")]
     assert sorted(os.listdir(os.path.join(work, "plain"))) == sorted(
         f for f in os.listdir(os.path.join(work, "ours")) if not f.endswith(".bits"))
+    # a second MakeChunks into a directory that holds .bits files, without the option: they go (rl_make_chunks writes
+    # into an existing directory; the CLI stage refuses one)
+    import ctypes as C
+    from relate_amd import api
+    lib = api.lib()
+    lib.rl_make_chunks.argtypes = [C.c_char_p] * 5 + [C.c_int, C.c_float]
+    env_before = os.environ.pop("RELATE_AMD_CHUNK_BITS", None)
+    try:
+        rc = lib.rl_make_chunks(os.path.join(work, "s.haps").encode(), os.path.join(work, "s.sample").encode(),
+                                os.path.join(work, "s.map").encode(), None, os.path.join(work, "ours").encode(), 1,
+                                C.c_float(0.0064))
+    finally:
+        if env_before is not None:
+            os.environ["RELATE_AMD_CHUNK_BITS"] = env_before
+    assert rc == 0, lib.rl_last_error()
+    assert not [f for f in os.listdir(os.path.join(work, "ours")) if f.endswith(".bits")]
 
 
 @pytest.mark.ref

@@ -112,7 +112,7 @@ def test_lanes_mode_at_the_headline_tile(painted):
     rows = [int(x) for x in zm["rows"]]
     scale = max(1.0, float(zm["logscale_max"][0]))
     report = {}
-    for mode, name in ((api.RL_SUM_EXACT, "exact"), (api.RL_SUM_LANES, "lanes")):
+    for mode, name in ((api.RL_SUM_EXACT, "exact"), (api.RL_SUM_LANES, "lanes"), (api.RL_SUM_LANES32, "lanes32")):
         ctx = api.Context()
         ctx.load_chunk(os.path.join(work, "out"), 0)
         ctx.paint(mode)
@@ -137,12 +137,17 @@ def test_lanes_mode_at_the_headline_tile(painted):
         report[name] = (worst, same)
         win.close()
         ctx.close()
-    print("lanes vs reference at N=5000: worst |diff| / tolerance %.3f, identical entries per matrix %s"
-          % (report["lanes"][0], ["%.4f" % x for x in report["lanes"][1]]))
+    for name in ("lanes", "lanes32"):
+        print("%s vs reference at N=5000: worst |diff| / tolerance %.3f, identical entries per matrix %s"
+              % (name, report[name][0], ["%.4f" % x for x in report[name][1]]))
+        bigtile.record("n5000_" + name + "_matrices", {"worst_diff_over_tolerance": report[name][0],
+                                                        "identical_entries_per_matrix": report[name][1]})
+        assert report[name][0] <= 1.0
 
 
-def test_lanes_mode_trees_at_the_headline_tile(painted, tmp_path):
-    """the trees `lanes` builds from its own stones: a valid tree sequence at the reference's positions is NOT
+@pytest.mark.parametrize("mode", ["lanes", "lanes32"])
+def test_lanes_mode_trees_at_the_headline_tile(painted, tmp_path, mode):
+    """the trees `lanes` / `lanes32` build from their own stones: a valid tree sequence at the reference's positions is NOT
     promised (MinMatch breaks exact float ties) -- the fraction of identical parent arrays is
     reported, the run must succeed and produce binary trees"""
     z, work, W = painted
@@ -153,7 +158,7 @@ def test_lanes_mode_trees_at_the_headline_tile(painted, tmp_path):
             os.symlink(os.path.join(work, "out", f), str(out / f))
     env = dict(os.environ, RELATE_AMD_GPU_BUILD="1")
     p = subprocess.run([CLI, "--mode", "PaintBuildTopology", "--chunk_index", "0", "--first_section", "0",
-                        "--last_section", "0", "--sum_mode", "lanes", "-o", "out"], cwd=str(tmp_path),
+                        "--last_section", "0", "--sum_mode", mode, "-o", "out"], cwd=str(tmp_path),
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     N, trees = rlutil.parse_anc(str(out / "chunk_0" / "out_0.anc"))
@@ -164,6 +169,11 @@ def test_lanes_mode_trees_at_the_headline_tile(painted, tmp_path):
         assert par[-1] == -1 and np.all(np.bincount(par[:-1], minlength=2 * N - 1)[N:] == 2)
         if t[0] in ref_pos and np.array_equal(md5(par.astype("<i4").tobytes()), z["tree_parent_md5"][ref_pos.index(t[0])]):
             same += 1
-    print("lanes at N=5000, section 0: %d trees (reference %d), %d with the reference's parent array (%.1f %%)"
-          % (len(trees), len(ref_pos), same, 100.0 * same / max(1, len(ref_pos))))
+    print("%s at N=5000, section 0: %d trees (reference %d), %d with the reference's parent array (%.1f %%)"
+          % (mode, len(trees), len(ref_pos), same, 100.0 * same / max(1, len(ref_pos))))
+    bigtile.record("n5000_" + mode + "_trees", {"trees": len(trees), "reference_trees": len(ref_pos),
+                                               "identical_parent_arrays": same,
+                                               "identical_fraction": same / max(1, len(ref_pos))})
+    # (a floor, so that a regression is red: most trees do not hinge on an exact float tie)
+    assert same >= 0.5 * len(ref_pos)
 

@@ -35,10 +35,12 @@ def job(tmp_path_factory):
     for fn in ("s.haps", "s.sample", "s.map"):
         assert np.array_equal(md5(os.path.join(work, fn)), z["in_md5/" + fn]), fn
     p = subprocess.run([CLI, "--mode", "MakeChunks", "--haps", "s.haps", "--sample", "s.sample", "--map", "s.map",
-                        "--memory", "%g" % float(z["memory"][0]), "-o", "job"], cwd=work, stderr=subprocess.PIPE)
+                        "--memory", "%g" % float(z["memory"][0]), "-o", "job"], cwd=work, stderr=subprocess.PIPE,
+                       env=dict(os.environ, RELATE_AMD_CHUNK_BITS="1"))  # (the bit-packed panel next to the .hap: opt-in)
     assert p.returncode == 0, p.stderr.decode()
     C = int(z["num_chunks"][0])
     assert rdist.read_parameters(os.path.join(work, "job"))["num_chunks"] == C and C >= 2
+    shutil.copytree(os.path.join(work, "job"), os.path.join(work, "pristine"))  # (copy2: modification times kept)
     return z, work, C
 
 
@@ -61,23 +63,34 @@ def test_every_chunk_through_run_chunks(job):
         shutil.rmtree(os.path.join(out, "chunk_%d" % c))
 
 
-@pytest.mark.parametrize("panel", ["bits", "hap"])
+@pytest.mark.parametrize("panel", ["bits", "hap", "stale_bits"])
 def test_two_stage_route_from_either_panel(job, panel):
     """Paint -> paint files -> BuildTopology -> FindEquivalentBranches (run_chunks(paint_files=True)); with
-    chunk_<i>.bits present rl_load_chunk reads the bit-packed panel, without it the reference's char panel"""
+    chunk_<i>.bits present rl_load_chunk reads the bit-packed panel, without it -- or next to a .hap it was not written
+    for (another size or modification time) -- the reference's char panel; the last stage removes the .bits"""
     z, work, C = job
     out = os.path.join(work, "job_" + panel)
-    shutil.copytree(os.path.join(work, "job"), out)
+    shutil.copytree(os.path.join(work, "pristine"), out)
     bits = [f for f in os.listdir(out) if f.endswith(".bits")]
     assert len(bits) == C
     if panel == "hap":
         for f in bits:
             os.remove(os.path.join(out, f))
-    else:  # the char panel must not be what is read: break it
+    elif panel == "stale_bits":  # a .hap written after the .bits: the .bits (made useless here) must not be read
         for c in range(C):
-            with open(os.path.join(out, "chunk_%d.hap" % c), "r+b") as f:
+            with open(os.path.join(out, "chunk_%d.bits" % c), "r+b") as f:
+                f.seek(32)
+                f.write(b"\xff" * 64)
+            st = os.stat(os.path.join(out, "chunk_%d.hap" % c))
+            os.utime(os.path.join(out, "chunk_%d.hap" % c), ns=(st.st_atime_ns, st.st_mtime_ns + 1000000000))
+    else:  # the char panel must not be what is read: break it (same size, same modification time)
+        for c in range(C):
+            fn = os.path.join(out, "chunk_%d.hap" % c)
+            st = os.stat(fn)
+            with open(fn, "r+b") as f:
                 f.seek(16)
                 f.write(b"\x00" * 64)
+            os.utime(fn, ns=(st.st_atime_ns, st.st_mtime_ns))
     # (the output name is the directory's base name, as with the CLI's -o)
     os.rename(out, os.path.join(work, "tmp_" + panel))
     os.makedirs(os.path.join(work, panel))
@@ -90,3 +103,4 @@ def test_two_stage_route_from_either_panel(job, panel):
             assert np.array_equal(md5(os.path.join(out, "chunk_%d" % c, "paint", "relate_%d.bin" % w)),
                                   z["c%d/paint/relate_%d.bin" % (c, w)]), (c, w)
         check_trees(z, out, c)
+        assert not os.path.exists(os.path.join(out, "chunk_%d.bits" % c))  # (FindEquivalentBranches took it along)
