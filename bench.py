@@ -99,9 +99,25 @@ def chunk_wallclock_full():
                             "Paint + BuildTopology of all %d sections in one process on one GPU, chunk files in, "
                             ".anc/.mut files out (no paint files)" % (d["windows"], d["sections"]),
                 "measured": True, "wall_s": d["wall_s"], "sections": d["sections"], "trees": d["trees_built"],
-                "trees_per_s": d["trees_per_s"], "anc_GB": d["anc_GB"], "stage_lines": d.get("stage_lines", [])[:4]}
+                "trees_per_s": d["trees_per_s"], "anc_GB": d["anc_GB"], "stage_lines": d.get("stage_lines", [])[:4],
+                **verify_c3(d.get("section_md5", {}))}
     except Exception as e:  # never a reason to lose the bench line
         return {"error": str(e)[:200]}
+
+
+def verify_c3(section_md5):
+    """this run's md5 of sections 0 / 133 / 266 of the C3 chunk against profiles/r04_c3_section_md5.json: the same
+    sections built by ANOTHER schedule of the path (tools/verify_c3_sections.py: one section per call, its whole window
+    resident -- one RePaint launch instead of ~37 --, the trees by the host's MinMatch instead of the device workers)"""
+    try:
+        ref = json.load(open(os.path.join(ROOT, "profiles", "r04_c3_section_md5.json")))
+        want = ref["check_md5"]
+        secs = sorted(set(int(k.split("_")[1].split(".")[0]) for k in want))
+        ok = [s for s in secs if all(section_md5.get("out_%d.%s" % (s, e)) == want["out_%d.%s" % (s, e)] for e in ("anc", "mut"))]
+        return {"verified_sections": ok, "checked_sections": secs, "verified_against": ref.get("against", ""),
+                "section_md5": section_md5}
+    except Exception as e:
+        return {"verified_sections": [], "verify_error": str(e)[:120], "section_md5": section_md5}
 
 
 def chunk_wallclock_sample(sections=8, host_builder=False):
@@ -159,6 +175,8 @@ def main():
                          "~121k SNPs (--memory 1), dealt to the GPUs round-robin as relate_amd.dist.run_chunks deals "
                          "them; each GPU paints --chunks-per-gpu of them per step")
     ap.add_argument("--chunks-per-gpu", dest="cpg", type=int, default=2)
+    ap.add_argument("--print-launch", dest="print_launch", action="store_true",
+                    help="with --gpus N > 1 and no launcher: print the launch command instead of running it")
     ap.add_argument("--shard", default="chunks", choices=["chunks", "targets"],
                     help="chunks (default, the contract's weak scaling): one chunk per GPU, no collective. "
                          "targets: ONE chunk for all ranks, each paints a range of target haplotypes (strong "
@@ -172,13 +190,19 @@ def main():
         import subprocess
         import torch
         have = torch.cuda.device_count()  # (counting devices does not initialise the GPU)
+        if args.print_launch:
+            have = args.gpus
         if have < args.gpus:
             sys.exit("bench.py: --gpus %d but %d GPU%s visible" % (args.gpus, have, "" if have == 1 else "s"))
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
             port = sk.getsockname()[1]
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + \
+              [a for a in sys.argv[1:] if a != "--print-launch"]
+        if args.print_launch:
+            print(json.dumps(cmd))
+            sys.exit(0)
         sys.exit(subprocess.run(cmd).returncode)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -1369,6 +1369,7 @@ constexpr int MM_XCDS = 8;          // a launch's workgroups are dealt to the XC
 struct WorkQueue {
   unsigned tail;
   unsigned pad[15];
+  unsigned gone[16];  // per launch: workers that have left (the host counts a launch's LIVE workers, not its size)
   unsigned words[MM_QUEUE_CAP][MM_PARAM_WORDS];
 };
 // device memory: the ticket counter, and per launch how many of its workers are building and when one last was
@@ -1446,6 +1447,7 @@ __global__ void __launch_bounds__(MM_BLOCK, 1)
         __builtin_amdgcn_s_sleep(127);  // (~3 us: the queue is read across PCIe)
       }
       if (trace && ticket == ~0u) __hip_atomic_fetch_add(&q->pad[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (ticket == ~0u) __hip_atomic_fetch_add(&q->gone[launch], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       sh.ticket = ticket;
     }
     __syncthreads();
@@ -1828,7 +1830,10 @@ class BuildQueue {
       }
       std::this_thread::sleep_for(std::chrono::microseconds(spins < 50 ? 100 : 250));
       if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(600)) {
+        // (the request may still be claimed or finished by a worker: the queue is done for -- every builder's wait
+        //  ends with an error -- and the caller keeps this tree's buffers out of circulation, ~DeviceMinMatch)
         set_error("tree builder: the tree was not built within 10 minutes");
+        failed_.store(true);
         rc = RL_EHIP;
         break;
       }
@@ -1923,7 +1928,9 @@ class BuildQueue {
           size[l] = 0;
           g_worker_launches.fetch_sub(1);
         }
-        alive += size[l];
+        // (workers decide to leave one by one -- idle past the limit and nobody of the launch building --, so a late
+        //  claim can keep one of them at work while its peers are gone: a launch counts for the workers it still has)
+        alive += size[l] - std::min(size[l], (int)__atomic_load_n(&q_->gone[l], __ATOMIC_ACQUIRE));
         busy_launches += size[l] > 0;
         if (size[l] == 0 && free_stream < 0) free_stream = l;
       }
@@ -1941,6 +1948,7 @@ class BuildQueue {
         n = (n + MM_XCDS - 1) / MM_XCDS * MM_XCDS;
         n = std::max(1, std::min(n, goal - alive));
         const int l = free_stream;
+        __atomic_store_n(&q_->gone[l], 0u, __ATOMIC_RELEASE);  // (the stream's previous launch is through)
         const long long idle = (long long)idle_ms_ * 100000LL;
         const int trace_flag = getenv("RELATE_AMD_MM_TRACE") ? 1 : 0;
         if (lds_)
@@ -2020,6 +2028,7 @@ struct DeviceMinMatch::Impl {
   int *h_tab = nullptr;   // pinned: the previous tree's tables for prior_kernel (6T + N ints), then N carrier flags
   float acc_val = 0.0f;   // d_acc holds acc[c] = val added c times for this val
   bool acc_valid = false;
+  bool abandoned = false;  // a tree was given up while its ticket may be live: nothing of this builder is recycled
   void drop_staging() {
     if (staging) DeviceShare::of(device).give(staging);
     staging = nullptr;
@@ -2036,6 +2045,18 @@ DeviceMinMatch::~DeviceMinMatch() {
     fprintf(stderr, "[gpu tree builder] %lld trees, host ms per tree: uploads + weave %.2f, submit -> done %.2f, "
                     "copy-out %.2f\n", impl->n_timed, 1e3 * impl->t_prep / impl->n_timed,
             1e3 * impl->t_wait / impl->n_timed, 1e3 * impl->t_out / impl->n_timed);
+  if (impl->abandoned) {
+    // (leaked on purpose: handed to the caches these blocks would be given out again at once, and a worker that
+    //  claims or finishes the abandoned ticket later would write into somebody else's tree)
+    for (DevBuf *b : {&impl->d_M, &impl->d_hits, &impl->d_f, &impl->d_i, &impl->d_feas, &impl->d_rowlist, &impl->d_status,
+                      &impl->d_flags, &impl->d_member, &impl->d_tab, &impl->d_acc}) {
+      b->p = nullptr;
+      b->bytes = 0;
+    }
+    impl->staging = nullptr;
+    delete impl;
+    return;
+  }
   if (impl->stream) (void)hipStreamDestroy(impl->stream);
   // (nothing goes back to the driver here: hipFree / hipHostFree would wait for the workers of the other builders)
   if (impl->h_done) done_word(impl->h_done);
@@ -2299,6 +2320,7 @@ int DeviceMinMatch::build_impl(MinMatch &tb, const float *d, const float *prior_
   __atomic_store_n(m.h_done, -1, __ATOMIC_RELEASE);
   if (queue->run(p)) {
     set_error("tree builder: the workers of device %d failed", m.device);
+    m.abandoned = true;  // a worker may still write this tree's state, merges and completion word
     return -1;
   }
   const auto tb2 = std::chrono::steady_clock::now();

@@ -432,6 +432,10 @@ def main(argv=None):
     ap.add_argument("--chunks", default=None, help="comma-separated subset of chunk indices")
     ap.add_argument("--paint-files", dest="paint_files", action="store_true",
                     help="Paint and BuildTopology as two stages with the paint files in between (the reference's route)")
+    ap.add_argument("--stages", default=None,
+                    help="importable module with stage_paint, stage_build_topology, stage_paint_build_topology, "
+                         "stage_find_equivalent_branches, num_sections (default: relate_amd.api, the GPU library) -- e.g. "
+                         "wrappers around another Relate binary")
     args = ap.parse_args(argv)
     painting = tuple(float(x) for x in args.painting.split(",")) if args.painting else None
     chunks = [int(x) for x in args.chunks.split(",")] if args.chunks else None
@@ -445,7 +449,11 @@ def main(argv=None):
         # (a rank dealt one chunk fewer waits for the others at the end: a chunk's stages can take longer than the
         #  backend's default timeout)
         dist.init_process_group("nccl" if on_gpu else "gloo", timeout=datetime.timedelta(hours=24))
-    mine = run_chunks(args.out_dir, painting=painting, chunks=chunks, paint_files=args.paint_files)
+    stages = None
+    if args.stages:
+        import importlib
+        stages = importlib.import_module(args.stages)
+    mine = run_chunks(args.out_dir, painting=painting, chunks=chunks, paint_files=args.paint_files, stages=stages)
     print("rank %d ran chunks %s" % (dist.get_rank() if launched else 0, mine), flush=True)
     if launched:
         dist.barrier()  # (the job ends together; nothing is exchanged)

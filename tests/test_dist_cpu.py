@@ -232,3 +232,47 @@ def test_dist_command_line_parses():
     assert e.value.code == 0
     with _pytest.raises(SystemExit):
         rdist.main([])  # the output directory is required
+
+
+def test_launcher_really_starts_two_ranks(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 -m relate_amd.dist OUT` as a user types it (gloo: no GPU
+    here), the stages replaced by recorders (--stages): both ranks come up, rendezvous, are dealt their chunks, run
+    them start to end on the device LOCAL_RANK names and leave together"""
+    import socket
+    import struct
+    import subprocess
+    out = tmp_path / "job"
+    out.mkdir()
+    C_ = 5
+    with open(out / "parameters.bin", "wb") as f:  # data.cpp:365-375
+        f.write(struct.pack("<iii", 40, 1000, C_) + struct.pack("<d", 5.0) + struct.pack("<%di" % (2 * C_), *range(2 * C_)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "tests")]))
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", "relate_amd.dist", str(out),
+                        "--stages", "stubs.stub_stages"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env,
+                       timeout=300)
+    text = p.stdout.decode()
+    assert p.returncode == 0, text[-2000:]
+    assert "rank 0 ran chunks [0, 2, 4]" in text and "rank 1 ran chunks [1, 3]" in text, text[-2000:]
+    calls0 = open(out / "calls_rank0.txt").read().split("\n")
+    calls1 = open(out / "calls_rank1.txt").read().split("\n")
+    assert calls0[:2] == ["0 fused 0 0-2 dev0", "0 feb 0"] and "0 fused 4 0-6 dev0" in calls0
+    assert calls1[:2] == ["1 fused 1 0-3 dev1", "1 feb 1"] and "1 fused 3 0-5 dev1" in calls1
+
+
+def test_bench_self_launch_command():
+    """`python bench.py --gpus 4` without a launcher starts its ranks itself, as a child: the command it would run
+    (--print-launch; the GPUs to run it on are not here)"""
+    import json
+    import subprocess
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "3", "--print-launch"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300,
+                       env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert p.returncode == 0, p.stderr.decode()[-1500:]
+    cmd = json.loads(p.stdout.decode().strip().split("\n")[-1])
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")

@@ -61,6 +61,15 @@ try:
             with open(os.path.join(d, "chunk_0", f), "rb") as fh:
                 kept += struct.unpack("<I", fh.read(9)[5:9])[0]
     out["trees_kept"] = kept
+    # md5 of a few sections' files: held against tools/verify_c3_sections.py's (the same sections rebuilt one per call,
+    # whole window resident, host tree builder), committed as profiles/r04_c3_section_md5.json -- bench.py compares
+    import hashlib
+    out["section_md5"] = {}
+    for sct in (0, W // 2, W - 1):
+        for e in ("anc", "mut"):
+            fn = os.path.join(d, "chunk_0", "out_%d.%s" % (sct, e))
+            if os.path.exists(fn):
+                out["section_md5"]["out_%d.%s" % (sct, e)] = hashlib.md5(open(fn, "rb").read()).hexdigest()
     out["trees_built"] = trees if trees else kept  # (built, incl. the rejected ones, only with the timing lines)
     out["trees_per_s"] = out["trees_built"] / out["wall_s"]
     out["anc_GB"] = sum(os.path.getsize(os.path.join(d, "chunk_0", f)) for f in os.listdir(os.path.join(d, "chunk_0"))
