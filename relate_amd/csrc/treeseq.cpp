@@ -890,11 +890,13 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
     // One worker per open section -- unless the windows are bounded: then RePaint runs all through the stage, on the
     // CUs the workers do not hold (a worker has a CU to itself), and it is the queue every section waits in.  At C3
     // (134 sections, 37 launches per window): 110 workers 207 s, 100 workers 177 s, 90 workers 190 s (RePaint 168 /
-    // 100 / 92 s busy; trees waiting 5 / 36 / 55 ms for a worker): the workers get 3/8 of the CUs.
+    // 100 / 92 s busy; trees waiting 5 / 36 / 55 ms for a worker): the workers got 3/8 of the CUs in round 3.  Round 4
+    // (prior_kernel through LDS: RePaint waits 3-4 s per window instead of 9-12): 96 workers 165.7 s, 104 workers
+    // 161.9 s, 112 workers 182.8 s (profiles/r04_c3_workers.json): 13/32 of the CUs.
     int workers = nthreads, cus = 256;
     if (cap_rows > 0) {
       if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 8) cus = 256;
-      workers = std::min(nthreads, 3 * cus / 8);
+      workers = std::min(nthreads, 13 * cus / 32);
     }
     if (o.workers > 0) workers = o.workers;  // (RELATE_AMD_BUILD_WORKERS overrides either, minmatch_gpu.hip)
     (void)device_builder_expect(device, ctx->N, workers);
