@@ -125,9 +125,10 @@ struct MatrixParams {
   const float *logscales;
   const int64_t *top_off;   // [nloc+1] row offsets into logscales
   const int64_t *slab_base;   // [nloc] posterior row j of target t is topology row slab_base[t] + j
-  const MatrixArg *args;      // [nloc], in PINNED HOST memory: the kernel reads them where the host wrote them (one
-                              // 32-byte scalar load per workgroup over PCIe) -- a copy engine between the host's
-                              // loop and a 0.08 ms kernel cost more than the kernel (0.5 ms per matrix through the ABI)
+  const MatrixArg *args;      // [nloc] in HBM ...
+  const MatrixArg *host_args; // ... copied there from this pinned host block by a small kernel ahead of the matrix
+                              // kernel (matrix_kernels.hip), or null: a copy engine between the host's loop and a
+                              // 0.08 ms kernel cost more than the kernel (0.5 ms per matrix through the ABI)
   float *matrix;              // [nloc][N]
 };
 

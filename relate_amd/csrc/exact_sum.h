@@ -238,9 +238,17 @@ RL_DEV double sum_exact_fast(const T &term, double L, WaveLink<WAVES> &lk) {
     // exponent fields of the two bracketing runs must agree after every term:
     // exdiff |= hi(c0) ^ hi(c3), one v_bitop3_b32 per term (bits 20..30 count)
     exdiff = __builtin_amdgcn_bitop3_b32(exdiff, hi32(c0), hi32(c3), 0xF6);
-    // tie the check to its partial sums: otherwise the scheduler first runs
-    // the chains to the end and keeps all partial sums alive
-    asm volatile("" : "+v"(exdiff), "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(thB), "+v"(nthB));
+    // Tie the check to its partial sums: otherwise the scheduler first runs the chains to the end and keeps all
+    // partial sums alive.  A scheduling barrier, not an empty asm statement with the sums as operands: the hazard
+    // recognizer treats an inline asm that names registers a double-precision instruction has just written as a
+    // reader of them and puts a wait state in front -- one s_nop per term, 80 of the ~1000 issue slots of a forward
+    // step (round 4, seen in the ISA).
+    // (The backward pass, whose terms are recomputed here four at a time, keeps the asm statement: with the barrier
+    //  alone its chain block spills 47 register pairs.)
+    if constexpr (REG_TERM)
+      __builtin_amdgcn_sched_barrier(0);
+    else
+      asm volatile("" : "+v"(exdiff), "+v"(c1), "+v"(c2), "+v"(thB), "+v"(nthB));  // (c0, c3: through exdiff)
   });
   const unsigned long long tk2 = RL_CLK();
   const int e_out = expo_field(c0);
@@ -391,7 +399,7 @@ RL_DEV double sum_exact_fast(const T &term, double L, WaveLink<WAVES> &lk) {
       double thC = term.th, nthC = term.nth;
       term.for_each(thC, nthC, [&](int, double x) {
         t += x;
-        if constexpr (!REG_TERM) asm volatile("" : "+v"(thC), "+v"(nthC), "+v"(t));
+        if constexpr (!REG_TERM) asm volatile("" : "+v"(thC), "+v"(nthC));  // (not t: a wait state per term, see the chain pass)
       });
       const double v = rd_lane_f64(t, q);
       delta = (int)((v - rd_lane_f64(Q, q)) * rd_lane_f64(inv_u_out, q));

@@ -71,7 +71,20 @@ __global__ void __launch_bounds__(256) matrix_kernel(const MatrixParams p, const
   for (int j = threadIdx.x; j < N; j += blockDim.x) out[j] = (j == n) ? 0.0f : vals[j] - mn;  // :190-192
 }
 
+// The per-target records come from a pinned host block.  Read there by the matrix kernel itself -- one 32-byte
+// scalar load per workgroup -- they cost 0.4 ms per matrix (5000 dependent reads across PCIe, a few at a time), as
+// much as a copy engine's hop; so a few wide, coalesced reads bring them to HBM first (160 KB: microseconds).
+__global__ void __launch_bounds__(256) stage_args_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, int n16) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n16) dst[i] = src[i];
+}
+
 hipError_t launch_matrix(const MatrixParams &p, const Layout &lay, int S, int waves, hipStream_t stream) {
+  if (p.host_args) {
+    const int n16 = (int)(((size_t)p.nloc * sizeof(MatrixArg) + 15) / 16);
+    hipLaunchKernelGGL(stage_args_kernel, dim3((n16 + 255) / 256), dim3(256), 0, stream,
+                       reinterpret_cast<const uint4 *>(p.host_args), reinterpret_cast<uint4 *>(const_cast<MatrixArg *>(p.args)), n16);
+  }
   hipLaunchKernelGGL(matrix_kernel, dim3(p.nloc), dim3(256), (size_t)p.N * sizeof(float), stream, p, lay, S, waves);
   return hipGetLastError();
 }

@@ -59,6 +59,7 @@ struct rl_window {
   unsigned char *h_stage = nullptr;  // pinned: the per-target arguments of one matrix (MatrixArg[nloc]), read by the
   size_t h_stage_bytes = 0;          // kernel where they lie (d_args: the block's device address)
   void *d_args = nullptr;
+  DevBuf d_stage;                    // ... and where a small kernel puts them for the matrix kernel
   std::vector<int32_t> e_cursor;     // [nloc] cursor position e_pn / e_np were computed for
   std::vector<float> e_pn, e_np;
   ~rl_window() {
@@ -707,7 +708,9 @@ static int window_matrix(rl_window *win, int snp, float *d_host, void *d_dev, fl
   p.logscales = win->d_ls.as<float>();
   p.top_off = win->d_top_off.as<int64_t>();
   p.slab_base = reinterpret_cast<const int64_t *>(win->d_place.as<unsigned char>() + (size_t)nloc * 8);
-  p.args = static_cast<const MatrixArg *>(win->d_args);
+  if ((rc = win->d_stage.alloc((size_t)nloc * sizeof(MatrixArg) + 64))) return rc;
+  p.args = win->d_stage.as<MatrixArg>();
+  p.host_args = static_cast<const MatrixArg *>(win->d_args);
   if (!d_dev && (rc = win->d_matrix.alloc((size_t)nloc * N * sizeof(float)))) return rc;
   p.matrix = d_dev ? static_cast<float *>(d_dev) : win->d_matrix.as<float>();
   RL_HIP(hipEventRecord(win->e0, win->stream));

@@ -33,6 +33,9 @@ for name in sorted(f):
         args = name.split("<")[1].split(">")[0].split(",")
         mode = {"0": "lanes", "1": "exact", "2": "exact_serial"}[args[2].strip()]
         key = mode + {"0": "_fwd_alone", "1": "_bwd_alone", "2": ""}[args[4].strip()]
+    elif "paint32_kernel<" in name:
+        args = name.split("<")[1].split(">")[0].split(",")
+        key = "lanes32" + {"0": "_fwd_alone", "1": "_bwd_alone", "2": ""}[args[3].strip()]
     elif "repaint_fwd_kernel" in name:
         key = "repaint_fwd"
     elif "repaint_bwd_kernel" in name:
