@@ -415,6 +415,38 @@ def stage_paint_build_topology(out_dir, chunk_index, first_section, last_section
              1 if no_consistency else 0, fb, sum_mode, device))
 
 
+class StageOpts(C.Structure):
+    """rl_stage_opts (include/relate_amd.h): every option of a stage call, per call"""
+    _fields_ = [("size", C.c_size_t), ("sum_mode", C.c_int), ("device", C.c_int), ("use_painting", C.c_int),
+                ("theta", C.c_double), ("rho", C.c_double), ("flags", C.c_int), ("fb", C.c_int),
+                ("sample_ages_path", C.c_char_p), ("gpu_build", C.c_int), ("window_rows", C.c_longlong),
+                ("window_parts", C.c_int), ("section_threads", C.c_int), ("workers", C.c_int),
+                ("repaint_lanes", C.c_int), ("park_stones", C.c_int), ("pin_threads", C.c_int)]
+
+
+def stage_opts(**kw):
+    """-> StageOpts with rl_stage_opts_init's defaults and the given fields (painting=(theta, rho) sets three)"""
+    o = StageOpts()
+    lib().rl_stage_opts_init.argtypes = [C.c_void_p]
+    lib().rl_stage_opts_init(C.byref(o))
+    assert o.size == C.sizeof(StageOpts), "StageOpts is out of step with include/relate_amd.h"
+    painting = kw.pop("painting", None)
+    if painting:
+        o.use_painting, o.theta, o.rho = 1, painting[0], painting[1]
+    for k, v in kw.items():
+        if k == "sample_ages_path" and v is not None:
+            v = v.encode()
+        setattr(o, k, v)
+    return o
+
+
+def stage_build_topology_ex(out_dir, chunk_index, first_section, last_section, opts, fused=False):
+    """rl_stage_build_topology_ex / rl_stage_paint_build_topology_ex (fused=True) with a StageOpts"""
+    f = lib().rl_stage_paint_build_topology_ex if fused else lib().rl_stage_build_topology_ex
+    f.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    _check(f(out_dir.encode(), chunk_index, first_section, last_section, C.byref(opts)))
+
+
 def stage_find_equivalent_branches(out_dir, chunk_index=0):
     _check(lib().rl_stage_find_equivalent_branches(out_dir.encode(), chunk_index))
 

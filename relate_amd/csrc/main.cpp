@@ -147,20 +147,28 @@ int main(int argc, char **argv) {
     use_painting = 1;
   }
   int rc;
+  // every option of the stage in one struct, per call (include/relate_amd.h rl_stage_opts)
+  rl_stage_opts so;
+  rl_stage_opts_init(&so);
+  so.sum_mode = sum_mode;
+  so.device = device;
+  so.use_painting = use_painting;
+  so.theta = theta;
+  so.rho = rho;
+  so.flags = opt.count("no_consistency") ? 1 : 0;
+  so.fb = opt.count("fb") ? (int)std::stof(opt["fb"]) : 0;  // BuildTopology.cpp:111-114
+  const std::string ages = opt.count("sample_ages") ? opt["sample_ages"] : std::string();
+  so.sample_ages_path = ages.empty() ? nullptr : ages.c_str();  // BuildTopology.cpp:93-108
   if (mode == "Paint") {
     std::cerr << "---------------------------------------------------------" << std::endl;
     std::cerr << "Painting sequences..." << std::endl;
-    rc = rl_stage_paint(out.c_str(), chunk, use_painting, theta, rho, sum_mode, device);
+    rc = rl_stage_paint_ex(out.c_str(), chunk, &so);
     if (rc == 0) usage_line();
   } else if (mode == "PaintBuildTopology") {
     // Paint + BuildTopology of the chunk in one process, the stepping stones kept in HBM: what `--mode All` does per
     // chunk (Relate.cpp:257-283) without the paint files.  Sections default to all of the chunk's.
-    if (opt.count("sample_ages")) rl_stage_set_sample_ages(opt["sample_ages"].c_str());
-    const int flags = opt.count("no_consistency") ? 1 : 0;
-    const int fb = opt.count("fb") ? (int)std::stof(opt["fb"]) : 0;
-    rc = rl_stage_paint_build_topology(out.c_str(), chunk, opt.count("first_section") ? atoi(opt["first_section"].c_str()) : 0,
-                                       opt.count("last_section") ? atoi(opt["last_section"].c_str()) : 1 << 30,
-                                       use_painting, theta, rho, flags, fb, sum_mode, device);
+    rc = rl_stage_paint_build_topology_ex(out.c_str(), chunk, opt.count("first_section") ? atoi(opt["first_section"].c_str()) : 0,
+                                          opt.count("last_section") ? atoi(opt["last_section"].c_str()) : 1 << 30, &so);
     if (rc == 1) return 1;
   } else if (mode == "BuildTopology") {
     if (!opt.count("first_section") || !opt.count("last_section")) {
@@ -168,12 +176,8 @@ int main(int argc, char **argv) {
       std::cerr << "Needed: first_section, last_section." << std::endl;
       return 1;
     }
-    if (opt.count("sample_ages")) rl_stage_set_sample_ages(opt["sample_ages"].c_str());  // BuildTopology.cpp:93-108
-    const int flags = opt.count("no_consistency") ? 1 : 0;
-    const int fb = opt.count("fb") ? (int)std::stof(opt["fb"]) : 0;  // BuildTopology.cpp:111-114
-    rc = rl_stage_build_topology(out.c_str(), chunk, atoi(opt["first_section"].c_str()),
-                                 atoi(opt["last_section"].c_str()), use_painting, theta, rho, flags, fb, sum_mode,
-                                 device);
+    rc = rl_stage_build_topology_ex(out.c_str(), chunk, atoi(opt["first_section"].c_str()),
+                                    atoi(opt["last_section"].c_str()), &so);
     if (rc == 1) return 1;  // first_section >= num_windows (BuildTopology.cpp:45)
   } else {
     std::cerr << "Mode " << mode << " is not part of this build: it replaces --mode MakeChunks, Paint, BuildTopology and FindEquivalentBranches "

@@ -428,7 +428,8 @@ def run_chunk_by_targets(out_dir, chunk_index=0, painting=None, device=None, sec
 def main(argv=None):
     """`python -m torch.distributed.run --nproc-per-node G -m relate_amd.dist OUT_DIR [--painting theta,rho]`:
     every chunk of OUT_DIR/parameters.bin through Paint, BuildTopology and FindEquivalentBranches, chunk c on rank
-    c mod G (RelateParallel.sh:216-262 for one process per GPU).  Without a launcher it is one rank on the local GPU."""
+    c mod G (RelateParallel.sh:216-262 for one process per GPU).  Without a launcher it is one rank on the local GPU.
+    `--by-targets`: every chunk on ALL ranks instead, sharded by target haplotype (config #5, run_chunk_by_targets)."""
     import argparse
     ap = argparse.ArgumentParser(prog="python -m relate_amd.dist")
     ap.add_argument("out_dir")
@@ -436,6 +437,12 @@ def main(argv=None):
     ap.add_argument("--chunks", default=None, help="comma-separated subset of chunk indices")
     ap.add_argument("--paint-files", dest="paint_files", action="store_true",
                     help="Paint and BuildTopology as two stages with the paint files in between (the reference's route)")
+    ap.add_argument("--by-targets", dest="by_targets", action="store_true",
+                    help="every chunk sharded by TARGET haplotype over all ranks (BASELINE.json config #5: a chunk whose "
+                         "stepping stones do not fit one GPU; run_chunk_by_targets) instead of chunk c on rank c mod G")
+    ap.add_argument("--in-flight", dest="in_flight", type=int, default=4, help="--by-targets: sections a rank owns at once")
+    ap.add_argument("--window-rows", dest="window_rows", type=int, default=0,
+                    help="--by-targets: posterior rows a window keeps resident per rank (0: all)")
     ap.add_argument("--stages", default=None,
                     help="importable module with stage_paint, stage_build_topology, stage_paint_build_topology, "
                          "stage_find_equivalent_branches, num_sections (default: relate_amd.api, the GPU library) -- e.g. "
@@ -457,7 +464,27 @@ def main(argv=None):
     if args.stages:
         import importlib
         stages = importlib.import_module(args.stages)
-    mine = run_chunks(args.out_dir, painting=painting, chunks=chunks, paint_files=args.paint_files, stages=stages)
+    if args.by_targets:
+        rank = dist.get_rank() if launched else 0
+        world = dist.get_world_size() if launched else 1
+        todo = list(range(read_parameters(args.out_dir)["num_chunks"])) if chunks is None else chunks
+        for c in todo:
+            shard_obj = None
+            if stages is not None and hasattr(stages, "Shard"):  # (a stand-in for api.Shard: tests, other back ends)
+                import numpy as np
+                N = int(np.fromfile(os.path.join(args.out_dir, "parameters_c%d.bin" % c), dtype=np.int32, count=1)[0])
+                shard_obj = stages.Shard(args.out_dir, c, *target_range(rank, world, N))
+            owned = run_chunk_by_targets(args.out_dir, c, painting=painting, in_flight=args.in_flight,
+                                         window_rows=args.window_rows, from_paint_files=args.paint_files, shard=shard_obj)
+            print("rank %d of %d: chunk %d by targets, owned sections %s" % (rank, world, c, sorted(owned)), flush=True)
+            if launched:
+                dist.barrier()  # (every section's files are written before the host-only stage reads them)
+            if rank == 0:
+                (stages if stages is not None else __import__("relate_amd.api", fromlist=["api"])).stage_find_equivalent_branches(
+                    args.out_dir, c)
+        mine = todo
+    else:
+        mine = run_chunks(args.out_dir, painting=painting, chunks=chunks, paint_files=args.paint_files, stages=stages)
     print("rank %d ran chunks %s" % (dist.get_rank() if launched else 0, mine), flush=True)
     if launched:
         dist.barrier()  # (the job ends together; nothing is exchanged)

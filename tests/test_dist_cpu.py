@@ -263,6 +263,38 @@ def test_launcher_really_starts_two_ranks(tmp_path):
     assert calls1[:2] == ["1 fused 1 0-3 dev1", "1 feb 1"] and "1 fused 3 0-5 dev1" in calls1
 
 
+def test_launcher_by_targets_three_ranks(tmp_path):
+    """the route of config #5 as a user starts it: `python -m torch.distributed.run --nproc-per-node 3 -m relate_amd.dist
+    OUT --by-targets` (gloo; stand-in shards): three real processes exchange request tables and row blocks (N = 10 over
+    3 ranks: uneven), every section is built by its owner from matrices assembled out of all ranks' rows and released
+    everywhere, rank 0 runs the host-only stage after the barrier"""
+    import socket
+    import struct
+    import subprocess
+    out = tmp_path / "job"
+    out.mkdir()
+    with open(out / "parameters.bin", "wb") as f:
+        f.write(struct.pack("<iii", 10, 1000, 1) + struct.pack("<d", 5.0) + struct.pack("<2i", 0, 1000))
+    with open(out / "parameters_c0.bin", "wb") as f:
+        f.write(struct.pack("<iii", 10, 1000, 4))  # (stub: N = 10; the stub's num_sections gives 3 + chunk)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "tests")]))
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", "relate_amd.dist", str(out),
+                        "--by-targets", "--in-flight", "2", "--stages", "stubs.stub_stages"], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, env=env, timeout=300)
+    text = p.stdout.decode()
+    assert p.returncode == 0, text[-2500:]
+    for r, owned in ((0, [0]), (1, [1]), (2, [2])):
+        assert "rank %d of 3: chunk 0 by targets, owned sections %s" % (r, owned) in text, text[-2500:]
+        calls = open(out / ("calls_rank%d.txt" % r)).read().split("\n")
+        assert "%d built 0 %d" % (r, owned[0]) in calls
+        assert sorted(c for c in calls if " release " in c) == ["%d release 0 %d" % (r, s) for s in range(3)]
+    assert "0 feb 0" in open(out / "calls_rank0.txt").read()
+
+
 def test_bench_self_launch_command():
     """`python bench.py --gpus 4` without a launcher starts its ranks itself, as a child: the command it would run
     (--print-launch; the GPUs to run it on are not here)"""

@@ -242,3 +242,34 @@ def test_cli_build_topology_with_sample_ages(tmp_path, tag, opts):
     if not tag:
         plain = Fixture("synth24", tmp_path / "plain") if (tmp_path / "plain").mkdir() is None else None
         assert any(fx.z["anc/%d" % w].tobytes() != plain.z["anc/%d" % w].tobytes() for w in range(fx.W))
+
+
+def test_stage_options_through_the_abi(tmp_path):
+    """rl_stage_opts (include/relate_amd.h): what the tests elsewhere set through the environment, per call -- two calls
+    of one process with different options: (1) sample ages through `sample_ages_path` (not the process-wide setter),
+    host trees; (2) no ages, the device builder, windows bounded to a third of their rows, one section thread, on the
+    plain fixture: each byte-identical to the reference's files for ITS options"""
+    from relate_amd import api
+    ages_dir, plain_dir = tmp_path / "ages" / "out", tmp_path / "plain" / "out"
+    ages_dir.mkdir(parents=True)
+    plain_dir.mkdir(parents=True)
+    fa, fp = Fixture("synth24_ages", ages_dir), Fixture("synth24", plain_dir)
+    with open(tmp_path / "ages.txt", "w") as f:
+        f.write("\n".join("%g" % a for a in fa.z["ages"]) + "\n")
+    fa.write_paint_files(str(ages_dir / "chunk_0" / "paint"))
+    api.stage_build_topology_ex(str(ages_dir), 0, 0, fa.W - 1, api.stage_opts(sample_ages_path=str(tmp_path / "ages.txt")))
+    for w in range(fa.W):
+        assert open(ages_dir / "chunk_0" / ("out_%d.anc" % w), "rb").read() == fa.z["anc/%d" % w].tobytes(), w
+        assert open(ages_dir / "chunk_0" / ("out_%d.mut" % w), "rb").read() == fa.z["mut/%d" % w].tobytes(), w
+    # the fused stage next, in the same process: the first call's ages must not stick
+    ctx = api.Context()
+    ctx.load_chunk(str(plain_dir), 0)
+    ctx.paint()
+    rows = max(sum(ctx.open_window(w, None, int(fp.chunk.wb[w])).rows(n) for n in range(fp.N)) for w in range(fp.W))
+    ctx.close()
+    api.stage_build_topology_ex(str(plain_dir), 0, 0, fp.W - 1,
+                                api.stage_opts(gpu_build=1, window_rows=max(8, rows // 3), section_threads=1, flags=1),
+                                fused=True)
+    for w in range(fp.W):
+        assert open(plain_dir / "chunk_0" / ("out_%d.anc" % w), "rb").read() == fp.z["anc_nc/%d" % w].tobytes(), w
+        assert open(plain_dir / "chunk_0" / ("out_%d.mut" % w), "rb").read() == fp.z["mut_nc/%d" % w].tobytes(), w
