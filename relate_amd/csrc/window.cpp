@@ -281,6 +281,9 @@ static int place_rows(rl_window *win, int snp, float *kernel_ms) {
           win->start_row[t] = win->b_row[t];  // (else: this target from the stone)
       }
     } else if (last_snp - part_last >= 24) {
+      // (Tried in round 4: the anchor 1.2 sqrt(parts left) parts above this one instead of halfway -- by a count of
+      //  part-lengths, tools/exp/anchor_rule.py, 177 instead of 252 for 37 parts -- made the stage SLOWER: 15 ms per
+      //  launch instead of 10, 172.7 s instead of 159.4 s at 108 workers.  The count is not the cost.)
       const int anchor = part_last + (last_snp - part_last) / 2;
       std::vector<int32_t> more(nloc, 0);
       for (int s0 = part_last + 1; s0 <= anchor; s0++)
