@@ -242,14 +242,19 @@ class ThreadFabric:
         self.hub.barrier.wait()  # (nobody overwrites its send block while another rank still copies from it)
 
 
+def on_device_rows(fab):
+    """does this fabric keep the row blocks on a GPU (then the windows' rows compete for its HBM)"""
+    return getattr(fab, "device", None) is not None and fab.device.type == "cuda"
+
+
 def deal_sections(sections, rank, world):
     """the sections a rank owns: round-robin in the given order (every rank computes the same deal)"""
     return [s for i, s in enumerate(sections) if i % world == rank]
 
 
 def run_chunk_by_targets(out_dir, chunk_index=0, painting=None, device=None, sections=None, in_flight=4,
-                         build_on_gpu=True, window_rows=0, sum_mode=0, from_paint_files=False, no_consistency=False,
-                         fb=0, fabric=None, shard=None, num_sections=None, N=None, idle_sleep=0.001):
+                         build_on_gpu=True, window_rows=None, sum_mode=0, from_paint_files=False, no_consistency=False,
+                         fb=0, fabric=None, shard=None, num_sections=None, N=None, idle_sleep=0.001):  # noqa: C901
     """Paint -> BuildTopology of ONE chunk too large for one GPU, sharded by target haplotype (BASELINE.json config #5):
     this rank paints target_range(rank, world, N), owns deal_sections(sections) -- at most `in_flight` at a time, a host
     thread each -- and serves its rows of every matrix any owner asks for (see the protocol above).  Writes
@@ -258,7 +263,8 @@ def run_chunk_by_targets(out_dir, chunk_index=0, painting=None, device=None, sec
 
     fabric: TorchFabric (default: the torch.distributed job, one process per GPU) or a ThreadFabric.  shard: an object
     with api.Shard's methods (default: api.Shard for this rank's range; tests pass stand-ins).  window_rows: posterior
-    rows a window keeps resident (0 = all; a rank holds in_flight x world windows of its share of the targets)."""
+    rows a window keeps resident (None = from the free HBM, 0 = all; a rank holds in_flight x world windows of its
+    share of the targets)."""
     import ctypes as C
     import threading
     import time
@@ -281,6 +287,18 @@ def run_chunk_by_targets(out_dir, chunk_index=0, painting=None, device=None, sec
     if (shard.k_begin, shard.k_end) != target_range(rank, world, N):
         raise ValueError("rank %d of %d holds targets %d..%d, not %s" % (rank, world, shard.k_begin, shard.k_end,
                                                                           target_range(rank, world, N)))
+    if window_rows is None:
+        # from the HBM that is free once the shard has painted: this rank serves in_flight x world windows at a time
+        # (its targets' rows of every section in flight anywhere), a posterior row is ~4.2 N bytes, and the trees of
+        # the sections it owns need ~17 N^2 bytes each on the device; 0.7 of what is left for the rows
+        window_rows = 0
+        if on_device_rows(fab):
+            free_b = torch.cuda.mem_get_info(fab.device)[0]
+            free_b -= (17.0 * N * N * min(max(1, int(in_flight)), max(1, len(deal_sections(
+                list(range(shard.W if num_sections is None else num_sections)) if sections is None else list(sections),
+                rank, world)))) if build_on_gpu else 0.0)
+            window_rows = max(3 * (shard.k_end - shard.k_begin) + 64,
+                              int(0.7 * max(free_b, 0.0) / (max(1, int(in_flight)) * world * 4.2 * N)))
     if window_rows:
         shard.set_window_rows(window_rows)
     todo = list(range(shard.W if num_sections is None else num_sections)) if sections is None else list(sections)
@@ -441,8 +459,8 @@ def main(argv=None):
                     help="every chunk sharded by TARGET haplotype over all ranks (BASELINE.json config #5: a chunk whose "
                          "stepping stones do not fit one GPU; run_chunk_by_targets) instead of chunk c on rank c mod G")
     ap.add_argument("--in-flight", dest="in_flight", type=int, default=4, help="--by-targets: sections a rank owns at once")
-    ap.add_argument("--window-rows", dest="window_rows", type=int, default=0,
-                    help="--by-targets: posterior rows a window keeps resident per rank (0: all)")
+    ap.add_argument("--window-rows", dest="window_rows", type=int, default=None,
+                    help="--by-targets: posterior rows a window keeps resident per rank (default: from the free HBM; 0: all)")
     ap.add_argument("--stages", default=None,
                     help="importable module with stage_paint, stage_build_topology, stage_paint_build_topology, "
                          "stage_find_equivalent_branches, num_sections (default: relate_amd.api, the GPU library) -- e.g. "
