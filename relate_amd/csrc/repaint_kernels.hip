@@ -119,7 +119,9 @@ RL_DEV void repaint_forward(const RepaintParams &p, int n, float *stage, WaveLin
     lsf = (float)p.fscal[(size_t)t * 4 + 2];
     ssum = 0.0;
   }
-  store_row<S>(ckrows + (int64_t)(f0 / CK) * ROW, a);  // the row the pass starts from is a checkpoint (row 0 always is)
+  // the row the pass starts from is a checkpoint (row 0 always is) -- kept if the backward pass rebuilds rows from its
+  // block (a later launch of a bounded window addresses the strips compactly, from the block of row_lo on: window.cpp)
+  if (!p.partial || f0 + CK > (int)p.row_lo[t]) store_row<S>(ckrows + (int64_t)(f0 / CK) * ROW, a);
   if (scribe) {
     side[(size_t)f0 * REPAINT_SIDE + 0] = 0.0;
     side[(size_t)f0 * REPAINT_SIDE + 1] = 0.0;

@@ -840,21 +840,6 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
       rl_destroy(ctx);
       return RL_ENOMEM;
     }
-    // RELATE_AMD_REPAINT_LANES=2: a second RePaint lane (common.h).  Not the default: its strips are sized for a
-    // window's first, whole pass like the first lane's (C3: 7 GB), and at C3 that is what lets 134 sections open
-    // instead of 89 -- two lanes and 89 sections in three waves: 183 s (no section waits for RePaint, 71 s busy),
-    // one lane and 134 sections: 173 s.
-    if (last_section > first_section && knob("RELATE_AMD_REPAINT_LANES", o.repaint_lanes, o.repaint_lanes > 0, 1) == 2 &&
-        !ctx->two_lanes) {
-      auto &ln = ctx->lane2;
-      if (ln.scratch.alloc(strips) == 0 && make_stream(&ln.s, false) == hipSuccess &&
-          hipEventCreate(&ln.e0) == hipSuccess && hipEventCreate(&ln.e1) == hipSuccess) {
-        ctx->two_lanes = true;
-      } else {
-        (void)hipGetLastError();
-        ln.scratch.release();
-      }
-    }
     size_t free_b = 0, total_b = 0;
     const bool known = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
     const double room = known ? 0.9 * (double)free_b : 0.0;
@@ -879,6 +864,30 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
       int parts = 1;
       while (parts < parts_max && fits(parts) < nthreads) parts++;
       if (parts > 1) cap_rows = (long long)std::max({max_rows / parts, 3.0 * ctx->nloc + 64.0});
+    }
+    // A SECOND lane of RePaint launches for bounded windows (common.h; RELATE_AMD_REPAINT_LANES / rl_stage_opts decide
+    // otherwise): a launch is a forward and a backward kernel of one workgroup per target, each as long as its longest
+    // target, on the CUs the tree builder's workers leave -- two windows' launches side by side fill each other's
+    // tails, and no section waits for its turn behind a hundred others.  Round 3 sized its strips like the first
+    // lane's, for a window's first whole pass (7 GB at C3: 45 sections' worth of rows); a partial launch addresses its
+    // strips compactly (window.cpp place_rows) and the second lane takes partial launches only: kept rows / 6 + 2 per
+    // target rows of doubles + the side records, 0.7 GB.  NOT the default all the same: with all 134 sections open the
+    // two lanes' launches share the CUs the workers leave and each takes as much longer as it overlaps (C3, 104
+    // workers: 162.6 s with two lanes, 161.9 s with one; 116 workers 166.5 s; 128 workers 219 s,
+    // profiles/r04_c3_workers.json) -- RePaint is bound by the CUs it gets, not by its queue.
+    if (last_section > first_section && cap_rows > 0 &&
+        knob("RELATE_AMD_REPAINT_LANES", o.repaint_lanes, o.repaint_lanes > 0, 1) == 2 && !ctx->two_lanes) {
+      auto &ln = ctx->lane2;
+      const size_t row_doubles = (size_t)ctx->S * 64 * ctx->waves;
+      const size_t small = (size_t)(((double)cap_rows / REPAINT_CHECKPOINT + 2.0 * ctx->nloc + 64.0) * (double)row_doubles +
+                                    max_rows * REPAINT_SIDE) * sizeof(double);
+      if (ln.scratch.alloc(small) == 0 && make_stream(&ln.s, false) == hipSuccess &&
+          hipEventCreate(&ln.e0) == hipSuccess && hipEventCreate(&ln.e1) == hipSuccess) {
+        ctx->two_lanes = true;
+      } else {
+        (void)hipGetLastError();
+        ln.scratch.release();
+      }
     }
     if (known) {
       const double per_window = window_bytes((first_section + last_section) / 2) + builder_bytes;

@@ -40,6 +40,7 @@ struct rl_window {
   // the device in ONE copy from a pinned block, on RePaint's stream and in its turn: six blocking copies from
   // pageable memory took 50-180 ms per launch with a hundred sections copying
   DevBuf d_place;
+  int64_t ck_rows_launch = 0;  // checkpoint rows the strips of the next launch hold (compact for a partial launch)
   unsigned char *h_place = nullptr;
   size_t h_place_bytes = 0;
   std::vector<int32_t> b_row, start_row, save_row;  // [nloc]
@@ -84,13 +85,16 @@ static int repaint_rows(rl_window *win, float *kernel_ms) {
   const int N = ctx->N, S = ctx->S, waves = ctx->waves, nloc = win->nloc;
   // the checkpoint rows and side records of the forward kernel are scratch of the launch: one buffer per context,
   // launches are serialised
-  const int64_t ck_doubles = win->ck_off[nloc] * (int64_t)S * 64 * waves;
+  const int64_t ck_doubles = win->ck_rows_launch * (int64_t)S * 64 * waves;
+  const size_t scratch_bytes = (size_t)(ck_doubles + win->top_off[nloc] * REPAINT_SIDE) * sizeof(double);
+  // (the second lane's strips are sized for partial launches: a window's first, whole pass takes the first lane)
+  const bool first_lane_only = !win->have_logscales || scratch_bytes > ctx->lane2.scratch.bytes;
   const auto t_ask = std::chrono::steady_clock::now();
   // (whichever lane is free; with both taken, the windows queue up behind the two in turn)
   static std::atomic<unsigned> turn{0};
   std::unique_lock<std::mutex> one_at_a_time(ctx->repaint_mutex, std::defer_lock);
   bool second = false;
-  if (!ctx->two_lanes) {
+  if (!ctx->two_lanes || first_lane_only) {
     one_at_a_time.lock();
   } else if (!one_at_a_time.try_lock()) {
     std::unique_lock<std::mutex> other(ctx->lane2.m, std::try_to_lock);
@@ -110,7 +114,7 @@ static int repaint_rows(rl_window *win, float *kernel_ms) {
   rl::DevBuf &scratch = second ? ctx->lane2.scratch : ctx->d_k2_scratch;
   const auto t_got = std::chrono::steady_clock::now();
   win->t_turn += std::chrono::duration<double>(t_got - t_ask).count();
-  int rc = scratch.alloc(repaint_scratch_bytes(win->top_off[nloc], nloc, S, waves));
+  int rc = scratch.alloc(scratch_bytes);
   if (rc) return rc;
   RepaintParams p;
   p.lay = ctx->lay;
@@ -145,7 +149,7 @@ static int repaint_rows(rl_window *win, float *kernel_ms) {
   p.topology = win->d_top.as<float>();
   p.logscales = win->d_ls.as<float>();
   p.scratch = scratch.as<double>();
-  p.ck_off = win->d_ck_off.as<int64_t>();
+  p.ck_off = reinterpret_cast<const int64_t *>(win->d_place.as<unsigned char>() + (size_t)nloc * 40);
   p.side = p.scratch + ck_doubles;
   p.order = win->d_order.as<int32_t>();
   p.sum_mode = win->sum_mode;
@@ -155,7 +159,7 @@ static int repaint_rows(rl_window *win, float *kernel_ms) {
   p.fstate = win->d_fstate.as<double>();
   p.fscal = win->d_fscal.as<double>();
   (void)N;
-  bool ok = hipMemcpyAsync(win->d_place.p, win->h_place, (size_t)nloc * 40, hipMemcpyHostToDevice, stream) == hipSuccess;
+  bool ok = hipMemcpyAsync(win->d_place.p, win->h_place, (size_t)nloc * 48, hipMemcpyHostToDevice, stream) == hipSuccess;
   ok = ok && hipEventRecord(e0, stream) == hipSuccess;
   hipError_t le = ok ? launch_repaint(p, S, waves, stream) : hipErrorUnknown;
   ok = ok && le == hipSuccess;
@@ -246,8 +250,8 @@ static int place_rows(rl_window *win, int snp, float *kernel_ms) {
               (long long)win->cap_rows);
     return RL_ENOMEM;
   }
-  int rc = win->d_place.alloc((size_t)nloc * 40);
-  if (!rc && !win->h_place && !(win->h_place = static_cast<unsigned char *>(pinned_cache_alloc((size_t)nloc * 40, &win->h_place_bytes)))) {
+  int rc = win->d_place.alloc((size_t)nloc * 48);
+  if (!rc && !win->h_place && !(win->h_place = static_cast<unsigned char *>(pinned_cache_alloc((size_t)nloc * 48, &win->h_place_bytes)))) {
     set_error("window %d: no pinned host memory for the launch arguments", win->w);
     rc = RL_ENOMEM;
   }
@@ -323,6 +327,25 @@ static int place_rows(rl_window *win, int snp, float *kernel_ms) {
     memcpy(hp + (size_t)nloc * 28, win->save_row.data(), (size_t)nloc * 4);
     memcpy(hp + (size_t)nloc * 32, win->fstart_row.data(), (size_t)nloc * 4);
     memcpy(hp + (size_t)nloc * 36, win->fsave_row.data(), (size_t)nloc * 4);
+    // Where target t's checkpoint rows lie in the launch's strips.  The first launch of a window makes ALL rows'
+    // logscales and checkpoints: the window-wide offsets (7 GB of strips at C3).  A later, partial launch writes and
+    // reads only the blocks its kept rows [row_lo, row_hi) are rebuilt from: those are packed target after target --
+    // ck_off'[t] + block = (blocks before t) - block(row_lo[t]) + block --, (kept rows / 6 + 2 per target) rows of
+    // doubles, 0.6 GB at C3: what lets a SECOND lane of RePaint launches cost no sections (round 4).
+    int64_t *ck = reinterpret_cast<int64_t *>(hp + (size_t)nloc * 40);
+    constexpr int CKR = REPAINT_CHECKPOINT;
+    if (!win->have_logscales) {
+      for (int t = 0; t < nloc; t++) ck[t] = win->ck_off[t];
+      win->ck_rows_launch = win->ck_off[nloc];
+    } else {
+      int64_t before = 0;
+      for (int t = 0; t < nloc; t++) {
+        const int b0 = win->row_lo[t] / CKR, b1 = std::max(win->row_hi[t] - 1, win->row_lo[t]) / CKR;
+        ck[t] = before - b0;
+        before += b1 - b0 + 1;
+      }
+      win->ck_rows_launch = before;
+    }
   }
   win->t_place += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_in).count();
   return rc ? rc : repaint_rows(win, kernel_ms);
