@@ -1946,7 +1946,16 @@ class BuildQueue {
         // launch -- its workgroups dealt to the XCDs in the same round-robin -- lasts as long as the XCD with the
         // fewest CUs left.  Whole rounds only.
         n = (n + MM_XCDS - 1) / MM_XCDS * MM_XCDS;
-        n = std::max(1, std::min(n, goal - alive));
+        if (goal >= MM_XCDS) {
+          // (`alive` counts live workers since round 4, so what is missing need not be a whole round: wait until it is)
+          n = std::min(n, (goal - alive) / MM_XCDS * MM_XCDS);
+          if (n <= 0) {
+            std::this_thread::sleep_for(std::chrono::microseconds(300));
+            continue;
+          }
+        } else {
+          n = std::max(1, std::min(n, goal - alive));
+        }
         const int l = free_stream;
         __atomic_store_n(&q_->gone[l], 0u, __ATOMIC_RELEASE);  // (the stream's previous launch is through)
         const long long idle = (long long)idle_ms_ * 100000LL;

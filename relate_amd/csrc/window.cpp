@@ -334,7 +334,8 @@ static int place_rows(rl_window *win, int snp, float *kernel_ms) {
     // doubles, 0.6 GB at C3: what lets a SECOND lane of RePaint launches cost no sections (round 4).
     int64_t *ck = reinterpret_cast<int64_t *>(hp + (size_t)nloc * 40);
     constexpr int CKR = REPAINT_CHECKPOINT;
-    if (!win->have_logscales) {
+    static const bool compact = !(getenv("RELATE_AMD_COMPACT_STRIPS") && atoi(getenv("RELATE_AMD_COMPACT_STRIPS")) == 0);
+    if (!win->have_logscales || !compact) {
       for (int t = 0; t < nloc; t++) ck[t] = win->ck_off[t];
       win->ck_rows_launch = win->ck_off[nloc];
     } else {
