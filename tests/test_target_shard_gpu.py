@@ -73,7 +73,7 @@ def test_target_ranges_reproduce_the_full_chunk(N, L, budget, parts, mode):
 
 @pytest.mark.parametrize("name,parts,build_on_gpu,in_flight,from_files", [
     ("synth70", 2, True, 2, False), ("synth70", 3, False, 3, False), ("synth24", 4, True, 1, True),
-    ("synth40_noisy", 3, True, 4, False)])
+    ("synth40_noisy", 3, True, 4, False), ("synth70", 8, True, 2, False)])
 def test_sharded_route_writes_the_reference_files(tmp_path, name, parts, build_on_gpu, in_flight, from_files):
     """relate_amd.dist.run_chunk_by_targets (config #5's route) on golden chunks: `parts` ranks (threads on this GPU)
     paint their target ranges, the sections are dealt to them as owners, every matrix is assembled from all ranks' rows
