@@ -273,3 +273,27 @@ def test_stage_options_through_the_abi(tmp_path):
     for w in range(fp.W):
         assert open(plain_dir / "chunk_0" / ("out_%d.anc" % w), "rb").read() == fp.z["anc_nc/%d" % w].tobytes(), w
         assert open(plain_dir / "chunk_0" / ("out_%d.mut" % w), "rb").read() == fp.z["mut_nc/%d" % w].tobytes(), w
+
+
+def test_cli_fast_mode_through_the_file_stages(tmp_path):
+    """--sum_mode lanes32 through the two file-based stages: Paint writes paint files of the reference's format (every
+    record decodes; the same boundary SNPs as the reference's), BuildTopology builds valid binary trees from them at the
+    reference's tree positions or others -- the fast mode promises the tolerance on the distances, not the bytes"""
+    import numpy as np
+    import rlutil
+    work = tmp_path / "work"
+    (work / "out").mkdir(parents=True)
+    fx = Fixture("synth70", work / "out")
+    run_cli(["--mode", "Paint", "--chunk_index", "0", "--sum_mode", "lanes32", "-o", "out"], str(work))
+    for w in range(fx.W):
+        got = open(work / "out" / "chunk_0" / "paint" / ("relate_%d.bin" % w), "rb").read()
+        assert got[:8] == fx.paint_file(w)[:8]  # (section_startpos, section_endpos of the first record)
+        assert 0.5 < len(got) / len(fx.paint_file(w)) < 2.0
+    run_cli(["--mode", "BuildTopology", "--chunk_index", "0", "--first_section", "0", "--last_section", str(fx.W - 1),
+             "--sum_mode", "lanes32", "-o", "out"], str(work))
+    for w in range(fx.W):
+        N, trees = rlutil.parse_anc(str(work / "out" / "chunk_0" / ("out_%d.anc" % w)))
+        assert N == fx.N and len(trees) >= 1
+        for t in trees:
+            par = t[1]
+            assert par[-1] == -1 and np.all(np.bincount(par[:-1], minlength=2 * N - 1)[N:] == 2)
