@@ -307,6 +307,13 @@ def main():
                               ms_per_step=1e3 * adt / max(1, args.steps), kernel_ms=ak, fwd_alone_ms=af, bwd_alone_ms=ab,
                               roofline_frac=(2.0 * N * sites / 8.0) / (ak * 1e-3) / 1e9 / HBM_PEAK_GBS,
                               bit_identical_to_reference=(name == "exact"))
+            # the resource that binds is VALU issue (one instruction per lane and cycle, packed or not): useful
+            # instructions per pair of directional updates -- 9 on doubles, 5 with two donors per packed instruction
+            useful_n = 5.0 if name == "lanes32" else 9.0
+            alts[name]["valu_issue"] = {"useful_instr_per_update_pair": useful_n,
+                                        "achieved_Tinstr_per_s": useful_n * N * sites / (ak * 1e-3) / 1e12,
+                                        "peak_Tinstr_per_s": FP64_PEAK_TINSTR,
+                                        "frac": useful_n * N * sites / (ak * 1e-3) / 1e12 / FP64_PEAK_TINSTR}
             if fast_report and name in ("lanes", "lanes32"):
                 alts[name]["against_reference_at_N5000"] = {
                     k[len("n5000_" + name + "_"):]: v for k, v in fast_report.items() if k.startswith("n5000_" + name + "_")}
