@@ -144,6 +144,7 @@ struct rl_ctx {
   float *h_alpha = nullptr, *h_beta = nullptr;
   rl::DevBuf d_k2_scratch;  // RePaint's checkpoint rows and side records of one launch, shared by the context's
                             // windows (window.cpp)
+  rl::DevBuf d_k2_dstate;   // ... and where the descent kernel of a bounded window's launch leaves its state
   // The fused Paint + BuildTopology stage owns the stones and nobody reads them after the windows: a window
   // quantises ITS slice where it lies (once: stone_quantised[w]) and re-paints from there, instead of keeping a
   // 2 N^2-float copy per open section.
@@ -161,7 +162,7 @@ struct rl_ctx {
     std::mutex m;
     hipStream_t s = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    rl::DevBuf scratch;
+    rl::DevBuf scratch, dstate;
   } lane2;
   bool two_lanes = false;
   std::atomic<long long> repaint_launches{0};  // RePaint launches of the context's windows

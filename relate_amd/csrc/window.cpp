@@ -158,6 +158,21 @@ static int repaint_rows(rl_window *win, float *kernel_ms) {
   p.bscal = win->d_bscal.as<double>();
   p.fstate = win->d_fstate.as<double>();
   p.fscal = win->d_fscal.as<double>();
+  // a bounded window's launch is mostly the way DOWN to its part: that goes first, as a kernel of its own at two waves
+  // a SIMD (repaint_kernels.hip: repaint_descent_kernel), through a state buffer of the lane
+  p.dstate = nullptr;
+  p.dscal = nullptr;
+  // (Built and measured in round 4, NOT the default: on one box, alternating, the C3 stage took 162.0 / 157.6 s with
+  //  it and 157.1 / 157.0 s without -- a third kernel per launch and 0.4 GB of state written and read back cost what
+  //  the second wave per SIMD gains.  RELATE_AMD_DESCENT_KERNEL=1 turns it on.)
+  static const bool descent = getenv("RELATE_AMD_DESCENT_KERNEL") && atoi(getenv("RELATE_AMD_DESCENT_KERNEL")) != 0;
+  if (descent && win->cap_rows < win->top_off[nloc]) {
+    rl::DevBuf &ds = second ? ctx->lane2.dstate : ctx->d_k2_dstate;
+    const size_t state_bytes = (size_t)nloc * S * 64 * waves * sizeof(double);
+    if ((rc = ds.alloc(state_bytes + (size_t)nloc * 4 * sizeof(double)))) return rc;
+    p.dstate = ds.as<double>();
+    p.dscal = reinterpret_cast<double *>(ds.as<unsigned char>() + state_bytes);
+  }
   (void)N;
   bool ok = hipMemcpyAsync(win->d_place.p, win->h_place, (size_t)nloc * 48, hipMemcpyHostToDevice, stream) == hipSuccess;
   ok = ok && hipEventRecord(e0, stream) == hipSuccess;
