@@ -5,6 +5,8 @@ needs the eight GPUs) through relate_amd.dist.run_chunk_by_targets -- `ranks` ta
 (1 by default), every matrix assembled from all ranks' rows, the trees built by the device workers.
 
     python tools/chunk_c5_sharded.py [N L memory_GB sections in_flight window_fraction ranks]
+    (window_fraction: share of a window's posterior rows kept resident; 1: all; < 0: from the free HBM, the default of
+    run_chunk_by_targets)
 
 Prints one JSON line: wall-clock of Paint + BuildTopology of the first `sections` sections, trees, trees/s, md5 of
 section 0's files (tools/chunk_wallclock_big.py N L mem 1 ref gives the reference's for the same chunk)."""
@@ -53,7 +55,8 @@ try:
     def body(rk):
         try:
             res[rk] = rdist.run_chunk_by_targets(d, 0, device=0, sections=list(range(sections)), in_flight=in_flight,
-                                                 build_on_gpu=True, window_rows=int(frac * rows / ranks) if frac < 1.0 else 0,
+                                                 build_on_gpu=True,
+                                                 window_rows=None if frac < 0 else (int(frac * rows / ranks) if frac < 1.0 else 0),  # (< 0: sized from the free HBM)
                                                  fabric=rdist.ThreadFabric(hub, rk, device=0))
         except BaseException as e:
             errs[rk] = e
