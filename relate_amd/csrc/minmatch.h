@@ -164,8 +164,12 @@ class MinMatch {
 // sample ages as a third key, gated by an expected-coalescence clock.  Sequential, stateful across builds where the
 // reference is (min_values_CF, the unique-age table, the `cand` scratch candidate).
 class MinMatchAges {
+  friend class DeviceMinMatch;
+
  public:
   MinMatchAges(int N, double theta);
+  // the sorted distinct sample ages and how many samples have each (tree_builder.cpp:1125-1152): once per builder
+  void prepare_levels(const std::vector<double> &sample_ages);
   // d: N*N floats, destroyed.  prior: N*N floats or nullptr.  sample_ages: N values.
   void quick_build(float *d, const float *prior, const std::vector<double> &sample_ages, HostTree &tree);
 
@@ -214,8 +218,12 @@ class DeviceMinMatch {
   DeviceMinMatch(const DeviceMinMatch &) = delete;
   DeviceMinMatch &operator=(const DeviceMinMatch &) = delete;
   int build(MinMatch &tb, const float *d, const float *prior, HostTree &tree);
+  // with sample ages (`--sample_ages`): the builder whose state this one takes and puts back is a MinMatchAges
+  int build(MinMatchAges &tb, const std::vector<double> &sample_ages, const float *d, const float *prior, HostTree &tree);
+  int build_resident(MinMatchAges &tb, const std::vector<double> &sample_ages, bool with_prior, HostTree &tree);
+  void forget_ages();  // the next build with sample ages comes with other ages: their table goes to the device again
   // the buffers a build keeps for itself (the woven matrix, 16 N^2 B, and small ones), allocated now: 0 or < 0
-  int reserve();
+  int reserve(bool ages = false);
   // The same without the matrices crossing PCIe: the caller has the distance matrix written into
   // device_matrix() (K3, rl_window_matrix_rows_device), the carrier penalty and the clade prior of the previous
   // tree are applied on the device (anc_builder.cpp:563-606), build_resident builds from what is there.
@@ -225,7 +233,9 @@ class DeviceMinMatch {
   int build_resident(MinMatch &tb, bool with_prior, HostTree &tree);
 
  private:
-  int build_impl(MinMatch &tb, const float *d, const float *prior, bool resident, bool with_prior, HostTree &tree);
+  template <class TB>
+  int build_impl(TB &tb, const std::vector<double> *sample_ages, const float *d, const float *prior, bool resident,
+                 bool with_prior, HostTree &tree);
   struct Impl;
   Impl *impl;
 };
@@ -235,6 +245,7 @@ class DeviceMinMatch {
 double device_builder_shared_bytes(int N);
 int device_builder_reserve_shared(int device, int N);
 // how many builders of trees of N leaves will ask the device's workers at the same time (0: unknown)
-int device_builder_expect(int device, int N, int builders);
+// (ages: the builders with sample ages -- their workers are another kernel)
+int device_builder_expect(int device, int N, int builders, bool ages = false);
 
 }  // namespace rl

@@ -201,6 +201,30 @@ void MinMatchAges::coalesce(int i, int j, const std::vector<double> &ages) {
   take_best(mc[j]);
 }
 
+// :1125-1152, once per builder
+void MinMatchAges::prepare_levels(const std::vector<double> &ages) {
+  if (!unique_ages.empty()) return;
+  std::vector<double> sorted = ages;
+  std::sort(sorted.begin(), sorted.end());
+  double a = sorted[0];
+  unique_ages.assign(sorted.size(), 0.0);
+  ages_count.assign(sorted.size(), 0);
+  int u = 0;
+  unique_ages[0] = a;
+  for (double x : sorted) {
+    if (x == a) {
+      ages_count[u]++;
+    } else {
+      a = x;
+      u++;
+      unique_ages[u] = a;
+      ages_count[u]++;
+    }
+  }
+  unique_ages.resize(u + 1);
+  ages_count.resize(u + 1);
+}
+
 // tree_builder.cpp:1061-1233 (no prior), :2358-2531 (prior); sample_ages.size() == N
 void MinMatchAges::quick_build(float *dmat, const float *prior, const std::vector<double> &sample_ages_in, HostTree &tree) {
   rng.seed(1);
@@ -225,27 +249,7 @@ void MinMatchAges::quick_build(float *dmat, const float *prior, const std::vecto
   if (!prior) best.replace = false;  // (:1117 -- the build with a prior leaves the flag as the last build left it)
   sym.reset();
 
-  if (unique_ages.empty()) {  // :1125-1152, once per builder
-    std::vector<double> sorted = ages;
-    std::sort(sorted.begin(), sorted.end());
-    double a = sorted[0];
-    unique_ages.assign(sorted.size(), 0.0);
-    ages_count.assign(sorted.size(), 0);
-    int u = 0;
-    unique_ages[0] = a;
-    for (double x : sorted) {
-      if (x == a) {
-        ages_count[u]++;
-      } else {
-        a = x;
-        u++;
-        unique_ages[u] = a;
-        ages_count[u]++;
-      }
-    }
-    unique_ages.resize(u + 1);
-    ages_count.resize(u + 1);
-  }
+  prepare_levels(ages);
   int level = 0;
   int num_lins = ages_count[level];
   // the clock starts one expected coalescence in without a prior (:1155), at the youngest samples with one (:2440)

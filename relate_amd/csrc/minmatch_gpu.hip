@@ -50,6 +50,7 @@ constexpr int MM_ROWS = MM_ROWS_N;  // rows of rebuilt clusters scanned per pass
 constexpr int MM_HITS = 64;       // mutually close pairs per row pairscan_kernel keeps; more: the host builds the tree
 constexpr int MM_UPD_MAX = 512;   // rebuilt clusters of one merge (list in LDS); more: the host builds the tree
 constexpr int MM_PAIRS_LDS = 768; // feasible pairs of one merge kept in LDS; more go through global scratch
+constexpr int MM_BUCKET_MIN = 2048;  // (the AGES build) more pairs than this are put in order bucket by bucket
 // M is stored in column panels of 64: element (a, b) at ((b / 64) * N + a) * 64 + b % 64.  A row is N / 64 runs of
 // 1 KB (a wavefront's 64 consecutive clusters: one run), 64 * N elements apart; a COLUMN -- what a merge scatters its
 // one store per cluster down -- strides by 1 KB inside one panel of N KB, a few 2 MB pages, instead of by a whole
@@ -117,7 +118,26 @@ constexpr int MM_Q_LDS = 5120 / MM_BLOCK, MM_Q_GLOB = MM_MAXN / MM_BLOCK;  // re
   PTR(volatile int) host_done;                                                                                       \
   long long pair_cap;                                                                                                \
   PTR(long long) timers; /* optional: 100 MHz ticks per phase (RELATE_AMD_TIMING) */                                 \
-  PTR(unsigned) trace;   /* optional (RELATE_AMD_MM_TRACE): [0] merge, [1] phase the workgroup has reached */
+  PTR(unsigned) trace;   /* optional (RELATE_AMD_MM_TRACE): [0] merge, [1] phase the workgroup has reached */     \
+  /* --sample_ages (the AGES build): the candidates' draw as a double and their third key as the INDEX of the age   \
+     among the sorted distinct sample ages (MM_AGE_EMPTY: no candidate); per cluster the index of its oldest sample \
+     (age_lvl0: as the samples are, age_lvl: the build's own copy); the distinct ages, how many samples have each */ \
+  PTR(double) mc_dist2d;                                                                                             \
+  PTR(int) mc_lvl;                                                                                                   \
+  PTR(int) age_lvl;                                                                                                  \
+  PTR(const int) age_lvl0;                                                                                           \
+  PTR(const double) unique_ages;                                                                                     \
+  PTR(const int) ages_count;                                                                                         \
+  int n_levels;                                                                                                      \
+  int Ne; /* pipeline/BuildTopology.cpp:36 */                                                                        \
+  /* the rebuilt clusters of a merge beyond MM_UPD_MAX (there a renamed candidate follows its lineage up the tree,  \
+     :2342, and a merge of that lineage sends every cluster holding one through the rebuilding branch) */          \
+  PTR(unsigned) upd_g; /* [N] */                                                                                     \
+  PTR(float) updv_g;   /* [N] */                                                                                     \
+  /* ... and, for a merge with thousands of feasible pairs, the pairs per later cluster: counts / fill marks and    \
+     offsets */                                                                                                      \
+  PTR(int) bucket;     /* [N + 1] */                                                                                 \
+  PTR(int) bucket_off; /* [N + 1] */
 #define MM_HOST_PTR(T) T *
 #ifdef MM_FLAT  // (experiment: pointers of unknown address space, as before round 3)
 #define MM_GLOBAL_PTR(T) T *
@@ -207,7 +227,7 @@ struct Best {
   int lin1, lin2;
 };
 
-constexpr int MM_PARAM_WORDS = 80;  // sizeof(MMParams) / 4 rounded up (static_assert below)
+constexpr int MM_PARAM_WORDS = 96;  // sizeof(MMParams) / 4 rounded up (static_assert below)
 struct Shared {
   unsigned praw[MM_PARAM_WORDS];  // the tree's parameters as the worker read them from the queue
   unsigned ticket;
@@ -227,6 +247,8 @@ struct Shared {
   float wave_f2[MM_WAVES];
   float lex_d[MM_WAVES], lex_d2[MM_WAVES];
   int lex_p[MM_WAVES];
+  double lex_d2d[MM_WAVES];  // (the AGES build: the draw is a double)
+  int a_lw;                  // ... and the last age level its clock has reached, for all waves
   int rowcount[MM_WAVES];
   float sym_dist;
   float red_f[MM_ROWS][MM_WAVES];
@@ -361,6 +383,48 @@ __device__ inline void block_min3(float &f, int &a, int &b, float *bf, int *ba, 
   }
 }
 
+// ---- the AGES build (`--sample_ages`; tree_builder.cpp:3-22, :149-252, :601-965 and their twins with a prior)
+// A candidate (dist, dist2, dist3, replace): dist3 -- the older of the pair's two sample ages -- is one of the distinct
+// sample ages and is kept as its index in their sorted table (comparisons of ages = comparisons of indices);
+// `replace` is not stored: after the refresh every merge begins with (:618) it equals "dist3 is beyond the clock" for
+// every candidate there is, and that is how it is set when one is made (:216, :234).  lw = the largest index whose
+// age the clock has reached.
+constexpr int MM_AGE_EMPTY = 0x7fffffff;
+struct AgeCand {
+  float d;
+  double d2;
+  int lv, l1, l2;
+};
+// operator> of tree_builder.cpp:7-22 (a = the holder): with a.replace and a.dist3 >= b.dist3 the first block returns
+// for a.dist3 > b.dist3 and otherwise tests what the second block tests again
+__device__ inline bool ages_gt(const AgeCand &a, float bd, double bd2, int blv, int lw) {
+  const bool a_replace = a.lv != MM_AGE_EMPTY && a.lv > lw;
+  return (a_replace && a.lv > blv) || a.d > bd || (a.d == bd && a.d2 > bd2);
+}
+// "may b take a's place": the test in front of every assignment to a candidate slot (:209-218) and to the running
+// best (:230-237)
+__device__ inline bool ages_takes(const AgeCand &a, float bd, double bd2, int blv, int lw) {
+  return (a.d == INFINITY || blv <= lw) && ages_gt(a, bd, bd2, blv, lw);
+}
+// lexicographic minimum of (d1, d2, pos) over the wave, in every lane
+__device__ inline void wave_lex_min_d(float &d1, double &d2, int &pos) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const float o1 = __shfl_xor(d1, o, 64);
+    const double o2 = __shfl_xor(d2, o, 64);
+    const int op = __shfl_xor(pos, o, 64);
+    if (o1 < d1 || (o1 == d1 && (o2 < d2 || (o2 == d2 && op < pos)))) {
+      d1 = o1;
+      d2 = o2;
+      pos = op;
+    }
+  }
+}
+// one expected coalescence of k lineages (:1155, :1226): 2 / (k (k - 1)) * Ne, every operation rounded by itself
+__device__ inline double ages_step(int k, int Ne) {
+  return __dmul_rn(__ddiv_rn(2.0, __dmul_rn((double)k, (double)k - 1.0)), (double)Ne);
+}
+
 // (32-bit element offsets from a scalar base -- N <= 10240: one address register per load instead of two)
 #define MM(a, b) p.M[mm_index((unsigned)(a), (unsigned)(b), (unsigned)N)]
 #define MM2(a, b) (((MM_GLOBAL_PTR(const f32x2))(p.M + mm_index((unsigned)(a), (unsigned)(b), (unsigned)N)))[0])  // (d(a,b), d(b,a))
@@ -387,8 +451,15 @@ __device__ inline void block_min3(float &f, int &a, int &b, float *bf, int *ba, 
 //      earliest position among exact ties;
 //   E. the merged-away cluster leaves the list.
 // Three dependent memory round trips and eight workgroup barriers per merge; everything else is LDS.
-template <bool LDS, int MAXQ>
+//
+// AGES (`--sample_ages`): the same merge with the candidates' third key and the coalescence clock.  What is a
+// reduction above -- the running best over the clusters in order -- is order-dependent there (a candidate beyond the
+// clock takes an EMPTY place only, one within the clock displaces it whatever its distance), so wave 0 walks the
+// live list once per merge, the pairs applied at their clusters' turns: exact, and slower (data sets with ancient
+// samples are small).  The per-cluster state of that build lives in global memory.
+template <bool LDS, int MAXQ, bool AGES = false>
 __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, unsigned char *dyn) {
+  static_assert(!(AGES && LDS), "the AGES build keeps its state in global memory");
   typedef typename State<LDS>::idx_t idx_t;
   constexpr int ROWS = MAXQ * MM_ROWS > 64 ? 64 / MAXQ : MM_ROWS;  // rows of rebuilt clusters per pass (ROWS * MAXQ <= 64 bits of survivors)
   const int N = p.N;
@@ -462,6 +533,11 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
     st.mcd[c] = INF;
     st.mcd2[c] = INF;
     st.flag[c] = 0;
+    if constexpr (AGES) {
+      p.mc_dist2d[c] = (double)INF;
+      p.mc_lvl[c] = MM_AGE_EMPTY;
+      p.age_lvl[c] = p.age_lvl0[c];
+    }
     if constexpr (LDS) {  // the state carried from tree to tree comes in
       st.lin1[c] = (idx_t)p.mc_lin1[c];
       st.lin2[c] = (idx_t)p.mc_lin2[c];
@@ -500,10 +576,13 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
   // (l + 1)-th uniform float from now -- std::uniform_real_distribution<double>(0,1) of libstdc++ (rng_unif),
   // narrowed to float (tree_builder.hpp:60) --; a pair then takes its number with one readlane instead of two LDS
   // reads and thirty dependent instructions on the ordered path.  (624 is even: a draw never straddles a renewal.)
+  // (the AGES build keeps the draw as the double it is: Candidate::dist2, tree_builder.hpp:26, assigned from the
+  //  distribution directly, :205)
+  typedef typename std::conditional<AGES, double, float>::type rnd_t;
   int ridx = 624;       // (wave 0: position in the generator's state)
-  float rnd_lane = 0.f; // lane l: draw number l of the batch
+  rnd_t rnd_lane = 0;   // lane l: draw number l of the batch
   int rnd_have = 0, rnd_at = 0;
-  auto next_rnd = [&]() -> float {
+  auto next_rnd = [&]() -> rnd_t {
     if (rnd_at >= rnd_have) {
       if (ridx >= 624) {
         rng_renew_wave(sh.rng, lane);
@@ -523,13 +602,69 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
       const double sum = (double)y1 + (double)y2 * 4294967296.0;
       double ret = sum / 18446744073709551616.0;
       if (ret >= 1.0) ret = 0.99999999999999988897769753748434595763683319091796875;
-      rnd_lane = (float)ret;
+      rnd_lane = (rnd_t)ret;
       ridx += 2 * rnd_have;
       rnd_at = 0;
     }
     const int at = __builtin_amdgcn_readfirstlane(rnd_at);
     rnd_at++;
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rnd_lane), at));
+    if constexpr (AGES) {
+      const long long bits = __double_as_longlong(rnd_lane);
+      const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(bits & 0xffffffffll), at);
+      const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(bits >> 32), at);
+      return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    } else {
+      return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rnd_lane), at));
+    }
+  };
+  // ---- AGES: the clock (wave 0 keeps it; tree_builder.cpp:1123-1155 / :2407-2440) and the candidate slots
+  int a_level = 0, a_lins = 0, a_lw = -1;  // sampling level reached, lineages alive there, last level within the clock
+  double a_age = 0.0;
+  auto clock_reaches = [&]() {  // a_lw follows a_age
+    while (a_lw + 1 < p.n_levels && p.unique_ages[a_lw + 1] <= a_age) a_lw++;
+  };
+  if constexpr (AGES) {
+    a_lins = p.ages_count[0];
+    // the clock starts one expected coalescence in without a prior (:1155), at the youngest samples with one (:2440)
+    a_age = p.has_prior ? p.unique_ages[0] : __dadd_rn(p.unique_ages[0], ages_step(a_lins, p.Ne));
+    clock_reaches();
+    if (tid == 0) sh.a_lw = a_lw;
+  }
+  auto slot_of = [&](int c) -> AgeCand {
+    return AgeCand{st.mcd[c], p.mc_dist2d[c], p.mc_lvl[c], (int)st.lin1[c], (int)st.lin2[c]};
+  };
+  // MinMatch's `cand` offered to both of its clusters (:205-218 and every block like it); xs / ys: what x and y hold
+  // afterwards
+  auto apply_ages = [&](int x, int y, float sym, AgeCand &xs, AgeCand &ys) {
+    const double rnd = (double)next_rnd();
+    xs = slot_of(x);
+    ys = slot_of(y);
+    const int clv = max((int)p.age_lvl[x], (int)p.age_lvl[y]);
+    const AgeCand c{sym, rnd, clv, x, y};
+    const bool tx = ages_takes(xs, sym, rnd, clv, a_lw), ty = ages_takes(ys, sym, rnd, clv, a_lw);
+    if (tx) xs = c;
+    if (ty) ys = c;
+    if (lane == 0) {
+      if (tx) {
+        st.lin1[x] = (idx_t)x;
+        st.lin2[x] = (idx_t)y;
+        st.mcd[x] = sym;
+        p.mc_dist2d[x] = rnd;
+        p.mc_lvl[x] = clv;
+      }
+      if (ty) {
+        st.lin1[y] = (idx_t)x;
+        st.lin2[y] = (idx_t)y;
+        st.mcd[y] = sym;
+        p.mc_dist2d[y] = rnd;
+        p.mc_lvl[y] = clv;
+      }
+    }
+  };
+  // the running best of Initialize / Coalesce (:230-237): wave 0's registers
+  AgeCand abest{INF, (double)INF, MM_AGE_EMPTY, -1, -1};
+  auto best_takes = [&](const AgeCand &mcand) {
+    if (ages_takes(abest, mcand.d, mcand.d2, mcand.lv, a_lw)) abest = mcand;
   };
   // one feasible pair in the reference's order: one draw, both clusters' best candidate (:1704-1716); -> the draw
   auto apply = [&](int x, int y, float sym) -> float {
@@ -554,6 +689,20 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
   // mutually close pairs in (a, b) order (:1690-1722): pairscan_kernel has found them; MM_BLOCK rows at a time they
   // are staged in LDS in order and wave 0 draws
   auto draw_staged = [&](int count) {  // wave 0: the staged pairs sh.pxy[0] / sh.psym[0] in order (:1704-1722)
+    if constexpr (AGES) {  // (:205-237)
+      for (int e = 0; e < count; e++) {
+        const unsigned xy = sh.pxy[0][e];
+        AgeCand xs, ys;
+        apply_ages((int)(xy >> 16), (int)(xy & 0xffffu), sh.psym[0][e], xs, ys);
+        best_takes(ys);
+      }
+      if (lane == 0) {
+        sh.best.dist = abest.d;
+        sh.best.lin1 = abest.l1;
+        sh.best.lin2 = abest.l2;
+      }
+      return;
+    }
     Best bb = sh.best;
     for (int e = 0; e < count; e++) {
       const unsigned xy = sh.pxy[0][e];
@@ -595,7 +744,11 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
           const int at = block_scan(hit ? 1 : 0, &cnt, sh.wave_i);
           if (hit) {
             float sym = e.y + e.x;
-            if (p.has_prior && e.z <= st.mvcf[ar] && e.w <= st.mvcf[b]) sym = 0.0f;
+            if constexpr (AGES) {  // (:1792-1797: the pairs the prior agrees with are kept, the others voided)
+              if (p.has_prior && !(e.z <= st.mvcf[ar] && e.w <= st.mvcf[b])) sym = INF;
+            } else {
+              if (p.has_prior && e.z <= st.mvcf[ar] && e.w <= st.mvcf[b]) sym = 0.0f;
+            }
             sh.pxy[0][at] = ((unsigned)ar << 16) | (unsigned)b;
             sh.psym[0][at] = sym;
           }
@@ -731,6 +884,8 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
 #endif
     int a_k[MAXQ];
     float mv_cf = INF, mvj = INF, bd = INF, bd2 = INF;
+    double bd2d = (double)INF;  // (AGES)
+    const int lw_all = AGES ? sh.a_lw : 0;
     int bpos = n;
 #pragma unroll
     for (int q = 0; q < MAXQ; q++) {
@@ -755,6 +910,8 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
       }
       float s_mv[QC], s_d1[QC], s_d2[QC];
       int s_l1[QC], s_l2[QC];
+      double s_d2d[AGES ? QC : 1];
+      int s_lv[AGES ? QC : 1];
 #pragma unroll
       for (int qq = 0; qq < QC; qq++) {
         const int k = a_k[q0 + qq] >= 0 ? a_k[q0 + qq] : 0;
@@ -763,6 +920,10 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
         s_l2[qq] = st.lin2[k];
         s_d1[qq] = st.mcd[k];
         s_d2[qq] = st.mcd2[k];
+        if constexpr (AGES) {
+          s_d2d[qq] = p.mc_dist2d[k];
+          s_lv[qq] = p.mc_lvl[k];
+        }
       }
 #pragma unroll
       for (int qq = 0; qq < QC; qq++) {
@@ -803,14 +964,40 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
         const int l1 = s_l1[qq], l2 = s_l2[qq];
         const bool touches = l1 == j || l2 == j || l1 == i || l2 == i;
         if (p.timers && rescan && !touches) atomicAdd(&sh.cnt_rescan_only, 1);
-        if (rescan || touches) {  // k rebuilds its candidates (:1893-1911)
+        // (AGES with a prior: a candidate that touches i or j alone does not send k through the rebuilding branch
+        //  when none of its four distances moved -- :2131 against :653 --, the candidate is renamed instead, :2342)
+        bool rebuilds = rescan || touches;
+        if constexpr (AGES) rebuilds = rescan || (touches && (!p.has_prior || dkj != dki || djk != dik));
+        if (rebuilds) {  // k rebuilds its candidates (:1893-1911)
           st.flag[k] = 1;
           st.mcd[k] = INF;
           st.mcd2[k] = INF;
+          if constexpr (AGES) {
+            p.mc_dist2d[k] = (double)INF;
+            p.mc_lvl[k] = MM_AGE_EMPTY;
+          }
           const int slot = atomicAdd(&sh.nupd, 1);
           if (slot < MM_UPD_MAX) {
             sh.upd[slot] = (unsigned)ik | (rescan ? 0x10000u : 0u);
             sh.updv[slot] = nkj;
+          } else if constexpr (AGES) {
+            p.upd_g[slot - MM_UPD_MAX] = (unsigned)ik | (rescan ? 0x10000u : 0u);
+            p.updv_g[slot - MM_UPD_MAX] = nkj;
+          }
+        } else if constexpr (AGES) {
+          if (l1 == i) st.lin1[k] = (idx_t)j;
+          if (l2 == i) st.lin2[k] = (idx_t)j;
+          // k keeps its candidate.  The running best (:230-237) takes the first candidate WITHIN the clock with a
+          // finite distance from whatever it holds, from then on nothing but a smaller one of that kind, and a slot
+          // leaves that kind only for a smaller one of it: if one of the clusters that keep theirs holds such a
+          // candidate, the best of the merge is the smallest (dist, dist2) among them all -- a reduction.  If none
+          // does, wave 0 walks the list (below).
+          const float d1 = s_d1[qq];
+          const double d2 = s_d2d[qq];
+          if (s_lv[qq] <= lw_all && d1 < INF && (bd > d1 || (bd == d1 && bd2d > d2))) {
+            bd = d1;
+            bd2d = d2;
+            bpos = ik;
           }
         } else {  // k keeps its candidate: what the reference's running best sees at k's turn
           const float d1 = s_d1[qq], d2 = s_d2[qq];
@@ -824,12 +1011,14 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
     }
     mvj = wave_min_f(mvj);
     mv_cf = wave_min_f(mv_cf);
-    wave_lex_min(bd, bd2, bpos);
+    if constexpr (AGES) wave_lex_min_d(bd, bd2d, bpos);
+    else wave_lex_min(bd, bd2, bpos);
     if (lane == 0) {
       sh.wave_f[wave] = mvj;
       sh.wave_f2[wave] = mv_cf;
       sh.lex_d[wave] = bd;
       sh.lex_d2[wave] = bd2;
+      if constexpr (AGES) sh.lex_d2d[wave] = bd2d;
       sh.lex_p[wave] = bpos;
     }
     __syncthreads();
@@ -843,10 +1032,19 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
     min_value_j += threshold;
     mvcf_j += threshold_CF;
     const int nupd = __builtin_amdgcn_readfirstlane(sh.nupd);
-    if (nupd > MM_UPD_MAX) {  // (degenerate matrices: this tree is the host's)
+    if (!AGES && nupd > MM_UPD_MAX) {  // (degenerate matrices: this tree is the host's)
       bail = 2;
       break;
     }
+    // (the AGES build keeps the list's tail in global memory)
+    auto upd_at = [&](int u) -> unsigned {
+      if constexpr (AGES) return u < MM_UPD_MAX ? sh.upd[u] : p.upd_g[u - MM_UPD_MAX];
+      else return sh.upd[u];
+    };
+    auto updv_at = [&](int u) -> float {
+      if constexpr (AGES) return u < MM_UPD_MAX ? sh.updv[u] : p.updv_g[u - MM_UPD_MAX];
+      else return sh.updv[u];
+    };
     if (p.timers && tid == 0) {
       sh.tacc[12] += nupd * 100;
       sh.tacc[13] += sh.cnt_rescan_only * 100;
@@ -947,7 +1145,7 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
 #pragma unroll
       for (int r = 0; r < ROWS; r++) {
         if (u0 + r >= nupd) continue;
-        const int up = (int)(sh.upd[u0 + r] & 0xffffu);
+        const int up = (int)(upd_at(u0 + r) & 0xffffu);
         const int ku = st.ci[up];
         const float mvk = st.mv[ku];
 #pragma unroll
@@ -968,7 +1166,7 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
         surv &= surv - 1;
         const int r = bit / MAXQ, q = bit - r * MAXQ;
         const int il = q * MM_BLOCK + tid, l = st.ci[il];
-        const int up = (int)(sh.upd[u0 + r] & 0xffffu), ku = st.ci[up];
+        const int up = (int)(upd_at(u0 + r) & 0xffffu), ku = st.ci[up];
         if (il < up)  // the rebuilt cluster meets the clusters before it
           append_pair(((unsigned)up << 16) | (unsigned)il, ku, l);
         else
@@ -1002,10 +1200,10 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
           patch[r] = INF;
         }
         for (; u < nupd && cnt < ROWS; u++) {
-          const unsigned e = sh.upd[u];
+          const unsigned e = upd_at(u);
           if (!(e >> 16)) continue;
           const int k = st.ci[e & 0xffffu];
-          const float pv = sh.updv[u];
+          const float pv = updv_at(u);
 #pragma unroll
           for (int r = 0; r < ROWS; r++)
             if (r == cnt) {
@@ -1022,7 +1220,7 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
       for (int u0 = 0; u0 < nupd; u0 += ROWS) {
         int ks[ROWS];
 #pragma unroll
-        for (int r = 0; r < ROWS; r++) ks[r] = u0 + r < nupd ? (int)st.ci[sh.upd[u0 + r] & 0xffffu] : -1;
+        for (int r = 0; r < ROWS; r++) ks[r] = u0 + r < nupd ? (int)st.ci[upd_at(u0 + r) & 0xffffu] : -1;
         load_rows(ks);
         test_rows(u0);
       }
@@ -1067,8 +1265,81 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
     // Every pair's symmetric distance (tree_builder.cpp:1699-1702): d(y,x) + d(x,y), or 0 when the pair is also
     // mutually closest under the prior -- one element M[x][y] per pair, all pairs at once -- and its place in the
     // reference's order (rank = number of smaller keys).
-    const int side = m > 0 ? 1 : 0;
-    if (m > 0) {
+    int side = m > 0 ? 1 : 0;
+    bool bucketed = false;
+    if constexpr (AGES) bucketed = m > MM_BUCKET_MIN;
+    if (bucketed) {
+      // A merge that sends most clusters through the rebuilding branch has tens of thousands of feasible pairs and the
+      // rank above is quadratic: the pairs are counted per later cluster (bucket n: the merged cluster's), moved to
+      // their bucket, and ranked inside it -- sides 0 -> 1 -> 0.  (Counts are read back past the L1: atomics do not
+      // update it.)
+      auto pair_put = [&](int sd, int e, unsigned key, unsigned xy, float sym) {
+        if (e < MM_PAIRS_LDS) {
+          sh.pk[sd][e] = key;
+          sh.pxy[sd][e] = xy;
+          sh.psym[sd][e] = sym;
+        } else {
+          auto g = p.pair_g + ((size_t)sd * p.pair_cap + (size_t)(e - MM_PAIRS_LDS)) * 3;
+          g[0] = key;
+          g[1] = xy;
+          g[2] = __float_as_uint(sym);
+        }
+      };
+      auto bucket_of = [&](unsigned key) -> int { return (key & 0x80000000u) ? n : (int)(key >> 16); };
+      auto count_of = [&](int b) -> int { return __hip_atomic_load(&p.bucket[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+      for (int x = tid; x <= n; x += MM_BLOCK) __hip_atomic_store(&p.bucket[x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      for (int e = tid; e < m; e += MM_BLOCK) {
+        unsigned key, xy;
+        float sym;
+        pair_at(0, e, key, xy, sym);
+        __hip_atomic_fetch_add(&p.bucket[bucket_of(key)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+      int run = 0;
+      for (int x0 = 0; x0 <= n; x0 += MM_BLOCK) {
+        const int x = x0 + tid;
+        const int c = x <= n ? count_of(x) : 0;
+        int tot;
+        const int off = block_scan(c, &tot, sh.wave_i);
+        if (x <= n) p.bucket_off[x] = run + off;
+        run += tot;
+        __syncthreads();
+      }
+      for (int x = tid; x <= n; x += MM_BLOCK) __hip_atomic_store(&p.bucket[x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      for (int e = tid; e < m; e += MM_BLOCK) {
+        unsigned key, xy;
+        float sym;
+        pair_at(0, e, key, xy, sym);
+        const int b = bucket_of(key);
+        const int at = p.bucket_off[b] + __hip_atomic_fetch_add(&p.bucket[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pair_put(1, at, key, xy, 0.0f);
+      }
+      __syncthreads();
+      for (int e = tid; e < m; e += MM_BLOCK) {
+        unsigned key, xy;
+        float sym;
+        pair_at(1, e, key, xy, sym);
+        const int b = bucket_of(key);
+        const int lo = p.bucket_off[b], hi = lo + count_of(b);
+        int rank = lo;
+        for (int g = lo; g < hi; g++) {
+          unsigned kg, xg;
+          float sg;
+          pair_at(1, g, kg, xg, sg);
+          rank += kg < key ? 1 : 0;
+        }
+        const int x = (int)(xy >> 16), y = (int)(xy & 0xffffu);
+        const f32x4 f = MM(x, y);
+        sym = f.y + f.x;
+        if (p.has_prior && f.z <= st.mvcf[x] && f.w <= (y == j ? mvcf_j : st.mvcf[y])) sym = 0.0f;
+        // (side 0 is read by nobody any more: every thread is past its last pair_at(0, ...) -- the barrier above)
+        pair_put(0, rank, key, xy, sym);
+      }
+      __syncthreads();
+      side = 0;
+    } else if (m > 0) {
       for (int e = tid; e < m; e += MM_BLOCK) {
         unsigned key, xy;
         float sym;
@@ -1099,7 +1370,7 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
     // -- E (first half): the merged-away cluster leaves the list, the rebuilt marks are taken back -- under the
     // ordered part, which names clusters, not positions, from here on (the symmetric path, rare, keeps the list
     // until it is through)
-    const bool sym_now = sh.use_sym != 0;
+    const bool sym_now = AGES || sh.use_sym != 0;  // (the AGES walk names positions: the list stays until it is through)
     int nxt[MAXQ];
     auto erase_read = [&]() {
       const int ipos = sh.ipos;
@@ -1110,7 +1381,7 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
         const int ik = q * MM_BLOCK + tid;
         nxt[q] = (ik >= ipos && ik + 1 < n) ? (int)st.ci[ik + 1] : -1;
       }
-      for (int u = tid; u < nupd; u += MM_BLOCK) st.flag[st.ci[sh.upd[u] & 0xffffu]] = 0;
+      for (int u = tid; u < nupd; u += MM_BLOCK) st.flag[st.ci[upd_at(u) & 0xffffu]] = 0;
     };
     auto erase_write = [&]() {
 #pragma unroll
@@ -1121,12 +1392,18 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
     // The best among the clusters that keep their candidate (a copy taken before the draws: they may still
     // change such a cluster's candidate, behind its turn)
     float ud = INF, ud2 = INF;
+    double ud2d = (double)INF;  // (AGES)
     int upos = n, bl1 = -1, bl2 = -1;
     if (wave == 0) {
       ud = lane < MM_WAVES ? sh.lex_d[lane] : INF;
       ud2 = lane < MM_WAVES ? sh.lex_d2[lane] : INF;
       upos = lane < MM_WAVES ? sh.lex_p[lane] : n;
-      wave_lex_min(ud, ud2, upos);
+      if constexpr (AGES) {
+        ud2d = lane < MM_WAVES ? sh.lex_d2d[lane] : (double)INF;
+        wave_lex_min_d(ud, ud2d, upos);
+      } else {
+        wave_lex_min(ud, ud2, upos);
+      }
       if (upos < n) {
         const int kb = st.ci[upos];
         bl1 = st.lin1[kb];
@@ -1139,7 +1416,131 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
       erase_write();
     }
     if (p.timers && tid == 0) sh.tacc[10] += wall_clock64() - sh.tmark;  // (of "ordered": before the first draw)
-    if (wave == 0) {
+    if constexpr (AGES) {
+      if (wave == 0) {
+        // Coalesce's loop over the clusters in order (:613-881 / :2085-2341) as far as candidates go: a cluster that
+        // is the LATER one of feasible pairs gets them at its turn (the reset of a rebuilt one happened in A: nothing
+        // reaches a slot before its cluster's turn -- pairs are applied at the turn of their later cluster), then the
+        // running best looks at what the cluster holds.  64 positions are fetched at a time; the empty ones are
+        // skipped, and what was fetched for a cluster is what it holds at its turn unless it has pairs of its own.
+        abest = AgeCand{INF, (double)INF, MM_AGE_EMPTY, sh.best.lin1, sh.best.lin2};  // (:611)
+        int e = 0;
+        unsigned key = 0x80000000u, xy = 0;
+        float sym = 0.0f;
+        if (m > 0) pair_at(side, 0, key, xy, sym);
+        // One of the clusters that keep their candidate holds one within the clock (A): the best of the merge is the
+        // smallest such candidate -- theirs, or what a cluster with pairs of its own holds behind them, or the merged
+        // cluster's.  Otherwise: the walk.
+        const bool reduced = upos < n;
+        if (reduced) {
+          AgeCand sb{INF, (double)INF, MM_AGE_EMPTY, -1, -1};
+          int spos = n;
+          while (e < m && !(key & 0x80000000u)) {
+            const int cur = (int)(key >> 16);
+            AgeCand t{INF, (double)INF, MM_AGE_EMPTY, -1, -1}, ys;
+            while (e < m && !(key & 0x80000000u) && (int)(key >> 16) == cur) {
+              const int x = (int)(xy >> 16), y = (int)(xy & 0xffffu);
+              const float symc = sym;
+              e++;
+              if (e < m) pair_at(side, e, key, xy, sym);
+              apply_ages(x, y, symc, t, ys);
+            }
+            if (t.lv <= a_lw && t.d < INF && (sb.d > t.d || (sb.d == t.d && sb.d2 > t.d2))) {  // (ascending positions)
+              sb = t;
+              spos = cur;
+            }
+          }
+          abest = AgeCand{ud, ud2d, 0, bl1, bl2};
+          if (spos < n && (sb.d < ud || (sb.d == ud && (sb.d2 < ud2d || (sb.d2 == ud2d && spos < upos))))) abest = sb;
+        }
+        for (int base = 0; base < n && !reduced; base += 64) {
+          const int pos_l = base + lane;
+          const int k_l = pos_l < n ? (int)st.ci[pos_l] : -1;
+          const bool valid = k_l >= 0 && k_l != i && k_l != j;
+          AgeCand r{INF, (double)INF, MM_AGE_EMPTY, -1, -1};
+          if (valid) r = slot_of(k_l);
+          unsigned long long mask = __ballot(valid && r.lv != MM_AGE_EMPTY);
+          for (;;) {
+            const unsigned key_u = (unsigned)__builtin_amdgcn_readfirstlane((int)key);
+            const int pnext = (e < m && !(key_u & 0x80000000u)) ? (int)(key_u >> 16) : 0x7fffffff;
+            const int pa = mask ? base + (int)__builtin_ctzll(mask) : 0x7fffffff;
+            const int pb = pnext < base + 64 ? pnext : 0x7fffffff;
+            const int ppos = min(pa, pb);
+            if (ppos == 0x7fffffff) break;
+            const int ln = __builtin_amdgcn_readfirstlane(ppos - base);
+            mask &= ~(1ull << ln);
+            AgeCand t;
+            if (ppos == pb) {  // its own pairs first
+              AgeCand ys;
+              t = AgeCand{INF, (double)INF, MM_AGE_EMPTY, -1, -1};
+              while (e < m && !(key & 0x80000000u) && (int)(key >> 16) == ppos) {
+                const int x = (int)(xy >> 16), y = (int)(xy & 0xffffu);
+                const float symc = sym;
+                e++;
+                if (e < m) pair_at(side, e, key, xy, sym);
+                apply_ages(x, y, symc, t, ys);
+              }
+            } else {
+              const long long bits = __double_as_longlong(r.d2);
+              const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(bits & 0xffffffffll), ln);
+              const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(bits >> 32), ln);
+              t.d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.d), ln));
+              t.d2 = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+              t.lv = __builtin_amdgcn_readlane(r.lv, ln);
+              t.l1 = __builtin_amdgcn_readlane(r.l1, ln);
+              t.l2 = __builtin_amdgcn_readlane(r.l2, ln);
+            }
+            best_takes(t);
+          }
+        }
+        // the merged cluster: new minima, an empty slot, its pairs (:883-963 / :2343-2353), the last look of the best
+        const int szi = st.csz[i], szj = st.csz[j];
+        const int li = p.age_lvl[i], lj = p.age_lvl[j];
+        if (lane == 0) {
+          st.mv[j] = min_value_j;
+          if (p.has_prior) st.mvcf[j] = mvcf_j;
+          st.mcd[j] = INF;
+          p.mc_dist2d[j] = (double)INF;
+          p.mc_lvl[j] = MM_AGE_EMPTY;
+        }
+        AgeCand js{INF, (double)INF, MM_AGE_EMPTY, -1, -1};
+        while (e < m) {
+          const int x = (int)(xy >> 16);
+          const float symc = sym;
+          e++;
+          if (e < m) pair_at(side, e, key, xy, sym);
+          AgeCand xs;
+          apply_ages(x, j, symc, xs, js);
+        }
+        if (reduced) {
+          if (js.lv <= a_lw && js.d < INF && (abest.d > js.d || (abest.d == js.d && abest.d2 > js.d2))) abest = js;
+        } else {
+          best_takes(js);
+        }
+        // ages[j], the clock (:1219-1226 / :2513-2524: with a prior it steps before the lineage count drops)
+        const int newl = max(li, lj);
+        const double before = a_age;
+        if (p.has_prior) a_age = __dadd_rn(a_age, ages_step(a_lins, p.Ne));
+        a_lins--;
+        while (a_level < newl) {
+          a_level++;
+          a_lins += p.ages_count[a_level];
+        }
+        if (!p.has_prior) a_age = __dadd_rn(a_age, ages_step(a_lins, p.Ne));
+        if (!(a_age >= before)) a_lw = -1;  // (0 or 1 lineages: the step is not a number the clock can add)
+        clock_reaches();
+        if (lane == 0) {
+          p.age_lvl[j] = newl;
+          sh.a_lw = a_lw;
+          sh.best.dist = abest.d;
+          sh.best.lin1 = abest.l1;
+          sh.best.lin2 = abest.l2;
+          st.csz[j] = (idx_t)(szi + szj);
+          sh.nupd = 0;
+          sh.npairs = 0;
+        }
+      }
+    } else if (wave == 0) {
       // the clusters whose candidates change, at their turn: after their own pairs
       float sd = INF, sd2 = INF;
       int sl1 = -1, sl2 = -1, spos = n;
@@ -1391,7 +1792,7 @@ static_assert(sizeof(MMParams) % 4 == 0 && sizeof(MMParams) / 4 <= MM_PARAM_WORD
 // its last workgroup is gone, so workers that trickled away one by one would leave streams occupied by a few
 // stragglers and no way to bring the others back.  Nothing a worker waits for can fail to arrive: the only loop
 // without a tree in it is the idle one, bounded by the clock.
-template <bool LDS, int MAXQ>
+template <bool LDS, int MAXQ, bool AGES = false>
 __global__ void __launch_bounds__(MM_BLOCK, 1)
     minmatch_worker(WorkQueue *q, WorkerState *ws, int launch, long long idle_ticks, int trace) {
   __shared__ Shared sh;
@@ -1461,7 +1862,7 @@ __global__ void __launch_bounds__(MM_BLOCK, 1)
     __syncthreads();
     MMParamsDev p;
     params_from_words(p, sh.praw);
-    build_tree<LDS, MAXQ>(p, sh, dyn);
+    build_tree<LDS, MAXQ, AGES>(p, sh, dyn);
     __syncthreads();  // (sh is the next tree's)
     had_tree = true;
   }
@@ -1520,8 +1921,8 @@ __global__ void __launch_bounds__(256) rowmin_kernel(const float *__restrict__ i
 // mvcf_old: min_values_CF as carried over from the previous tree (:2399-2400).
 __global__ void __launch_bounds__(256) pairscan_kernel(const float4 *__restrict__ M, const float *__restrict__ rowmin_D,
                                                        const float *__restrict__ rowmin_CF,
-                                                       const float *__restrict__ mvcf_old, int has_prior, float threshold,
-                                                       float threshold_CF, int N, int *__restrict__ hit_cnt,
+                                                       const float *__restrict__ mvcf_old, int has_prior, int ages,
+                                                       float threshold, float threshold_CF, int N, int *__restrict__ hit_cnt,
                                                        unsigned *__restrict__ hit_b, float *__restrict__ hit_sym) {
   __shared__ int wcnt[4];
   const int a = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1550,7 +1951,9 @@ __global__ void __launch_bounds__(256) pairscan_kernel(const float4 *__restrict_
       if (has_prior) {
         const float old = mvcf_old[b], mc_ = rowmin_CF[b];
         const float mvcf_b = (old > mc_ ? mc_ : old) + threshold_CF;
-        if (e.z <= mvcf_a && e.w <= mvcf_b) sym = 0.0f;
+        // (with sample ages the initialisation keeps the pairs the prior agrees with and voids the others, :1792-1797)
+        const bool agrees = e.z <= mvcf_a && e.w <= mvcf_b;
+        if (ages ? !agrees : agrees) sym = ages ? INFINITY : 0.0f;
       }
       hit_b[(size_t)a * MM_HITS + at] = (unsigned)b;
       hit_sym[(size_t)a * MM_HITS + at] = sym;
@@ -1776,15 +2179,16 @@ int device_builder_reserve_shared(int device, int N) {
 // builders the stage announced, expect()).
 class BuildQueue {
  public:
-  static BuildQueue *of(int device, int N) {
+  // (ages: the builders with sample ages have workers of their own -- another kernel)
+  static BuildQueue *of(int device, int N, bool ages = false) {
     // (the queues live as long as the process and are never destroyed: their launcher threads wait on them)
     static std::mutex gm;
     static std::vector<BuildQueue *> *all = new std::vector<BuildQueue *>();
     std::lock_guard<std::mutex> lk(gm);
-    const bool lds = lds_state_fits(N);
+    const bool lds = !ages && lds_state_fits(N);
     for (BuildQueue *q : *all)
-      if (q->device_ == device && q->N_ == N) return q;
-    BuildQueue *q = new BuildQueue(device, N, lds);
+      if (q->device_ == device && q->N_ == N && q->ages_ == ages) return q;
+    BuildQueue *q = new BuildQueue(device, N, lds, ages);
     if (!q->ok_) return nullptr;
     all->push_back(q);
     return q;
@@ -1844,7 +2248,7 @@ class BuildQueue {
   }
 
  private:
-  BuildQueue(int device, int N, bool lds) : device_(device), N_(N), lds_(lds) {
+  BuildQueue(int device, int N, bool lds, bool ages) : device_(device), N_(N), lds_(lds), ages_(ages) {
     if (hipSetDevice(device) != hipSuccess) return;
     if (hipHostMalloc(reinterpret_cast<void **>(&q_), sizeof(WorkQueue), hipHostMallocCoherent) != hipSuccess) return;
     memset(q_, 0, sizeof(WorkQueue));
@@ -1960,7 +2364,13 @@ class BuildQueue {
         __atomic_store_n(&q_->gone[l], 0u, __ATOMIC_RELEASE);  // (the stream's previous launch is through)
         const long long idle = (long long)idle_ms_ * 100000LL;
         const int trace_flag = getenv("RELATE_AMD_MM_TRACE") ? 1 : 0;
-        if (lds_)
+        if (ages_ && N_ <= MM_Q_LDS * MM_BLOCK)
+          hipLaunchKernelGGL((minmatch_worker<false, MM_Q_LDS, true>), dim3((unsigned)n), dim3(MM_BLOCK), 0, streams[l], q_,
+                             d_state_.as<WorkerState>(), l, idle, trace_flag);
+        else if (ages_)
+          hipLaunchKernelGGL((minmatch_worker<false, MM_Q_GLOB, true>), dim3((unsigned)n), dim3(MM_BLOCK), 0, streams[l], q_,
+                             d_state_.as<WorkerState>(), l, idle, trace_flag);
+        else if (lds_)
           hipLaunchKernelGGL((minmatch_worker<true, MM_Q_LDS>), dim3((unsigned)n), dim3(MM_BLOCK), dyn, streams[l], q_,
                              d_state_.as<WorkerState>(), l, idle, trace_flag);
         else
@@ -1982,7 +2392,7 @@ class BuildQueue {
     }
   }
   int device_, N_;
-  bool lds_, ok_ = false;
+  bool lds_, ages_, ok_ = false;
   WorkQueue *q_ = nullptr;
   DevBuf d_state_;
   int cap_ = 224, idle_ms_ = 50;
@@ -1993,9 +2403,9 @@ class BuildQueue {
   int outstanding_ = 0, expected_ = 0;
   std::atomic<bool> failed_{false};
 };
-int device_builder_expect(int device, int N, int builders) {
+int device_builder_expect(int device, int N, int builders, bool ages) {
   if (hipSetDevice(device) != hipSuccess) return -1;
-  BuildQueue *q = BuildQueue::of(device, N);
+  BuildQueue *q = BuildQueue::of(device, N, ages);
   if (!q) return -1;
   q->expect(builders);
   return 0;
@@ -2025,6 +2435,8 @@ struct DeviceMinMatch::Impl {
   hipStream_t stream = nullptr;
   DeviceShare::Staging *staging = nullptr;  // held from device_matrix() / the upload until the matrices are woven
   DevBuf d_M, d_hits, d_f, d_i, d_feas, d_rowlist, d_status, d_flags, d_member, d_tab, d_acc;
+  DevBuf d_ages;  // --sample_ages: the third key and the draw of the candidates, the clusters' age levels, the table
+  bool ages_up = false;  // ... whose constant part is in place
   long long builds = 0, n_built = 0;
   double t_prep = 0, t_wait = 0, t_out = 0;  // RELATE_AMD_TIMING: uploads + weave, submit -> tree done, copy-out (s)
   long long n_timed = 0;
@@ -2058,7 +2470,7 @@ DeviceMinMatch::~DeviceMinMatch() {
     // (leaked on purpose: handed to the caches these blocks would be given out again at once, and a worker that
     //  claims or finishes the abandoned ticket later would write into somebody else's tree)
     for (DevBuf *b : {&impl->d_M, &impl->d_hits, &impl->d_f, &impl->d_i, &impl->d_feas, &impl->d_rowlist, &impl->d_status,
-                      &impl->d_flags, &impl->d_member, &impl->d_tab, &impl->d_acc}) {
+                      &impl->d_flags, &impl->d_member, &impl->d_tab, &impl->d_acc, &impl->d_ages}) {
       b->p = nullptr;
       b->bytes = 0;
     }
@@ -2073,6 +2485,8 @@ DeviceMinMatch::~DeviceMinMatch() {
   if (impl->h_tab) pinned_cache_release(impl->h_tab, impl->h_tab_bytes);
   delete impl;
 }
+
+void DeviceMinMatch::forget_ages() { impl->ages_up = false; }
 
 float *DeviceMinMatch::device_matrix() {
   Impl &m = *impl;
@@ -2151,11 +2565,11 @@ int DeviceMinMatch::apply_prior(const HostTree &t, float val) {
   return 0;
 }
 
-int DeviceMinMatch::reserve() {
+int DeviceMinMatch::reserve(bool ages) {
   Impl &m = *impl;
   const int N = m.N;
   if (hipSetDevice(m.device) != hipSuccess) return -1;
-  const long long pair_cap = (long long)8 * N;
+  const long long pair_cap = (long long)(ages ? 32 : 8) * N;  // (build_impl)
   int rc = m.d_M.alloc(mm_elements(N) * 16);
   rc = rc ? rc : m.d_hits.alloc(((size_t)N + (size_t)2 * N * MM_HITS) * 4);
   rc = rc ? rc : m.d_f.alloc((size_t)8 * N * 4);  // min_values, min_values_CF, mc_dist, mc_dist2, 2 of the symmetric path, 2 row minima
@@ -2168,21 +2582,40 @@ int DeviceMinMatch::reserve() {
 }
 
 int DeviceMinMatch::build_resident(MinMatch &tb, bool with_prior, HostTree &tree) {
-  const int rc = build_impl(tb, nullptr, nullptr, true, with_prior, tree);
+  const int rc = build_impl(tb, nullptr, nullptr, nullptr, true, with_prior, tree);
   impl->drop_staging();
   return rc;
 }
 
 int DeviceMinMatch::build(MinMatch &tb, const float *d, const float *prior, HostTree &tree) {
-  const int rc = build_impl(tb, d, prior, false, prior != nullptr, tree);
+  const int rc = build_impl(tb, nullptr, d, prior, false, prior != nullptr, tree);
   impl->drop_staging();
   return rc;
 }
 
-int DeviceMinMatch::build_impl(MinMatch &tb, const float *d, const float *prior_host, bool resident, bool with_prior,
-                               HostTree &tree) {
+int DeviceMinMatch::build_resident(MinMatchAges &tb, const std::vector<double> &sample_ages, bool with_prior, HostTree &tree) {
+  const int rc = build_impl(tb, &sample_ages, nullptr, nullptr, true, with_prior, tree);
+  impl->drop_staging();
+  return rc;
+}
+
+int DeviceMinMatch::build(MinMatchAges &tb, const std::vector<double> &sample_ages, const float *d, const float *prior,
+                          HostTree &tree) {
+  const int rc = build_impl(tb, &sample_ages, d, prior, false, prior != nullptr, tree);
+  impl->drop_staging();
+  return rc;
+}
+
+template <class TB>
+int DeviceMinMatch::build_impl(TB &tb, const std::vector<double> *sample_ages, const float *d, const float *prior_host,
+                               bool resident, bool with_prior, HostTree &tree) {
   Impl &m = *impl;
   const int N = m.N;
+  constexpr bool ages = std::is_same<TB, MinMatchAges>::value;
+  if (ages && (!sample_ages || (int)sample_ages->size() != N)) {
+    set_error("tree builder: one sample age per haplotype");
+    return -1;
+  }
   if (N < 2 || N > MM_MAXN) return 1;  // (the painting kernels stop at N = 10240 too)
   if (resident) {  // tests: every k-th resident build is handed to the host, as a tree with too many tied candidates is
     static const int every = getenv("RELATE_AMD_BUILDER_HANDOVER_EVERY") ? atoi(getenv("RELATE_AMD_BUILDER_HANDOVER_EVERY")) : 0;
@@ -2190,7 +2623,7 @@ int DeviceMinMatch::build_impl(MinMatch &tb, const float *d, const float *prior_
   }
   RL_HIP(hipSetDevice(m.device));
   if (!m.stream) RL_HIP(make_stream(&m.stream, false, true));
-  BuildQueue *queue = BuildQueue::of(m.device, N);
+  BuildQueue *queue = BuildQueue::of(m.device, N, ages);
   if (!queue) {
     set_error("tree builder: no queue on device %d (pinned host memory)", m.device);
     return -1;
@@ -2206,12 +2639,14 @@ int DeviceMinMatch::build_impl(MinMatch &tb, const float *d, const float *prior_
   const bool prior = with_prior;
   const size_t NN = (size_t)N * N;
   const auto tb0 = std::chrono::steady_clock::now();
-  const long long pair_cap = (long long)8 * N;
-  if (reserve()) return -1;
+  // (with sample ages a merge of the lineage the last tree's candidates were renamed to sends most clusters through
+  //  the rebuilding branch: every feasible pair of the matrix again)
+  const long long pair_cap = (long long)(ages ? 32 : 8) * N;
+  if (reserve(ages)) return -1;
   MMParams p;
   memset(&p, 0, sizeof(p));
   p.N = N;
-  p.lds_state = lds_state_fits(N) ? 1 : 0;
+  p.lds_state = (!ages && lds_state_fits(N)) ? 1 : 0;
   p.threshold = tb.threshold;
   p.threshold_CF = tb.threshold_CF;
   p.M = m.d_M.as<float4>();
@@ -2251,6 +2686,38 @@ int DeviceMinMatch::build_impl(MinMatch &tb, const float *d, const float *prior_
     return -1;
   }
   p.host_done = m.h_done;
+  if constexpr (ages) {
+    // the age levels: a candidate's third key is the index of an age in the sorted table of the distinct sample ages
+    // (tree_builder.cpp:1125-1152)
+    tb.prepare_levels(*sample_ages);
+    const std::vector<double> *unique = &tb.unique_ages;
+    const std::vector<int> *count = &tb.ages_count;
+    p.Ne = tb.Ne;
+    const int nlev = (int)unique->size();
+    if (m.d_ages.alloc((size_t)48 * N + 64)) return -1;
+    double *ad = m.d_ages.as<double>();
+    int *ai = reinterpret_cast<int *>(ad + 2 * (size_t)N);
+    p.mc_dist2d = ad;
+    p.unique_ages = ad + N;
+    p.mc_lvl = ai;
+    p.age_lvl = ai + N;
+    p.age_lvl0 = ai + 2 * (size_t)N;
+    p.ages_count = ai + 3 * (size_t)N;
+    p.upd_g = reinterpret_cast<unsigned *>(ai + 4 * (size_t)N);
+    p.updv_g = reinterpret_cast<float *>(ai + 5 * (size_t)N);
+    p.bucket = ai + 6 * (size_t)N;
+    p.bucket_off = ai + 7 * (size_t)N + 8;
+    p.n_levels = nlev;
+    if (!m.ages_up) {  // (one set of ages per builder)
+      std::vector<int> lvl0((size_t)N);
+      for (int c = 0; c < N; c++)
+        lvl0[c] = (int)(std::lower_bound(unique->begin(), unique->end(), (*sample_ages)[c]) - unique->begin());
+      RL_HIP(hipMemcpy(ad + N, unique->data(), (size_t)nlev * 8, hipMemcpyHostToDevice));
+      RL_HIP(hipMemcpy(ai + 2 * (size_t)N, lvl0.data(), (size_t)N * 4, hipMemcpyHostToDevice));
+      RL_HIP(hipMemcpy(ai + 3 * (size_t)N, count->data(), (size_t)nlev * 4, hipMemcpyHostToDevice));
+      m.ages_up = true;
+    }
+  }
   const bool timing = getenv("RELATE_AMD_TIMING") != nullptr;
   p.timers = nullptr;  // (set below: a corner of the pinned block, read when the tree is out -- no copy)
 
@@ -2296,7 +2763,7 @@ int DeviceMinMatch::build_impl(MinMatch &tb, const float *d, const float *prior_
     hipLaunchKernelGGL(rowmin_kernel, dim3(prior ? 2 * N : N), dim3(256), 0, m.stream, dD, f + 6 * (size_t)N, dCF,
                        f + 7 * (size_t)N, N);
     hipLaunchKernelGGL(pairscan_kernel, dim3(N), dim3(256), 0, m.stream, p.M, p.rowmin_D, p.rowmin_CF, mvcf_dev,
-                       p.has_prior, p.threshold, p.threshold_CF, N, hits, reinterpret_cast<unsigned *>(hits + N),
+                       p.has_prior, ages ? 1 : 0, p.threshold, p.threshold_CF, N, hits, reinterpret_cast<unsigned *>(hits + N),
                        reinterpret_cast<float *>(hits + N + (size_t)N * MM_HITS));
     RL_HIP(hipGetLastError());
   }
@@ -2426,17 +2893,14 @@ int rl_builder_build(rl_builder *b, float *d, const float *d_prior, int *parent,
   }
   rl::HostTree t;
   int st = 1;
-  if (b->ages_tb) {
-    b->ages_tb->quick_build(d, d_prior, b->ages, t);
-    b->last_on_gpu = 0;
-    st = 0;
-  } else if (b->dev) {
-    st = b->dev->build(b->tb, d, d_prior, t);
+  if (b->dev) {
+    st = b->ages_tb ? b->dev->build(*b->ages_tb, b->ages, d, d_prior, t) : b->dev->build(b->tb, d, d_prior, t);
     if (st < 0) return RL_EHIP;
   }
-  if (!b->ages_tb) {
-    b->last_on_gpu = st == 0;
-    if (st != 0) b->tb.quick_build(d, d_prior, t);
+  b->last_on_gpu = st == 0;
+  if (st != 0) {
+    if (b->ages_tb) b->ages_tb->quick_build(d, d_prior, b->ages, t);
+    else b->tb.quick_build(d, d_prior, t);
   }
   const int N = b->N;
   for (int i = 0; i < 2 * N - 1; i++) parent[i] = t.parent[i];
@@ -2455,6 +2919,7 @@ int rl_builder_set_sample_ages(rl_builder *b, const double *ages, int n) {
   b->ages.assign(ages, ages + n);
   delete b->ages_tb;
   b->ages_tb = new rl::MinMatchAges(b->N, b->theta);
+  if (b->dev) b->dev->forget_ages();
   return RL_OK;
 }
 

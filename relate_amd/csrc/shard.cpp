@@ -35,7 +35,7 @@ namespace rl {
 rl_treeseq *treeseq_borrowing(int N, int L, const uint32_t *bits, int row_words, const double *rpos, const int *bp_pos,
                               const int *state, double theta);
 int device_builder_reserve_shared(int device, int N);
-int device_builder_expect(int device, int N, int builders);
+int device_builder_expect(int device, int N, int builders, bool ages = false);
 }  // namespace rl
 
 using namespace rl;

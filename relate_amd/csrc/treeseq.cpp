@@ -373,31 +373,34 @@ int rl_treeseq_build(rl_treeseq *ts, int start, int end, rl_matrix_fn matrix, rl
         }
   };
   MinMatch tb(N, ts->theta);
-  // with sample ages (ancient samples) the candidates carry a third key and a clock: its own builder, on the host
+  // with sample ages (ancient samples) the candidates carry a third key and a clock: its own builder (and its own
+  // workers on the device, minmatch_gpu.hip AGES)
   std::unique_ptr<MinMatchAges> tb_ages;
   if ((int)ts->sample_ages.size() == N) tb_ages.reset(new MinMatchAges(N, ts->theta));
   DeviceMinMatch *dev = nullptr;
-  if (ts->build_device >= 0 && N <= 10240 && !tb_ages) {  // (its registers per thread)
+  if (ts->build_device >= 0 && N <= 10240) {  // (its registers per thread)
     if (!ts->dev_builder) ts->dev_builder = new DeviceMinMatch(N, ts->build_device);
     dev = ts->dev_builder;
   }
   int build_rc = 0;
+  auto host_build = [&](float *dm, const float *prior, HostTree &t) {
+    ts->host_trees++;
+    if (tb_ages) tb_ages->quick_build(dm, prior, ts->sample_ages, t);
+    else tb.quick_build(dm, prior, t);
+  };
   auto build_tree = [&](float *dm, const float *prior, HostTree &t) {
-    if (tb_ages) {
-      ts->host_trees++;
-      tb_ages->quick_build(dm, prior, ts->sample_ages, t);
-      return;
-    }
     if (dev) {
-      const int st = dev->build(tb, dm, prior, t);
+      const int st = tb_ages ? dev->build(*tb_ages, ts->sample_ages, dm, prior, t) : dev->build(tb, dm, prior, t);
       if (st == 0) {
         ts->gpu_trees++;
         return;
       }
       if (st < 0) build_rc = RL_EHIP;
     }
-    ts->host_trees++;
-    tb.quick_build(dm, prior, t);
+    host_build(dm, prior, t);
+  };
+  auto build_resident = [&](bool with_prior, HostTree &t) {
+    return tb_ages ? dev->build_resident(*tb_ages, ts->sample_ages, with_prior, t) : dev->build_resident(tb, with_prior, t);
   };
   MatrixBuf d((size_t)N * N), dist;
   float min_value = 0.f, min_value_alt = 0.f;
@@ -409,12 +412,11 @@ int rl_treeseq_build(rl_treeseq *ts, int start, int end, rl_matrix_fn matrix, rl
     float *dd = dev->device_matrix();
     if (!dd) return RL_ENOMEM;
     if ((rc = ts->matrix_dev(user, start, dd))) return rc;
-    const int st = dev->build_resident(tb, false, ts->trees.back());
+    const int st = build_resident(false, ts->trees.back());
     if (st < 0) return RL_EHIP;
     if (st > 0) {  // this tree is the host's (tb untouched): the matrix again, to the host
       if ((rc = matrix(user, start, d.data()))) return rc;
-      ts->host_trees++;
-      tb.quick_build(d.data(), nullptr, ts->trees.back());
+      host_build(d.data(), nullptr, ts->trees.back());
     } else {
       ts->gpu_trees++;
     }
@@ -472,7 +474,7 @@ int rl_treeseq_build(rl_treeseq *ts, int start, int end, rl_matrix_fn matrix, rl
           st = st ? st : dev->apply_prior(pt, val);
           lap(t_prior);
         }
-        st = st ? st : dev->build_resident(tb, consistency, nt);
+        st = st ? st : build_resident(consistency, nt);
         if (st < 0) {
           set_error("tree builder on the device failed at SNP %d", snp);
           return RL_EHIP;
@@ -493,8 +495,7 @@ int rl_treeseq_build(rl_treeseq *ts, int start, int end, rl_matrix_fn matrix, rl
             });
             clade_prior(pt, val, dist);
           }
-          ts->host_trees++;
-          tb.quick_build(d.data(), consistency ? dist.data() : nullptr, nt);
+          host_build(d.data(), consistency ? dist.data() : nullptr, nt);
         } else {
           ts->gpu_trees++;
         }
@@ -556,6 +557,7 @@ int rl_treeseq_set_sample_ages(rl_treeseq *ts, const double *ages, int n) {
     return RL_EINVAL;
   }
   ts->sample_ages.assign(ages, ages + n);
+  if (ts->dev_builder) ts->dev_builder->forget_ages();
   return RL_OK;
 }
 
@@ -895,7 +897,7 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
       nthreads = std::min(nthreads, concurrent);
     }
   }
-  if (gpu_build && sample_ages.empty()) {
+  if (gpu_build) {
     // One worker per open section -- unless the windows are bounded: then RePaint runs all through the stage, on the
     // CUs the workers do not hold (a worker has a CU to itself), and it is the queue every section waits in.  At C3
     // (134 sections, 37 launches per window): 110 workers 207 s, 100 workers 177 s, 90 workers 190 s (RePaint 168 /
@@ -908,7 +910,7 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
       workers = std::min(nthreads, 13 * cus / 32);
     }
     if (o.workers > 0) workers = o.workers;  // (RELATE_AMD_BUILD_WORKERS overrides either, minmatch_gpu.hip)
-    (void)device_builder_expect(device, ctx->N, workers);
+    (void)device_builder_expect(device, ctx->N, workers, !sample_ages.empty());
   }
   // Host threads left over by the sections help inside each tree build (minmatch.h BuildThreads).  Helpers are the
   // less efficient use of a core (a merge is split 8 ways for a 2.5x shorter build) and a helper that loses its
@@ -967,7 +969,7 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
       return;
     }
     if (!sample_ages.empty()) rl_treeseq_set_sample_ages(ts, sample_ages.data(), (int)sample_ages.size());
-    if (gpu_build && sample_ages.empty()) {
+    if (gpu_build) {
       rl_treeseq_set_build_device(ts, device);
       if (ctx->nloc == ctx->N) rl_treeseq_set_device_matrix(ts, win_matrix_dev);
     }
@@ -981,7 +983,7 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
       const std::string pf = od + "/chunk_" + c + "/paint/relate_" + std::to_string(section) + ".bin";
       rl_window *win = nullptr;
       // (this thread's builder keeps its buffers from section to section: only the first one asks for them)
-      const bool builder_new = gpu_build && sample_ages.empty() && !ts->dev_builder;
+      const bool builder_new = gpu_build && !ts->dev_builder;
       const double need = window_bytes(section) + (builder_new ? builder_bytes : 0.0);
       for (;;) {  // admission: wait until the window fits next to the ones that are open or being opened
         bool admitted = false;
@@ -1002,7 +1004,7 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
                                        nullptr);
           if (win && builder_new) {  // (while the reservation stands)
             ts->dev_builder = new DeviceMinMatch(ctx->N, device);
-            if (ts->dev_builder->reserve()) {
+            if (ts->dev_builder->reserve(!sample_ages.empty())) {
               rl_window_close(win);
               win = nullptr;
             }
@@ -1048,7 +1050,7 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
     for (int t = 0; t < nthreads; t++) th.emplace_back(worker);
     for (auto &x : th) x.join();
   }
-  if (gpu_build && sample_ages.empty()) (void)device_builder_expect(device, ctx->N, 0);
+  if (gpu_build) (void)device_builder_expect(device, ctx->N, 0, !sample_ages.empty());
   rc = first_error.load();
   if (rc) set_error("%s", first_message.c_str());
   if (getenv("RELATE_AMD_TIMING"))

@@ -246,8 +246,8 @@ def test_cli_build_topology_with_sample_ages(tmp_path, tag, opts):
 
 def test_stage_options_through_the_abi(tmp_path):
     """rl_stage_opts (include/relate_amd.h): what the tests elsewhere set through the environment, per call -- two calls
-    of one process with different options: (1) sample ages through `sample_ages_path` (not the process-wide setter),
-    host trees; (2) no ages, the device builder, windows bounded to a third of their rows, one section thread, on the
+    of one process with different options: (1) sample ages through `sample_ages_path` (not the process-wide setter);
+    (2) no ages, the device builder, windows bounded to a third of their rows, one section thread, on the
     plain fixture: each byte-identical to the reference's files for ITS options"""
     from relate_amd import api
     ages_dir, plain_dir = tmp_path / "ages" / "out", tmp_path / "plain" / "out"
