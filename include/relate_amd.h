@@ -230,7 +230,8 @@ rl_builder *rl_builder_create(int N, double theta, int device);
 int rl_builder_build(rl_builder *b, float *d, const float *d_prior,
                      int *parent, int *child_left, int *child_right);
 /* MinMatch::QuickBuild's sample_ages (N doubles): from here on the builder's trees are built with the sample-age
- * key and clock of src/tree_builder.cpp:1123-1233 / :2407-2531, on the host. */
+ * key and clock of src/tree_builder.cpp:1123-1233 / :2407-2531 -- on the builder's device (device >= 0), else on the
+ * host. */
 int rl_builder_set_sample_ages(rl_builder *b, const double *ages, int n);
 int rl_builder_last_on_gpu(const rl_builder *b);
 void rl_builder_destroy(rl_builder *b);
