@@ -273,6 +273,9 @@ struct State {
   ptr<idx_t> ci;                   // the live clusters in order
   ptr<idx_t> csz;                  // cluster sizes (floats in the reference: exact integers)
   ptr<unsigned char> flag;         // rebuilt in this merge
+  // the AGES build: the candidate's draw as a double and its age level, the cluster's own age level
+  ptr<double> d2d;
+  ptr<idx_t> lv, alv;
 };
 
 // Wave reductions on the DPP crossbar (quad swaps, half-row and row mirrors, the two row broadcasts: the total
@@ -389,7 +392,7 @@ __device__ inline void block_min3(float &f, int &a, int &b, float *bf, int *ba, 
 // `replace` is not stored: after the refresh every merge begins with (:618) it equals "dist3 is beyond the clock" for
 // every candidate there is, and that is how it is set when one is made (:216, :234).  lw = the largest index whose
 // age the clock has reached.
-constexpr int MM_AGE_EMPTY = 0x7fffffff;
+constexpr int MM_AGE_EMPTY = 0x7fff;  // (more than any level: N <= 10240; fits the shorts of the state in LDS)
 struct AgeCand {
   float d;
   double d2;
@@ -459,7 +462,6 @@ __device__ inline double ages_step(int k, int Ne) {
 // samples are small).  The per-cluster state of that build lives in global memory.
 template <bool LDS, int MAXQ, bool AGES = false>
 __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, unsigned char *dyn) {
-  static_assert(!(AGES && LDS), "the AGES build keeps its state in global memory");
   typedef typename State<LDS>::idx_t idx_t;
   constexpr int ROWS = MAXQ * MM_ROWS > 64 ? 64 / MAXQ : MM_ROWS;  // rows of rebuilt clusters per pass (ROWS * MAXQ <= 64 bits of survivors)
   const int N = p.N;
@@ -467,7 +469,22 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
   const float INF = INFINITY;
   const float threshold = p.threshold, threshold_CF = p.threshold_CF;
   State<LDS> st;
-  if constexpr (LDS) {
+  if constexpr (LDS && AGES) {  // 33 bytes per cluster (the float draw of the plain build has no place here)
+    st.d2d = reinterpret_cast<double *>(dyn);
+    float *f = reinterpret_cast<float *>(st.d2d + N);
+    st.mv = f;
+    st.mvcf = f + N;
+    st.mcd = f + 2 * (size_t)N;
+    st.mcd2 = nullptr;
+    short *s = reinterpret_cast<short *>(f + 3 * (size_t)N);
+    st.lin1 = s;
+    st.lin2 = s + N;
+    st.ci = s + 2 * (size_t)N;
+    st.csz = s + 3 * (size_t)N;
+    st.lv = s + 4 * (size_t)N;
+    st.alv = s + 5 * (size_t)N;
+    st.flag = reinterpret_cast<unsigned char *>(s + 6 * (size_t)N);
+  } else if constexpr (LDS) {
     float *f = reinterpret_cast<float *>(dyn);
     st.mv = f;
     st.mvcf = f + N;
@@ -480,6 +497,9 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
     st.csz = s + 3 * (size_t)N;
     st.flag = reinterpret_cast<unsigned char *>(s + 4 * (size_t)N);
   } else {
+    st.d2d = p.mc_dist2d;
+    st.lv = p.mc_lvl;
+    st.alv = p.age_lvl;
     st.mv = p.min_values;
     st.mvcf = p.min_values_CF;
     st.mcd = p.mc_dist;
@@ -531,12 +551,13 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
     st.csz[c] = (idx_t)1;
     st.mv[c] = INF;
     st.mcd[c] = INF;
-    st.mcd2[c] = INF;
     st.flag[c] = 0;
     if constexpr (AGES) {
-      p.mc_dist2d[c] = (double)INF;
-      p.mc_lvl[c] = MM_AGE_EMPTY;
-      p.age_lvl[c] = p.age_lvl0[c];
+      st.d2d[c] = (double)INF;
+      st.lv[c] = (idx_t)MM_AGE_EMPTY;
+      st.alv[c] = (idx_t)p.age_lvl0[c];
+    } else {
+      st.mcd2[c] = INF;
     }
     if constexpr (LDS) {  // the state carried from tree to tree comes in
       st.lin1[c] = (idx_t)p.mc_lin1[c];
@@ -631,7 +652,7 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
     if (tid == 0) sh.a_lw = a_lw;
   }
   auto slot_of = [&](int c) -> AgeCand {
-    return AgeCand{st.mcd[c], p.mc_dist2d[c], p.mc_lvl[c], (int)st.lin1[c], (int)st.lin2[c]};
+    return AgeCand{st.mcd[c], st.d2d[c], (int)st.lv[c], (int)st.lin1[c], (int)st.lin2[c]};
   };
   // MinMatch's `cand` offered to both of its clusters (:205-218 and every block like it); xs / ys: what x and y hold
   // afterwards
@@ -639,7 +660,7 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
     const double rnd = (double)next_rnd();
     xs = slot_of(x);
     ys = slot_of(y);
-    const int clv = max((int)p.age_lvl[x], (int)p.age_lvl[y]);
+    const int clv = max((int)st.alv[x], (int)st.alv[y]);
     const AgeCand c{sym, rnd, clv, x, y};
     const bool tx = ages_takes(xs, sym, rnd, clv, a_lw), ty = ages_takes(ys, sym, rnd, clv, a_lw);
     if (tx) xs = c;
@@ -649,15 +670,15 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
         st.lin1[x] = (idx_t)x;
         st.lin2[x] = (idx_t)y;
         st.mcd[x] = sym;
-        p.mc_dist2d[x] = rnd;
-        p.mc_lvl[x] = clv;
+        st.d2d[x] = rnd;
+        st.lv[x] = (idx_t)clv;
       }
       if (ty) {
         st.lin1[y] = (idx_t)x;
         st.lin2[y] = (idx_t)y;
         st.mcd[y] = sym;
-        p.mc_dist2d[y] = rnd;
-        p.mc_lvl[y] = clv;
+        st.d2d[y] = rnd;
+        st.lv[y] = (idx_t)clv;
       }
     }
   };
@@ -919,10 +940,10 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
         s_l1[qq] = st.lin1[k];
         s_l2[qq] = st.lin2[k];
         s_d1[qq] = st.mcd[k];
-        s_d2[qq] = st.mcd2[k];
+        if constexpr (!AGES) s_d2[qq] = st.mcd2[k];
         if constexpr (AGES) {
-          s_d2d[qq] = p.mc_dist2d[k];
-          s_lv[qq] = p.mc_lvl[k];
+          s_d2d[qq] = st.d2d[k];
+          s_lv[qq] = st.lv[k];
         }
       }
 #pragma unroll
@@ -971,10 +992,11 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
         if (rebuilds) {  // k rebuilds its candidates (:1893-1911)
           st.flag[k] = 1;
           st.mcd[k] = INF;
-          st.mcd2[k] = INF;
           if constexpr (AGES) {
-            p.mc_dist2d[k] = (double)INF;
-            p.mc_lvl[k] = MM_AGE_EMPTY;
+            st.d2d[k] = (double)INF;
+            st.lv[k] = (idx_t)MM_AGE_EMPTY;
+          } else {
+            st.mcd2[k] = INF;
           }
           const int slot = atomicAdd(&sh.nupd, 1);
           if (slot < MM_UPD_MAX) {
@@ -1495,13 +1517,13 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
         }
         // the merged cluster: new minima, an empty slot, its pairs (:883-963 / :2343-2353), the last look of the best
         const int szi = st.csz[i], szj = st.csz[j];
-        const int li = p.age_lvl[i], lj = p.age_lvl[j];
+        const int li = st.alv[i], lj = st.alv[j];
         if (lane == 0) {
           st.mv[j] = min_value_j;
           if (p.has_prior) st.mvcf[j] = mvcf_j;
           st.mcd[j] = INF;
-          p.mc_dist2d[j] = (double)INF;
-          p.mc_lvl[j] = MM_AGE_EMPTY;
+          st.d2d[j] = (double)INF;
+          st.lv[j] = (idx_t)MM_AGE_EMPTY;
         }
         AgeCand js{INF, (double)INF, MM_AGE_EMPTY, -1, -1};
         while (e < m) {
@@ -1530,7 +1552,7 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
         if (!(a_age >= before)) a_lw = -1;  // (0 or 1 lineages: the step is not a number the clock can add)
         clock_reaches();
         if (lane == 0) {
-          p.age_lvl[j] = newl;
+          st.alv[j] = (idx_t)newl;
           sh.a_lw = a_lw;
           sh.best.dist = abest.d;
           sh.best.lin1 = abest.l1;
@@ -2022,17 +2044,20 @@ int rng_restatement_mismatches(unsigned seed, int n) {
 
 // ---- host side
 // dynamic LDS of a build whose per-cluster state lives there: 4 floats, 4 shorts and a flag per cluster
-static size_t lds_state_bytes(int N) { return (((size_t)25 * N) + 255) & ~(size_t)255; }
+// (with sample ages: the draw as a double instead of a float, two more shorts -- 33 bytes)
+static size_t lds_state_bytes(int N, bool ages = false) { return (((size_t)(ages ? 33 : 25) * N) + 255) & ~(size_t)255; }
 // ... and whether it fits next to the kernel's static LDS (160 KB per workgroup on gfx950)
-static bool lds_state_fits(int N) {
-  static std::atomic<size_t> fixed{0};  // (a property of the code object, the same on every device)
-  size_t f = fixed.load();
+static bool lds_state_fits(int N, bool ages = false) {
+  static std::atomic<size_t> fixed[2];  // (a property of the code object, the same on every device)
+  size_t f = fixed[ages].load();
   if (!f) {
     hipFuncAttributes a;
-    if (hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&minmatch_worker<true, MM_Q_LDS>)) != hipSuccess) return false;
-    fixed.store(f = a.sharedSizeBytes);
+    const void *fn = ages ? reinterpret_cast<const void *>(&minmatch_worker<true, MM_Q_LDS, true>)
+                          : reinterpret_cast<const void *>(&minmatch_worker<true, MM_Q_LDS>);
+    if (hipFuncGetAttributes(&a, fn) != hipSuccess) return false;
+    fixed[ages].store(f = a.sharedSizeBytes);
   }
-  return N <= MM_Q_LDS * MM_BLOCK && f + lds_state_bytes(N) <= (size_t)160 * 1024;
+  return N <= MM_Q_LDS * MM_BLOCK && f + lds_state_bytes(N, ages) <= (size_t)160 * 1024;
 }
 
 static int env_int(const char *name, int fallback, int lo, int hi) {
@@ -2185,7 +2210,7 @@ class BuildQueue {
     static std::mutex gm;
     static std::vector<BuildQueue *> *all = new std::vector<BuildQueue *>();
     std::lock_guard<std::mutex> lk(gm);
-    const bool lds = !ages && lds_state_fits(N);
+    const bool lds = lds_state_fits(N, ages);
     for (BuildQueue *q : *all)
       if (q->device_ == device && q->N_ == N && q->ages_ == ages) return q;
     BuildQueue *q = new BuildQueue(device, N, lds, ages);
@@ -2278,14 +2303,15 @@ class BuildQueue {
       }
     size_t dyn = 0;
     if (lds_) {  // the per-cluster state of a build in LDS: more than the default 64 KB of dynamic LDS
-      const void *fn = reinterpret_cast<const void *>(&minmatch_worker<true, MM_Q_LDS>);
+      const void *fn = ages_ ? reinterpret_cast<const void *>(&minmatch_worker<true, MM_Q_LDS, true>)
+                             : reinterpret_cast<const void *>(&minmatch_worker<true, MM_Q_LDS>);
       hipFuncAttributes a;
       if (hipFuncGetAttributes(&a, fn) != hipSuccess ||
           hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)a.sharedSizeBytes) != hipSuccess) {
         failed_.store(true);
         return;
       }
-      dyn = lds_state_bytes(N_);
+      dyn = lds_state_bytes(N_, ages_);
     }
     const bool verbose = getenv("RELATE_AMD_TIMING") != nullptr;
     for (;;) {
@@ -2364,7 +2390,10 @@ class BuildQueue {
         __atomic_store_n(&q_->gone[l], 0u, __ATOMIC_RELEASE);  // (the stream's previous launch is through)
         const long long idle = (long long)idle_ms_ * 100000LL;
         const int trace_flag = getenv("RELATE_AMD_MM_TRACE") ? 1 : 0;
-        if (ages_ && N_ <= MM_Q_LDS * MM_BLOCK)
+        if (ages_ && lds_)
+          hipLaunchKernelGGL((minmatch_worker<true, MM_Q_LDS, true>), dim3((unsigned)n), dim3(MM_BLOCK), dyn, streams[l], q_,
+                             d_state_.as<WorkerState>(), l, idle, trace_flag);
+        else if (ages_ && N_ <= MM_Q_LDS * MM_BLOCK)
           hipLaunchKernelGGL((minmatch_worker<false, MM_Q_LDS, true>), dim3((unsigned)n), dim3(MM_BLOCK), 0, streams[l], q_,
                              d_state_.as<WorkerState>(), l, idle, trace_flag);
         else if (ages_)
@@ -2646,7 +2675,7 @@ int DeviceMinMatch::build_impl(TB &tb, const std::vector<double> *sample_ages, c
   MMParams p;
   memset(&p, 0, sizeof(p));
   p.N = N;
-  p.lds_state = (!ages && lds_state_fits(N)) ? 1 : 0;
+  p.lds_state = lds_state_fits(N, ages) ? 1 : 0;
   p.threshold = tb.threshold;
   p.threshold_CF = tb.threshold_CF;
   p.M = m.d_M.as<float4>();
