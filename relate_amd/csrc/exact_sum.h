@@ -254,7 +254,12 @@ RL_DEV double sum_exact_fast(const T &term, double L, WaveLink<WAVES> &lk) {
   const int e_out = expo_field(c0);
   // exit unit = entry unit of the next lane = ulp of the binade of Q
   const int e_next = expo_field(Q);
-  const double inv_u_out = pow2_field(1075 + 1023 - e_next);  // 1 / 2^(e_next - 1075)
+  // An exit offset (c - Q) / ulp is asked for only where c lies in Q's binade (every other lane is invalid or walked
+  // from its exact entry): there it is the difference of the two bit patterns -- one integer subtraction of the low
+  // words instead of a subtraction, a multiplication and a quarter-rate conversion in double precision, six times
+  // per sum (round 4).
+  const unsigned q_lo = (unsigned)__double_as_longlong(Q);
+  auto exit_offset = [&](double c) -> int { return (int)((unsigned)__double_as_longlong(c) - q_lo); };
 
   // ---- classification
   const bool same_seq = (exdiff >> 20) == 0;
@@ -277,15 +282,15 @@ RL_DEV double sum_exact_fast(const T &term, double L, WaveLink<WAVES> &lk) {
   // offsets are in units of the exit ulp.  Exit offsets of the four runs
   // (|A_h| < 2^15) and entry offsets B_h = (r_h - P)/ulp_in of their starts:
   int A0 = 0, A1 = 0, A2 = 0, A3 = 0;
-  if (constant) A0 = (int)((c0 - Q) * inv_u_out);
+  if (constant) A0 = exit_offset(c0);
   // exact entry: the exit is c0 itself; offset 0 wherever the approximate prefix Q is that same sum (lane 0,
   // all-zero prefixes), a few ulp for lane 1
-  if (zero_entry && __double_as_longlong(c0) != __double_as_longlong(Q)) A0 = (int)((c0 - Q) * inv_u_out);
+  if (zero_entry && __double_as_longlong(c0) != __double_as_longlong(Q)) A0 = exit_offset(c0);
   if (!invalid && !jump && !zero_entry) {
-    A0 = (int)((c0 - Q) * inv_u_out);
-    A1 = (int)((c1 - Q) * inv_u_out);
-    A2 = (int)((c2 - Q) * inv_u_out);
-    A3 = (int)((c3 - Q) * inv_u_out);
+    A0 = exit_offset(c0);
+    A1 = exit_offset(c1);
+    A2 = exit_offset(c2);
+    A3 = exit_offset(c3);
   }
   const int B0 = -p0 - G4, B1 = 1 - p0, B2 = 2 - p0, B3 = 3 - p0 + G4;
   // Is the lane's map delta -> A_h + ((delta - B_h) >> sh), h = (p0 + delta) & 3,
@@ -402,7 +407,8 @@ RL_DEV double sum_exact_fast(const T &term, double L, WaveLink<WAVES> &lk) {
         if constexpr (!REG_TERM) asm volatile("" : "+v"(thC), "+v"(nthC));  // (not t: a wait state per term, see the chain pass)
       });
       const double v = rd_lane_f64(t, q);
-      delta = (int)((v - rd_lane_f64(Q, q)) * rd_lane_f64(inv_u_out, q));
+      // (the true exit lies between the bracketing runs, which end in Q's binade -- else the lane were invalid)
+      delta = (int)((unsigned)__double_as_longlong(v) - (unsigned)__builtin_amdgcn_readlane((int)q_lo, q));
     } else {
       const int qp0 = m & 3, qsh = (m >> 2) & 3;
       const int h = (qp0 + delta) & 3;
