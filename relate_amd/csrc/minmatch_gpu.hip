@@ -249,6 +249,7 @@ struct Shared {
   int lex_p[MM_WAVES];
   double lex_d2d[MM_WAVES];  // (the AGES build: the draw is a double)
   int a_lw;                  // ... and the last age level its clock has reached, for all waves
+  int guess_i, guess_j;      // (MM_PREFETCH) the likely next pair: the best of the clusters that keep their candidate
   int rowcount[MM_WAVES];
   float sym_dist;
   float red_f[MM_ROWS][MM_WAVES];
@@ -808,6 +809,9 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
   // behind this call, and an exit the compiler takes for divergent -- it hangs on values read from LDS -- is laid
   // out as a loop in which a wave passes the caller's barriers once per group of lanes.
   int bail = -1;
+#ifdef MM_PREFETCH
+  int pf_sink = 0;
+#endif
   for (int num_nodes = N; num_nodes < 2 * N - 1; num_nodes++) {
     const int n = sh.n;
     if (sh.best.dist == INF && !sh.use_sym) {
@@ -1070,7 +1074,9 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
     if (p.timers && tid == 0) {
       sh.tacc[12] += nupd * 100;
       sh.tacc[13] += sh.cnt_rescan_only * 100;
+#ifndef MM_EXP_GUESS
       sh.tacc[14] += nupd == 0 ? 100 : 0;
+#endif
       sh.tacc[15] += sh.cnt_rescan_only > 0 ? 100 : 0;
       sh.cnt_rescan_only = 0;
     }
@@ -1431,12 +1437,54 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
         bl1 = st.lin1[kb];
         bl2 = st.lin2[kb];
       }
+#ifdef MM_PREFETCH
+      if (lane == 0) {
+        sh.guess_i = upos < n ? bl1 : -1;
+        sh.guess_j = upos < n ? bl2 : -1;
+      }
+#endif
     }
     if (!sym_now) {
       erase_read();
       __syncthreads();
       erase_write();
     }
+#ifdef MM_PREFETCH
+    // (experiment, off: -DMM_PREFETCH) While wave 0 is in the ordered part the other seven ask for the rows of the LIKELY
+    // next pair -- the best of the clusters that keep their candidate is the next pair in 56 % of the merges
+    // (-DMM_EXP_GUESS counts them) -- so that phase A of the next merge finds them in the L2.  Measured on three real
+    // N = 5000 builds (tools/bench_builder_variants.sh): A 29.6 -> 25.4 ms per tree, but the loads have to land before
+    // their register is anybody else's, and that wait at the end of the merge costs 9.6 ms: 112.9 -> 119.4 ms per
+    // tree.  What it would take: a destination that is not a register (global_load ... lds into a dump area) and a
+    // bare s_barrier at the end of the merge, whose fence otherwise waits for every load in flight.
+    if constexpr (LDS && !AGES) {
+      const int gi = sh.guess_i, gj = sh.guess_j;
+      if (wave != 0 && !sym_now && gi >= 0 && gj >= 0 && gi != i && gj != i && gi < N && gj < N) {
+        auto ask = [&](int row, int k) {
+          MM_GLOBAL_PTR(const f32x4) ptr = p.M + mm_index((unsigned)row, (unsigned)k, (unsigned)N);
+          pf_sink ^= ((MM_GLOBAL_PTR(const int))ptr)[0];
+        };
+#pragma unroll
+        for (int q = 0; q < MAXQ; q++) {
+          if (q >= nq) break;
+          const int k = a_k[q];
+          if (k >= 0) {
+            ask(gi, k);
+            ask(gj, k);
+          }
+          if (q % (MM_WAVES - 1) == wave - 1) {  // wave 0's columns, dealt to the others
+            const int pos0 = q * MM_BLOCK + lane;
+            if (pos0 < n - 1) {
+              const int k0 = st.ci[pos0];
+              ask(gi, k0);
+              ask(gj, k0);
+            }
+          }
+        }
+        asm volatile("" : "+v"(pf_sink));  // (the loads are waited for here)
+      }
+    }
+#endif
     if (p.timers && tid == 0) sh.tacc[10] += wall_clock64() - sh.tmark;  // (of "ordered": before the first draw)
     if constexpr (AGES) {
       if (wave == 0) {
@@ -1639,6 +1687,9 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
         b.lin2 = st.lin2[j];
       }
       if (lane == 0) {
+#ifdef MM_EXP_GUESS  // (experiment: how often the best of the clusters that keep their candidate is the next pair)
+        if (p.timers) sh.tacc[14] += (upos < n && b.lin1 == bl1 && b.lin2 == bl2) ? 100 : 0;
+#endif
         sh.best = b;
         st.csz[j] = (idx_t)(szi + szj);
         sh.nupd = 0;
