@@ -250,6 +250,9 @@ struct Shared {
   double lex_d2d[MM_WAVES];  // (the AGES build: the draw is a double)
   int a_lw;                  // ... and the last age level its clock has reached, for all waves
   int guess_i, guess_j;      // (MM_PREFETCH) the likely next pair: the best of the clusters that keep their candidate
+#ifdef MM_PREFETCH_LDS
+  unsigned pf_dump[64];      // ... and where the words asked for ahead land (nobody reads them)
+#endif
   int rowcount[MM_WAVES];
   float sym_dist;
   float red_f[MM_ROWS][MM_WAVES];
@@ -1453,16 +1456,27 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
     // (experiment, off: -DMM_PREFETCH) While wave 0 is in the ordered part the other seven ask for the rows of the LIKELY
     // next pair -- the best of the clusters that keep their candidate is the next pair in 56 % of the merges
     // (-DMM_EXP_GUESS counts them) -- so that phase A of the next merge finds them in the L2.  Measured on three real
-    // N = 5000 builds (tools/bench_builder_variants.sh): A 29.6 -> 25.4 ms per tree, but the loads have to land before
-    // their register is anybody else's, and that wait at the end of the merge costs 9.6 ms: 112.9 -> 119.4 ms per
-    // tree.  What it would take: a destination that is not a register (global_load ... lds into a dump area) and a
-    // bare s_barrier at the end of the merge, whose fence otherwise waits for every load in flight.
+    // N = 5000 builds (tools/bench_builder_variants.sh): A 29.6 -> 25.4 ms per tree either way, but (1) into a register
+    // the loads have to land before the register is anybody else's, and that wait at the end of the merge costs 9.6 ms:
+    // 112.9 -> 119.4 ms per tree; (2) -DMM_PREFETCH_LDS: straight into LDS (global_load_lds_dword, nothing to wait for)
+    // with a bare s_barrier at the end of the merge -- issuing the ~23 loads per thread and their addresses costs what
+    // A gains (the ordered part, which shares its SIMD with a prefetching wave, +1.5 ms, the wait for the seven waves
+    // +2.1): 113.0 -> 112.9 ms per tree.
     if constexpr (LDS && !AGES) {
       const int gi = sh.guess_i, gj = sh.guess_j;
       if (wave != 0 && !sym_now && gi >= 0 && gj >= 0 && gi != i && gj != i && gi < N && gj < N) {
+#ifdef MM_PREFETCH_LDS
+        const unsigned dump = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void *)sh.pf_dump;
+#endif
         auto ask = [&](int row, int k) {
           MM_GLOBAL_PTR(const f32x4) ptr = p.M + mm_index((unsigned)row, (unsigned)k, (unsigned)N);
+#ifdef MM_PREFETCH_LDS
+          // straight into LDS: no register to keep, nothing to wait for (the compiler does not know of these loads;
+          // its own waits are for younger ones and the counter runs in order)
+          asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dword %0, off" : : "v"(ptr), "s"(dump) : "memory", "m0");
+#else
           pf_sink ^= ((MM_GLOBAL_PTR(const int))ptr)[0];
+#endif
         };
 #pragma unroll
         for (int q = 0; q < MAXQ; q++) {
@@ -1803,7 +1817,14 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
       erase_write();
     }
     LAP(7);
+#ifdef MM_PREFETCH_LDS
+    // (a bare barrier: the fence of __syncthreads would wait for the words asked for ahead; nothing global is written
+    //  between the erase's barrier and this one when the state lives in LDS, the LDS writes are waited for)
+    if (LDS && !AGES && !sym_now) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else __syncthreads();
+#else
     __syncthreads();
+#endif
     LAP(8);
   }
   if (bail < 0) {
