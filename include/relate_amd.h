@@ -155,6 +155,16 @@ int rl_get_stones(rl_ctx *ctx, int w, float *alpha, float *beta,
  * <paint_dir>/relate_<w>.bin for every window, byte-compatible with the
  * reference (lossy RLE included). */
 int rl_write_paint_files(rl_ctx *ctx, const char *paint_dir);
+/* One window's file only (what a section-parallel consumer of the reference,
+ * scripts/RelateParallel/RelateParallel.sh:231-257, reads), at `path`. */
+int rl_write_paint_file(rl_ctx *ctx, int w, const char *path);
+/* One record of window w's paint file: target k's `int start, int end`, then
+ * the alpha and the beta stone as CollapsedMatrix::DumpToFile writes them
+ * (src/fast_painting.cpp:589-601, src/collapsed_matrix.hpp:228-265) -- the
+ * bytes FastPainting::PaintSteppingStones(data, wb, pfiles, k) appends to
+ * pfiles[w].  Two rows of N floats leave the device.  *len receives the
+ * record's length; with out == NULL only the bound a buffer needs. */
+int rl_paint_record(rl_ctx *ctx, int w, int k, unsigned char *out, size_t cap, size_t *len);
 
 /* The whole `Relate --mode Paint` stage (pipeline/Paint.cpp:17-108): load,
  * optional --painting, mkdir chunk_<c>/paint, paint, write files. */
@@ -293,7 +303,8 @@ int rl_stage_build_topology(const char *out_dir, int chunk_index,
 
 /* Everything a stage call can be told, per call (the positional entry points above and below take the reference's
  * command-line options only: pipeline/BuildTopology.cpp:20-40).  rl_stage_opts_init fills in the defaults and the
- * struct's size; a caller built against an older header passes a shorter struct and gets the defaults for the rest.
+ * struct's size; a caller built against an older header passes a shorter struct and gets the defaults for the rest;
+ * a struct whose size field was never set (0) is refused with RL_EINVAL.
  * 0 / -1 = "decide from the chunk and the device" wherever noted.  The RELATE_AMD_* environment variables of the
  * same names override the struct -- they exist for experiments (tools/, profiles/), not as the interface. */
 typedef struct rl_stage_opts {
@@ -309,7 +320,7 @@ typedef struct rl_stage_opts {
   long long window_rows;    /* posterior rows a window keeps resident; 0: from the HBM that is free; < 0: all      */
   int window_parts;         /* a window keeps at least 1/window_parts of its rows (0: 32)                          */
   int section_threads;      /* sections open at once at most (0: from HBM and the device)                          */
-  int workers;              /* tree-builder workgroups on the device (0: one per open section, 3/8 of the CUs when the windows are bounded) */
+  int workers;              /* tree-builder workgroups on the device (0: one per open section, 13/32 of the CUs when the windows are bounded) */
   int repaint_lanes;        /* RePaint launches side by side: 1 or 2 (0: 1)                                        */
   int park_stones;          /* fused stage: stepping stones to pinned host memory after Paint (rl_park_stones)     */
   int pin_threads;          /* section threads pinned to L3 groups: 1 / 0 (-1: 1)                                  */

@@ -19,6 +19,16 @@
 //   ref_harness treeseq  <outdir> <chunk> <window> <dump.bin>
 //       runs AncesTreeBuilder::BuildTopology and dumps, for every tree,
 //       int pos; int parent[2N-1]
+//   ref_harness paint_targets <outdir> <chunk> <dump.bin> k [k ...]
+//       FastPainting::PaintSteppingStones for the listed targets only (the
+//       loop body of pipeline/Paint.cpp:81-87), every window's record kept
+//       dump: per target, per window: int k; int w; int len; bytes[len]
+//   ref_harness paint_window <outdir> <chunk> <window> <k0> <k1> <part.bin>
+//       PaintSteppingStones for targets [k0, k1); only <window>'s records
+//       are kept (the others go to /dev/null): the parts of consecutive
+//       ranges concatenated ARE the reference's relate_<window>.bin
+//   ref_harness repaint_targets <outdir> <chunk> <window> <dump.bin> k [k ...]
+//       as repaint, for the listed targets only (ascending)
 //
 // This file only exists in this container's workflow: /root/reference does
 // not travel to the GPU box; the fixtures it produces do (tests/golden/).
@@ -174,6 +184,61 @@ int main(int argc, char **argv) {
     return 0;
   }
 
+  if (mode == "paint_targets" || mode == "paint_window") {
+    std::string out = argv[2];
+    int chunk = atoi(argv[3]);
+    int N, L;
+    std::vector<int> wb;
+    read_params(out, chunk, N, L, wb);
+    int W = (int)wb.size() - 1;
+    Data *pd = load(out, chunk);
+    Data &data = *pd;
+    apply_painting(data);
+    if (mode == "paint_targets") {
+      FILE *fo = fopen(argv[4], "wb");
+      if (!fo) return 1;
+      std::vector<char> buf;
+      for (int a = 5; a < argc; a++) {
+        int k = atoi(argv[a]);
+        std::vector<FILE *> pfiles(W);
+        for (int w = 0; w < W; w++) {
+          pfiles[w] = tmpfile();
+          if (!pfiles[w]) return 1;
+        }
+        FastPainting painter(data);
+        painter.PaintSteppingStones(data, wb, pfiles, k);
+        for (int w = 0; w < W; w++) {
+          int len = (int)ftell(pfiles[w]);
+          buf.resize(len);
+          rewind(pfiles[w]);
+          if (fread(buf.data(), 1, len, pfiles[w]) != (size_t)len) return 1;
+          fclose(pfiles[w]);
+          fwrite(&k, 4, 1, fo);
+          fwrite(&w, 4, 1, fo);
+          fwrite(&len, 4, 1, fo);
+          fwrite(buf.data(), 1, len, fo);
+        }
+        fflush(fo);
+      }
+      fclose(fo);
+      return 0;
+    }
+    int window = atoi(argv[4]), k0 = atoi(argv[5]), k1 = atoi(argv[6]);
+    FILE *fo = fopen(argv[7], "wb");
+    FILE *fnull = fopen("/dev/null", "wb");
+    if (!fo || !fnull || window < 0 || window >= W) return 1;
+    std::vector<FILE *> pfiles(W, fnull);
+    pfiles[window] = fo;
+    for (int k = k0; k < k1; k++) {
+      FastPainting painter(data);
+      painter.PaintSteppingStones(data, wb, pfiles, k);
+      if ((k - k0) % 25 == 0) { fflush(fo); fprintf(stderr, "[paint_window %d] %d/%d\n", window, k - k0, k1 - k0); }
+    }
+    fclose(fo);
+    fclose(fnull);
+    return 0;
+  }
+
   std::string out = argv[2];
   int chunk = atoi(argv[3]);
   int window = atoi(argv[4]);
@@ -186,7 +251,9 @@ int main(int argc, char **argv) {
   FILE *fo = fopen(argv[5], "wb");
   if (!fo) return 1;
 
-  if (mode == "repaint") {
+  if (mode == "repaint" || mode == "repaint_targets") {
+    std::vector<char> wanted(N, mode == "repaint");
+    for (int a = 6; a < argc && mode == "repaint_targets"; a++) wanted[atoi(argv[a])] = 1;
     FastPainting painter(data);
     char fn[2048];
     snprintf(fn, sizeof fn, "%s_%i.bin", data.name.c_str(), window);
@@ -201,6 +268,8 @@ int main(int argc, char **argv) {
       if (fread(&s0, 4, 1, fp) != 1 || fread(&s1, 4, 1, fp) != 1) return 1;
       ab.ReadFromFile(fp, bb, la);
       bend.ReadFromFile(fp, be, lb);
+      if (!wanted[n]) continue;
+      if (mode == "repaint_targets") fwrite(&n, 4, 1, fo);
       painter.RePaintSection(data, top, ls, ab, bend, bb, be, la, lb, n);
       int D = (int)ls.size();
       fwrite(&D, 4, 1, fo);

@@ -184,6 +184,18 @@ class Context:
         os.makedirs(paint_dir, exist_ok=True)
         _check(lib().rl_write_paint_files(C.c_void_p(self._h), paint_dir.encode()))
 
+    def write_paint_file(self, w, path):
+        """window w's paint file alone (rl_write_paint_file)"""
+        _check(lib().rl_write_paint_file(C.c_void_p(self._h), int(w), path.encode()))
+
+    def paint_record(self, w, k):
+        """-> bytes: target k's record of window w's paint file (rl_paint_record)"""
+        n = C.c_size_t(0)
+        _check(lib().rl_paint_record(C.c_void_p(self._h), int(w), int(k), None, C.c_size_t(0), C.byref(n)))
+        buf = C.create_string_buffer(n.value)
+        _check(lib().rl_paint_record(C.c_void_p(self._h), int(w), int(k), buf, C.c_size_t(n.value), C.byref(n)))
+        return buf.raw[:n.value]
+
     def open_window(self, w, paint_file=None, first_snp=None, sum_mode=RL_SUM_EXACT, max_rows=0):
         """max_rows > 0: keep at most that many posterior rows resident (rl_window_open_bounded)"""
         return Window(self, w, paint_file, first_snp, sum_mode, max_rows)

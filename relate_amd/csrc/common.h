@@ -60,7 +60,12 @@ void device_cache_trim();
 // launches of tree-builder workers that are alive (minmatch_gpu.hip): while any is, a failed allocation does not
 // trim the cache (hipFree would wait for the workers) -- it takes a larger cached block, or waits for them to leave
 extern std::atomic<int> g_worker_launches;
-size_t device_cache_held();  // bytes of device memory the cache holds for re-use (on any device)
+// bytes of `device`'s memory the cache holds for re-use in blocks of at least min_block bytes (cache_alloc hands out
+// whole blocks only: smaller ones are no room for a request of min_block)
+size_t device_cache_held(int device, size_t min_block);
+// device / pinned allocations that failed on this thread (DevBuf::alloc, the window's pinned buffers): a caller that
+// can wait for memory (the stage's admission loop) tells "out of memory" from any other failure by it
+extern thread_local unsigned tl_alloc_failures;
 
 // owning device buffer
 struct DevBuf {
@@ -87,6 +92,7 @@ struct DevBuf {
     p = device_cache_alloc(n, &got);
     if (!p) {
       set_error("hipMalloc(%zu bytes) failed", n);
+      tl_alloc_failures++;
       return RL_ENOMEM;
     }
     bytes = got;
@@ -183,3 +189,7 @@ size_t decode_stone(const unsigned char *in, size_t avail, int N, float *v, int 
 float fast_log_host(float v);
 }  // namespace rl
 
+
+// the caller's rl_stage_opts, whatever its age, onto the defaults (treeseq.cpp); RL_EINVAL for a struct that never
+// went through rl_stage_opts_init
+extern "C" int rl_internal_resolve_opts(const rl_stage_opts *in, rl_stage_opts *out);

@@ -25,6 +25,7 @@
 namespace rl {
 
 static thread_local std::string g_err;
+thread_local unsigned tl_alloc_failures = 0;
 
 void set_error(const char *fmt, ...) {
   char buf[1024];
@@ -95,7 +96,9 @@ void *cache_alloc(BlockCache &c, size_t bytes, size_t *got, AllocFn raw_alloc) {
         return q;
       }
     }
-    for (int waited = 0; g_worker_launches.load() > 0 && waited < 600; waited++)
+    // (workers leave 50 ms after the last tree: a few seconds cover a caller that follows a build; inside a busy
+    //  stage they never leave, and the stage's admission loop is the one that waits -- treeseq.cpp)
+    for (int waited = 0; g_worker_launches.load() > 0 && waited < 50; waited++)
       std::this_thread::sleep_for(std::chrono::milliseconds(100));
     if (g_worker_launches.load() == 0) {
       device_cache_trim();
@@ -122,9 +125,13 @@ void *device_cache_alloc(size_t bytes, size_t *got) {
   });
 }
 void device_cache_release(void *p, size_t bytes) { cache_release(g_dev_cache, p, bytes); }
-size_t device_cache_held() {
+size_t device_cache_held(int device, size_t min_block) {
   std::lock_guard<std::mutex> lk(g_dev_cache.m);
-  return g_dev_cache.held;
+  size_t sum = 0;
+  for (auto it = g_dev_cache.free_blocks.lower_bound({device, min_block});
+       it != g_dev_cache.free_blocks.end() && it->first.first == device; ++it)
+    sum += it->first.second;
+  return sum;
 }
 void *pinned_cache_alloc(size_t bytes, size_t *got) {
   return cache_alloc(g_pin_cache, bytes, got, [](size_t n) -> void * {
@@ -985,11 +992,69 @@ int rl_get_stones(rl_ctx *ctx, int w, float *alpha, float *beta, float *ls_alpha
   return RL_OK;
 }
 
+int rl_paint_record(rl_ctx *ctx, int w, int k, unsigned char *out, size_t cap, size_t *len) {
+  if (!ctx || !ctx->painted || !len) {
+    set_error("rl_paint_record: call rl_paint first");
+    return RL_ESTATE;
+  }
+  const size_t N = ctx->N, W = ctx->W, nloc = ctx->nloc, k0 = ctx->k0;
+  if (w < 0 || w >= ctx->W || k < (int)k0 || k >= (int)(k0 + nloc)) {
+    set_error("rl_paint_record: window %d / target %d out of range", w, k);
+    return RL_EINVAL;
+  }
+  const size_t maxrec = 8 + 2 * (28 + N * 8);
+  *len = maxrec;
+  if (!out || cap < maxrec) {  // (the bound, for the caller to size its buffer)
+    if (!out) return RL_OK;
+    set_error("rl_paint_record: buffer of %zu bytes, a record may take %zu", cap, maxrec);
+    return RL_EINVAL;
+  }
+  RL_HIP(hipSetDevice(ctx->device));
+  const size_t t = (size_t)k - k0;
+  std::vector<float> a(N), b(N);
+  float la, lb;
+  if (ctx->h_alpha) {
+    memcpy(a.data(), ctx->h_alpha + (w * nloc + t) * N, N * 4);
+    memcpy(b.data(), ctx->h_beta + (w * nloc + t) * N, N * 4);
+  } else {
+    RL_HIP(hipMemcpy(a.data(), ctx->d_alpha.as<float>() + (w * nloc + t) * N, N * 4, hipMemcpyDeviceToHost));
+    RL_HIP(hipMemcpy(b.data(), ctx->d_beta.as<float>() + (w * nloc + t) * N, N * 4, hipMemcpyDeviceToHost));
+  }
+  RL_HIP(hipMemcpy(&la, ctx->d_lsa.as<float>() + w * nloc + t, 4, hipMemcpyDeviceToHost));
+  RL_HIP(hipMemcpy(&lb, ctx->d_lsb.as<float>() + w * nloc + t, 4, hipMemcpyDeviceToHost));
+  const int start = ctx->wb[w], end = ctx->wb[w + 1] - 1;  // fast_painting.cpp:591-594
+  unsigned char *q = out;
+  memcpy(q, &start, 4); q += 4;
+  memcpy(q, &end, 4); q += 4;
+  q += encode_stone(a.data(), (int)N, ctx->plan.bb[(size_t)k * W + w], la, q);
+  q += encode_stone(b.data(), (int)N, ctx->plan.be[(size_t)k * W + w], lb, q);
+  *len = (size_t)(q - out);
+  return RL_OK;
+}
+
+static int write_paint_files(rl_ctx *ctx, const char *paint_dir, int only_window, const char *only_path);
+
 int rl_write_paint_files(rl_ctx *ctx, const char *paint_dir) {
   if (!ctx || !ctx->painted || !paint_dir) {
     set_error("rl_write_paint_files: call rl_paint first");
     return RL_ESTATE;
   }
+  return write_paint_files(ctx, paint_dir, -1, nullptr);
+}
+
+int rl_write_paint_file(rl_ctx *ctx, int w, const char *path) {
+  if (!ctx || !ctx->painted || !path) {
+    set_error("rl_write_paint_file: call rl_paint first");
+    return RL_ESTATE;
+  }
+  if (w < 0 || w >= ctx->W) {
+    set_error("window %d out of range", w);
+    return RL_EINVAL;
+  }
+  return write_paint_files(ctx, nullptr, w, path);
+}
+
+static int write_paint_files(rl_ctx *ctx, const char *paint_dir, int only_window, const char *only_path) {
   if (ctx->nloc != ctx->N) {
     set_error("rl_write_paint_files: a paint file holds every target; this context paints targets %d..%d only",
               ctx->k0, ctx->k0 + ctx->nloc - 1);
@@ -1003,6 +1068,7 @@ int rl_write_paint_files(rl_ctx *ctx, const char *paint_dir) {
   const size_t per_thread = (size_t)N * N * 8 + (size_t)N * maxrec;
   int nthreads = (int)std::max<size_t>(1, std::min<size_t>({(size_t)W, (size_t)4, ((size_t)6 << 30) / per_thread}));
   if (const char *e = getenv("RELATE_AMD_WRITER_THREADS")) nthreads = std::max(1, atoi(e));
+  if (only_window >= 0) nthreads = 1;
   std::mutex gpu_mutex;
   std::atomic<int> failed{0};
   std::string first_error;
@@ -1011,7 +1077,8 @@ int rl_write_paint_files(rl_ctx *ctx, const char *paint_dir) {
     std::vector<int> bb(N), be(N);
     std::vector<unsigned char> recs((size_t)N * maxrec);
     std::vector<size_t> lens(N);
-    for (int w = tid; w < W && !failed; w += nthreads) {
+    for (int w = only_window >= 0 ? only_window : tid; w < (only_window >= 0 ? only_window + 1 : W) && !failed;
+         w += nthreads) {
       int rc;
       {
         std::lock_guard<std::mutex> lk(gpu_mutex);
@@ -1029,7 +1096,8 @@ int rl_write_paint_files(rl_ctx *ctx, const char *paint_dir) {
         lens[k] = (size_t)(p - p0);
       };
       parallel_for(N, encode);
-      const std::string fn = std::string(paint_dir) + "/relate_" + std::to_string(w) + ".bin";
+      const std::string fn = only_path ? std::string(only_path)
+                                       : std::string(paint_dir) + "/relate_" + std::to_string(w) + ".bin";
       FILE *fp = fopen(fn.c_str(), "wb");
       if (!fp) {
         std::lock_guard<std::mutex> lk(gpu_mutex);
@@ -1094,8 +1162,7 @@ int rl_stage_paint(const char *out_dir, int chunk_index, int use_painting, doubl
 
 int rl_stage_paint_ex(const char *out_dir, int chunk_index, const rl_stage_opts *opts) {
   rl_stage_opts o;
-  rl_stage_opts_init(&o);
-  if (opts && opts->size >= sizeof(size_t)) memcpy(&o, opts, std::min(opts->size, sizeof(o)));
+  if (int orc = rl_internal_resolve_opts(opts, &o)) return orc;
   return rl_stage_paint(out_dir, chunk_index, o.use_painting, o.theta, o.rho, o.sum_mode, o.device);
 }
 

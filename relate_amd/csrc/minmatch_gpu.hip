@@ -2424,7 +2424,7 @@ class BuildQueue {
         // whole rounds of the XCDs (below): the goal too
         if (goal >= MM_XCDS) goal -= goal % MM_XCDS;
       }
-      int alive = 0, free_stream = -1, busy_launches = 0;
+      int alive = 0, free_stream = -1;
       for (int l = 0; l < MM_LAUNCHES; l++) {
         if (size[l] > 0 && hipStreamQuery(streams[l]) == hipSuccess) {  // its last worker has left
           size[l] = 0;
@@ -2433,7 +2433,6 @@ class BuildQueue {
         // (workers decide to leave one by one -- idle past the limit and nobody of the launch building --, so a late
         //  claim can keep one of them at work while its peers are gone: a launch counts for the workers it still has)
         alive += size[l] - std::min(size[l], (int)__atomic_load_n(&q_->gone[l], __ATOMIC_ACQUIRE));
-        busy_launches += size[l] > 0;
         if (size[l] == 0 && free_stream < 0) free_stream = l;
       }
       // Workers follow the trees that are waiting or being built, not the sections that exist: a section spends half
@@ -2478,6 +2477,13 @@ class BuildQueue {
           hipLaunchKernelGGL((minmatch_worker<false, MM_Q_GLOB>), dim3((unsigned)n), dim3(MM_BLOCK), 0, streams[l], q_,
                              d_state_.as<WorkerState>(), l, idle, trace_flag);
         if (hipGetLastError() != hipSuccess) {
+          // (this thread ends: the launches it still counted alive are nobody's to take off the count any more --
+          //  the memory cache would wait for them on every failed allocation, and never trim)
+          for (int m = 0; m < MM_LAUNCHES; m++)
+            if (size[m] > 0) {
+              size[m] = 0;
+              g_worker_launches.fetch_sub(1);
+            }
           failed_.store(true);
           return;
         }

@@ -985,21 +985,29 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
       // (this thread's builder keeps its buffers from section to section: only the first one asks for them)
       const bool builder_new = gpu_build && !ts->dev_builder;
       const double need = window_bytes(section) + (builder_new ? builder_bytes : 0.0);
+      // cache_alloc hands out whole cached blocks: of what the cache holds only blocks that can take one of the
+      // window's large buffers (a kept state of a bounded window, or else its rows) count as room
+      const double kept_rows = cap_rows > 0 ? std::min(rows_of[section], (double)cap_rows) : rows_of[section];
+      const size_t min_block = (size_t)(0.85 * (cap_rows > 0 && cap_rows < rows_of[section]
+                                                    ? std::min(kept_rows * row_bytes, bstate_bytes / 4.0)
+                                                    : kept_rows * row_bytes));
+      int open_rc = RL_EIO;
       for (;;) {  // admission: wait until the window fits next to the ones that are open or being opened
         bool admitted = false;
         {
           std::lock_guard<std::mutex> lk(g_gpu_mutex);
           size_t free_b = 0, total_b = 0;
           const bool known = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
-          // (closed windows give their blocks to the library's cache, not to the driver: what the cache holds is
-          //  free for the next window too -- cache_alloc takes any cached block that is large enough)
-          if (!known || (double)free_b + (double)device_cache_held() - reserved_bytes >= need ||
+          // (closed windows give their blocks to the library's cache, not to the driver: what the cache holds in
+          //  blocks of a useful size is free for the next window too)
+          if (!known || (double)free_b + (double)device_cache_held(device, min_block) - reserved_bytes >= need ||
               (open_sections.load() == 0 && reserved_bytes == 0.0)) {
             reserved_bytes += need;
             admitted = true;
           }
         }
         if (admitted) {  // (reading and decoding the paint file, the uploads and RePaint: outside the lock)
+          const unsigned oom_before = tl_alloc_failures;
           win = rl_window_open_bounded(ctx, section, from_files ? pf.c_str() : nullptr, start, sum_mode, cap_rows,
                                        nullptr);
           if (win && builder_new) {  // (while the reservation stands)
@@ -1007,17 +1015,38 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
             if (ts->dev_builder->reserve(!sample_ages.empty())) {
               rl_window_close(win);
               win = nullptr;
+              delete ts->dev_builder;
+              ts->dev_builder = nullptr;
+              tl_alloc_failures++;
             }
           }
-          std::lock_guard<std::mutex> lk(g_gpu_mutex);
-          reserved_bytes -= need;
-          if (win) most_open = std::max(most_open, ++open_sections);
+          bool others;
+          {
+            std::lock_guard<std::mutex> lk(g_gpu_mutex);
+            reserved_bytes -= need;
+            if (win) most_open = std::max(most_open, ++open_sections);
+            others = open_sections.load() > 0 || reserved_bytes > 0.0;
+          }
+          if (win) break;
+          // Out of memory although admitted (the estimate counts bytes, the allocator needs blocks): not the
+          // stage's failure while other sections hold memory they will give back -- wait for one to close and ask
+          // again.  Alone on the device it IS the failure.
+          if (tl_alloc_failures != oom_before && others && !first_error.load()) {
+            open_rc = RL_ENOMEM;
+            const int open_then = open_sections.load();
+            for (int i = 0; i < 1200 && open_sections.load() >= open_then && open_sections.load() > 0 &&
+                            !first_error.load(); i++)
+              std::this_thread::sleep_for(std::chrono::milliseconds(50));
+            std::this_thread::sleep_for(std::chrono::milliseconds(50));
+            continue;
+          }
+          if (tl_alloc_failures != oom_before) open_rc = RL_ENOMEM;
           break;
         }
         if (first_error.load()) break;
         std::this_thread::sleep_for(std::chrono::milliseconds(50));
       }
-      int r = win ? RL_OK : (first_error.load() ? first_error.load() : RL_EIO);
+      int r = win ? RL_OK : (first_error.load() ? first_error.load() : open_rc);
       const double t_open = std::chrono::duration<double>(std::chrono::steady_clock::now() - stage_t0).count();
       if (!r) r = rl_treeseq_build(ts, start, end, win_matrix, win_advance, win, flags, fb);
       if (getenv("RELATE_AMD_TIMING"))  // (when the sections start and end: the stage's ramp and tail)
@@ -1087,18 +1116,25 @@ void rl_stage_opts_init(rl_stage_opts *o) {
 }
 
 // the caller's struct, whatever its age: fields past its `size` keep their defaults
-static rl_stage_opts resolve_opts(const rl_stage_opts *in) {
-  rl_stage_opts o;
-  rl_stage_opts_init(&o);
-  if (in && in->size >= sizeof(size_t)) memcpy(&o, in, std::min(in->size, sizeof(o)));
-  o.size = sizeof(o);
-  return o;
+// (a struct that never went through rl_stage_opts_init -- size 0, or a size no version of the header ever had -- is
+//  refused: silently running with the defaults instead of the caller's options is the worse answer)
+int rl_internal_resolve_opts(const rl_stage_opts *in, rl_stage_opts *out) {
+  rl_stage_opts_init(out);
+  if (!in) return RL_OK;
+  if (in->size < 2 * sizeof(size_t) || in->size > 4096 || in->size % sizeof(int) != 0) {
+    set_error("rl_stage_opts.size = %zu: initialise the struct with rl_stage_opts_init()", in->size);
+    return RL_EINVAL;
+  }
+  memcpy(out, in, std::min(in->size, sizeof(*out)));
+  out->size = sizeof(*out);
+  return RL_OK;
 }
 
 int rl_stage_build_topology_ex(const char *out_dir, int chunk_index, int first_section, int last_section,
                                const rl_stage_opts *opts) {
   if (!out_dir) return RL_EINVAL;
-  const rl_stage_opts o = resolve_opts(opts);
+  rl_stage_opts o;
+  if (int orc = rl_internal_resolve_opts(opts, &o)) return orc;
   rl_ctx *ctx = rl_create(o.device);
   if (!ctx) return RL_ENODEVICE;
   int rc = rl_load_chunk(ctx, out_dir, chunk_index);
@@ -1141,7 +1177,8 @@ int rl_stage_set_sample_ages(const char *file) {
 int rl_stage_paint_build_topology_ex(const char *out_dir, int chunk_index, int first_section, int last_section,
                                      const rl_stage_opts *opts) {
   if (!out_dir) return RL_EINVAL;
-  const rl_stage_opts o = resolve_opts(opts);
+  rl_stage_opts o;
+  if (int orc = rl_internal_resolve_opts(opts, &o)) return orc;
   const int device = o.device, sum_mode = o.sum_mode, use_painting = o.use_painting;
   const double theta = o.theta, rho = o.rho;
   // RELATE_AMD_TIMING=1: wall-clock of what precedes the sections on stderr

@@ -57,6 +57,7 @@ struct rl_window {
   // a window's distance matrices run on its own stream: the sections of a stage ask for theirs at the same time
   hipStream_t stream = nullptr;
   hipEvent_t e0 = nullptr, e2 = nullptr;
+  bool matrix_ready = false;  // stream, events, argument block and cursor caches of rl_window_matrix all exist
   unsigned char *h_stage = nullptr;  // pinned: the per-target arguments of one matrix (MatrixArg[nloc]), read by the
   size_t h_stage_bytes = 0;          // kernel where they lie (d_args: the block's device address)
   void *d_args = nullptr;
@@ -268,6 +269,7 @@ static int place_rows(rl_window *win, int snp, float *kernel_ms) {
   int rc = win->d_place.alloc((size_t)nloc * 48);
   if (!rc && !win->h_place && !(win->h_place = static_cast<unsigned char *>(pinned_cache_alloc((size_t)nloc * 48, &win->h_place_bytes)))) {
     set_error("window %d: no pinned host memory for the launch arguments", win->w);
+    tl_alloc_failures++;
     rc = RL_ENOMEM;
   }
   if (rc) return rc;
@@ -683,17 +685,24 @@ static int window_matrix(rl_window *win, int snp, float *d_host, void *d_dev, fl
   RL_HIP(hipSetDevice(ctx->device));
   const int N = ctx->N, L = ctx->L, k0 = win->k0, nloc = win->nloc;
   // the per-target arguments are written where the kernel reads them: a pinned block of the window
-  if (!win->stream) {
-    if (make_stream(&win->stream, false, true) != hipSuccess ||
-        hipEventCreate(&win->e0) != hipSuccess || hipEventCreate(&win->e2) != hipSuccess ||
-        !(win->h_stage = static_cast<unsigned char *>(pinned_cache_alloc((size_t)nloc * sizeof(MatrixArg) + 64, &win->h_stage_bytes))) ||
+  if (!win->matrix_ready) {  // (first use; a failure half way leaves nothing a later call would trust)
+    if (!win->stream && make_stream(&win->stream, false, true) != hipSuccess) win->stream = nullptr;
+    if (win->stream && !win->e0 && hipEventCreate(&win->e0) != hipSuccess) win->e0 = nullptr;
+    if (win->stream && !win->e2 && hipEventCreate(&win->e2) != hipSuccess) win->e2 = nullptr;
+    if (win->stream && !win->h_stage) {
+      win->h_stage = static_cast<unsigned char *>(pinned_cache_alloc((size_t)nloc * sizeof(MatrixArg) + 64, &win->h_stage_bytes));
+      if (!win->h_stage) tl_alloc_failures++;
+    }
+    if (!win->stream || !win->e0 || !win->e2 || !win->h_stage ||
         hipHostGetDevicePointer(&win->d_args, win->h_stage, 0) != hipSuccess) {
+      win->d_args = nullptr;
       set_error("rl_window_matrix: stream / argument block creation failed");
       return RL_EHIP;
     }
     win->e_cursor.assign((size_t)nloc, -2);
     win->e_pn.assign((size_t)nloc, 1.0f);
     win->e_np.assign((size_t)nloc, 1.0f);
+    win->matrix_ready = true;
   }
   MatrixArg *args = reinterpret_cast<MatrixArg *>(win->h_stage);
   bool covered = true;  // a bounded window: are the rows this tree reads resident?

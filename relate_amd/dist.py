@@ -305,8 +305,11 @@ def run_chunk_by_targets(out_dir, chunk_index=0, painting=None, device=None, sec
     mine = deal_sections(todo, rank, world)
     Q = max(1, int(in_flight))
     maxrows = -(-N // world)
-    send = fab.buffer(maxrows, N)
-    recv = fab.buffer(world * maxrows, N)
+    # a block = this rank's rows + one row whose first float says whether they are good (1.0 = shard.rows failed on
+    # that rank and the block is stale: the owner must not build from it)
+    stride = maxrows + 1
+    send = fab.buffer(stride, N)
+    recv = fab.buffer(world * stride, N)
     on_device = send.is_cuda
     gpu_build = bool(build_on_gpu and on_device)
     if gpu_build:
@@ -366,7 +369,7 @@ def run_chunk_by_targets(out_dir, chunk_index=0, painting=None, device=None, sec
             a, b = target_range(r, world, N)
             if b == a:
                 continue
-            blk = recv[r * maxrows: r * maxrows + (b - a)]
+            blk = recv[r * stride: r * stride + (b - a)]
             if to_device:
                 shard.copy_on_device(ptr + a * N * 4, blk.data_ptr(), (b - a) * N * 4)
             else:
@@ -414,8 +417,13 @@ def run_chunk_by_targets(out_dir, chunk_index=0, painting=None, device=None, sec
                             shard.rows(section, snp, send.data_ptr())
                     except BaseException as e:  # (keep the collectives aligned; the next tick stops the job)
                         abort = e
+                        send[maxrows, 0] = 1.0
                     fab.all_gather_rows(send, recv)
                     served += 1
+                    bad = [int(x) for x in torch.nonzero(recv[maxrows::stride, 0].cpu()).flatten()]
+                    if bad and abort is None:  # (every rank sees the same flags: all stop in the next tick)
+                        abort = RuntimeError("run_chunk_by_targets: rows of section %d at SNP %d failed on rank%s %s"
+                                             % (section, snp, "s" if len(bad) > 1 else "", bad))
                 elif kind == REQ_RELEASE:
                     try:
                         shard.release_section(section)
@@ -425,6 +433,8 @@ def run_chunk_by_targets(out_dir, chunk_index=0, painting=None, device=None, sec
                     req = snapshot[q]
                     if kind == REQ_MATRIX and abort is None:
                         deliver(req)
+                    elif kind == REQ_MATRIX:  # (no tree from a matrix with stale rows in it)
+                        req[6] = abort
                     with lock:
                         pending[q] = None
                     req[5].set()
@@ -487,13 +497,32 @@ def main(argv=None):
         world = dist.get_world_size() if launched else 1
         todo = list(range(read_parameters(args.out_dir)["num_chunks"])) if chunks is None else chunks
         for c in todo:
+            if args.paint_files:
+                # the reference's route: the Paint stage writes the chunk's paint files (rank 0, all targets), the
+                # shards read their targets' records from them
+                if rank == 0:
+                    (stages if stages is not None else __import__("relate_amd.api", fromlist=["api"])).stage_paint(
+                        args.out_dir, c, painting=painting, device=local_device())
+                if launched:
+                    dist.barrier()
             shard_obj = None
             if stages is not None and hasattr(stages, "Shard"):  # (a stand-in for api.Shard: tests, other back ends)
+                import inspect
                 import numpy as np
                 N = int(np.fromfile(os.path.join(args.out_dir, "parameters_c%d.bin" % c), dtype=np.int32, count=1)[0])
-                shard_obj = stages.Shard(args.out_dir, c, *target_range(rank, world, N))
-            owned = run_chunk_by_targets(args.out_dir, c, painting=painting, in_flight=args.in_flight,
-                                         window_rows=args.window_rows, from_paint_files=args.paint_files, shard=shard_obj)
+                kw = {}
+                accepted = inspect.signature(stages.Shard).parameters
+                for name, val in (("painting", painting), ("from_paint_files", args.paint_files)):
+                    if name in accepted:
+                        kw[name] = val
+                shard_obj = stages.Shard(args.out_dir, c, *target_range(rank, world, N), **kw)
+            try:
+                owned = run_chunk_by_targets(args.out_dir, c, painting=painting, in_flight=args.in_flight,
+                                             window_rows=args.window_rows, from_paint_files=args.paint_files,
+                                             shard=shard_obj)
+            finally:
+                if shard_obj is not None and hasattr(shard_obj, "close"):
+                    shard_obj.close()  # (run_chunk_by_targets closes only the shard it opened itself)
             print("rank %d of %d: chunk %d by targets, owned sections %s" % (rank, world, c, sorted(owned)), flush=True)
             if launched:
                 dist.barrier()  # (every section's files are written before the host-only stage reads them)

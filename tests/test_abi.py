@@ -62,3 +62,16 @@ def test_synth_panel_deterministic_and_chunk_files_roundtrip(tmp_path):
         assert open(d1 / fn, "rb").read() == open(d2 / fn, "rb").read(), fn
     c = rlutil.read_chunk(str(d1))
     assert np.array_equal(c.seq, a.seq) and np.array_equal(c.wb, a.wb)
+
+
+def test_stage_opts_that_never_saw_init_are_refused():
+    """a zeroed rl_stage_opts (size 0) must not silently run with the defaults: RL_EINVAL before any
+    device work, from all three *_ex stages"""
+    lib = api.lib()
+    raw = (C.c_ubyte * 256)()  # larger than the struct, all zero: size field 0
+    for fn, args in ((lib.rl_stage_paint_ex, (b"/nonexistent", 0)),
+                     (lib.rl_stage_build_topology_ex, (b"/nonexistent", 0, 0, 0)),
+                     (lib.rl_stage_paint_build_topology_ex, (b"/nonexistent", 0, 0, 0))):
+        fn.argtypes = [C.c_char_p] + [C.c_int] * (len(args) - 1) + [C.c_void_p]
+        assert fn(*args, C.cast(raw, C.c_void_p)) == -1, fn  # RL_EINVAL
+        assert b"rl_stage_opts_init" in lib.rl_last_error()

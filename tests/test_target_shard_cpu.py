@@ -109,14 +109,17 @@ def test_protocol_over_threads(world, N, W, in_flight):
     assert sorted(owned) == list(range(W))
 
 
-def test_a_failing_rank_stops_every_rank():
+@pytest.mark.parametrize("bad_rank,fail_at", [(1, 7), (0, 1), (2, 4), (1, 12), (0, 9), (2, 17)])
+def test_a_failing_rank_stops_every_rank(bad_rank, fail_at):
+    """... and no owner ever gets a matrix with the failing rank's stale rows in it (the blocks carry a flag row):
+    FakeShard.build_section would raise an AssertionError, not the job's RuntimeError"""
     world, N, W = 3, 10, 6
     hub = rdist.ThreadFabric.Hub(world)
     errors = [None] * world
 
     def body(r):
         try:
-            run_rank(rdist.ThreadFabric(hub, r), N, W, fail_at=7 if r == 1 else None)
+            run_rank(rdist.ThreadFabric(hub, r), N, W, fail_at=fail_at if r == bad_rank else None)
         except BaseException as e:
             errors[r] = e
 
@@ -127,7 +130,7 @@ def test_a_failing_rank_stops_every_rank():
         t.join(timeout=120)
         assert not t.is_alive()
     assert all(isinstance(e, RuntimeError) for e in errors), errors
-    assert "injected" in str(errors[1])
+    assert "injected" in str(errors[bad_rank])
 
 
 def _gloo_worker(rank, world, port, q):
