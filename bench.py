@@ -88,36 +88,73 @@ def cpu_baseline(N, L, bits, r, rpos, wb, seconds_target=12.0):
 def chunk_wallclock_full():
     """The metric's other half MEASURED: the whole C3 chunk -- Paint + BuildTopology of all 267 sections, files in ->
     .anc / .mut files out -- through `Relate --mode PaintBuildTopology` in a child process (tools/chunk_c3_fused.py).
-    Minutes; before this process touches the GPU."""
+    BENCH_C3_RUNS runs (default 2; ~2.7 minutes each): the first with the stage's timing lines (RELATE_AMD_TIMING:
+    trees built, RePaint busy seconds, `stage_lines`), the others without; every run's seconds are reported.  Before
+    this process touches the GPU."""
+    import statistics
     import subprocess
     tool = os.path.join(ROOT, "tools", "chunk_c3_fused.py")
+    runs = max(1, int(os.environ.get("BENCH_C3_RUNS", "2")))
+    results = []
     try:
-        p = subprocess.run([sys.executable, tool, "267"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500,
-                           env=dict(os.environ, C3_NO_TIMING="1"))
-        d = json.loads(p.stdout.decode().strip().split("\n")[-1])
-        return {"workload": "the C3 chunk, synthetic N=5000 x L=500000, %d windows: Relate --mode PaintBuildTopology, "
-                            "Paint + BuildTopology of all %d sections in one process on one GPU, chunk files in, "
-                            ".anc/.mut files out (no paint files)" % (d["windows"], d["sections"]),
-                "measured": True, "wall_s": d["wall_s"], "sections": d["sections"], "trees": d["trees_built"],
-                "trees_per_s": d["trees_per_s"], "anc_GB": d["anc_GB"], "stage_lines": d.get("stage_lines", [])[:4],
-                **verify_c3(d.get("section_md5", {}))}
+        for i in range(runs):
+            env = dict(os.environ)
+            if i > 0:
+                env["C3_NO_TIMING"] = "1"
+            else:
+                env.pop("C3_NO_TIMING", None)
+            p = subprocess.run([sys.executable, tool, "267"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500,
+                               env=env)
+            results.append(json.loads(p.stdout.decode().strip().split("\n")[-1]))
+        d = results[0]
+        walls = [x["wall_s"] for x in results]
+        checks = [verify_c3(x.get("section_md5", {})) for x in results]
+        out = {"workload": "the C3 chunk, synthetic N=5000 x L=500000, %d windows: Relate --mode PaintBuildTopology, "
+                           "Paint + BuildTopology of all %d sections in one process on one GPU, chunk files in, "
+                           ".anc/.mut files out (no paint files)" % (d["windows"], d["sections"]),
+               "measured": True, "wall_s": statistics.median(walls), "runs_s": walls, "min_s": min(walls),
+               "max_s": max(walls), "runs": "run 0 with the stage's timing lines, the others without",
+               "sections": d["sections"], "trees_kept": d["trees_kept"], "trees_built": d.get("trees_built"),
+               "trees_built_per_s": (d["trees_built"] / d["wall_s"]) if d.get("trees_built") else None,
+               "trees_kept_per_s": d["trees_kept"] / statistics.median(walls), "anc_GB": d["anc_GB"],
+               "stage_lines": d.get("stage_lines", [])[:6]}
+        out.update(checks[0])
+        out["every_run_matches_reference"] = all(c.get("matches_reference") for c in checks)
+        return out
     except Exception as e:  # never a reason to lose the bench line
-        return {"error": str(e)[:200]}
+        return {"error": str(e)[:200], "runs_s": [x.get("wall_s") for x in results]}
 
 
 def verify_c3(section_md5):
-    """this run's md5 of sections 0 / 133 / 266 of the C3 chunk against profiles/r04_c3_section_md5.json: the same
-    sections built by ANOTHER schedule of the path (tools/verify_c3_sections.py: one section per call, its whole window
-    resident -- one RePaint launch instead of ~37 --, the trees by the host's MinMatch instead of the device workers)"""
+    """This run's md5 of the C3 chunk's sections 0 / 133 / 266 against what is on file:
+    * section 133 against the REFERENCE: tests/golden/c3_full.npz holds the md5 of out_133.anc / out_133.mut as the
+      unmodified reference binary wrote them (its own paint file of window 133 from PaintSteppingStones at full
+      length, then Relate --mode BuildTopology of that section; tools/make_golden_c3.py);
+    * sections 0 and 266 against ANOTHER SCHEDULE of this library (profiles/r04_c3_section_md5.json: one section per
+      call, whole window resident, host MinMatch)."""
+    out = {"section_md5": section_md5, "verified_sections": [], "matches_reference": False}
+    try:
+        z = np.load(os.path.join(ROOT, "tests", "golden", "c3_full.npz"))
+        w = int(z["pin_window"][0])
+        want = {"out_%d.anc" % w: z["w/anc_md5"].tobytes().hex(), "out_%d.mut" % w: z["w/mut_md5"].tobytes().hex()}
+        out["reference_held_section"] = w
+        out["matches_reference"] = all(section_md5.get(k) == v for k, v in want.items())
+        if out["matches_reference"]:
+            out["verified_sections"].append(w)
+        out["verified_against"] = ("section %d: the unmodified reference binary's .anc / .mut (tests/golden/c3_full.npz)"
+                                   % w)
+    except Exception as e:
+        out["verify_error"] = str(e)[:120]
     try:
         ref = json.load(open(os.path.join(ROOT, "profiles", "r04_c3_section_md5.json")))
         want = ref["check_md5"]
         secs = sorted(set(int(k.split("_")[1].split(".")[0]) for k in want))
         ok = [s for s in secs if all(section_md5.get("out_%d.%s" % (s, e)) == want["out_%d.%s" % (s, e)] for e in ("anc", "mut"))]
-        return {"verified_sections": ok, "checked_sections": secs, "verified_against": ref.get("against", ""),
-                "section_md5": section_md5}
+        out["same_as_other_schedule"] = ok
+        out["checked_sections"] = secs
     except Exception as e:
-        return {"verified_sections": [], "verify_error": str(e)[:120], "section_md5": section_md5}
+        out["verify_error_other_schedule"] = str(e)[:120]
+    return out
 
 
 def chunk_wallclock_sample(sections=8, host_builder=False):

@@ -1962,124 +1962,178 @@ __global__ void __launch_bounds__(MM_BLOCK, 1)
   }
 }
 
-// M[a][b] = (d(a,b), d(b,a), cf(a,b), cf(b,a)) from the row-major matrices (cf may be null), 32 x 32 tiles
-// through LDS
-__global__ void __launch_bounds__(256) pack_kernel(const float *__restrict__ D, const float *__restrict__ CF,
-                                                   float4 *__restrict__ M, int N) {
-  __shared__ float t1[32][33], t2[32][33], c1[32][33], c2[32][33];
-  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-#pragma unroll
-  for (int r = ty; r < 32; r += 8) {
-    if (by + r < N && bx + tx < N) {
-      t1[r][tx] = D[(size_t)(by + r) * N + bx + tx];
-      if (CF) c1[r][tx] = CF[(size_t)(by + r) * N + bx + tx];
-    }
-    if (bx + r < N && by + tx < N) {
-      t2[r][tx] = D[(size_t)(bx + r) * N + by + tx];
-      if (CF) c2[r][tx] = CF[(size_t)(bx + r) * N + by + tx];
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int r = ty; r < 32; r += 8)
-    if (by + r < N && bx + tx < N)
-      M[mm_index(by + r, bx + tx, N)] =
-          make_float4(t1[r][tx], t2[tx][r], CF ? c1[r][tx] : 0.0f, CF ? c2[tx][r] : 0.0f);
-}
+// ---- the per-tree kernels around the build: every tree pays them on the CUs the workers leave, next to RePaint, so
+// they are counted in bytes.  Round 5: four passes over the matrices instead of six --
+//   rowmin_penalty_kernel  the carrier penalty of a tree's distance matrix (in place) AND its row minima, one pass;
+//   prior_kernel           the clade prior row by row AND its row minima (the row is in LDS anyway);
+//   weave_kernel           M[a][b] = (d(a,b), d(b,a), cf(a,b), cf(b,a)) AND the pair scan of the initialisation (the
+//                          row minima are complete by then): the woven matrix is written once and never read back.
+// Before: penalty (in place), prior, pack (read 2 x 2 matrices, write M), rowmin (read both matrices again), pairscan
+// (read half of M): 0.42 ms of kernels and ~1.5 GB per tree at N = 5000; now ~1.1 GB.
 
-// out[a] = min over l != a of in[a][l]: the row minima of tree_builder.cpp:1659-1666, a workgroup per row
-// (blocks N .. 2N-1: the same for the second matrix, the clade prior)
-__global__ void __launch_bounds__(256) rowmin_kernel(const float *__restrict__ in, float *__restrict__ out,
-                                                    const float *__restrict__ in2, float *__restrict__ out2, int N) {
+// Carrier penalty of AncesTreeBuilder::BuildTopology (anc_builder.cpp:563-581): every entry of a carrier's row gets
+// + val, and - val again where the column is a carrier too (the same two operations in the same order per entry as
+// the host loop); member == nullptr: no penalty (the first tree of a section, --no_consistency).  And, of the row as
+// it then is, out[a] = min over l != a: the row minima of tree_builder.cpp:1659-1666.  A workgroup per row.
+__global__ void __launch_bounds__(256) rowmin_penalty_kernel(float *__restrict__ D, int N,
+                                                            const unsigned char *__restrict__ member, float val,
+                                                            float *__restrict__ out) {
   __shared__ float part[4];
-  int a = blockIdx.x;
-  if (a >= N) {
-    a -= N;
-    in = in2;
-    out = out2;
-  }
-  const float *row = in + (size_t)a * N;
+  const int a = blockIdx.x;
+  float *row = D + (size_t)a * N;
+  const bool carrier = member && member[a];
   float mv = INFINITY;
-  for (int l = threadIdx.x; l < N; l += 256)
-    if (l != a) mv = fminf(mv, row[l]);
+  for (int col = threadIdx.x; col < N; col += 256) {
+    float x = row[col];
+    if (carrier) {
+      x = x + val;
+      if (member[col]) x -= val;
+      row[col] = x;
+    }
+    if (col != a) mv = fminf(mv, x);
+  }
   mv = wave_min_f(mv);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mv;
   __syncthreads();
   if (threadIdx.x == 0) out[a] = fminf(fminf(part[0], part[1]), fminf(part[2], part[3]));
 }
 
-// The pair scan of MinMatch's initialisation (tree_builder.cpp:1690-1722) on the whole chip: row a's partners
-// b > a with d(a,b) <= min_a and d(b,a) <= min_b (minima + threshold), in order, with the symmetric distance the
-// reference's loop would compute for the pair (0 when the pair is also mutually closest under the prior, :1699-1702).
-// mvcf_old: min_values_CF as carried over from the previous tree (:2399-2400).
-__global__ void __launch_bounds__(256) pairscan_kernel(const float4 *__restrict__ M, const float *__restrict__ rowmin_D,
-                                                       const float *__restrict__ rowmin_CF,
-                                                       const float *__restrict__ mvcf_old, int has_prior, int ages,
-                                                       float threshold, float threshold_CF, int N, int *__restrict__ hit_cnt,
-                                                       unsigned *__restrict__ hit_b, float *__restrict__ hit_sym) {
-  __shared__ int wcnt[4];
-  const int a = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float mva = rowmin_D[a] + threshold;
-  float mvcf_a = 0.0f;
-  if (has_prior) {
-    const float old = mvcf_old[a], mc_ = rowmin_CF[a];
-    mvcf_a = (old > mc_ ? mc_ : old) + threshold_CF;
-  }
-  int base = 0;
-  for (int b0 = a + 1; b0 < N; b0 += 256) {
-    const int b = b0 + (int)threadIdx.x;
-    bool hit = false;
-    float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (b < N) {
-      e = M[mm_index(a, b, N)];
-      hit = mva >= e.x && rowmin_D[b] + threshold >= e.y;
+// The woven matrix M[a][b] = (d(a,b), d(b,a), cf(a,b), cf(b,a)) from the row-major matrices (CF may be null) and, in
+// the same pass, the pair scan of MinMatch's initialisation (tree_builder.cpp:1690-1722): row a's partners b > a
+// with d(a,b) <= min_a and d(b,a) <= min_b (minima + threshold), in order, with the symmetric distance the
+// reference's loop would compute for the pair (0 when the pair is also mutually closest under the prior,
+// :1699-1702).  mvcf_old: min_values_CF as carried over from the previous tree (:2399-2400).
+// One workgroup per strip of 32 rows, walking the column panels of 64 in order (so a row's hits come out in
+// order): wave w holds rows a0 + 8 w + r, lane l column 64 pb + l.  d(a,b) and cf(a,b) arrive as the lanes need
+// them (a wave reads 256 contiguous bytes of a row), d(b,a) and cf(b,a) -- 64 rows b, 32 columns -- through LDS;
+// a wave's store is 1 KB of M's panel.  The next panel's loads are in flight while this one is woven.
+constexpr int WV_ROWS = 32;
+template <bool PRIOR>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) weave_kernel(const float *__restrict__ D, const float *__restrict__ CF,
+                                                    float4 *__restrict__ M, int N, const float *__restrict__ rowmin_D,
+                                                    const float *__restrict__ rowmin_CF,
+                                                    const float *__restrict__ mvcf_old, int ages, float threshold,
+                                                    float threshold_CF, int *__restrict__ hit_cnt,
+                                                    unsigned *__restrict__ hit_b, float *__restrict__ hit_sym) {
+  __shared__ float tD[64][WV_ROWS + 1], tC[PRIOR ? 64 : 1][WV_ROWS + 1];
+  // (the wave's index as a scalar: its rows' addresses are scalar bases, the lane's column a 32-bit offset)
+  const int a0 = blockIdx.x * WV_ROWS, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int trow = threadIdx.x >> 2, tcol = (threadIdx.x & 3) * 8;  // the thread's 8 floats of the transposed tile
+  typedef const __attribute__((address_space(1))) float *GF;
+  typedef const __attribute__((address_space(1))) f32x4 *GF4;
+  const GF Dg = (GF)D, CFg = (GF)CF;
+  const bool vec = (N & 3) == 0;                                     // (rows 16-byte aligned: float4 loads)
+  float mva[8], mvcfa[8];
+  int cnt[8];
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    const int a = a0 + wave * 8 + r;
+    cnt[r] = 0;
+    mva[r] = a < N ? rowmin_D[a] + threshold : 0.0f;
+    mvcfa[r] = 0.0f;
+    if (PRIOR && a < N) {
+      const float old = mvcf_old[a], mc_ = rowmin_CF[a];
+      mvcfa[r] = (old > mc_ ? mc_ : old) + threshold_CF;
     }
-    const unsigned long long m = __ballot(hit);
-    if (lane == 0) wcnt[wave] = __popcll(m);
-    __syncthreads();
-    int at = base + __popcll(m & ((1ull << lane) - 1ull));
-    for (int w = 0; w < wave; w++) at += wcnt[w];
-    if (hit && at < MM_HITS) {
-      float sym = e.y + e.x;
-      if (has_prior) {
-        const float old = mvcf_old[b], mc_ = rowmin_CF[b];
-        const float mvcf_b = (old > mc_ ? mc_ : old) + threshold_CF;
-        // (with sample ages the initialisation keeps the pairs the prior agrees with and voids the others, :1792-1797)
-        const bool agrees = e.z <= mvcf_a && e.w <= mvcf_b;
-        if (ages ? !agrees : agrees) sym = ages ? INFINITY : 0.0f;
+  }
+  struct Panel {
+    float x[8], z[8];    // d(a,b), cf(a,b) of the wave's rows at the lane's column
+    float td[8], tc[8];  // the thread's piece of the transposed tile: d(b', a0 + tcol ..), cf likewise
+  };
+  auto load = [&](int pb, Panel &q) {
+    const unsigned b = (unsigned)(pb * 64 + lane);
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      const int a = a0 + wave * 8 + r;  // (wave-uniform)
+      const bool in = a < N && (int)b < N;
+      const GF drow = Dg + (size_t)a * N, crow = CFg + (size_t)a * N;
+      q.x[r] = in ? drow[b] : 0.0f;
+      q.z[r] = (PRIOR && in) ? crow[b] : 0.0f;
+    }
+    const int bb = pb * 64 + trow;
+    const unsigned toff = (unsigned)bb * (unsigned)N + (unsigned)(a0 + tcol);  // (N <= 10240: N * N < 2^32)
+    if (vec && bb < N && a0 + tcol + 8 <= N) {
+      const GF4 s4 = (GF4)(Dg + toff);
+      const f32x4 u = s4[0], v = s4[1];
+      q.td[0] = u.x, q.td[1] = u.y, q.td[2] = u.z, q.td[3] = u.w, q.td[4] = v.x, q.td[5] = v.y, q.td[6] = v.z, q.td[7] = v.w;
+      if (PRIOR) {
+        const GF4 c4 = (GF4)(CFg + toff);
+        const f32x4 cu = c4[0], cv = c4[1];
+        q.tc[0] = cu.x, q.tc[1] = cu.y, q.tc[2] = cu.z, q.tc[3] = cu.w, q.tc[4] = cv.x, q.tc[5] = cv.y, q.tc[6] = cv.z, q.tc[7] = cv.w;
       }
-      hit_b[(size_t)a * MM_HITS + at] = (unsigned)b;
-      hit_sym[(size_t)a * MM_HITS + at] = sym;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const bool in = bb < N && a0 + tcol + k < N;
+        q.td[k] = in ? Dg[toff + k] : 0.0f;
+        q.tc[k] = (PRIOR && in) ? CFg[toff + k] : 0.0f;
+      }
     }
-    base += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+  };
+  auto weave = [&](int pb, const Panel &q) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      tD[trow][tcol + k] = q.td[k];
+      if (PRIOR) tC[trow][tcol + k] = q.tc[k];
+    }
     __syncthreads();
+    const int b = pb * 64 + lane;
+    const float mvb = b < N ? rowmin_D[b] + threshold : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      const int a = a0 + wave * 8 + r;
+      const float y = tD[lane][wave * 8 + r], w = PRIOR ? tC[lane][wave * 8 + r] : 0.0f;
+      const bool in = a < N && b < N;
+      if (in) M[mm_index(a, b, N)] = make_float4(q.x[r], y, q.z[r], w);
+      const bool hit = in && b > a && mva[r] >= q.x[r] && mvb >= y;
+      const unsigned long long m = __ballot(hit);
+      if (m) {  // (wave-uniform, rare)
+        const int at = cnt[r] + __popcll(m & ((1ull << lane) - 1ull));
+        if (hit && at < MM_HITS) {
+          float sym = y + q.x[r];
+          if (PRIOR) {
+            const float old = mvcf_old[b], mc_ = rowmin_CF[b];
+            const float mvcf_b = (old > mc_ ? mc_ : old) + threshold_CF;
+            // (with sample ages the initialisation keeps the pairs the prior agrees with and voids the others, :1792-1797)
+            const bool agrees = q.z[r] <= mvcfa[r] && w <= mvcf_b;
+            if (ages ? !agrees : agrees) sym = ages ? INFINITY : 0.0f;
+          }
+          hit_b[(size_t)a * MM_HITS + at] = (unsigned)b;
+          hit_sym[(size_t)a * MM_HITS + at] = sym;
+        }
+        cnt[r] += __popcll(m);
+      }
+    }
+    __syncthreads();
+  };
+  const int P = (N + 63) / 64;
+  Panel p0, p1;
+  load(0, p0);
+  for (int pb = 0; pb < P; pb += 2) {
+    if (pb + 1 < P) load(pb + 1, p1);
+    weave(pb, p0);
+    if (pb + 1 < P) {
+      if (pb + 2 < P) load(pb + 2, p0);
+      weave(pb + 1, p1);
+    }
   }
-  if (threadIdx.x == 0) hit_cnt[a] = base;
-}
-
-// Carrier penalty of AncesTreeBuilder::BuildTopology (anc_builder.cpp:563-581) on the device: every entry of a
-// carrier's row gets + val, and - val again where the column is a carrier too (the same two operations in
-// the same order per entry as the host loop).
-__global__ void penalty_kernel(float *__restrict__ D, int N, const unsigned char *__restrict__ member, float val) {
-  const int c = blockIdx.x;
-  if (!member[c]) return;
-  float *row = D + (size_t)c * N;
-  for (int col = threadIdx.x; col < N; col += blockDim.x) {
-    float x = row[col] + val;
-    if (member[col]) x -= val;
-    row[col] = x;
+  if (lane == 0) {
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      const int a = a0 + wave * 8 + r;
+      if (a < N) hit_cnt[a] = cnt[r];
+    }
   }
 }
 
 // Clade prior from the previous tree (treeseq.cpp: clade_prior; anc_builder.cpp:583-606): row a holds, for
 // every other leaf b, acc[depth(parent(a)) - depth(mrca(a,b))]; the leaves under the sibling of every ancestor
 // step are a contiguous range of the depth-first leaf order.
-__global__ void prior_kernel(float *__restrict__ CF, int N, const int *__restrict__ parent,
+__global__ void __launch_bounds__(256) prior_kernel(float *__restrict__ CF, int N, const int *__restrict__ parent,
                              const int *__restrict__ child_left, const int *__restrict__ child_right,
                              const int *__restrict__ depth, const int *__restrict__ lo,
                              const int *__restrict__ size, const int *__restrict__ order,
-                             const float *__restrict__ acc) {
+                             const float *__restrict__ acc, float *__restrict__ rowmin) {
   // The row is put together in LDS -- the ranges are contiguous in depth-first order, the entries they name are
   // scattered over the row (order[q]): as 4-byte stores to HBM the kernel wrote its 100 MB at 0.4 TB/s, 0.24 ms per
   // tree at N = 5000 and the largest of the per-tree kernels that share the chip with RePaint -- and leaves the block
@@ -2098,7 +2152,17 @@ __global__ void prior_kernel(float *__restrict__ CF, int N, const int *__restric
   }
   __syncthreads();
   float *__restrict__ row = CF + (size_t)a * N;
-  for (int j = threadIdx.x; j < N; j += blockDim.x) row[j] = prior_row[j];
+  float mv = INFINITY;  // the row's minimum off the diagonal (tree_builder.cpp:1659-1666), while the row is here
+  for (int j = threadIdx.x; j < N; j += blockDim.x) {
+    const float x = prior_row[j];
+    row[j] = x;
+    if (j != a) mv = fminf(mv, x);
+  }
+  __shared__ float part[4];
+  mv = wave_min_f(mv);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mv;
+  __syncthreads();
+  if (threadIdx.x == 0) rowmin[a] = fminf(fminf(part[0], part[1]), fminf(part[2], part[3]));
 }
 
 }  // namespace
@@ -2557,9 +2621,12 @@ struct DeviceMinMatch::Impl {
   float acc_val = 0.0f;   // d_acc holds acc[c] = val added c times for this val
   bool acc_valid = false;
   bool abandoned = false;  // a tree was given up while its ticket may be live: nothing of this builder is recycled
+  // the row minima of the staged matrices are in d_f already (apply_penalty / apply_prior took them in their pass)
+  bool rowmin_d_ready = false, rowmin_cf_ready = false;
   void drop_staging() {
     if (staging) DeviceShare::of(device).give(staging);
     staging = nullptr;
+    rowmin_d_ready = rowmin_cf_ready = false;
   }
 };
 
@@ -2616,10 +2683,13 @@ int DeviceMinMatch::apply_penalty(const char *member, float val) {
   }
   char *flags = reinterpret_cast<char *>(m.h_tab + tab_ints);
   memcpy(flags, member, (size_t)N);
+  if (m.d_f.alloc((size_t)8 * N * 4)) return -1;  // (reserve()'s: the row minima live at 6N and 7N)
   RL_HIP(hipMemcpyAsync(m.d_member.p, flags, (size_t)N, hipMemcpyHostToDevice, m.stream));
-  hipLaunchKernelGGL(penalty_kernel, dim3(N), dim3(256), 0, m.stream, m.staging->D.as<float>(), N,
-                     m.d_member.as<unsigned char>(), val);
+  // the penalty and, of the rows as they then are, the row minima of the build: one pass over the matrix
+  hipLaunchKernelGGL(rowmin_penalty_kernel, dim3(N), dim3(256), 0, m.stream, m.staging->D.as<float>(), N,
+                     m.d_member.as<unsigned char>(), val, m.d_f.as<float>() + 6 * (size_t)N);
   RL_HIP(hipGetLastError());
+  m.rowmin_d_ready = true;
   return 0;
 }
 
@@ -2655,6 +2725,7 @@ int DeviceMinMatch::apply_prior(const HostTree &t, float val) {
   for (int i = 0; i < N; i++) order[lo[i]] = i;
   int rc = m.d_tab.alloc(tab_ints * 4);
   rc = rc ? rc : m.d_acc.alloc(((size_t)N + 1) * 4);
+  rc = rc ? rc : m.d_f.alloc((size_t)8 * N * 4);  // (reserve()'s: the row minima live at 6N and 7N)
   if (rc) return -1;
   if (!m.acc_valid || m.acc_val != val) {  // (one val per section: once)
     std::vector<float> acc((size_t)N + 1, 0.0f);
@@ -2667,8 +2738,9 @@ int DeviceMinMatch::apply_prior(const HostTree &t, float val) {
   const int *q = m.d_tab.as<int>();
   hipLaunchKernelGGL(prior_kernel, dim3(N), dim3(256), (size_t)N * sizeof(float), m.stream, m.staging->CF.as<float>(), N, q, q + T,
                      q + 2 * (size_t)T, q + 3 * (size_t)T, q + 4 * (size_t)T, q + 5 * (size_t)T, q + 6 * (size_t)T,
-                     m.d_acc.as<float>());
+                     m.d_acc.as<float>(), m.d_f.as<float>() + 7 * (size_t)N);
   RL_HIP(hipGetLastError());
+  m.rowmin_cf_ready = true;
   return 0;
 }
 
@@ -2864,14 +2936,23 @@ int DeviceMinMatch::build_impl(TB &tb, const std::vector<double> *sample_ages, c
     if (prior) RL_HIP(hipMemcpyAsync(dCF, prior_host, NN * 4, hipMemcpyHostToDevice, m.stream));
   }
   {
-    // the woven matrix and the row minima, on the whole chip; the build itself is one workgroup
-    const dim3 grid((N + 31) / 32, (N + 31) / 32);
-    hipLaunchKernelGGL(pack_kernel, grid, dim3(256), 0, m.stream, dD, dCF, p.M, N);
-    hipLaunchKernelGGL(rowmin_kernel, dim3(prior ? 2 * N : N), dim3(256), 0, m.stream, dD, f + 6 * (size_t)N, dCF,
-                       f + 7 * (size_t)N, N);
-    hipLaunchKernelGGL(pairscan_kernel, dim3(N), dim3(256), 0, m.stream, p.M, p.rowmin_D, p.rowmin_CF, mvcf_dev,
-                       p.has_prior, ages ? 1 : 0, p.threshold, p.threshold_CF, N, hits, reinterpret_cast<unsigned *>(hits + N),
-                       reinterpret_cast<float *>(hits + N + (size_t)N * MM_HITS));
+    // the row minima (where the penalty / prior passes have not left them already), then the woven matrix and the
+    // pair scan of the initialisation in one pass, on the whole chip; the build itself is one workgroup
+    if (!m.rowmin_d_ready)
+      hipLaunchKernelGGL(rowmin_penalty_kernel, dim3(N), dim3(256), 0, m.stream, dD, N, (const unsigned char *)nullptr, 0.0f,
+                         f + 6 * (size_t)N);
+    if (prior && !m.rowmin_cf_ready)
+      hipLaunchKernelGGL(rowmin_penalty_kernel, dim3(N), dim3(256), 0, m.stream, dCF, N, (const unsigned char *)nullptr, 0.0f,
+                         f + 7 * (size_t)N);
+    const dim3 grid((N + WV_ROWS - 1) / WV_ROWS);
+    if (prior)
+      hipLaunchKernelGGL(weave_kernel<true>, grid, dim3(256), 0, m.stream, dD, dCF, p.M, N, p.rowmin_D, p.rowmin_CF, mvcf_dev,
+                         ages ? 1 : 0, p.threshold, p.threshold_CF, hits, reinterpret_cast<unsigned *>(hits + N),
+                         reinterpret_cast<float *>(hits + N + (size_t)N * MM_HITS));
+    else
+      hipLaunchKernelGGL(weave_kernel<false>, grid, dim3(256), 0, m.stream, dD, dCF, p.M, N, p.rowmin_D, p.rowmin_CF, mvcf_dev,
+                         ages ? 1 : 0, p.threshold, p.threshold_CF, hits, reinterpret_cast<unsigned *>(hits + N),
+                         reinterpret_cast<float *>(hits + N + (size_t)N * MM_HITS));
     RL_HIP(hipGetLastError());
   }
   static const bool trace = getenv("RELATE_AMD_MM_TRACE") != nullptr;

@@ -70,8 +70,11 @@ try:
             fn = os.path.join(d, "chunk_0", "out_%d.%s" % (sct, e))
             if os.path.exists(fn):
                 out["section_md5"]["out_%d.%s" % (sct, e)] = hashlib.md5(open(fn, "rb").read()).hexdigest()
-    out["trees_built"] = trees if trees else kept  # (built, incl. the rejected ones, only with the timing lines)
-    out["trees_per_s"] = out["trees_built"] / out["wall_s"]
+    # (built = kept + the rebuilt trees that were dropped again, anc_builder.cpp:621-630: counted by the stage's
+    #  per-section lines, i.e. only in a run with the timing lines; never one under the other's name)
+    out["trees_built"] = trees if trees else None
+    out["trees_per_s"] = (trees if trees else kept) / out["wall_s"]
+    out["trees_per_s_counts"] = "built" if trees else "kept"
     out["anc_GB"] = sum(os.path.getsize(os.path.join(d, "chunk_0", f)) for f in os.listdir(os.path.join(d, "chunk_0"))
                         if f.endswith(".anc")) / 1e9
     out["stage_lines"] = [l.strip() for l in err.split("\n") if l.startswith("[") and "\r" not in l and "[window " not in l and "tree sequence" not in l
