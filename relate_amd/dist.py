@@ -119,14 +119,16 @@ def read_parameters(out_dir):
     return dict(N=N, L=L, num_chunks=C, memory_gb=mem, start=start, end=end)
 
 
-def run_chunks(out_dir, painting=None, device=None, stages=None, chunks=None, paint_files=False):
+def run_chunks(out_dir, painting=None, device=None, stages=None, chunks=None, paint_files=False, timings=None):
     """The many-chunks route (BASELINE.json config #4; scripts/RelateParallel/RelateParallel.sh:216-262): the chunks of
     a MakeChunks directory are dealt round-robin to the ranks of the job (one process per GPU) and every rank runs
     its chunks start to end -- Paint + BuildTopology of all sections in ONE stage call with the stepping stones kept
     in HBM (rl_stage_paint_build_topology; paint_files=True takes the reference's two stages with the paint files in
     between: 12.8 GB per C4-sized chunk, eight ranks on one filesystem), then FindEquivalentBranches -- with NO
     data-path collective and no barrier: chunks share nothing but the input directory, a rank is done when its
-    chunks are.  Returns the chunk indices this rank ran.  `chunks`: a subset to run (default: all of parameters.bin)."""
+    chunks are.  Returns the chunk indices this rank ran.  `chunks`: a subset to run (default: all of parameters.bin).
+    `timings`: a list that receives (chunk, stage name, seconds) per stage call (tools/c4_job_one_gpu.py)."""
+    import time
     if stages is None:
         from relate_amd import api as stages
     live = dist.is_available() and dist.is_initialized()
@@ -135,14 +137,21 @@ def run_chunks(out_dir, painting=None, device=None, stages=None, chunks=None, pa
     dev = device if device is not None else local_device()
     todo = list(range(read_parameters(out_dir)["num_chunks"])) if chunks is None else list(chunks)
     mine = shard(todo, rank, world)
+    def timed(c, name, fn, *a, **kw):
+        t0 = time.time()
+        fn(*a, **kw)
+        if timings is not None:
+            timings.append((c, name, time.time() - t0))
+
     for c in mine:
         last = stages.num_sections(out_dir, c) - 1
         if paint_files:
-            stages.stage_paint(out_dir, c, painting=painting, device=dev)
-            stages.stage_build_topology(out_dir, c, 0, last, painting=painting, device=dev)
+            timed(c, "paint", stages.stage_paint, out_dir, c, painting=painting, device=dev)
+            timed(c, "build_topology", stages.stage_build_topology, out_dir, c, 0, last, painting=painting, device=dev)
         else:
-            stages.stage_paint_build_topology(out_dir, c, 0, last, painting=painting, device=dev)
-        stages.stage_find_equivalent_branches(out_dir, c)
+            timed(c, "paint_build_topology", stages.stage_paint_build_topology, out_dir, c, 0, last, painting=painting,
+                  device=dev)
+        timed(c, "find_equivalent_branches", stages.stage_find_equivalent_branches, out_dir, c)
     return mine
 
 
