@@ -101,8 +101,22 @@ try:
     out["job_files_GB"] = sum(os.path.getsize(os.path.join(job, f)) for f in os.listdir(job)) / 1e9
     todo = list(range(chunks if not max_chunks else min(chunks, max_chunks)))
     timings = []
+    sections = trees = 0
+    anc_bytes = 0
     t0 = time.time()
-    rdist.run_chunks(job, chunks=todo, timings=timings)  # one rank: every chunk, start to end
+    for c in todo:  # one rank: every chunk, start to end (run_chunks' loop; a chunk's files are counted and removed
+        rdist.run_chunks(job, chunks=[c], timings=timings)  # before the next one: ~1.7 GB of .anc per chunk)
+        d = os.path.join(job, "chunk_%d" % c)
+        for fn in os.listdir(d):
+            if fn.endswith(".anc"):
+                sections += 1
+                anc_bytes += os.path.getsize(os.path.join(d, fn))
+                with open(os.path.join(d, fn), "rb") as fh:
+                    trees += int(np.frombuffer(fh.read(9)[5:9], dtype=np.uint32)[0])
+        shutil.rmtree(d, ignore_errors=True)
+        for fn in os.listdir(job):
+            if fn.startswith("chunk_%d." % c):
+                os.remove(os.path.join(job, fn))
     out["chunks_run"] = len(todo)
     out["run_chunks_s"] = time.time() - t0
     per = {}
@@ -114,16 +128,6 @@ try:
         for k, v in st.items():
             tot[k] = tot.get(k, 0.0) + v
     out["stage_totals_s"] = {k: round(v, 1) for k, v in tot.items()}
-    sections = trees = 0
-    anc_bytes = 0
-    for c in todo:
-        d = os.path.join(job, "chunk_%d" % c)
-        for fn in os.listdir(d):
-            if fn.endswith(".anc"):
-                sections += 1
-                anc_bytes += os.path.getsize(os.path.join(d, fn))
-                with open(os.path.join(d, fn), "rb") as fh:
-                    trees += int(np.frombuffer(fh.read(9)[5:9], dtype=np.uint32)[0])
     out["sections"] = sections
     out["trees_kept"] = trees
     out["anc_GB"] = anc_bytes / 1e9

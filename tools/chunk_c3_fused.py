@@ -101,6 +101,20 @@ try:
                                     "sections_done_by_s": {str(q): ends[min(len(ends) - 1, int(q * len(ends) / 100))] for q in (10, 25, 50, 75, 90, 95, 99)},
                                     "last_done_s": ends[-1],
                                     "open_sections_at_s": {str(t): sum(1 for x in sec if x[2] <= t < x[3]) for t in range(0, int(ends[-1]) + 10, 10)}}
+    if os.environ.get("C3_FEB") and sections == W:
+        # the stage downstream on the same files (pipeline/FindEquivalentBranches.cpp:78-145): reads every .anc of the
+        # chunk, associates the branches of neighbouring trees, rewrites the files in place
+        t0 = time.time()
+        p = subprocess.run([exe, "--mode", "FindEquivalentBranches", "--chunk_index", "0", "-o", "out"], cwd=work,
+                           stderr=subprocess.PIPE, env=dict(os.environ, RELATE_AMD_TIMING="1"))
+        out["find_equivalent_branches_s"] = time.time() - t0
+        out["find_equivalent_branches_rc"] = p.returncode
+        out["find_equivalent_branches_lines"] = [l.strip() for l in p.stderr.decode().split("\n") if l.strip()][-8:]
+        out["feb_md5"] = {}
+        for sct in (0, W // 2, W - 1):
+            fn = os.path.join(d, "chunk_0", "out_%d.anc" % sct)
+            if os.path.exists(fn):
+                out["feb_md5"]["out_%d.anc" % sct] = hashlib.md5(open(fn, "rb").read()).hexdigest()
 finally:
     shutil.rmtree(work, ignore_errors=True)
 print(json.dumps(out))
