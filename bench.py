@@ -157,6 +157,16 @@ def verify_c3(section_md5):
     return out
 
 
+def sample_against_reference(md5s):
+    try:
+        ref = json.load(open(os.path.join(ROOT, "tests", "golden", "n5000_l20k_ref.json")))
+        return {"matches_reference": all(md5s.get(k) == v for k, v in ref["md5"].items()),
+                "reference_seconds_one_thread": {"paint": ref["reference_paint_s"],
+                                                 "build_topology_section_0": ref["reference_build_topology_section_0_s"]}}
+    except Exception as e:
+        return {"matches_reference": None, "reference_error": str(e)[:120]}
+
+
 def chunk_wallclock_sample(sections=8, host_builder=False):
     """The other half of BASELINE.json's metric, "chunk wall-clock, N=5000": a bounded sample through the drop-in
     CLI, files in -> files out, in a child process (tools/chunk_wallclock_big.py): the Paint stage of an N=5000 x
@@ -181,9 +191,10 @@ def chunk_wallclock_sample(sections=8, host_builder=False):
                 "snps_in_sections": d["snps_in_timed_sections"], "host_threads": d["host_threads"],
                 "gpu_builder_ms_per_tree": d.get("gpu_builder_ms_per_tree"),
                 "build_topology_phases": d.get("build_topology_phases", [])[:1],
-                # section 0's files: the unmodified reference binary gives 741212a3... / ed4c987f... / 85df74d6...
-                # on this chunk (tests/test_n5000_gpu.py pins the tile against the reference in the suite)
-                "md5": {k: v for k, v in d["md5"].items() if k.startswith("paint/") or "_0." in k}}
+                # window 0's paint file and section 0's .anc / .mut against the unmodified reference binary's on
+                # the same chunk (tests/golden/n5000_l20k_ref.json: its md5s and its seconds in the build container)
+                "md5": {k: v for k, v in d["md5"].items() if k.startswith("paint/") or "_0." in k},
+                **sample_against_reference(d["md5"])}
     except Exception as e:  # a sample, never a reason to lose the bench line
         return {"error": str(e)[:200]}
 
@@ -494,7 +505,7 @@ def main():
                 out["config"]["chunk_wallclock_c3"] = chunk_full
             if chunk_host is not None and "cpu_baseline" in out:
                 # the same 8 sections with the trees built on the host's cores (this library's threaded MinMatch;
-                # the reference binary builds section 0 alone in 1211 s)
+                # the reference binary builds section 0 alone in 1211 s, DESIGN_NOTES.md 6)
                 out["cpu_baseline"]["chunk_wallclock_sample_host_builder"] = {
                     k: chunk_host.get(k) for k in ("build_topology_s", "sections", "trees", "trees_per_s", "host_threads",
                                                    "error") if k in chunk_host}

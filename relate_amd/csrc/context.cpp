@@ -512,7 +512,7 @@ const char *rl_version(void) { return "relate_amd 0.1 (gfx950)"; }
 
 int rl_device_count(void) {
   // The stage keeps a stream per open window and per tree builder; HIP maps them onto GPU_MAX_HW_QUEUES hardware
-  // queues (4 by default: 91 s -> 96 s for 80 sections; past 16 the device time-slices them).  Read by
+  // queues (4 by default: 91 s -> 96 s for 80 sections; past 16 the device time-slices them, DESIGN_NOTES.md 6).  Read by
   // the runtime when it initialises, so set before the first HIP call of the process; the user's value wins.
   setenv("GPU_MAX_HW_QUEUES", "12", 0);
   int n = 0;

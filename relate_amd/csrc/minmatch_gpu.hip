@@ -5,7 +5,7 @@
 // (minmatch.cpp) states the algorithm and why a merge splits into a parallel part and an ordered part with
 // identical results; this file is the same split on one workgroup:
 //   * the N-1 merges of a tree are sequential and each walks down two columns of a 100 MB matrix -- a new
-//     line per cluster: on a host dozens of open sections are bound by DRAM, in HBM one
+//     line per cluster: on a host dozens of open sections are bound by DRAM (DESIGN_NOTES.md 5), in HBM one
 //     workgroup per tree leaves the other 255 CUs to the trees of the other sections;
 //   * the parts that are order-free (distance updates, row-minimum rescans, candidate tests, reductions) run
 //     on all 1024 threads; the random draws -- one per feasible pair, in the reference's order -- and the

@@ -854,7 +854,7 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
       // P <= RELATE_AMD_WINDOW_PARTS (32).  And the sections go in WAVES of whatever is open at once: 267 sections
       // 112 at a time are three waves, the last one a third full; 134 at a time are two full ones.  So: the fewest
       // waves the memory allows at P_max, the sections spread evenly over them, and the smallest P that opens
-      // that many (C3: 2 waves of 134, P = 20: 234 s -> see DESIGN.md 6).
+      // that many (C3: 2 waves of 134, P = 20: 234 s -> see DESIGN_NOTES.md 6).
       const int parts_max = std::max(1, (int)knob("RELATE_AMD_WINDOW_PARTS", o.window_parts, o.window_parts > 0, 32));
       auto fits = [&](int parts) {
         return (int)(room / (max_rows / parts * row_bytes + fixed_bytes + builder_bytes + (parts > 1 ? bstate_bytes : 0.0)));
