@@ -324,6 +324,11 @@ typedef struct rl_stage_opts {
   int repaint_lanes;        /* RePaint launches side by side: 1 or 2 (0: 1)                                        */
   int park_stones;          /* fused stage: stepping stones to pinned host memory after Paint (rl_park_stones)     */
   int pin_threads;          /* section threads pinned to L3 groups: 1 / 0 (-1: 1)                                  */
+  int find_equivalent_branches; /* 1: the next stage, FindEquivalentBranches (pipeline/FindEquivalentBranches.cpp:13-167), fused
+                               behind BuildTopology -- the sections' trees are associated in memory while other sections
+                               still build, every .anc is written ONCE, as that stage would leave it (same bytes as
+                               BuildTopology followed by rl_stage_find_equivalent_branches).  Only for a call that covers
+                               all sections of the chunk; host memory: ~0.3 MB per tree at N = 5000                  */
 } rl_stage_opts;
 void rl_stage_opts_init(rl_stage_opts *opts);
 int rl_stage_paint_ex(const char *out_dir, int chunk_index, const rl_stage_opts *opts);

@@ -417,9 +417,19 @@ def stage_build_topology(out_dir, chunk_index, first_section, last_section, pain
                                          sum_mode, device))
 
 
+# this module's stage_paint_build_topology takes find_equivalent_branches=True (relate_amd.dist.run_chunks asks)
+FUSED_FEB = True
+
+
 def stage_paint_build_topology(out_dir, chunk_index, first_section, last_section, painting=None,
-                               no_consistency=False, fb=0, sum_mode=RL_SUM_EXACT, device=0):
-    """Paint + BuildTopology of a chunk with the stepping stones kept in HBM (no paint files)"""
+                               no_consistency=False, fb=0, sum_mode=RL_SUM_EXACT, device=0,
+                               find_equivalent_branches=False):
+    """Paint + BuildTopology of a chunk with the stepping stones kept in HBM (no paint files);
+    find_equivalent_branches: the stage downstream fused in (every .anc written once, as that stage leaves it)"""
+    if find_equivalent_branches:
+        o = stage_opts(painting=painting, flags=1 if no_consistency else 0, fb=fb, sum_mode=sum_mode, device=device,
+                       find_equivalent_branches=1)
+        return stage_build_topology_ex(out_dir, chunk_index, first_section, last_section, o, fused=True)
     th, rho = painting if painting else (0.001, 1.0)
     f = lib().rl_stage_paint_build_topology
     f.argtypes = lib().rl_stage_build_topology.argtypes
@@ -433,7 +443,8 @@ class StageOpts(C.Structure):
                 ("theta", C.c_double), ("rho", C.c_double), ("flags", C.c_int), ("fb", C.c_int),
                 ("sample_ages_path", C.c_char_p), ("gpu_build", C.c_int), ("window_rows", C.c_longlong),
                 ("window_parts", C.c_int), ("section_threads", C.c_int), ("workers", C.c_int),
-                ("repaint_lanes", C.c_int), ("park_stones", C.c_int), ("pin_threads", C.c_int)]
+                ("repaint_lanes", C.c_int), ("park_stones", C.c_int), ("pin_threads", C.c_int),
+                ("find_equivalent_branches", C.c_int)]
 
 
 def stage_opts(**kw):

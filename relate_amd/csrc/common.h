@@ -193,3 +193,14 @@ float fast_log_host(float v);
 // the caller's rl_stage_opts, whatever its age, onto the defaults (treeseq.cpp); RL_EINVAL for a struct that never
 // went through rl_stage_opts_init
 extern "C" int rl_internal_resolve_opts(const rl_stage_opts *in, rl_stage_opts *out);
+
+// FindEquivalentBranches fused behind BuildTopology (equivalent.cpp): the sections' trees go from the stage to the
+// association in memory, every .anc file is written once
+namespace rl {
+struct FebJob;
+struct HostTree;
+FebJob *feb_job_create(int N, int W, int threads);
+int feb_job_add_section(FebJob *job, int w, const std::vector<HostTree> &trees);
+int feb_job_finish(FebJob *job, const std::string &dir_base);  // writes <dir_base>_<w>.anc for every section
+void feb_job_destroy(FebJob *job);
+}  // namespace rl

@@ -23,8 +23,11 @@
 #include <tgmath.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <functional>
+#include <mutex>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -32,6 +35,7 @@
 #include <vector>
 
 #include "common.h"
+#include "minmatch.h"
 
 using namespace rl;
 
@@ -127,7 +131,8 @@ int write_anc(const std::string &fn, const AncFile &a) {
     for (int i = 0; i < nodes; i++) {
       unsigned char *q = rec.data() + (size_t)i * 24;
       memcpy(q, &tr.parent[i], 4);
-      memcpy(q + 4, &tr.branch_length[i], 8);
+      const double bl = tr.branch_length.empty() ? 0.0 : tr.branch_length[i];  // (empty: all zero, BuildTopology's trees)
+      memcpy(q + 4, &bl, 8);
       memcpy(q + 12, &tr.num_events[i], 4);
       memcpy(q + 16, &tr.snp_begin[i], 4);
       memcpy(q + 20, &tr.snp_end[i], 4);
@@ -338,7 +343,205 @@ struct BranchMatcher {
   }
 };
 
+// AssociateTrees (src/anc_builder.cpp:658-800): num_events / SNP_begin carried forward along equivalent branches,
+// num_events / SNP_end back; eq[m]: branches of tree m -> branches of tree m-1 (eq[0] unused)
+void propagate(const std::vector<AncTree *> &seq, const std::vector<std::vector<int>> &eq, int N) {
+  const size_t M = seq.size();
+  const int nodes = 2 * N - 1;
+  for (size_t m = 1; m < M; m++) {
+    AncTree &cur = *seq[m];
+    const AncTree &prev = *seq[m - 1];
+    for (int i = 0; i < nodes; i++) {
+      const int e = eq[m][i];
+      if (e != -1) {
+        cur.num_events[i] += prev.num_events[e];
+        cur.snp_begin[i] = prev.snp_begin[e];
+      }
+    }
+  }
+  // ... and back
+  for (size_t m = M - 1; m >= 1; m--) {
+    const AncTree &next = *seq[m];
+    AncTree &cur = *seq[m - 1];
+    for (int i = 0; i < nodes; i++) {
+      const int e = eq[m][i];
+      if (e != -1) {
+        cur.num_events[e] = next.num_events[i];
+        cur.snp_end[e] = next.snp_end[i];
+      }
+    }
+  }
+}
+
 }  // namespace
+
+// ---- the same stage fused behind BuildTopology (rl_stage_opts.find_equivalent_branches): the sections' trees never
+// leave memory between the two stages.  A section that is built hands its trees over (feb_job_add_section); a few
+// pool threads associate the neighbouring trees INSIDE finished sections while the stage's other sections are still
+// building (the host's cores are idle then: a section thread mostly waits for its tree on the device); when the last
+// section is in, feb_job_finish associates the pairs ACROSS section boundaries, carries events and SNP ranges
+// forward and back over the whole chunk (the only sequential part: ~1e9 simple operations at C3) and writes every
+// .anc file ONCE, as FindEquivalentBranches would leave it -- instead of BuildTopology writing 22.9 GB, this stage
+// reading them back, and writing them again.
+namespace rl {
+
+struct FebJob {
+  int N = 0, W = 0;
+  std::vector<AncFile> ancs;
+  std::vector<std::vector<std::vector<int>>> eq;  // eq[w][t]: tree t of section w -> the tree before it (t = 0: the
+                                                  // last tree of section w - 1)
+  std::vector<char> have;
+  BranchMatcher bm;
+  std::mutex m;
+  std::condition_variable cv;
+  std::vector<std::pair<int, int>> tasks;  // (section, tree >= 1), taken from the back
+  int running = 0;
+  bool closing = false;
+  std::vector<std::thread> pool;
+  double cpu_s = 0.0;
+  explicit FebJob(int n, int w, int threads) : N(n), W(w), ancs(w), eq(w), have(w, 0), bm(n) {
+    for (int t = 0; t < threads; t++) pool.emplace_back([this]() { work(); });
+  }
+  void work() {
+    std::unique_lock<std::mutex> lk(m);
+    for (;;) {
+      cv.wait(lk, [&] { return closing || !tasks.empty(); });
+      if (tasks.empty()) {
+        if (closing) return;
+        continue;
+      }
+      const std::pair<int, int> t = tasks.back();
+      tasks.pop_back();
+      running++;
+      lk.unlock();
+      bm.associate(ancs[t.first].trees[t.second - 1], ancs[t.first].trees[t.second], eq[t.first][t.second]);
+      lk.lock();
+      running--;
+      if (tasks.empty() && running == 0) cv.notify_all();
+    }
+  }
+  ~FebJob() {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      closing = true;
+      tasks.clear();
+    }
+    cv.notify_all();
+    for (auto &t : pool) t.join();
+  }
+};
+
+FebJob *feb_job_create(int N, int W, int threads) { return new FebJob(N, W, std::max(1, threads)); }
+void feb_job_destroy(FebJob *j) { delete j; }
+
+int feb_job_add_section(FebJob *j, int w, const std::vector<HostTree> &trees) {
+  if (!j || w < 0 || w >= j->W || trees.empty() || j->have[w]) {
+    set_error("find equivalent branches (fused): section %d out of range, empty or given twice", w);
+    return RL_EINVAL;
+  }
+  const int nodes = 2 * j->N - 1;
+  AncFile &a = j->ancs[w];
+  a.has_ages = false;
+  a.N = (unsigned)j->N;
+  a.trees.assign(trees.size(), AncTree());
+  for (size_t t = 0; t < trees.size(); t++) {  // what read_anc would make of the file rl_treeseq_write writes
+    const HostTree &h = trees[t];
+    AncTree &tr = a.trees[t];
+    tr.pos = h.pos;
+    tr.parent = h.parent;
+    tr.snp_begin = h.snp_begin;
+    tr.snp_end = h.snp_end;
+    tr.num_events = h.num_events;
+    tr.child_left.assign(nodes, -1);
+    tr.child_right.assign(nodes, -1);
+    for (int i = 0; i < nodes; i++) {  // children as Tree::ReadTreeBin assigns them: in node order
+      const int p = tr.parent[i];
+      if (p == -1) continue;
+      if (p < 0 || p >= nodes) {
+        set_error("find equivalent branches (fused): section %d, tree %zu: parent of node %d out of range", w, t, i);
+        return RL_EINVAL;
+      }
+      if (tr.child_left[p] == -1) tr.child_left[p] = i;
+      else tr.child_right[p] = i;
+    }
+  }
+  j->eq[w].assign(trees.size(), std::vector<int>());
+  {
+    std::lock_guard<std::mutex> lk(j->m);
+    j->have[w] = 1;
+    for (int t = (int)trees.size() - 1; t >= 1; t--) j->tasks.emplace_back(w, t);
+  }
+  j->cv.notify_all();
+  return RL_OK;
+}
+
+int feb_job_finish(FebJob *j, const std::string &dir_base) {
+  const bool timing = getenv("RELATE_AMD_TIMING") != nullptr;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_mark = now();
+  auto lap = [&](const char *what) {
+    const double t = now();
+    if (timing) fprintf(stderr, "[find equivalent branches, fused] %-45s %.3f s\n", what, t - t_mark);
+    t_mark = t;
+  };
+  for (int w = 0; w < j->W; w++)
+    if (!j->have[w]) {
+      set_error("find equivalent branches (fused): section %d was not built", w);
+      return RL_ESTATE;
+    }
+  {  // what the pool has not got to yet: with every host thread now
+    std::vector<std::pair<int, int>> rest;
+    {
+      std::lock_guard<std::mutex> lk(j->m);
+      rest.swap(j->tasks);
+    }
+    for (int w = 1; w < j->W; w++) rest.emplace_back(w, 0);  // the pairs across section boundaries
+    std::atomic<size_t> next(0);
+    const int T = std::max(1, std::min<int>(host_threads(), (int)rest.size()));
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; t++)
+      th.emplace_back([&]() {
+        for (size_t k = next.fetch_add(1); k < rest.size(); k = next.fetch_add(1)) {
+          const int w = rest[k].first, tt = rest[k].second;
+          const AncTree &prev = tt > 0 ? j->ancs[w].trees[tt - 1] : j->ancs[w - 1].trees.back();
+          j->bm.associate(prev, j->ancs[w].trees[tt], j->eq[w][tt]);
+        }
+      });
+    for (auto &x : th) x.join();
+    std::unique_lock<std::mutex> lk(j->m);  // (pairs a pool thread had taken before the swap)
+    j->cv.wait(lk, [&] { return j->running == 0; });
+  }
+  lap("associations left after the last section");
+  std::vector<AncTree *> seq;
+  std::vector<std::vector<int>> eq;
+  for (int w = 0; w < j->W; w++)
+    for (size_t t = 0; t < j->ancs[w].trees.size(); t++) {
+      seq.push_back(&j->ancs[w].trees[t]);
+      eq.emplace_back();
+      eq.back().swap(j->eq[w][t]);
+    }
+  propagate(seq, eq, j->N);
+  lap("events and SNP ranges carried forward and back");
+  const int W = j->W, T = std::max(1, std::min({host_threads(), W, 32}));
+  std::vector<int> rcs(T, RL_OK);
+  std::vector<std::string> msgs(T);
+  std::vector<std::thread> th;
+  for (int t = 0; t < T; t++)
+    th.emplace_back([&, t]() {
+      for (int w = t; w < W && rcs[t] == RL_OK; w += T)
+        if ((rcs[t] = write_anc(dir_base + "_" + std::to_string(w) + ".anc", j->ancs[w])) != RL_OK) msgs[t] = rl_last_error();
+    });
+  for (auto &x : th) x.join();
+  for (int t = 0; t < T; t++)
+    if (rcs[t] != RL_OK) {
+      set_error("%s", msgs[t].c_str());
+      return rcs[t];
+    }
+  lap(".anc files written (once)");
+  return RL_OK;
+}
+
+}  // namespace rl
 
 extern "C" int rl_stage_find_equivalent_branches(const char *out_dir, int chunk_index) {
   if (!out_dir) return RL_EINVAL;
@@ -418,31 +621,7 @@ extern "C" int rl_stage_find_equivalent_branches(const char *out_dir, int chunk_
     for (auto &x : th) x.join();
   }
   lap("branches of neighbouring trees associated");
-  // AssociateTrees (src/anc_builder.cpp:658-800): forward ...
-  const int nodes = 2 * N - 1;
-  for (size_t m = 1; m < M; m++) {
-    AncTree &cur = *seq[m];
-    const AncTree &prev = *seq[m - 1];
-    for (int i = 0; i < nodes; i++) {
-      const int e = eq[m][i];
-      if (e != -1) {
-        cur.num_events[i] += prev.num_events[e];
-        cur.snp_begin[i] = prev.snp_begin[e];
-      }
-    }
-  }
-  // ... and back
-  for (size_t m = M - 1; m >= 1; m--) {
-    const AncTree &next = *seq[m];
-    AncTree &cur = *seq[m - 1];
-    for (int i = 0; i < nodes; i++) {
-      const int e = eq[m][i];
-      if (e != -1) {
-        cur.num_events[e] = next.num_events[i];
-        cur.snp_end[e] = next.snp_end[i];
-      }
-    }
-  }
+  propagate(seq, eq, N);
   lap("events and SNP ranges carried forward and back");
   frc = over_files([&](int w) -> int { return write_anc(dir + base + "_" + std::to_string(w) + ".anc", ancs[w]); });
   if (frc) return frc;

@@ -7,7 +7,8 @@
 // Same options, files and stderr banners as include/pipeline/Relate.cpp:19-115,
 // Paint.cpp, BuildTopology.cpp of the reference; every other --mode is refused
 // (use the reference binary for them).  Extra options: --device n,
-// --sum_mode exact|lanes|lanes32.
+// --sum_mode exact|lanes|lanes32, --find_equivalent_branches (with PaintBuildTopology / BuildTopology over all
+// sections of a chunk: the stage downstream fused in, every .anc written once).
 #include <sys/resource.h>
 
 #include <cstdio>
@@ -43,6 +44,7 @@ int main(int argc, char **argv) {
       {"mode", true}, {"chunk_index", true}, {"first_section", true}, {"last_section", true},
       {"output", true}, {"painting", true}, {"seed", true}, {"fb", true}, {"sample_ages", true},
       {"no_consistency", false}, {"device", true}, {"sum_mode", true}, {"help", false},
+      {"find_equivalent_branches", false},  // (PaintBuildTopology / BuildTopology of a whole chunk: the next stage fused in)
       // accepted and ignored by these two modes in the reference as well
       {"haps", true}, {"sample", true}, {"map", true}, {"mutation_rate", true}, {"effectiveN", true},
       {"memory", true}, {"dist", true}, {"annot", true}, {"coal", true}, {"transversion", false}};
@@ -159,6 +161,7 @@ int main(int argc, char **argv) {
   so.fb = opt.count("fb") ? (int)std::stof(opt["fb"]) : 0;  // BuildTopology.cpp:111-114
   const std::string ages = opt.count("sample_ages") ? opt["sample_ages"] : std::string();
   so.sample_ages_path = ages.empty() ? nullptr : ages.c_str();  // BuildTopology.cpp:93-108
+  so.find_equivalent_branches = opt.count("find_equivalent_branches") ? 1 : 0;
   if (mode == "Paint") {
     std::cerr << "---------------------------------------------------------" << std::endl;
     std::cerr << "Painting sequences..." << std::endl;

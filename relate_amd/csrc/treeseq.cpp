@@ -948,6 +948,16 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
   };
   const std::vector<cpu_set_t> groups = cache_groups(o.pin_threads);
   std::atomic<int> next_slot(0);
+  // rl_stage_opts.find_equivalent_branches: the stage downstream on the trees while they are in memory (equivalent.cpp)
+  FebJob *feb = nullptr;
+  if (knob("RELATE_AMD_FUSED_FEB", o.find_equivalent_branches, true, 0) != 0) {
+    if (first_section != 0 || last_section != W - 1 || W < 2) {
+      set_error("find_equivalent_branches needs a call that covers all %d sections of the chunk (and at least two)", W);
+      rl_destroy(ctx);
+      return RL_EINVAL;
+    }
+    feb = feb_job_create(ctx->N, W, std::max(4, std::min(32, host_threads() / 8)));
+  }
   auto worker = [&]() {
     cpu_set_t before;
     CPU_ZERO(&before);
@@ -1060,7 +1070,9 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
       }
       if (!r) {
         const std::string b = od + "/chunk_" + c + "/" + base + "_" + std::to_string(section);
-        r = rl_treeseq_write(ts, (b + ".anc").c_str(), (b + ".mut").c_str());
+        // (fused FindEquivalentBranches: the .anc is written at the end, once, with what that stage carries across)
+        r = rl_treeseq_write(ts, feb ? nullptr : (b + ".anc").c_str(), (b + ".mut").c_str());
+        if (!r && feb) r = feb_job_add_section(feb, section, ts->trees);
       }
       if (r) {
         fail(r);
@@ -1082,6 +1094,12 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
   if (gpu_build) (void)device_builder_expect(device, ctx->N, 0, !sample_ages.empty());
   rc = first_error.load();
   if (rc) set_error("%s", first_message.c_str());
+  if (feb) {
+    if (!rc) rc = feb_job_finish(feb, od + "/chunk_" + c + "/" + base);
+    feb_job_destroy(feb);
+    // (as rl_stage_find_equivalent_branches: the last stage that reads chunk_<c>.bits removes it)
+    if (!rc) (void)remove((od + "/chunk_" + c + ".bits").c_str());
+  }
   if (getenv("RELATE_AMD_TIMING"))
     fprintf(stderr, "[stage] sections %d..%d on %d threads, up to %d open at once, %lld of at most %.0f posterior rows "
             "resident per window, %lld RePaint launches (%.1f s on the device), %s tree builder, %.1f s\n", first_section,

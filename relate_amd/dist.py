@@ -148,6 +148,12 @@ def run_chunks(out_dir, painting=None, device=None, stages=None, chunks=None, pa
         if paint_files:
             timed(c, "paint", stages.stage_paint, out_dir, c, painting=painting, device=dev)
             timed(c, "build_topology", stages.stage_build_topology, out_dir, c, 0, last, painting=painting, device=dev)
+        elif getattr(stages, "FUSED_FEB", False) and last > 0:
+            # (the GPU library: FindEquivalentBranches runs on the trees while they are in memory, every .anc is
+            #  written once -- same bytes as the two stages one after the other)
+            timed(c, "paint_build_topology_feb", stages.stage_paint_build_topology, out_dir, c, 0, last,
+                  painting=painting, device=dev, find_equivalent_branches=True)
+            continue
         else:
             timed(c, "paint_build_topology", stages.stage_paint_build_topology, out_dir, c, 0, last, painting=painting,
                   device=dev)

@@ -297,3 +297,32 @@ def test_cli_fast_mode_through_the_file_stages(tmp_path):
         for t in trees:
             par = t[1]
             assert par[-1] == -1 and np.all(np.bincount(par[:-1], minlength=2 * N - 1)[N:] == 2)
+
+
+@pytest.mark.parametrize("name,mode,builder", [("synth24", "PaintBuildTopology", "1"), ("synth70", "PaintBuildTopology", "0"),
+                                               ("synth40_noisy", "BuildTopology", "1"), ("example8", "PaintBuildTopology", "1")])
+def test_find_equivalent_branches_fused_behind_build_topology(tmp_path, name, mode, builder):
+    """--find_equivalent_branches (rl_stage_opts.find_equivalent_branches): the stage downstream
+    (pipeline/FindEquivalentBranches.cpp:13-167) runs on the sections' trees while they are in memory and every .anc is
+    written once -- the bytes the reference's BuildTopology + FindEquivalentBranches leave (`feb_anc/*` of the
+    fixtures), the .mut files untouched; through both stage entry points, host and device builder.  A call that does
+    not cover the whole chunk is refused."""
+    work = tmp_path / "work"
+    (work / "out").mkdir(parents=True)
+    fx = Fixture(name, work / "out")
+    if "feb_anc/0" not in fx.z.files or fx.W < 2:
+        pytest.skip("fixture without FindEquivalentBranches outputs / with one section")
+    if mode == "BuildTopology":
+        run_cli(["--mode", "Paint", "--chunk_index", "0", "-o", "out"], str(work))
+    args = ["--mode", mode, "--chunk_index", "0", "--first_section", "0", "--last_section", str(fx.W - 1), "-o", "out",
+            "--find_equivalent_branches"]
+    p = subprocess.run([CLI] + args, cwd=str(work), stderr=subprocess.PIPE,
+                       env=dict(os.environ, RELATE_AMD_GPU_BUILD=builder, RELATE_AMD_TIMING="1"))
+    assert p.returncode == 0, p.stderr.decode()
+    assert "find equivalent branches, fused" in p.stderr.decode()
+    for w in range(fx.W):
+        assert open(work / "out" / "chunk_0" / ("out_%d.mut" % w), "rb").read() == fx.z["mut/%d" % w].tobytes(), w
+        assert open(work / "out" / "chunk_0" / ("out_%d.anc" % w), "rb").read() == fx.z["feb_anc/%d" % w].tobytes(), w
+    p = subprocess.run([CLI, "--mode", mode, "--chunk_index", "0", "--first_section", "0", "--last_section", "0", "-o",
+                        "out", "--find_equivalent_branches"], cwd=str(work), stderr=subprocess.PIPE)
+    assert p.returncode != 0 and b"covers all" in p.stderr

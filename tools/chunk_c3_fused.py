@@ -38,8 +38,11 @@ try:
     del seq
     exe = os.path.join(ROOT, "relate_amd", "Relate")
     t0 = time.time()
+    # C3_FUSED_FEB=1: FindEquivalentBranches fused behind the stage (every .anc written once, as that stage leaves it)
+    fused_feb = ["--find_equivalent_branches"] if os.environ.get("C3_FUSED_FEB") and sections == W else []
+    out["fused_find_equivalent_branches"] = bool(fused_feb)
     p = subprocess.run([exe, "--mode", "PaintBuildTopology", "--chunk_index", "0", "--first_section", "0",
-                        "--last_section", str(sections - 1), "-o", "out"], cwd=work, stderr=subprocess.PIPE,
+                        "--last_section", str(sections - 1), "-o", "out"] + fused_feb, cwd=work, stderr=subprocess.PIPE,
                        env=dict(os.environ) if os.environ.get("C3_NO_TIMING") else dict(os.environ, RELATE_AMD_TIMING="1"))
     out["wall_s"] = time.time() - t0
     err = p.stderr.decode()
@@ -77,7 +80,8 @@ try:
     out["trees_per_s_counts"] = "built" if trees else "kept"
     out["anc_GB"] = sum(os.path.getsize(os.path.join(d, "chunk_0", f)) for f in os.listdir(os.path.join(d, "chunk_0"))
                         if f.endswith(".anc")) / 1e9
-    out["stage_lines"] = [l.strip() for l in err.split("\n") if l.startswith("[") and "\r" not in l and "[window " not in l and "tree sequence" not in l
+    out["fused_feb_lines"] = [l.strip() for l in err.split("\n") if "find equivalent branches, fused" in l]
+    out["stage_lines"] = [l.strip() for l in err.split("\n") if l.startswith("[") and "find equivalent" not in l and "\r" not in l and "[window " not in l and "tree sequence" not in l
                           and "[tree builder workers]" not in l and "[gpu tree builder]" not in l][:12]
     out["builder_worker_launches"] = [l.strip() for l in err.split("\n") if "[tree builder workers]" in l][:24]
     out["builder_host_side"] = [l.strip() for l in err.split("\n") if "host ms per tree" in l][:6]
