@@ -216,6 +216,13 @@ int rl_window_matrix(rl_window *win, int snp, float *d_host, float *kernel_ms);
  * context) * N floats -- the send buffer of the all-gather when the chunk is
  * sharded by target (rl_set_target_range). */
 int rl_window_matrix_rows_device(rl_window *win, int snp, void *d_rows, float *kernel_ms);
+/* The same with what AncesTreeBuilder::BuildTopology does to the matrix next folded into the kernel's last pass over
+ * each row: carriers (N flags, host memory; NULL: none) -- the carrier penalty of src/anc_builder.cpp:563-581,
+ * d[c][j] += val along a carrier's row, -= val again at carrier columns --, and d_rowmin (device, one float per row
+ * of the context's targets; NULL: not wanted) -- the row minima off the diagonal MinMatch::Initialize starts from
+ * (src/tree_builder.cpp:1659-1666), of the rows as they then are. */
+int rl_window_matrix_rows_device_ex(rl_window *win, int snp, void *d_rows, const char *carriers, float val,
+                                    void *d_rowmin, float *kernel_ms);
 
 /* --------------------------------------------------------------- host side */
 /* Replaces MinMatch::QuickBuild (src/tree_builder.cpp:1061-1303 without
@@ -282,6 +289,11 @@ int rl_treeseq_set_build_device(rl_treeseq *ts, int device);
  * then run there too and no matrix crosses PCIe. */
 typedef int (*rl_matrix_dev_fn)(void *user, int snp, void *d_dev);
 int rl_treeseq_set_device_matrix(rl_treeseq *ts, rl_matrix_dev_fn matrix_dev);
+/* ... and a provider that also applies the carrier penalty and leaves the row minima (rl_window_matrix_rows_device_ex):
+ * with it the device builder skips its own pass over the matrix.  carriers: N flags or NULL. */
+typedef int (*rl_matrix_dev_ex_fn)(void *user, int snp, void *d_matrix, const char *carriers, float val,
+                                   void *d_rowmin);
+int rl_treeseq_set_device_matrix_ex(rl_treeseq *ts, rl_matrix_dev_ex_fn matrix_dev_ex);
 int rl_treeseq_build(rl_treeseq *ts, int start, int end, rl_matrix_fn matrix,
                      rl_advance_fn advance, void *user, int flags, int fb);
 int rl_treeseq_num_trees(const rl_treeseq *ts);

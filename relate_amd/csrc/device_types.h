@@ -134,6 +134,12 @@ struct MatrixParams {
                               // kernel (matrix_kernels.hip), or null: a copy engine between the host's loop and a
                               // 0.08 ms kernel cost more than the kernel (0.5 ms per matrix through the ABI)
   float *matrix;              // [nloc][N]
+  // optional (rl_window_matrix_rows_device_ex): the carrier penalty of the tree-sequence loop applied to the rows as
+  // they leave (anc_builder.cpp:563-581: + val along a carrier's row, - val again at carrier columns) and the rows'
+  // minima off the diagonal as they then are (tree_builder.cpp:1659-1666) -- what a pass of its own over the matrix did
+  const unsigned char *member;  // [N] carrier flags behind `args` in HBM (staged with them), or null: no penalty
+  float val;
+  float *rowmin;                // [nloc], or null
 };
 
 }  // namespace rl

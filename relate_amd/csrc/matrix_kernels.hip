@@ -68,7 +68,32 @@ __global__ void __launch_bounds__(256) matrix_kernel(const MatrixParams p, const
   }
   mn = red[0];
   float *__restrict__ out = p.matrix + (size_t)t * N;
-  for (int j = threadIdx.x; j < N; j += blockDim.x) out[j] = (j == n) ? 0.0f : vals[j] - mn;  // :190-192
+  if (!p.member && !p.rowmin) {
+    for (int j = threadIdx.x; j < N; j += blockDim.x) out[j] = (j == n) ? 0.0f : vals[j] - mn;  // :190-192
+    return;
+  }
+  // ... and, while the row is here, the carrier penalty (the same two operations per entry, in the same order, as the
+  // loop of anc_builder.cpp:567-574 performs on the finished matrix) and the row's minimum off the diagonal
+  const bool carrier = p.member && p.member[n];
+  float rm = INFINITY;
+  for (int j = threadIdx.x; j < N; j += blockDim.x) {
+    float x = (j == n) ? 0.0f : vals[j] - mn;
+    if (carrier) {
+      x = x + p.val;
+      if (p.member[j]) x -= p.val;
+    }
+    out[j] = x;
+    if (j != n) rm = fminf(rm, x);
+  }
+  if (!p.rowmin) return;
+  __syncthreads();  // (red is read above by every thread)
+  red[threadIdx.x] = rm;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] = fminf(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) p.rowmin[t] = red[0];
 }
 
 // The per-target records come from a pinned host block.  Read there by the matrix kernel itself -- one 32-byte
@@ -81,7 +106,8 @@ __global__ void __launch_bounds__(256) stage_args_kernel(const uint4 *__restrict
 
 hipError_t launch_matrix(const MatrixParams &p, const Layout &lay, int S, int waves, hipStream_t stream) {
   if (p.host_args) {
-    const int n16 = (int)(((size_t)p.nloc * sizeof(MatrixArg) + 15) / 16);
+    // (the carrier flags, when there are any, lie behind the records in both blocks)
+    const int n16 = (int)(((size_t)p.nloc * sizeof(MatrixArg) + (p.member ? (size_t)p.N : 0) + 15) / 16);
     hipLaunchKernelGGL(stage_args_kernel, dim3((n16 + 255) / 256), dim3(256), 0, stream,
                        reinterpret_cast<const uint4 *>(p.host_args), reinterpret_cast<uint4 *>(const_cast<MatrixArg *>(p.args)), n16);
   }

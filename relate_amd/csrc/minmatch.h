@@ -228,6 +228,10 @@ class DeviceMinMatch {
   // device_matrix() (K3, rl_window_matrix_rows_device), the carrier penalty and the clade prior of the previous
   // tree are applied on the device (anc_builder.cpp:563-606), build_resident builds from what is there.
   float *device_matrix();
+  // where the row minima of the staged distance matrix go when the caller's matrix kernel takes them itself
+  // (rl_window_matrix_rows_device_ex), and the caller's word that they are there (with the penalty applied)
+  float *rowmin_device();
+  void rowmin_is_ready();
   int apply_penalty(const char *member, float val);
   int apply_prior(const HostTree &previous, float val);
   int build_resident(MinMatch &tb, bool with_prior, HostTree &tree);

@@ -1967,7 +1967,8 @@ __global__ void __launch_bounds__(MM_BLOCK, 1)
 //   rowmin_penalty_kernel  the carrier penalty of a tree's distance matrix (in place) AND its row minima, one pass;
 //   prior_kernel           the clade prior row by row AND its row minima (the row is in LDS anyway);
 //   weave_kernel           M[a][b] = (d(a,b), d(b,a), cf(a,b), cf(b,a)) AND the pair scan of the initialisation (the
-//                          row minima are complete by then): the woven matrix is written once and never read back.
+//                          row minima are complete by then): every element of D / CF read once, M written once and
+//                          never read back.
 // Before: penalty (in place), prior, pack (read 2 x 2 matrices, write M), rowmin (read both matrices again), pairscan
 // (read half of M): 0.42 ms of kernels and ~1.5 GB per tree at N = 5000; now ~1.1 GB.
 
@@ -2003,8 +2004,8 @@ __global__ void __launch_bounds__(256) rowmin_penalty_kernel(float *__restrict__
 // with d(a,b) <= min_a and d(b,a) <= min_b (minima + threshold), in order, with the symmetric distance the
 // reference's loop would compute for the pair (0 when the pair is also mutually closest under the prior,
 // :1699-1702).  mvcf_old: min_values_CF as carried over from the previous tree (:2399-2400).
-// One workgroup per strip of 32 rows, walking the column panels of 64 in order (so a row's hits come out in
-// order): wave w holds rows a0 + 8 w + r, lane l column 64 pb + l.  d(a,b) and cf(a,b) arrive as the lanes need
+// One workgroup per strip of 32 rows, walking the column panels of 64 from its own on, in order (so a row's hits
+// come out in order): wave w holds rows a0 + 8 w + r, lane l column 64 pb + l.  d(a,b) and cf(a,b) arrive as the lanes need
 // them (a wave reads 256 contiguous bytes of a row), d(b,a) and cf(b,a) -- 64 rows b, 32 columns -- through LDS;
 // a wave's store is 1 KB of M's panel.  The next panel's loads are in flight while this one is woven.
 constexpr int WV_ROWS = 32;
@@ -2015,7 +2016,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) w
                                                     const float *__restrict__ mvcf_old, int ages, float threshold,
                                                     float threshold_CF, int *__restrict__ hit_cnt,
                                                     unsigned *__restrict__ hit_b, float *__restrict__ hit_sym) {
-  __shared__ float tD[64][WV_ROWS + 1], tC[PRIOR ? 64 : 1][WV_ROWS + 1];
+  __shared__ float tD[64][WV_ROWS + 1], tC[PRIOR ? 64 : 1][WV_ROWS + 1];  // [b][a]: d(b,a), cf(b,a)
+  __shared__ float tX[WV_ROWS][64 + 1], tZ[PRIOR ? WV_ROWS : 1][64 + 1];   // [a][b]: d(a,b), cf(a,b)
   // (the wave's index as a scalar: its rows' addresses are scalar bases, the lane's column a 32-bit offset)
   const int a0 = blockIdx.x * WV_ROWS, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int trow = threadIdx.x >> 2, tcol = (threadIdx.x & 3) * 8;  // the thread's 8 floats of the transposed tile
@@ -2070,11 +2072,24 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) w
       }
     }
   };
+  // Every element of D and CF is read ONCE: the strip walks the panels from its own on (pa), and a tile right of
+  // the diagonal panel is woven both ways -- M[a][b] for the strip's rows, a wave's store 1 KB of panel pb, and
+  // M[b][a] = (d(b,a), d(a,b), cf(b,a), cf(a,b)) for the panel's 64 rows b at the strip's 32 columns, 512 B runs of
+  // panel pa -- so nobody reads the tiles left of its diagonal.
+  const int pa = a0 / 64;
   auto weave = [&](int pb, const Panel &q) {
+    const bool both = pb > pa;  // (wave-uniform)
 #pragma unroll
     for (int k = 0; k < 8; k++) {
       tD[trow][tcol + k] = q.td[k];
       if (PRIOR) tC[trow][tcol + k] = q.tc[k];
+    }
+    if (both) {
+#pragma unroll
+      for (int r = 0; r < 8; r++) {
+        tX[wave * 8 + r][lane] = q.x[r];
+        if (PRIOR) tZ[wave * 8 + r][lane] = q.z[r];
+      }
     }
     __syncthreads();
     const int b = pb * 64 + lane;
@@ -2104,12 +2119,21 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) w
         cnt[r] += __popcll(m);
       }
     }
+    if (both) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int bl = wave * 16 + 2 * k + (lane >> 5), al = lane & 31;
+        const int bq = pb * 64 + bl, aq = a0 + al;
+        if (aq < N && bq < N)
+          M[mm_index(bq, aq, N)] = make_float4(tD[bl][al], tX[al][bl], PRIOR ? tC[bl][al] : 0.0f, PRIOR ? tZ[al][bl] : 0.0f);
+      }
+    }
     __syncthreads();
   };
   const int P = (N + 63) / 64;
   Panel p0, p1;
-  load(0, p0);
-  for (int pb = 0; pb < P; pb += 2) {
+  load(pa, p0);
+  for (int pb = pa; pb < P; pb += 2) {
     if (pb + 1 < P) load(pb + 1, p1);
     weave(pb, p0);
     if (pb + 1 < P) {
@@ -2668,6 +2692,13 @@ float *DeviceMinMatch::device_matrix() {
   if (!m.staging) m.staging = DeviceShare::of(m.device).take(m.N);
   return m.staging ? m.staging->D.as<float>() : nullptr;
 }
+
+float *DeviceMinMatch::rowmin_device() {
+  Impl &m = *impl;
+  if (hipSetDevice(m.device) != hipSuccess || m.d_f.alloc((size_t)8 * m.N * 4)) return nullptr;
+  return m.d_f.as<float>() + 6 * (size_t)m.N;
+}
+void DeviceMinMatch::rowmin_is_ready() { impl->rowmin_d_ready = true; }
 
 int DeviceMinMatch::apply_penalty(const char *member, float val) {
   Impl &m = *impl;

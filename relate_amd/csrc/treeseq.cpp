@@ -57,6 +57,7 @@ struct rl_treeseq {
   int num_carriers = 0;
   int build_device = -1;  // >= 0: trees are built on that GPU (minmatch_gpu.hip), the host builder as fallback
   rl_matrix_dev_fn matrix_dev = nullptr;  // with it the distance matrices never leave the device
+  rl_matrix_dev_ex_fn matrix_dev_ex = nullptr;  // ... and arrive with the carrier penalty applied and their row minima
   long long gpu_trees = 0, host_trees = 0;
   std::vector<double> sample_ages;  // N values (--sample_ages) or empty
   // the device builder's buffers (16 N^2 B of woven matrix) outlive a section: the next one of this object reuses them
@@ -411,7 +412,13 @@ int rl_treeseq_build(rl_treeseq *ts, int start, int end, rl_matrix_fn matrix, rl
   if (resident) {
     float *dd = dev->device_matrix();
     if (!dd) return RL_ENOMEM;
-    if ((rc = ts->matrix_dev(user, start, dd))) return rc;
+    float *rmin = ts->matrix_dev_ex ? dev->rowmin_device() : nullptr;
+    if (rmin) {  // (no penalty for a section's first tree: the row minima alone)
+      if ((rc = ts->matrix_dev_ex(user, start, dd, nullptr, 0.0f, rmin))) return rc;
+      dev->rowmin_is_ready();
+    } else if ((rc = ts->matrix_dev(user, start, dd))) {
+      return rc;
+    }
     const int st = build_resident(false, ts->trees.back());
     if (st < 0) return RL_EHIP;
     if (st > 0) {  // this tree is the host's (tb untouched): the matrix again, to the host
@@ -466,11 +473,18 @@ int rl_treeseq_build(rl_treeseq *ts, int start, int end, rl_matrix_fn matrix, rl
       builds++;
       if (resident) {  // matrix, carrier penalty, clade prior and the build itself on the device
         float *dd = dev->device_matrix();
-        if ((rc = ts->matrix_dev(user, snp, dd))) return rc;
+        if (!dd) return RL_ENOMEM;
+        float *rmin = ts->matrix_dev_ex ? dev->rowmin_device() : nullptr;
+        if (rmin) {  // the penalty and the row minima in the matrix kernel's own last pass over each row
+          if ((rc = ts->matrix_dev_ex(user, snp, dd, consistency ? ts->member.data() : nullptr, val, rmin))) return rc;
+          dev->rowmin_is_ready();
+        } else if ((rc = ts->matrix_dev(user, snp, dd))) {
+          return rc;
+        }
         lap(t_matrix);
         int st = 0;
         if (consistency) {
-          st = dev->apply_penalty(ts->member.data(), val);
+          if (!rmin) st = dev->apply_penalty(ts->member.data(), val);
           st = st ? st : dev->apply_prior(pt, val);
           lap(t_prior);
         }
@@ -571,6 +585,12 @@ int rl_treeseq_set_build_device(rl_treeseq *ts, int device) {
   return RL_OK;
 }
 
+int rl_treeseq_set_device_matrix_ex(rl_treeseq *ts, rl_matrix_dev_ex_fn matrix_dev_ex) {
+  if (!ts) return RL_EINVAL;
+  ts->matrix_dev_ex = matrix_dev_ex;
+  return RL_OK;
+}
+
 int rl_treeseq_set_device_matrix(rl_treeseq *ts, rl_matrix_dev_fn matrix_dev) {
   if (!ts) return RL_EINVAL;
   ts->matrix_dev = matrix_dev;
@@ -661,6 +681,9 @@ std::string g_stage_sample_ages;  // rl_stage_set_sample_ages: the --sample_ages
 static int win_matrix(void *user, int snp, float *d) { return rl_window_matrix((rl_window *)user, snp, d, nullptr); }
 static int win_matrix_dev(void *user, int snp, void *d_dev) {
   return rl_window_matrix_rows_device((rl_window *)user, snp, d_dev, nullptr);
+}
+static int win_matrix_dev_ex(void *user, int snp, void *d_dev, const char *carriers, float val, void *d_rowmin) {
+  return rl_window_matrix_rows_device_ex((rl_window *)user, snp, d_dev, carriers, val, d_rowmin, nullptr);
 }
 static int win_advance(void *user, int snp) { return rl_window_advance((rl_window *)user, snp); }
 
@@ -981,7 +1004,10 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
     if (!sample_ages.empty()) rl_treeseq_set_sample_ages(ts, sample_ages.data(), (int)sample_ages.size());
     if (gpu_build) {
       rl_treeseq_set_build_device(ts, device);
-      if (ctx->nloc == ctx->N) rl_treeseq_set_device_matrix(ts, win_matrix_dev);
+      if (ctx->nloc == ctx->N) {
+        rl_treeseq_set_device_matrix(ts, win_matrix_dev);
+        if (!getenv("RELATE_AMD_NO_K3_FUSION")) rl_treeseq_set_device_matrix_ex(ts, win_matrix_dev_ex);
+      }
     }
     for (;;) {
       const int turn = next.fetch_add(1);

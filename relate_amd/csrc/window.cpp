@@ -676,7 +676,8 @@ int rl_window_advance(rl_window *win, int snp) {
 }
 
 // rows of the window's targets: [nloc][N] (the whole matrix for a context with all targets)
-static int window_matrix(rl_window *win, int snp, float *d_host, void *d_dev, float *kernel_ms) {
+static int window_matrix(rl_window *win, int snp, float *d_host, void *d_dev, float *kernel_ms,
+                         const char *member = nullptr, float val = 0.0f, float *rowmin_dev = nullptr) {
   if (!win || snp < 0 || snp >= win->ctx->L) {
     set_error("rl_window_matrix: bad arguments");
     return RL_EINVAL;
@@ -690,7 +691,8 @@ static int window_matrix(rl_window *win, int snp, float *d_host, void *d_dev, fl
     if (win->stream && !win->e0 && hipEventCreate(&win->e0) != hipSuccess) win->e0 = nullptr;
     if (win->stream && !win->e2 && hipEventCreate(&win->e2) != hipSuccess) win->e2 = nullptr;
     if (win->stream && !win->h_stage) {
-      win->h_stage = static_cast<unsigned char *>(pinned_cache_alloc((size_t)nloc * sizeof(MatrixArg) + 64, &win->h_stage_bytes));
+      // (the records of one matrix and, behind them, the N carrier flags of rl_window_matrix_rows_device_ex)
+      win->h_stage = static_cast<unsigned char *>(pinned_cache_alloc((size_t)nloc * sizeof(MatrixArg) + (size_t)N + 64, &win->h_stage_bytes));
       if (!win->h_stage) tl_alloc_failures++;
     }
     if (!win->stream || !win->e0 || !win->e2 || !win->h_stage ||
@@ -759,9 +761,16 @@ static int window_matrix(rl_window *win, int snp, float *d_host, void *d_dev, fl
   p.logscales = win->d_ls.as<float>();
   p.top_off = win->d_top_off.as<int64_t>();
   p.slab_base = reinterpret_cast<const int64_t *>(win->d_place.as<unsigned char>() + (size_t)nloc * 8);
-  if ((rc = win->d_stage.alloc((size_t)nloc * sizeof(MatrixArg) + 64))) return rc;
+  if ((rc = win->d_stage.alloc((size_t)nloc * sizeof(MatrixArg) + (size_t)N + 64))) return rc;
   p.args = win->d_stage.as<MatrixArg>();
   p.host_args = static_cast<const MatrixArg *>(win->d_args);
+  p.member = nullptr;
+  p.val = val;
+  p.rowmin = rowmin_dev;
+  if (member) {  // the carrier flags travel with the records (one staging kernel, no copy of their own)
+    memcpy(win->h_stage + (size_t)nloc * sizeof(MatrixArg), member, (size_t)N);
+    p.member = win->d_stage.as<unsigned char>() + (size_t)nloc * sizeof(MatrixArg);
+  }
   if (!d_dev && (rc = win->d_matrix.alloc((size_t)nloc * N * sizeof(float)))) return rc;
   p.matrix = d_dev ? static_cast<float *>(d_dev) : win->d_matrix.as<float>();
   RL_HIP(hipEventRecord(win->e0, win->stream));
@@ -786,6 +795,15 @@ int rl_window_matrix_rows_device(rl_window *win, int snp, void *d_rows, float *k
     return RL_EINVAL;
   }
   return window_matrix(win, snp, nullptr, d_rows, kernel_ms);
+}
+
+int rl_window_matrix_rows_device_ex(rl_window *win, int snp, void *d_rows, const char *carriers, float val,
+                                    void *d_rowmin, float *kernel_ms) {
+  if (!d_rows) {
+    set_error("rl_window_matrix_rows_device_ex: null device pointer");
+    return RL_EINVAL;
+  }
+  return window_matrix(win, snp, nullptr, d_rows, kernel_ms, carriers, val, static_cast<float *>(d_rowmin));
 }
 
 }  // extern "C"
