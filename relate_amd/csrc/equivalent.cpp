@@ -155,7 +155,10 @@ int write_anc(const std::string &fn, const AncFile &a) {
 // keeps, per node, the positions of its leaves sorted -- and an intersection is two binary searches.
 
 // nodes of a tree, every node after its children
-std::vector<int> children_first(const AncTree &t) {
+// (every container of a pair's association is filled into storage the calling thread keeps from pair to pair: with
+//  fresh vectors -- several of them past malloc's mmap threshold -- 256 threads spent their time in the kernel's
+//  address-space lock: 95,000 pairs of N = 5000 trees took 196 s of wall-clock for 3157 s of CPU)
+void children_first(const AncTree &t, std::vector<int> &order, std::vector<int> &todo) {
   const int nodes = (int)t.parent.size(), N = (nodes + 1) / 2;
   int root = nodes - 1;
   if (t.parent[root] != -1)  // (as Tree::FindAllLeaves looks for it, :452-461)
@@ -164,9 +167,9 @@ std::vector<int> children_first(const AncTree &t) {
         root = i;
         break;
       }
-  std::vector<int> order;
+  order.clear();
   order.reserve(nodes);
-  std::vector<int> todo(1, root);
+  todo.assign(1, root);
   while (!todo.empty()) {  // parents first, left subtree last to leave the stack ...
     const int v = todo.back();
     todo.pop_back();
@@ -177,18 +180,18 @@ std::vector<int> children_first(const AncTree &t) {
     }
   }
   std::reverse(order.begin(), order.end());  // ... reversed: children first
-  return order;
 }
 
 struct IntervalTree {  // the reference tree of a pair
   std::vector<int> lo, size;   // per node: its leaves are the positions [lo, lo + size)
   std::vector<int> position;   // per leaf
-  explicit IntervalTree(const AncTree &t) {
+  std::vector<int> order, todo;
+  void build(const AncTree &t) {
     const int nodes = (int)t.parent.size();
     lo.assign(nodes, 0);
     size.assign(nodes, 0);
     position.assign((nodes + 1) / 2, 0);
-    const std::vector<int> order = children_first(t);
+    children_first(t, order, todo);
     for (int v : order) size[v] = t.child_left[v] == -1 ? 1 : size[t.child_left[v]] + size[t.child_right[v]];
     for (auto it = order.rbegin(); it != order.rend(); ++it) {  // parents first: hand the interval down
       const int v = *it;
@@ -205,10 +208,11 @@ struct IntervalTree {  // the reference tree of a pair
 struct PositionSets {  // the other tree of the pair: per node the sorted positions (in the reference tree) of its leaves
   std::vector<size_t> off;
   std::vector<int> pos;
-  PositionSets(const AncTree &t, const IntervalTree &ref) {
+  std::vector<int> order, todo, n_below;
+  void build(const AncTree &t, const IntervalTree &ref) {
     const int nodes = (int)t.parent.size();
-    const std::vector<int> order = children_first(t);
-    std::vector<int> n_below(nodes, 0);
+    children_first(t, order, todo);
+    n_below.assign(nodes, 0);
     for (int v : order) n_below[v] = t.child_left[v] == -1 ? 1 : n_below[t.child_left[v]] + n_below[t.child_right[v]];
     off.assign((size_t)nodes + 1, 0);
     for (int v = 0; v < nodes; v++) off[v + 1] = off[v] + (size_t)n_below[v];
@@ -272,10 +276,20 @@ struct BranchMatcher {
   // reference's branches of the same clade size); the rest by descending correlation among counterparts of a
   // compatible size, greedily.
   void associate(const AncTree &ref_tree, const AncTree &tree, std::vector<int> &match) const {
+    struct Workspace {
+      IntervalTree ref;
+      PositionSets sets;
+      std::vector<int> taken, by_size, class_end, open;
+      std::vector<ScoredPair> candidates;
+    };
+    static thread_local Workspace ws;
     match.assign(nodes, -1);
-    std::vector<int> taken(nodes, -1);  // per reference branch: who has it
-    const IntervalTree ref(ref_tree);
-    const PositionSets sets(tree, ref);
+    std::vector<int> &taken = ws.taken;  // per reference branch: who has it
+    taken.assign(nodes, -1);
+    IntervalTree &ref = ws.ref;
+    ref.build(ref_tree);
+    PositionSets &sets = ws.sets;
+    sets.build(tree, ref);
     auto corr = [&](int v, int rv) {
       return leaf_set_correlation(sets.size(v), ref.size[rv], sets.shared(v, ref.lo[rv], ref.size[rv]), N);
     };
@@ -287,10 +301,12 @@ struct BranchMatcher {
     // the reference's branches by clade size.  (std::sort, unstable, on the identity permutation with this
     // comparison: the order INSIDE a size class is whatever that call leaves, and the greedy round below depends on
     // it through its own unstable sort -- the same two calls on the same data as anc_builder.cpp:1477-1480, :1603.)
-    std::vector<int> by_size(nodes);
+    std::vector<int> &by_size = ws.by_size;
+    by_size.resize(nodes);
     for (int v = 0; v < nodes; v++) by_size[v] = v;
     std::sort(by_size.begin(), by_size.end(), [&](int a, int b) { return ref.size[a] < ref.size[b]; });
-    std::vector<int> class_end(N, 0);  // class_end[s]: branches with <= s leaves (the root, N leaves, is no candidate)
+    std::vector<int> &class_end = ws.class_end;
+    class_end.assign(N, 0);  // class_end[s]: branches with <= s leaves (the root, N leaves, is no candidate)
     for (int v = 0; v < nodes; v++)
       if (v != nodes - 1 && ref.size[v] < N) class_end[ref.size[v]]++;
     for (int s = 1; s < N; s++) class_end[s] += class_end[s - 1];
@@ -312,7 +328,8 @@ struct BranchMatcher {
         pair_up(leaf, leaf);
       }
     }
-    std::vector<int> open;
+    std::vector<int> &open = ws.open;
+    open.clear();
     for (int v = N; v < nodes - 1; v++) {  // :1553-1583
       auto perfect = [&](int rv) { return corr(v, rv) >= 0.9999 && corr(tree.parent[v], ref_tree.parent[rv]) >= 0.9999; };
       if (perfect(v)) pair_up(v, v);
@@ -326,7 +343,8 @@ struct BranchMatcher {
       }
       if (match[v] == -1) open.push_back(v);
     }
-    std::vector<ScoredPair> candidates;  // :1586-1601
+    std::vector<ScoredPair> &candidates = ws.candidates;  // :1586-1601
+    candidates.clear();
     for (int v : open)
       for (int s : sizes_near[sets.size(v) - 1]) {
         const auto cls = size_class(s);

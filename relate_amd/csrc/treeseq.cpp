@@ -555,13 +555,20 @@ int rl_treeseq_build(rl_treeseq *ts, int start, int end, rl_matrix_fn matrix, rl
     }
   }
   std::fill(ts->trees.back().snp_end.begin(), ts->trees.back().snp_end.end(), end);
-  if (timing)
+  if (timing) {
+    // (the host builder's own phases only when it built trees: for the device's workers the per-phase times are the
+    //  "[gpu tree builder]" lines, one per tree, and its host side the line the builder prints when it is destroyed)
+    char host_phases[256] = "";
+    if (ts->host_trees > 0)
+      snprintf(host_phases, sizeof host_phases,
+               "; host builder: row minima + pair scan %.2f, merges: parallel part %.2f [updates %.2f] + ordered part "
+               "%.2f, %.2f rebuilt clusters per merge", tb.t_init, tb.t_phase1, tb.t_phase1a, tb.t_phase2,
+               (double)tb.n_updated / std::max<long long>(1, tb.n_merges));
     fprintf(stderr,
             "[tree sequence] SNPs %d..%d: %d trees kept of %d built; distance matrices %.2f s, penalty + clade prior "
-            "%.2f s, MinMatch %.2f s (row minima + pair scan %.2f, merges: parallel part %.2f [updates %.2f] + ordered part %.2f, "
-            "%.2f rebuilt clusters per merge; %lld trees on the GPU, %lld on the host), mutation mapping %.2f s\n",
-            start, end, num_tree, builds + 1, t_matrix, t_prior, t_build, tb.t_init, tb.t_phase1, tb.t_phase1a, tb.t_phase2,
-            (double)tb.n_updated / std::max<long long>(1, tb.n_merges), ts->gpu_trees, ts->host_trees, t_map);
+            "%.2f s, tree builds %.2f s (%lld trees on the GPU, %lld on the host%s), mutation mapping %.2f s\n",
+            start, end, num_tree, builds + 1, t_matrix, t_prior, t_build, ts->gpu_trees, ts->host_trees, host_phases, t_map);
+  }
   return RL_OK;
 }
 

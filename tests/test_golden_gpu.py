@@ -38,6 +38,13 @@ def test_paint_files_byte_identical_to_reference(tmp_path, name, painting):
     ctx.write_paint_files(out)
     for w in range(fx.W):
         assert open(os.path.join(out, "relate_%d.bin" % w), "rb").read() == fx.paint_file(w), "window %d" % w
+    # one window's file alone, and the file as the sequence of its targets' records (rl_write_paint_file,
+    # rl_paint_record: what PaintSteppingStones(data, wb, pfiles, k) appends to pfiles[w])
+    w = fx.W // 2
+    one = str(tmp_path / "one_window.bin")
+    ctx.write_paint_file(w, one)
+    assert open(one, "rb").read() == fx.paint_file(w)
+    assert b"".join(ctx.paint_record(w, k) for k in range(ctx.N)) == fx.paint_file(w)
     ctx.close()
 
 
