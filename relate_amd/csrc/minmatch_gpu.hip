@@ -2009,7 +2009,9 @@ __global__ void __launch_bounds__(256) rowmin_penalty_kernel(float *__restrict__
 // them (a wave reads 256 contiguous bytes of a row), d(b,a) and cf(b,a) -- 64 rows b, 32 columns -- through LDS;
 // a wave's store is 1 KB of M's panel.  The next panel's loads are in flight while this one is woven.
 constexpr int WV_ROWS = 32;
-template <bool PRIOR>
+// (TWO_WAY = false: every strip walks ALL panels and weaves its own rows only -- each element read twice, no
+//  512-byte runs; kept for A/B runs, RELATE_AMD_WEAVE_ONE_WAY=1)
+template <bool PRIOR, bool TWO_WAY = true>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) weave_kernel(const float *__restrict__ D, const float *__restrict__ CF,
                                                     float4 *__restrict__ M, int N, const float *__restrict__ rowmin_D,
                                                     const float *__restrict__ rowmin_CF,
@@ -2076,9 +2078,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) w
   // the diagonal panel is woven both ways -- M[a][b] for the strip's rows, a wave's store 1 KB of panel pb, and
   // M[b][a] = (d(b,a), d(a,b), cf(b,a), cf(a,b)) for the panel's 64 rows b at the strip's 32 columns, 512 B runs of
   // panel pa -- so nobody reads the tiles left of its diagonal.
-  const int pa = a0 / 64;
+  const int pa = TWO_WAY ? a0 / 64 : 0;
   auto weave = [&](int pb, const Panel &q) {
-    const bool both = pb > pa;  // (wave-uniform)
+    const bool both = TWO_WAY && pb > pa;  // (wave-uniform)
 #pragma unroll
     for (int k = 0; k < 8; k++) {
       tD[trow][tcol + k] = q.td[k];
@@ -2976,7 +2978,12 @@ int DeviceMinMatch::build_impl(TB &tb, const std::vector<double> *sample_ages, c
       hipLaunchKernelGGL(rowmin_penalty_kernel, dim3(N), dim3(256), 0, m.stream, dCF, N, (const unsigned char *)nullptr, 0.0f,
                          f + 7 * (size_t)N);
     const dim3 grid((N + WV_ROWS - 1) / WV_ROWS);
-    if (prior)
+    static const bool one_way = getenv("RELATE_AMD_WEAVE_ONE_WAY") && atoi(getenv("RELATE_AMD_WEAVE_ONE_WAY")) != 0;
+    if (prior && one_way)
+      hipLaunchKernelGGL((weave_kernel<true, false>), grid, dim3(256), 0, m.stream, dD, dCF, p.M, N, p.rowmin_D, p.rowmin_CF, mvcf_dev,
+                         ages ? 1 : 0, p.threshold, p.threshold_CF, hits, reinterpret_cast<unsigned *>(hits + N),
+                         reinterpret_cast<float *>(hits + N + (size_t)N * MM_HITS));
+    else if (prior)
       hipLaunchKernelGGL(weave_kernel<true>, grid, dim3(256), 0, m.stream, dD, dCF, p.M, N, p.rowmin_D, p.rowmin_CF, mvcf_dev,
                          ages ? 1 : 0, p.threshold, p.threshold_CF, hits, reinterpret_cast<unsigned *>(hits + N),
                          reinterpret_cast<float *>(hits + N + (size_t)N * MM_HITS));

@@ -51,7 +51,7 @@ def test_section_0_trees_at_config5_N(chunk, builder):
         bigtile.run_cli("Paint", work, "host")
     err = bigtile.run_cli("BuildTopology", work, builder)
     if builder == "gpu":
-        assert "; 0 trees on the GPU" not in err, err[-800:]
+        assert "(0 trees on the GPU" not in err, err[-800:]
     bigtile.check_section_0(z, os.path.join(work, "out"))
 
 

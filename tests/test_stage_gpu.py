@@ -110,10 +110,9 @@ def test_cli_build_topology_trees_built_on_the_gpu(tmp_path, name):
                         "--last_section", str(fx.W - 1), "-o", "out"], cwd=str(work), stderr=subprocess.PIPE,
                        env=dict(os.environ, RELATE_AMD_GPU_BUILD="1", RELATE_AMD_TIMING="1"))
     assert p.returncode == 0, p.stderr.decode()
-    on_gpu = sum(int(l.split(" trees on the GPU")[0].split()[-1]) for l in p.stderr.decode().split("\n")
-                 if " trees on the GPU" in l)
-    on_host = sum(int(l.split(" on the host")[0].split()[-1]) for l in p.stderr.decode().split("\n")
-                  if " on the host" in l)
+    import re
+    on_gpu = sum(int(x) for x in re.findall(r"(\d+) trees on the GPU", p.stderr.decode()))
+    on_host = sum(int(x) for x in re.findall(r"trees on the GPU, (\d+) on the host", p.stderr.decode()))
     assert on_gpu > 0 and on_host == 0
     for w in range(fx.W):
         assert open(work / "out" / "chunk_0" / ("out_%d.mut" % w), "rb").read() == fx.z["mut/%d" % w].tobytes(), w
