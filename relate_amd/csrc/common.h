@@ -60,6 +60,10 @@ void device_cache_trim();
 // launches of tree-builder workers that are alive (minmatch_gpu.hip): while any is, a failed allocation does not
 // trim the cache (hipFree would wait for the workers) -- it takes a larger cached block, or waits for them to leave
 extern std::atomic<int> g_worker_launches;
+// section threads waiting for their turn at a context's RePaint lane right now (window.cpp): the tree builder's
+// launcher follows it -- RePaint runs on the CUs the workers leave, and past a certain worker count its queue, not
+// the workers, is what the sections wait in
+extern std::atomic<int> g_repaint_waiting;
 // bytes of `device`'s memory the cache holds for re-use in blocks of at least min_block bytes (cache_alloc hands out
 // whole blocks only: smaller ones are no room for a request of min_block)
 size_t device_cache_held(int device, size_t min_block);

@@ -61,6 +61,7 @@ struct BlockCache {
 BlockCache g_dev_cache, g_pin_cache;
 }  // namespace
 std::atomic<int> g_worker_launches{0};
+std::atomic<int> g_repaint_waiting{0};
 namespace {
 
 template <typename AllocFn>

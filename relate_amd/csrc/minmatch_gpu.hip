@@ -1865,6 +1865,8 @@ struct WorkQueue {
   unsigned tail;
   unsigned pad[15];
   unsigned gone[16];  // per launch: workers that have left (the host counts a launch's LIVE workers, not its size)
+  unsigned retire[16];  // per launch: its workers leave after the tree they are building (the launcher, when RePaint
+                        // needs the CUs more than the trees do)
   unsigned words[MM_QUEUE_CAP][MM_PARAM_WORDS];
 };
 // device memory: the ticket counter, and per launch how many of its workers are building and when one last was
@@ -1916,6 +1918,7 @@ __global__ void __launch_bounds__(MM_BLOCK, 1)
       unsigned seen = __hip_atomic_load(&mine.activity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       long long since = wall_clock64();
       for (;;) {
+        if (__hip_atomic_load(&q->retire[launch], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) break;  // (the launch is sent home)
         const unsigned h = __hip_atomic_load(&ws->head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned t = __hip_atomic_load(&q->tail, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
         if ((int)(t - h) > 0) {
@@ -2476,6 +2479,21 @@ class BuildQueue {
       dyn = lds_state_bytes(N_, ages_);
     }
     const bool verbose = getenv("RELATE_AMD_TIMING") != nullptr;
+    // RELATE_AMD_ADAPTIVE_WORKERS=lo:start:hi (experiment): the worker count follows RePaint's queue.  RePaint and the
+    // per-tree kernels run on the CUs the workers leave; with too many workers every section waits seconds for its
+    // window's next part, with too few the trees wait for a worker -- and where the edge lies moves with the box and
+    // the phase of the stage (C3: 143 s and 185 s from the same 124 workers).  Every 2 s: more than `hi_wait` section
+    // threads waiting for the lane on average -> the smallest launch is sent home (its workers leave after their
+    // tree); fewer than `lo_wait` -> eight more workers may come.
+    int a_lo = 0, a_start = 0, a_hi = 0, dyn_goal = 1 << 30;
+    if (const char *e = getenv("RELATE_AMD_ADAPTIVE_WORKERS"))
+      if (sscanf(e, "%d:%d:%d", &a_lo, &a_start, &a_hi) == 3 && a_lo > 0 && a_lo <= a_start && a_start <= a_hi) dyn_goal = a_start;
+    const double hi_wait = getenv("RELATE_AMD_ADAPTIVE_HI") ? atof(getenv("RELATE_AMD_ADAPTIVE_HI")) : 8.0;
+    const double lo_wait = getenv("RELATE_AMD_ADAPTIVE_LO") ? atof(getenv("RELATE_AMD_ADAPTIVE_LO")) : 2.0;
+    double wait_sum = 0.0;
+    long long wait_n = 0;
+    auto wait_t0 = std::chrono::steady_clock::now();
+    bool retiring[MM_LAUNCHES] = {};
     for (;;) {
       int demand = 0, goal = 0;
       {
@@ -2511,6 +2529,7 @@ class BuildQueue {
         // (the stage's word, expect(), is a limit -- it knows what RePaint needs of the chip; RELATE_AMD_BUILD_WORKERS
         //  overrides it)
         goal = (expected_ > 0 && !cap_from_env_) ? std::min(cap_, expected_) : cap_;
+        if (a_hi > 0) goal = std::min(goal, dyn_goal);
         // whole rounds of the XCDs (below): the goal too
         if (goal >= MM_XCDS) goal -= goal % MM_XCDS;
       }
@@ -2520,10 +2539,52 @@ class BuildQueue {
           size[l] = 0;
           g_worker_launches.fetch_sub(1);
         }
+        if (size[l] == 0 && retiring[l]) {  // (sent home and gone: the stream can carry a launch again)
+          retiring[l] = false;
+          __atomic_store_n(&q_->retire[l], 0u, __ATOMIC_RELEASE);
+        }
         // (workers decide to leave one by one -- idle past the limit and nobody of the launch building --, so a late
         //  claim can keep one of them at work while its peers are gone: a launch counts for the workers it still has)
-        alive += size[l] - std::min(size[l], (int)__atomic_load_n(&q_->gone[l], __ATOMIC_ACQUIRE));
+        if (!retiring[l]) alive += size[l] - std::min(size[l], (int)__atomic_load_n(&q_->gone[l], __ATOMIC_ACQUIRE));
         if (size[l] == 0 && free_stream < 0) free_stream = l;
+      }
+      if (a_hi > 0) {
+        wait_sum += (double)g_repaint_waiting.load();
+        wait_n++;
+        const auto nowt = std::chrono::steady_clock::now();
+        if (nowt - wait_t0 > std::chrono::seconds(2)) {
+          const double avg = wait_sum / (double)std::max<long long>(1, wait_n);
+          wait_sum = 0.0;
+          wait_n = 0;
+          wait_t0 = nowt;
+          if (avg > hi_wait && alive > a_lo) {
+            int pick = -1;
+            for (int l = 0; l < MM_LAUNCHES; l++) {
+              const int live = size[l] - std::min(size[l], (int)__atomic_load_n(&q_->gone[l], __ATOMIC_ACQUIRE));
+              if (size[l] > 0 && !retiring[l] && live > 0 && alive - live >= a_lo &&
+                  (pick < 0 || size[l] < size[pick]))
+                pick = l;
+            }
+            if (pick >= 0) {
+              const int live = size[pick] - std::min(size[pick], (int)__atomic_load_n(&q_->gone[pick], __ATOMIC_ACQUIRE));
+              retiring[pick] = true;
+              __atomic_store_n(&q_->retire[pick], 1u, __ATOMIC_RELEASE);
+              dyn_goal = std::max(a_lo, alive - live);
+              alive -= live;
+              if (verbose) {
+                fprintf(stderr, "[tree builder workers] %.1f sections waiting for RePaint: launch %d (%d workers) sent home, goal %d\n",
+                        avg, pick, live, dyn_goal);
+                fflush(stderr);
+              }
+            }
+          } else if (avg < lo_wait && dyn_goal < a_hi && alive + MM_XCDS > dyn_goal) {
+            dyn_goal = std::min(a_hi, dyn_goal + MM_XCDS);
+            if (verbose) {
+              fprintf(stderr, "[tree builder workers] %.1f sections waiting for RePaint: goal %d\n", avg, dyn_goal);
+              fflush(stderr);
+            }
+          }
+        }
       }
       // Workers follow the trees that are waiting or being built, not the sections that exist: a section spends half
       // of its time outside the build (distance matrix, RePaint, mapping), and a worker without a tree still holds

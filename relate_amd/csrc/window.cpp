@@ -91,6 +91,15 @@ static int repaint_rows(rl_window *win, float *kernel_ms) {
   // (the second lane's strips are sized for partial launches: a window's first, whole pass takes the first lane)
   const bool first_lane_only = !win->have_logscales || scratch_bytes > ctx->lane2.scratch.bytes;
   const auto t_ask = std::chrono::steady_clock::now();
+  g_repaint_waiting.fetch_add(1);
+  struct Waiting {  // (counted until the lane is this thread's, whichever way the function leaves)
+    bool on = true;
+    void off() {
+      if (on) g_repaint_waiting.fetch_sub(1);
+      on = false;
+    }
+    ~Waiting() { off(); }
+  } waiting;
   // (whichever lane is free; with both taken, the windows queue up behind the two in turn)
   static std::atomic<unsigned> turn{0};
   std::unique_lock<std::mutex> one_at_a_time(ctx->repaint_mutex, std::defer_lock);
@@ -114,6 +123,7 @@ static int repaint_rows(rl_window *win, float *kernel_ms) {
   hipEvent_t e0 = second ? ctx->lane2.e0 : ctx->ev0, e1 = second ? ctx->lane2.e1 : ctx->ev2;
   rl::DevBuf &scratch = second ? ctx->lane2.scratch : ctx->d_k2_scratch;
   const auto t_got = std::chrono::steady_clock::now();
+  waiting.off();
   win->t_turn += std::chrono::duration<double>(t_got - t_ask).count();
   int rc = scratch.alloc(scratch_bytes);
   if (rc) return rc;

@@ -84,7 +84,7 @@ try:
     out["stage_lines"] = [l.strip() for l in err.split("\n") if l.startswith("[") and "find equivalent" not in l and "\r" not in l and "[window " not in l and "tree sequence" not in l
                           and "[tree builder workers]" not in l and "[gpu tree builder]" not in l][:12]
     out["stage_summary"] = [l.strip() for l in err.split("\n") if l.startswith("[stage] sections") or l.startswith("[stage] context")]
-    out["builder_worker_launches"] = [l.strip() for l in err.split("\n") if "[tree builder workers]" in l][:24]
+    out["builder_worker_launches"] = [l.strip() for l in err.split("\n") if "[tree builder workers]" in l][:24] + [l.strip() for l in err.split("\n") if "waiting for RePaint:" in l][:60]
     out["builder_host_side"] = [l.strip() for l in err.split("\n") if "host ms per tree" in l][:6]
     acc, ntr = {}, 0
     for l in err.split("\n"):
