@@ -2529,7 +2529,8 @@ class BuildQueue {
         // (the stage's word, expect(), is a limit -- it knows what RePaint needs of the chip; RELATE_AMD_BUILD_WORKERS
         //  overrides it)
         goal = (expected_ > 0 && !cap_from_env_) ? std::min(cap_, expected_) : cap_;
-        if (a_hi > 0) goal = std::min(goal, dyn_goal);
+        // (adaptive: the stage's word -- its rule of thumb for bounded windows -- gives way to what RePaint's queue says)
+        if (a_hi > 0) goal = std::min(cap_, dyn_goal);
         // whole rounds of the XCDs (below): the goal too
         if (goal >= MM_XCDS) goal -= goal % MM_XCDS;
       }

@@ -96,6 +96,21 @@ try:
         out["gpu_builder_ms_per_tree"] = {k: round(v / ntr / 1000.0, 2) for k, v in acc.items()}
     wl = [l.strip() for l in err.split("\n") if l.startswith("[window ")]
     out["window_lines"] = wl[:3] + wl[len(wl) // 2: len(wl) // 2 + 3]
+    # over ALL windows: what a section waited for RePaint's turn, its launches, its matrices (means, seconds per window)
+    agg = {"turn": [], "launches": [], "matrices": [], "rows": []}
+    for l in wl:
+        m = re.search(r"rows \+ uploads ([\d.]+), waiting for RePaint's turn ([\d.]+), RePaint launches ([\d.]+), matrices ([\d.]+)", l)
+        if m:
+            agg["rows"].append(float(m.group(1))); agg["turn"].append(float(m.group(2)))
+            agg["launches"].append(float(m.group(3))); agg["matrices"].append(float(m.group(4)))
+    if agg["turn"]:
+        out["per_window_mean_s"] = {k: round(sum(v) / len(v), 2) for k, v in agg.items()}
+        out["per_window_max_wait_s"] = max(agg["turn"])
+    ts = [l for l in err.split("\n") if "[tree sequence]" in l]
+    tb = [float(x) for l in ts for x in re.findall(r"tree builds ([\d.]+) s", l)]
+    tm = [float(x) for l in ts for x in re.findall(r"distance matrices ([\d.]+) s", l)]
+    if tb:
+        out["per_section_mean_s"] = {"tree_builds": round(sum(tb) / len(tb), 1), "distance_matrices_incl_repaint": round(sum(tm) / len(tm), 1)}
     out["one_section"] = [l.strip() for l in err.split("\n") if "[tree sequence]" in l][:1]
     # when each section's window was open and when its trees were done, seconds after the stage began
     sec = [(int(m.group(1)), int(m.group(2)), float(m.group(3)), float(m.group(4))) for m in
