@@ -933,11 +933,15 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
     // (134 sections, 37 launches per window): 110 workers 207 s, 100 workers 177 s, 90 workers 190 s (RePaint 168 /
     // 100 / 92 s busy; trees waiting 5 / 36 / 55 ms for a worker): the workers got 3/8 of the CUs in round 3.  Round 4
     // (prior_kernel through LDS: RePaint waits 3-4 s per window instead of 9-12): 96 workers 165.7 s, 104 workers
-    // 161.9 s, 112 workers 182.8 s (profiles/r04_c3_workers.json): 13/32 of the CUs.
+    // 161.9 s, 112 workers 182.8 s (profiles/r04_c3_workers.json): 13/32 of the CUs.  Round 5 (six passes of per-tree
+    // kernels fused into three; 22 runs in profiles/r05_c3_runs.json): 104 workers 154-156 s, 116 workers 146-152 s,
+    // 124 workers 143-185 s, 132 workers 150-173 s, 140-148 workers 171-179 s -- past ~120 workers the stage is bistable
+    // (RePaint's lane is ~134 launches of 14 ms per 1.9 s part: at the edge of saturation any slow-down becomes a
+    // convoy of sections waiting 15 s per window): 29/64 of the CUs.
     int workers = nthreads, cus = 256;
     if (cap_rows > 0) {
       if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 8) cus = 256;
-      workers = std::min(nthreads, 13 * cus / 32);
+      workers = std::min(nthreads, 29 * cus / 64);
     }
     if (o.workers > 0) workers = o.workers;  // (RELATE_AMD_BUILD_WORKERS overrides either, minmatch_gpu.hip)
     (void)device_builder_expect(device, ctx->N, workers, !sample_ages.empty());
