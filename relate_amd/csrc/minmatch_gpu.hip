@@ -2494,6 +2494,9 @@ class BuildQueue {
     long long wait_n = 0;
     auto wait_t0 = std::chrono::steady_clock::now();
     bool retiring[MM_LAUNCHES] = {};
+    int ceiling = 1 << 30;
+    const int hold_s = getenv("RELATE_AMD_ADAPTIVE_HOLD") ? atoi(getenv("RELATE_AMD_ADAPTIVE_HOLD")) : 30;
+    auto ceiling_until = std::chrono::steady_clock::now();
     for (;;) {
       int demand = 0, goal = 0;
       {
@@ -2558,6 +2561,7 @@ class BuildQueue {
           wait_sum = 0.0;
           wait_n = 0;
           wait_t0 = nowt;
+          bool sent_home = false;
           if (avg > hi_wait && alive > a_lo) {
             int pick = -1;
             for (int l = 0; l < MM_LAUNCHES; l++) {
@@ -2570,16 +2574,23 @@ class BuildQueue {
               const int live = size[pick] - std::min(size[pick], (int)__atomic_load_n(&q_->gone[pick], __ATOMIC_ACQUIRE));
               retiring[pick] = true;
               __atomic_store_n(&q_->retire[pick], 1u, __ATOMIC_RELEASE);
+              // (the count at which the queue formed is remembered for a while: the edge is sharp -- one section
+              //  waiting on average at 112 workers, twenty at 120 -- and every visit beyond it costs all sections seconds)
+              ceiling = std::max(a_lo, std::min(dyn_goal, alive) - MM_XCDS);
+              ceiling_until = nowt + std::chrono::seconds(hold_s);
               dyn_goal = std::max(a_lo, alive - live);
               alive -= live;
+              sent_home = true;
               if (verbose) {
-                fprintf(stderr, "[tree builder workers] %.1f sections waiting for RePaint: launch %d (%d workers) sent home, goal %d\n",
-                        avg, pick, live, dyn_goal);
+                fprintf(stderr, "[tree builder workers] %.1f sections waiting for RePaint: launch %d (%d workers) sent home, goal %d, "
+                        "no more than %d for %d s\n", avg, pick, live, dyn_goal, ceiling, hold_s);
                 fflush(stderr);
               }
             }
-          } else if (avg < lo_wait && dyn_goal < a_hi && alive + MM_XCDS > dyn_goal) {
-            dyn_goal = std::min(a_hi, dyn_goal + MM_XCDS);
+          }
+          const int limit = nowt < ceiling_until ? std::min(a_hi, ceiling) : a_hi;
+          if (!sent_home && avg < lo_wait && dyn_goal < limit && alive + MM_XCDS > dyn_goal) {
+            dyn_goal = std::min(limit, dyn_goal + MM_XCDS);
             if (verbose) {
               fprintf(stderr, "[tree builder workers] %.1f sections waiting for RePaint: goal %d\n", avg, dyn_goal);
               fflush(stderr);
