@@ -527,6 +527,11 @@ rl_ctx *rl_create(int device) {
     set_error("no usable HIP device (visible devices: %d, requested %d)", n, device);
     return nullptr;
   }
+  // RELATE_AMD_BLOCKING_SYNC=1 (experiment): waits for the device block instead of spinning -- a stage keeps ~140 host
+  // threads in hipStreamSynchronize / hipEventSynchronize, and a host that gives the process 16 cores' worth of CPU
+  // (the GPU box's quota) has none to spare for spinning
+  if (const char *e = getenv("RELATE_AMD_BLOCKING_SYNC"))
+    if (atoi(e) != 0) (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
   if (hipSetDevice(device) != hipSuccess) {
     set_error("hipSetDevice(%d) failed", device);
     return nullptr;

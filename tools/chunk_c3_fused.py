@@ -45,6 +45,14 @@ try:
                         "--last_section", str(sections - 1), "-o", "out"] + fused_feb, cwd=work, stderr=subprocess.PIPE,
                        env=dict(os.environ) if os.environ.get("C3_NO_TIMING") else dict(os.environ, RELATE_AMD_TIMING="1"))
     out["wall_s"] = time.time() - t0
+    import resource
+    ru = resource.getrusage(resource.RUSAGE_CHILDREN)
+    out["stage_cpu_s"] = {"user": round(ru.ru_utime, 1), "sys": round(ru.ru_stime, 1),
+                          "cores_busy_on_average": round((ru.ru_utime + ru.ru_stime) / out["wall_s"], 1)}
+    try:
+        out["cgroup_cpu_max"] = open("/sys/fs/cgroup/cpu.max").read().strip()
+    except Exception:
+        pass
     err = p.stderr.decode()
     if os.environ.get("C3_KEEP_STDERR"):  # (everything but the per-tree and per-window lines)
         with open(os.path.join(ROOT, os.environ["C3_KEEP_STDERR"]), "w") as fh:
