@@ -82,6 +82,12 @@ def cpu_baseline(N, L, bits, r, rpos, wb, seconds_target=12.0):
 
     out = sample(min(os.cpu_count() or 1, 64), seconds_target)
     out["single_thread"] = sample(1, seconds_target)
+    try:  # (a container may grant the process fewer cores' worth of CPU than it shows: the threads above share them)
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            out["cpu_quota_cores"] = float(quota) / float(period)
+    except Exception:
+        pass
     return out
 
 
@@ -387,7 +393,7 @@ def main():
     roofline_k2 = None
     pmc = None
     pmc_file = None
-    for cand in ("r04_pmc_c3.json", "r03_pmc_c3.json", "r02_pmc_c3.json"):  # HBM bytes per launch: separate rocprofv3 --pmc runs
+    for cand in ("r05_pmc_c3.json", "r04_pmc_c3.json", "r03_pmc_c3.json", "r02_pmc_c3.json"):  # HBM bytes per launch: separate rocprofv3 --pmc runs
         try:                                              # (tools/gpu_profile_r03.sh), committed summary
             pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))
             if pmc["N"] != N or pmc["L"] != L or by_target or args.workload != "c3":
