@@ -95,6 +95,7 @@ struct RepaintParams {
   const int32_t *order;       // [nloc] targets (global index), longest first
   int sum_mode;
   int partial;                // the logscales of every row are in place (an earlier launch of this window wrote them):
+  int nostrip;                // a part launch's backward kernel without the LDS strip, two waves a SIMD (repaint_kernels.hip)
                               // the forward pass may stop below row_hi, the backward pass at row_lo
   // A bounded window keeps ONE state of the backward pass per target -- beta (doubles, register-major like a
   // checkpoint row), the step's factor and the running logscale as they stand before row r is done -- so that a

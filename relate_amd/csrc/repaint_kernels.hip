@@ -200,15 +200,28 @@ RL_DEV void repaint_forward(const RepaintParams &p, int n, float *stage, WaveLin
 // ---------------- K2b: the backward pass of one target (:887-1073) and its posterior rows
 // The block's checkpoint row is held on chip while the pass walks down the block: registers 0 .. LREG-1 in the
 // wave's LDS strip [register][lane] (filled by global->LDS loads that bypass the VGPRs), the rest in VGPRs.
-template <int S>
+// NOSTRIP (a bounded window's part launches): nothing is held -- a product row reads the block's checkpoint row
+// where it lies, a chunk of 8 registers at a time (41 KB per target and row, through the L2: the forward kernel of the
+// same launch has just written it, and a part is ~6 rows per target) -- so the kernel needs no strip and TWO waves
+// share a SIMD: a part launch is mostly the beta-only way down to the part, and those loops run 1.77 x slower with
+// one wave a SIMD.  The whole-window pass (200 rows per target) keeps the strip: there the re-reads would be traffic.
+template <int S, bool NOSTRIP = false>
 struct HeldRow {
-  static constexpr int LREG = S < 76 ? S : 76;  // 76 * 512 B = 38 KB: four waves of a CU fit their strips in LDS
-  static constexpr int VREG = S - LREG;
+  static constexpr int LREG = NOSTRIP ? 0 : (S < 76 ? S : 76);  // 76 * 512 B = 38 KB: four waves of a CU fit their strips in LDS
+  static constexpr int VREG = NOSTRIP ? 0 : S - LREG;
   double *lds;  // the wave's strip (wave-uniform)
   double v[VREG > 0 ? VREG : 1];
-  RL_DEV double get(int i, int lane) const { return i < LREG ? lds[i * 64 + lane] : v[i - LREG < 0 ? 0 : i - LREG]; }
+  const __attribute__((address_space(1))) double *grow = nullptr;  // (NOSTRIP) the row, [register][lane], at this lane
+  RL_DEV double get(int i, int lane) const {
+    if constexpr (NOSTRIP) return grow[i * 64];
+    return i < LREG ? lds[i * 64 + lane] : v[i - LREG < 0 ? 0 : i - LREG];
+  }
   // request the [register][lane] row of doubles at `row` (wave-uniform)
   RL_DEV void request(const double *row, int lane) {
+    if constexpr (NOSTRIP) {
+      grow = (const __attribute__((address_space(1))) double *)(row + lane);
+      return;
+    }
     typedef const __attribute__((address_space(1))) void *GP;
     typedef __attribute__((address_space(3))) void *LP;
     // one scalar base per 4 KB (four instructions with immediate offsets 0 .. 3 KB), the lane's 16 bytes as a
@@ -242,8 +255,8 @@ struct HeldRow {
   }
 };
 // Posterior row of the block's checkpoint row itself (no forward step): trow = float(ck * b)
-template <int S>
-RL_DEV void product_last(const HeldRow<S> &ck, int lane, const double (&b)[S], float *trow_lane) {
+template <int S, bool NS>
+RL_DEV void product_last(const HeldRow<S, NS> &ck, int lane, const double (&b)[S], float *trow_lane) {
 #pragma unroll
   for (int c = 0; c < S / 8; c++) {
     GlobalF32 q = (GlobalF32)(trow_lane + c * 8 * 64);
@@ -256,8 +269,8 @@ RL_DEV void product_last(const HeldRow<S> &ck, int lane, const double (&b)[S], f
 // step's constant, multiply the mismatching donors by K1, divide where the step rescaled) and is stored as
 // float(alpha * b).  !DIV: exactly R steps, no divisions, straight-line; DIV: r <= R steps, each tested.
 // The masks of the (chunk, step) pairs come in one behind the other (scalar loads, one pair ahead).
-template <int S, int R, bool DIV, int CKN>
-RL_DEV void product_steps(const HeldRow<S> &ck, int lane, const double (&b)[S], float *trow_lane,
+template <int S, int R, bool DIV, int CKN, bool NS>
+RL_DEV void product_steps(const HeldRow<S, NS> &ck, int lane, const double (&b)[S], float *trow_lane,
                           const MaskRow (&rows)[CKN], const double (&cfs)[CKN], const double (&dvs)[CKN], int r,
                           double K1) {
   constexpr int NC = S / 8;
@@ -297,7 +310,7 @@ RL_DEV void product_steps(const HeldRow<S> &ck, int lane, const double (&b)[S], 
 // from the state an earlier launch kept, down to the first row ABOVE the part, where it leaves its state for the
 // product kernel (p.dstate).  No posterior rows up there, so no checkpoint strip: two waves share a SIMD instead of
 // one (the same loops run 1.77 x slower one wave a SIMD, §4 K2), and a launch of a part is mostly descent.
-template <int S, int TAIL, int MODE, int WAVES, bool DESCENT = false>
+template <int S, int TAIL, int MODE, int WAVES, bool DESCENT = false, bool NOSTRIP = false>
 RL_DEV void repaint_backward(const RepaintParams &p, int n, float *stage, double *strip, WaveLink<WAVES> &lk) {
   const int wv = lk.w;
   PaintLane<S> pl;
@@ -377,10 +390,10 @@ RL_DEV void repaint_backward(const RepaintParams &p, int n, float *stage, double
     block_records(cpb, rec, sit);
     block_records(cpb - CK, rec_next, sit_next);
   }
-  HeldRow<S> ck;  // (the strip shares its LDS with `stage`, which is done with by now)
+  HeldRow<S, NOSTRIP> ck;  // (the strip shares its LDS with `stage`, which is done with by now)
   ck.lds = strip;
 #pragma unroll
-  for (int i = 0; i < (HeldRow<S>::VREG > 0 ? HeldRow<S>::VREG : 1); i++) ck.v[i] = 0.0;
+  for (int i = 0; i < (HeldRow<S, NOSTRIP>::VREG > 0 ? HeldRow<S, NOSTRIP>::VREG : 1); i++) ck.v[i] = 0.0;
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   if constexpr (!DESCENT) {  // the checkpoint row of the block the first row to be done belongs to
     const int first_row = jstart < 0 ? D - 1 : jstart;
@@ -405,7 +418,7 @@ RL_DEV void repaint_backward(const RepaintParams &p, int n, float *stage, double
     const bool kept = j >= row_lo && j < row_hi;  // (uniform over the workgroup)
     float *__restrict__ trow = top + (int64_t)(j - row_lo) * TROW;
     if (r == 0) {
-      if (kept) product_last<S>(ck, pl.lane, b, trow);
+      if (kept) product_last(ck, pl.lane, b, trow);
       if (block_kept(cpb - CK)) ck.request(ckrows + (int64_t)(cpb / CK - 1) * ROW - pl.lane, pl.lane);
       return;
     }
@@ -559,6 +572,17 @@ __global__ void __launch_bounds__(64 * WAVES, 2) repaint_bwd_kernel(const Repain
   repaint_backward<S, TAIL, MODE, WAVES>(p, p.order[blockIdx.x], (float *)strip, strip, lk);
 }
 
+// ... and without the strip (HeldRow NOSTRIP): the part launches of a bounded window, two waves a SIMD
+template <int S, int TAIL, int MODE, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES, 2) repaint_bwd_nostrip_kernel(const RepaintParams p) {
+  __shared__ float stage[WAVES][16 * 64];
+  __shared__ WaveLinkStorage link;
+  WaveLink<WAVES> lk;
+  lk.s = &link;
+  lk.w = WAVES > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+  repaint_backward<S, TAIL, MODE, WAVES, false, true>(p, p.order[blockIdx.x], stage[lk.w], nullptr, lk);
+}
+
 template <int S, int TAIL, int MODE, int WAVES>
 __global__ void __launch_bounds__(64 * WAVES, 2) repaint_descent_kernel(const RepaintParams p) {
   __shared__ float stage[WAVES][16 * 64];
@@ -591,7 +615,10 @@ static hipError_t launch_repaint_t(const RepaintParams &p, hipStream_t stream) {
   //  but in a window's first launch it takes the forward logscales from them: behind the forward kernel, same stream)
   if (p.dstate)
     hipLaunchKernelGGL((repaint_descent_kernel<S, TAIL, RL_MODE, WAVES>), dim3(p.nloc), dim3(64 * WAVES), 0, stream, p);
-  hipLaunchKernelGGL((repaint_bwd_kernel<S, TAIL, RL_MODE, WAVES>), dim3(p.nloc), dim3(64 * WAVES), strips, stream, p);
+  if (p.partial && p.nostrip)
+    hipLaunchKernelGGL((repaint_bwd_nostrip_kernel<S, TAIL, RL_MODE, WAVES>), dim3(p.nloc), dim3(64 * WAVES), 0, stream, p);
+  else
+    hipLaunchKernelGGL((repaint_bwd_kernel<S, TAIL, RL_MODE, WAVES>), dim3(p.nloc), dim3(64 * WAVES), strips, stream, p);
   return hipGetLastError();
 }
 

@@ -165,6 +165,10 @@ static int repaint_rows(rl_window *win, float *kernel_ms) {
   p.order = win->d_order.as<int32_t>();
   p.sum_mode = win->sum_mode;
   p.partial = win->have_logscales ? 1 : 0;
+  // (experiment, RELATE_AMD_REPAINT_NOSTRIP=1: the part launches' backward kernel reads the checkpoint rows where they
+  //  lie instead of holding them in an LDS strip -- two waves a SIMD)
+  static const bool nostrip = getenv("RELATE_AMD_REPAINT_NOSTRIP") && atoi(getenv("RELATE_AMD_REPAINT_NOSTRIP")) != 0;
+  p.nostrip = nostrip ? 1 : 0;
   p.bstate = win->d_bstate.as<double>();
   p.bscal = win->d_bscal.as<double>();
   p.fstate = win->d_fstate.as<double>();
