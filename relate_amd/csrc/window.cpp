@@ -165,9 +165,12 @@ static int repaint_rows(rl_window *win, float *kernel_ms) {
   p.order = win->d_order.as<int32_t>();
   p.sum_mode = win->sum_mode;
   p.partial = win->have_logscales ? 1 : 0;
-  // (experiment, RELATE_AMD_REPAINT_NOSTRIP=1: the part launches' backward kernel reads the checkpoint rows where they
-  //  lie instead of holding them in an LDS strip -- two waves a SIMD)
-  static const bool nostrip = getenv("RELATE_AMD_REPAINT_NOSTRIP") && atoi(getenv("RELATE_AMD_REPAINT_NOSTRIP")) != 0;
+  // The part launches of a bounded window run their backward kernel WITHOUT the LDS strip (repaint_kernels.hip:
+  // HeldRow NOSTRIP): a part is ~6 rows per target behind ~40 beta-only steps of descent, the checkpoint rows are read
+  // where they lie (through the L2), and two waves share a SIMD.  C3, 116 workers, same boxes, alternating: 147.6 /
+  // 147.1 / 144.6 s against 161.6 / 148.0 / 150.4 s with the strip; RePaint 57-68 s on the device instead of 77-120,
+  // a section waits 1-2 s per window for its turn (profiles/r05_c3_runs.json).  RELATE_AMD_REPAINT_NOSTRIP=0: the strip.
+  static const bool nostrip = !(getenv("RELATE_AMD_REPAINT_NOSTRIP") && atoi(getenv("RELATE_AMD_REPAINT_NOSTRIP")) == 0);
   p.nostrip = nostrip ? 1 : 0;
   p.bstate = win->d_bstate.as<double>();
   p.bscal = win->d_bscal.as<double>();
