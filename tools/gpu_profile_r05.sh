@@ -3,7 +3,7 @@
 # builder's workers on one section.  STEP=tests|bench|prof|builder picks a part (default: all).
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-OUT=gpurun_out/r05final
+OUT=gpurun_out/r05final2
 mkdir -p $OUT
 STEP=${STEP:-all}
 if [ $STEP = all ] || [ $STEP = tests ]; then
