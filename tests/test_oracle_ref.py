@@ -231,3 +231,18 @@ def test_builder_with_sample_ages_matches_reference_minmatch(tmp_path, seed, N, 
     plain.close()
     if levels > 1:
         assert differs > 0  # (the ages matter: the builder without them gives other trees)
+
+
+@pytest.mark.parametrize("N,trees,moves", [(2000, 10, 5), (2000, 8, 200), (3000, 6, 1500)])
+def test_find_equivalent_branches_on_random_tree_sequences(N, trees, moves):
+    """the chain search of round 5 (a branch's candidates from the ancestors of ONE leaf of the other tree instead of
+    whole size classes) against the reference binary where neighbouring trees differ a little, a lot, and almost
+    everywhere: random binary trees, `moves` single-leaf prune-and-regraft moves between neighbours
+    (tools/check_feb_synthetic_trees.py: both binaries on the same .anc files, byte for byte)"""
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "check_feb_synthetic_trees.py")
+    p = subprocess.run([sys.executable, tool, str(N), str(trees), str(moves), "11"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr.decode()[-600:]
+    assert "same bytes" in p.stdout.decode(), p.stdout.decode()
