@@ -56,10 +56,28 @@ constexpr int MM_BUCKET_MIN = 2048;  // (the AGES build) more pairs than this ar
 // one store per cluster down -- strides by 1 KB inside one panel of N KB, a few 2 MB pages, instead of by a whole
 // row (80 KB at N = 5000: every store on another page, the address translation of 2500 pages per merge).
 constexpr int MM_PANEL = 64;
+// MM_RBLOCK > 0 (experiment): the rows in blocks of MM_RBLOCK -- element (a, b) at
+// (((a / R) * P + b / 64) * R + a % R) * 64 + b % 64, P panels: a row's 1 KB runs lie R KB apart (a row spans P * R KB
+// instead of P * N KB), a column's stores fall into N / R regions.  Pages of 2 MB a merge touches at N = 5000 (two rows
+// read, ~3 rows rescanned, one column stored): ~390 in the panel layout, ~70 with R = 128.
+#ifndef MM_RBLOCK
+#define MM_RBLOCK 0
+#endif
 __host__ __device__ inline unsigned mm_index(unsigned a, unsigned b, unsigned N) {
+#if MM_RBLOCK > 0
+  const unsigned P = (N + MM_PANEL - 1) / MM_PANEL;
+  return (((a / MM_RBLOCK) * P + b / MM_PANEL) * MM_RBLOCK + a % MM_RBLOCK) * MM_PANEL + (b % MM_PANEL);
+#else
   return ((b / MM_PANEL) * N + a) * MM_PANEL + (b % MM_PANEL);
+#endif
 }
-__host__ __device__ inline size_t mm_elements(size_t N) { return ((N + MM_PANEL - 1) / MM_PANEL) * N * MM_PANEL; }
+__host__ __device__ inline size_t mm_elements(size_t N) {
+#if MM_RBLOCK > 0
+  return ((N + MM_RBLOCK - 1) / MM_RBLOCK) * MM_RBLOCK * ((N + MM_PANEL - 1) / MM_PANEL) * MM_PANEL;
+#else
+  return ((N + MM_PANEL - 1) / MM_PANEL) * N * MM_PANEL;
+#endif
+}
 constexpr int MM_MAXN = 10240;    // one thread holds up to 20 clusters of a merge in registers
 constexpr int MM_Q_LDS = 5120 / MM_BLOCK, MM_Q_GLOB = MM_MAXN / MM_BLOCK;  // register slots per thread: state in LDS / global
 
