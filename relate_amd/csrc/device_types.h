@@ -96,6 +96,7 @@ struct RepaintParams {
   int sum_mode;
   int partial;                // the logscales of every row are in place (an earlier launch of this window wrote them):
   int nostrip;                // a part launch's backward kernel without the LDS strip, two waves a SIMD (repaint_kernels.hip)
+  int grid_cap;               // ... and at most this many workgroups for its two kernels (0: one per target)
                               // the forward pass may stop below row_hi, the backward pass at row_lo
   // A bounded window keeps ONE state of the backward pass per target -- beta (doubles, register-major like a
   // checkpoint row), the step's factor and the running logscale as they stand before row r is done -- so that a

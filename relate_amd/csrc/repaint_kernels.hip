@@ -10,6 +10,7 @@
 // pass reads it back, two chunks of registers ahead of their use, and writes the
 // posterior rows `topology = float(alpha*beta)` in the same register-major
 // layout (4 B per donor per visited site: the kernel is HBM-bound).
+#include <algorithm>
 #include <atomic>
 
 #include "paint_device.h"
@@ -553,7 +554,12 @@ __global__ void __launch_bounds__(64 * WAVES, 2) repaint_fwd_kernel(const Repain
   WaveLink<WAVES> lk;
   lk.s = &link;
   lk.w = WAVES > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
-  repaint_forward<S, TAIL, MODE, WAVES>(p, p.order[blockIdx.x], stage[lk.w], lk);
+  // (a part launch may come with fewer workgroups than targets -- p.grid_cap, window.cpp --: a workgroup then takes
+  //  every gridDim.x-th target of the longest-first order)
+  for (int idx = blockIdx.x; idx < p.nloc; idx += gridDim.x) {
+    repaint_forward<S, TAIL, MODE, WAVES>(p, p.order[idx], stage[lk.w], lk);
+    if (WAVES > 1) __syncthreads();
+  }
 }
 // One wave per SIMD (the LDS strips decide that): beta in registers, the block's checkpoint row in LDS.  The strips
 // are dynamic LDS so that the compiler budgets registers for two waves per SIMD (256 VGPRs, no AGPR copies).
@@ -581,6 +587,22 @@ __global__ void __launch_bounds__(64 * WAVES, 2) repaint_bwd_nostrip_kernel(cons
   lk.s = &link;
   lk.w = WAVES > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
   repaint_backward<S, TAIL, MODE, WAVES, false, true>(p, p.order[blockIdx.x], stage[lk.w], nullptr, lk);
+}
+// ... with fewer workgroups than targets (p.grid_cap): a kernel of its own -- the loop around the pass costs the
+// compiler 108 bytes of scratch per lane, which the one-workgroup-per-target kernel does not pay
+template <int S, int TAIL, int MODE, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES, 2) repaint_bwd_nostrip_loop_kernel(const RepaintParams p) {
+  __shared__ float stage[WAVES][16 * 64];
+  __shared__ WaveLinkStorage link;
+  WaveLink<WAVES> lk;
+  lk.s = &link;
+  lk.w = WAVES > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+#pragma clang loop unroll(disable)
+  for (int idx = blockIdx.x; idx < p.nloc; idx += gridDim.x) {
+    const int n = __builtin_amdgcn_readfirstlane(p.order[__builtin_amdgcn_readfirstlane(idx)]);
+    repaint_backward<S, TAIL, MODE, WAVES, false, true>(p, n, stage[lk.w], nullptr, lk);
+    if (WAVES > 1) __syncthreads();
+  }
 }
 
 template <int S, int TAIL, int MODE, int WAVES>
@@ -610,12 +632,17 @@ static hipError_t launch_repaint_t(const RepaintParams &p, hipStream_t stream) {
       if (dev <= 127) done[(dev >> 6) & 1].fetch_or(bit, std::memory_order_release);
     }
   }
-  hipLaunchKernelGGL((repaint_fwd_kernel<S, TAIL, RL_MODE, WAVES>), dim3(p.nloc), dim3(64 * WAVES), 0, stream, p);
+  // (part launches of the strip-less kind may be capped: the two kernels then leave room on the CUs for the sections'
+  //  own small kernels, whose latency is on every tree's path)
+  const int capped = (p.partial && p.nostrip && p.grid_cap > 0) ? std::min(p.nloc, p.grid_cap) : p.nloc;
+  hipLaunchKernelGGL((repaint_fwd_kernel<S, TAIL, RL_MODE, WAVES>), dim3(capped), dim3(64 * WAVES), 0, stream, p);
   // (the descent reads nothing the forward kernel writes in a partial launch -- the records above row_hi are not made --
   //  but in a window's first launch it takes the forward logscales from them: behind the forward kernel, same stream)
   if (p.dstate)
     hipLaunchKernelGGL((repaint_descent_kernel<S, TAIL, RL_MODE, WAVES>), dim3(p.nloc), dim3(64 * WAVES), 0, stream, p);
-  if (p.partial && p.nostrip)
+  if (p.partial && p.nostrip && capped < p.nloc)
+    hipLaunchKernelGGL((repaint_bwd_nostrip_loop_kernel<S, TAIL, RL_MODE, WAVES>), dim3(capped), dim3(64 * WAVES), 0, stream, p);
+  else if (p.partial && p.nostrip)
     hipLaunchKernelGGL((repaint_bwd_nostrip_kernel<S, TAIL, RL_MODE, WAVES>), dim3(p.nloc), dim3(64 * WAVES), 0, stream, p);
   else
     hipLaunchKernelGGL((repaint_bwd_kernel<S, TAIL, RL_MODE, WAVES>), dim3(p.nloc), dim3(64 * WAVES), strips, stream, p);
