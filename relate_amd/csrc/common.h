@@ -64,6 +64,10 @@ extern std::atomic<int> g_worker_launches;
 // launcher follows it -- RePaint runs on the CUs the workers leave, and past a certain worker count its queue, not
 // the workers, is what the sections wait in
 extern std::atomic<int> g_repaint_waiting;
+// at most this many workgroups for the two kernels of a bounded window's part launch (0: one per target): set by a
+// stage whose trees are built by resident workers -- the CUs they leave are shared by RePaint and the sections' own
+// small kernels, and a part launch that fills every free CU (2 x 254 registers per SIMD) leaves those no room
+extern std::atomic<int> g_repaint_grid_cap;
 // bytes of `device`'s memory the cache holds for re-use in blocks of at least min_block bytes (cache_alloc hands out
 // whole blocks only: smaller ones are no room for a request of min_block)
 size_t device_cache_held(int device, size_t min_block);

@@ -62,6 +62,7 @@ BlockCache g_dev_cache, g_pin_cache;
 }  // namespace
 std::atomic<int> g_worker_launches{0};
 std::atomic<int> g_repaint_waiting{0};
+std::atomic<int> g_repaint_grid_cap{0};
 namespace {
 
 template <typename AllocFn>

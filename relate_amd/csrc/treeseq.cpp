@@ -945,6 +945,10 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
     }
     if (o.workers > 0) workers = o.workers;  // (RELATE_AMD_BUILD_WORKERS overrides either, minmatch_gpu.hip)
     (void)device_builder_expect(device, ctx->N, workers, !sample_ages.empty());
+    // (RePaint's part launches can be capped to a share of the wave slots the workers leave -- g_repaint_grid_cap,
+    //  RELATE_AMD_REPAINT_GRID=n -- so that the sections' own kernels keep CUs to run on: 124 workers + 768 workgroups
+    //  gave 142.2 s once and 146.2 / 157.0 s on another box against 143.6-148.7 s for 116 workers uncapped
+    //  (profiles/r05_c3_runs.json): not the default)
   }
   // Host threads left over by the sections help inside each tree build (minmatch.h BuildThreads).  Helpers are the
   // less efficient use of a core (a merge is split 8 ways for a 2.5x shorter build) and a helper that loses its
@@ -1129,6 +1133,7 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
     for (auto &x : th) x.join();
   }
   if (gpu_build) (void)device_builder_expect(device, ctx->N, 0, !sample_ages.empty());
+  g_repaint_grid_cap.store(0);
   rc = first_error.load();
   if (rc) set_error("%s", first_message.c_str());
   if (feb) {

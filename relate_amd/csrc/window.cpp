@@ -172,9 +172,10 @@ static int repaint_rows(rl_window *win, float *kernel_ms) {
   // a section waits 1-2 s per window for its turn (profiles/r05_c3_runs.json).  RELATE_AMD_REPAINT_NOSTRIP=0: the strip.
   static const bool nostrip = !(getenv("RELATE_AMD_REPAINT_NOSTRIP") && atoi(getenv("RELATE_AMD_REPAINT_NOSTRIP")) == 0);
   p.nostrip = nostrip ? 1 : 0;
-  // (experiment, RELATE_AMD_REPAINT_GRID=n: a part launch with at most n workgroups)
-  static const int grid_cap = getenv("RELATE_AMD_REPAINT_GRID") ? atoi(getenv("RELATE_AMD_REPAINT_GRID")) : 0;
-  p.grid_cap = grid_cap;
+  // (at most so many workgroups per part launch: the stage's word, common.h; RELATE_AMD_REPAINT_GRID=n overrides, 0 =
+  //  one per target)
+  static const int grid_env = getenv("RELATE_AMD_REPAINT_GRID") ? atoi(getenv("RELATE_AMD_REPAINT_GRID")) : -1;
+  p.grid_cap = grid_env >= 0 ? grid_env : g_repaint_grid_cap.load();
   p.bstate = win->d_bstate.as<double>();
   p.bscal = win->d_bscal.as<double>();
   p.fstate = win->d_fstate.as<double>();
