@@ -325,3 +325,25 @@ def test_find_equivalent_branches_fused_behind_build_topology(tmp_path, name, mo
     p = subprocess.run([CLI, "--mode", mode, "--chunk_index", "0", "--first_section", "0", "--last_section", "0", "-o",
                         "out", "--find_equivalent_branches"], cwd=str(work), stderr=subprocess.PIPE)
     assert p.returncode != 0 and b"covers all" in p.stderr
+
+
+def test_an_out_of_memory_window_open_waits_instead_of_failing_the_stage(tmp_path):
+    """a window that is admitted on the byte count but finds no block to take must go back to waiting while
+    other sections hold memory they will give back -- not fail the stage.  RELATE_AMD_TEST_FAIL_OPENS makes admitted
+    opens fail as if the allocator had run dry: with other sections open the stage waits and finishes with the
+    reference's bytes; when the ONLY section's open fails there is nobody to wait for and the stage reports it."""
+    work = tmp_path / "work"
+    (work / "out").mkdir(parents=True)
+    fx = Fixture("synth24", work / "out")
+    env = dict(os.environ, RELATE_AMD_GPU_BUILD="1", RELATE_AMD_SECTION_THREADS="4", RELATE_AMD_TEST_FAIL_OPENS="3")
+    # the first opens succeed only for the threads that come after the three injected failures: those wait and retry
+    p = subprocess.run([CLI, "--mode", "PaintBuildTopology", "--chunk_index", "0", "-o", "out"], cwd=str(work),
+                       stderr=subprocess.PIPE, env=env)
+    assert p.returncode == 0, p.stderr.decode()[-800:]
+    for w in range(fx.W):
+        assert open(work / "out" / "chunk_0" / ("out_%d.mut" % w), "rb").read() == fx.z["mut/%d" % w].tobytes(), w
+        assert open(work / "out" / "chunk_0" / ("out_%d.anc" % w), "rb").read() == fx.z["anc/%d" % w].tobytes(), w
+    p = subprocess.run([CLI, "--mode", "PaintBuildTopology", "--chunk_index", "0", "--first_section", "0",
+                        "--last_section", "0", "-o", "out"], cwd=str(work), stderr=subprocess.PIPE,
+                       env=dict(os.environ, RELATE_AMD_TEST_FAIL_OPENS="1"))
+    assert p.returncode != 0 and b"hipMalloc failed" in p.stderr
