@@ -1059,10 +1059,14 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
         }
         if (admitted) {  // (reading and decoding the paint file, the uploads and RePaint: outside the lock)
           const unsigned oom_before = tl_alloc_failures;
-          // (test hook, RELATE_AMD_TEST_FAIL_OPENS=k: the first k admitted opens of the process fail as if the device
-          //  were out of memory -- the retry below is otherwise reached only when the allocator really runs dry)
+          // (test hook, RELATE_AMD_TEST_FAIL_OPENS=k: k > 0 -- the next k admitted opens that happen while another
+          //  section is open fail as if the device were out of memory; k < 0 -- the next |k| opens whatever else is
+          //  open.  The retry below is otherwise reached only when the allocator really runs dry)
           static std::atomic<int> fail_opens{getenv("RELATE_AMD_TEST_FAIL_OPENS") ? atoi(getenv("RELATE_AMD_TEST_FAIL_OPENS")) : 0};
-          if (fail_opens.load() > 0 && fail_opens.fetch_sub(1) > 0) {
+          bool injected = false;
+          if (fail_opens.load() > 0 && open_sections.load() > 0) injected = fail_opens.fetch_sub(1) > 0;
+          else if (fail_opens.load() < 0) injected = fail_opens.fetch_add(1) < 0;
+          if (injected) {
             tl_alloc_failures++;
             set_error("hipMalloc failed (injected by RELATE_AMD_TEST_FAIL_OPENS)");
             win = nullptr;

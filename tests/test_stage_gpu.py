@@ -336,7 +336,7 @@ def test_an_out_of_memory_window_open_waits_instead_of_failing_the_stage(tmp_pat
     (work / "out").mkdir(parents=True)
     fx = Fixture("synth24", work / "out")
     env = dict(os.environ, RELATE_AMD_GPU_BUILD="1", RELATE_AMD_SECTION_THREADS="4", RELATE_AMD_TEST_FAIL_OPENS="3")
-    # the first opens succeed only for the threads that come after the three injected failures: those wait and retry
+    # (three opens that happen while other sections are open fail: those threads wait for a section to close and retry)
     p = subprocess.run([CLI, "--mode", "PaintBuildTopology", "--chunk_index", "0", "-o", "out"], cwd=str(work),
                        stderr=subprocess.PIPE, env=env)
     assert p.returncode == 0, p.stderr.decode()[-800:]
@@ -345,5 +345,5 @@ def test_an_out_of_memory_window_open_waits_instead_of_failing_the_stage(tmp_pat
         assert open(work / "out" / "chunk_0" / ("out_%d.anc" % w), "rb").read() == fx.z["anc/%d" % w].tobytes(), w
     p = subprocess.run([CLI, "--mode", "PaintBuildTopology", "--chunk_index", "0", "--first_section", "0",
                         "--last_section", "0", "-o", "out"], cwd=str(work), stderr=subprocess.PIPE,
-                       env=dict(os.environ, RELATE_AMD_TEST_FAIL_OPENS="1"))
+                       env=dict(os.environ, RELATE_AMD_TEST_FAIL_OPENS="-1"))
     assert p.returncode != 0 and b"hipMalloc failed" in p.stderr
