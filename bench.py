@@ -394,7 +394,7 @@ def main():
     pmc = None
     pmc_file = None
     for cand in ("r05_pmc_c3.json", "r04_pmc_c3.json", "r03_pmc_c3.json", "r02_pmc_c3.json"):  # HBM bytes per launch: separate rocprofv3 --pmc runs
-        try:                                              # (tools/archive/gpu_profile_r03.sh), committed summary
+        try:                                              # (tools/gpu_profile_r05.sh), committed summary
             pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))
             if pmc["N"] != N or pmc["L"] != L or by_target or args.workload != "c3":
                 pmc = None
@@ -451,7 +451,7 @@ def main():
         alg_bytes = 2.0 * N * sites / 8.0
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         # HBM bytes per launch: PMC passes (FETCH_SIZE + WRITE_SIZE) are separate rocprofv3 runs
-        # (tools/archive/gpu_profile_r02.sh); the committed summary is read here, NOT measured in this run
+        # (tools/gpu_profile_r05.sh); the committed summary is read here, NOT measured in this run
         traffic = pmc["kernels"][args.mode]["hbm_bytes_per_launch"] if pmc and args.mode in pmc["kernels"] else None
         traffic_from = pmc_file if traffic is not None else None
         # SURVEY.md 8d caveat H5: at 1 bit per update the FP64 vector pipe, not HBM, is the resource that binds.
