@@ -434,6 +434,10 @@ int rl_stage_make_chunks(const char *haps_fn, const char *sample_fn,
  * finds equivalent branches in neighbouring trees and rewrites the files with
  * num_events / SNP_begin / SNP_end carried along them.  Host code. */
 int rl_stage_find_equivalent_branches(const char *out_dir, int chunk_index);
+/* Test hook (no GPU): the association fused behind BuildTopology (rl_stage_opts.find_equivalent_branches) fed from the
+ * chunk's .anc FILES, sections handed over in `order` (all of them, any order), pool_threads associating. */
+int rl_debug_feb_fused_from_files(const char *out_dir, int chunk_index, const int *order, int n_order,
+                                  int pool_threads);
 
 /* ------------------------------------------------------------------ tools */
 /* Synthetic block-coalescent panel (stand-in for MakeChunks input,

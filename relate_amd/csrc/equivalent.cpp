@@ -573,6 +573,54 @@ int feb_job_finish(FebJob *j, const std::string &dir_base) {
 
 }  // namespace rl
 
+// Test hook: the fused job fed from FILES -- every section's .anc read back into the stage's own tree type and handed
+// to the job in the given order (as sections finish in any order), then the job's tail.  Same bytes as the stage below
+// (tests/test_equivalent_cpu.py: the pool, the pairs across section boundaries, the order of arrival; no GPU).
+extern "C" int rl_debug_feb_fused_from_files(const char *out_dir, int chunk_index, const int *order, int n_order,
+                                             int pool_threads) {
+  if (!out_dir || !order) return RL_EINVAL;
+  const std::string out(out_dir);
+  int N = 0, L = 0, W = 0;
+  {
+    const std::string pf = out + "/parameters_c" + std::to_string(chunk_index) + ".bin";
+    FILE *fp = fopen(pf.c_str(), "rb");
+    if (!fp) {
+      set_error("cannot open %s", pf.c_str());
+      return RL_EIO;
+    }
+    const bool ok = fread(&N, 4, 1, fp) == 1 && fread(&L, 4, 1, fp) == 1 && fread(&W, 4, 1, fp) == 1;
+    fclose(fp);
+    if (!ok || N < 2 || W < 2) return RL_EIO;
+    W--;
+  }
+  if (n_order != W) {
+    set_error("rl_debug_feb_fused_from_files: %d sections, an order of %d", W, n_order);
+    return RL_EINVAL;
+  }
+  const std::string base = out.substr(out.find_last_of('/') == std::string::npos ? 0 : out.find_last_of('/') + 1);
+  const std::string dir = out + "/chunk_" + std::to_string(chunk_index) + "/";
+  FebJob *job = feb_job_create(N, W, pool_threads);
+  int rc = RL_OK;
+  for (int k = 0; k < W && !rc; k++) {
+    const int w = order[k];
+    AncFile a;
+    if ((rc = read_anc(dir + base + "_" + std::to_string(w) + ".anc", a))) break;
+    std::vector<HostTree> trees(a.trees.size());
+    for (size_t t = 0; t < a.trees.size(); t++) {
+      trees[t].reset(N);
+      trees[t].pos = a.trees[t].pos;
+      trees[t].parent = a.trees[t].parent;
+      trees[t].num_events = a.trees[t].num_events;
+      trees[t].snp_begin = a.trees[t].snp_begin;
+      trees[t].snp_end = a.trees[t].snp_end;
+    }
+    rc = feb_job_add_section(job, w, trees);
+  }
+  if (!rc) rc = feb_job_finish(job, dir + base);
+  feb_job_destroy(job);
+  return rc;
+}
+
 extern "C" int rl_stage_find_equivalent_branches(const char *out_dir, int chunk_index) {
   if (!out_dir) return RL_EINVAL;
   const std::string out(out_dir);
