@@ -1042,7 +1042,7 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
       const size_t min_block = (size_t)(0.85 * (cap_rows > 0 && cap_rows < rows_of[section]
                                                     ? std::min(kept_rows * row_bytes, bstate_bytes / 4.0)
                                                     : kept_rows * row_bytes));
-      int open_rc = RL_EIO;
+      int open_rc = RL_EIO, oom_alone = 0;
       for (;;) {  // admission: wait until the window fits next to the ones that are open or being opened
         bool admitted = false;
         {
@@ -1101,6 +1101,13 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
                             !first_error.load(); i++)
               std::this_thread::sleep_for(std::chrono::milliseconds(50));
             std::this_thread::sleep_for(std::chrono::milliseconds(50));
+            continue;
+          }
+          // (alone by now -- the sections that held memory a moment ago may just have closed, and what they gave back
+          //  sits in the cache: twice more before it is the stage's failure)
+          if (tl_alloc_failures != oom_before && !first_error.load() && ++oom_alone <= 2) {
+            open_rc = RL_ENOMEM;
+            std::this_thread::sleep_for(std::chrono::milliseconds(100));
             continue;
           }
           if (tl_alloc_failures != oom_before) open_rc = RL_ENOMEM;

@@ -345,5 +345,5 @@ def test_an_out_of_memory_window_open_waits_instead_of_failing_the_stage(tmp_pat
         assert open(work / "out" / "chunk_0" / ("out_%d.anc" % w), "rb").read() == fx.z["anc/%d" % w].tobytes(), w
     p = subprocess.run([CLI, "--mode", "PaintBuildTopology", "--chunk_index", "0", "--first_section", "0",
                         "--last_section", "0", "-o", "out"], cwd=str(work), stderr=subprocess.PIPE,
-                       env=dict(os.environ, RELATE_AMD_TEST_FAIL_OPENS="-1"))
+                       env=dict(os.environ, RELATE_AMD_TEST_FAIL_OPENS="-3"))  # (the open and its two retries)
     assert p.returncode != 0 and b"hipMalloc failed" in p.stderr
