@@ -94,7 +94,8 @@ def cpu_baseline(N, L, bits, r, rpos, wb, seconds_target=12.0):
 def chunk_wallclock_full():
     """The metric's other half MEASURED: the whole C3 chunk -- Paint + BuildTopology of all 267 sections, files in ->
     .anc / .mut files out -- through `Relate --mode PaintBuildTopology` in a child process (tools/chunk_c3_fused.py).
-    BENCH_C3_RUNS runs (default 2; ~2.7 minutes each): the first with the stage's timing lines (RELATE_AMD_TIMING:
+    BENCH_C3_RUNS runs (default 2 -- a third would take the default bench past ten minutes; BENCH_C3_RUNS=3 for
+    minimum / median / maximum; ~3 minutes each with the chunk's generation; profiles/r05_c3_runs.json holds sixty): the first with the stage's timing lines (RELATE_AMD_TIMING:
     trees built, RePaint busy seconds, `stage_lines`), the others without; every run's seconds are reported.  Before
     this process touches the GPU."""
     import statistics
@@ -119,7 +120,7 @@ def chunk_wallclock_full():
                            "Paint + BuildTopology of all %d sections in one process on one GPU, chunk files in, "
                            ".anc/.mut files out (no paint files)" % (d["windows"], d["sections"]),
                "measured": True, "wall_s": statistics.median(walls), "runs_s": walls, "min_s": min(walls),
-               "max_s": max(walls), "runs": "run 0 with the stage's timing lines, the others without",
+               "median_s": statistics.median(walls), "max_s": max(walls), "runs": "run 0 with the stage's timing lines, the others without",
                "sections": d["sections"], "trees_kept": d["trees_kept"], "trees_built": d.get("trees_built"),
                "trees_built_per_s": (d["trees_built"] / d["wall_s"]) if d.get("trees_built") else None,
                "trees_kept_per_s": d["trees_kept"] / statistics.median(walls), "anc_GB": d["anc_GB"],
@@ -222,7 +223,12 @@ def main():
     ap.add_argument("--skip-full-chunk", dest="skip_full", action="store_true",
                     help="skip the whole-C3-chunk wall-clock (Paint + all 267 sections, ~3 minutes)")
     ap.add_argument("--skip-host-builder", dest="skip_host", action="store_true",
-                    help="skip the host-builder run of the chunk sample (the CPU figure beside it, ~2 minutes)")
+                    help="(the default since round 5: the whole-chunk runs take the time) skip the host-builder run "
+                         "of the chunk sample")
+    ap.add_argument("--host-builder", dest="with_host", action="store_true",
+                    help="also run the 8-section chunk sample with the trees built by the host's threaded MinMatch (the "
+                         "CPU figure beside the chunk wall-clock, ~2 minutes; round 5: 94.3 s against 58.6 s on the device, "
+                         "profiles/r05_bench_c3_before_stripless_parts.json)")
     ap.add_argument("--workload", default="c3", choices=["c3", "c4"],
                     help="c3 (default; the configuration BASELINE.json's metric is quoted on): one chunk of N=5000 x "
                          "L=500k per GPU.  c4 (BASELINE.json config #4): N=2000 x 5M SNPs cut into ~50 chunks of "
@@ -266,7 +272,7 @@ def main():
     chunk_sample = chunk_full = chunk_host = None
     if world == 1 and args.n == 5000 and args.workload == "c3" and not args.skip_chunk:
         chunk_sample = chunk_wallclock_sample()
-        if not args.skip_host:
+        if args.with_host and not args.skip_host:
             chunk_host = chunk_wallclock_sample(host_builder=True)
         if not args.skip_full:
             chunk_full = chunk_wallclock_full()
