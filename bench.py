@@ -80,8 +80,20 @@ def cpu_baseline(N, L, bits, r, rpos, wb, seconds_target=12.0):
                     sample="%d of %d targets (every %d-th) of the same chunk, oracle ro_paint_sample on %d "
                            "thread%s, %.1f s wall" % (count, N, stride, cores, "s" if cores > 1 else "", dt))
 
-    out = sample(min(os.cpu_count() or 1, 64), seconds_target)
-    out["single_thread"] = sample(1, seconds_target)
+    port = sample(min(os.cpu_count() or 1, 64), seconds_target)
+    port["single_thread"] = sample(1, seconds_target)
+    # The REFERENCE itself where its build travelled with the snapshot (oracle/_ref, compiled from /root/reference by
+    # oracle/Makefile in the build container): FastPainting::PaintSteppingStones of a few targets of the same chunk on
+    # one thread (the reference's Paint is single-threaded), the harness's start-up (reading the 2.5 GB .hap) timed by
+    # itself and taken off.
+    out = port
+    try:
+        ref = reference_baseline(N, L, seq, r, rpos, wb, o, d, per_target, seconds_target)
+        if ref:
+            ref["port"] = port
+            out = ref
+    except Exception as e:
+        port["reference_error"] = str(e)[:160]
     try:  # (a container may grant the process fewer cores' worth of CPU than it shows: the threads above share them)
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
         if quota != "max":
@@ -89,6 +101,47 @@ def cpu_baseline(N, L, bits, r, rpos, wb, seconds_target=12.0):
     except Exception:
         pass
     return out
+
+
+def reference_baseline(N, L, seq, r, rpos, wb, o, d, per_target, seconds_target):
+    import subprocess
+    import tempfile
+    harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    if not os.path.exists(harness):
+        return None
+    from relate_amd import api
+    lib = api.lib()
+    count = max(2, min(8, int(seconds_target / max(per_target, 1e-3))))
+    stride = max(1, N // count)
+    targets = [i * stride for i in range(count)]
+    with tempfile.TemporaryDirectory() as work:
+        dd = os.path.join(work, "out")
+        os.makedirs(dd)
+        W = len(wb) - 1
+        bp = (np.arange(L, dtype=np.int64) * 100).astype(np.int32)  # (positions are not read by the painting)
+        wbf = np.zeros(L + 2, dtype=np.int32)
+        wbf[:W + 1] = wb
+        lib.rl_write_chunk_files.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int]
+        assert lib.rl_write_chunk_files(dd.encode(), 0, N, L, seq.ctypes.data_as(C.c_void_p), bp.ctypes.data_as(C.c_void_p),
+                                        r.ctypes.data_as(C.c_void_p), rpos.ctypes.data_as(C.c_void_p),
+                                        wbf.ctypes.data_as(C.c_void_p), W) == 0
+
+        def timed(ks):
+            t0 = time.time()
+            subprocess.run([harness, "paint_targets", "out", "0", "dump.bin"] + [str(k) for k in ks], cwd=work, check=True,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
+            return time.time() - t0
+        t_load = timed([])
+        t_all = timed(targets)
+    # the sites those targets visit (the oracle's count of the same plan)
+    sites = o.ro_paint_sample(C.byref(d), wb.ctypes.data_as(C.c_void_p), len(wb) - 1, 0, stride, count, count)
+    if sites <= 0:
+        return None
+    dt = max(t_all - t_load, 1e-6)
+    return dict(value=2.0 * N * sites / dt, unit="updates/s", cores=1, kind="reference",
+                sample="%d of %d targets (%s) of the same chunk through the unmodified reference's "
+                       "FastPainting::PaintSteppingStones (oracle/_ref/ref_harness paint_targets, one thread): %.1f s, "
+                       "of which %.1f s start-up (chunk files read) taken off" % (len(targets), N, targets, t_all, t_load))
 
 
 def chunk_wallclock_full():
@@ -133,34 +186,29 @@ def chunk_wallclock_full():
 
 
 def verify_c3(section_md5):
-    """This run's md5 of the C3 chunk's sections 0 / 133 / 266 against what is on file:
-    * section 133 against the REFERENCE: tests/golden/c3_full.npz holds the md5 of out_133.anc / out_133.mut as the
-      unmodified reference binary wrote them (its own paint file of window 133 from PaintSteppingStones at full
-      length, then Relate --mode BuildTopology of that section; tools/make_golden_c3.py);
-    * sections 0 and 266 against ANOTHER SCHEDULE of this library (profiles/r04_c3_section_md5.json: one section per
-      call, whole window resident, host MinMatch)."""
+    """This run's md5 of the C3 chunk's sections 0 / 133 / 266 against the REFERENCE's: tests/golden/c3_full.npz
+    (section 133) and tests/golden/c3_ends.npz (the boundary sections 0 and 266) hold the md5 of out_<w>.anc /
+    out_<w>.mut as the unmodified reference binary wrote them -- its own paint file of the window from
+    PaintSteppingStones at full length, then Relate --mode BuildTopology of that section (tools/make_golden_c3.py,
+    tools/make_golden_full.py)."""
     out = {"section_md5": section_md5, "verified_sections": [], "matches_reference": False}
     try:
+        want = {}
         z = np.load(os.path.join(ROOT, "tests", "golden", "c3_full.npz"))
         w = int(z["pin_window"][0])
-        want = {"out_%d.anc" % w: z["w/anc_md5"].tobytes().hex(), "out_%d.mut" % w: z["w/mut_md5"].tobytes().hex()}
-        out["reference_held_section"] = w
-        out["matches_reference"] = all(section_md5.get(k) == v for k, v in want.items())
-        if out["matches_reference"]:
-            out["verified_sections"].append(w)
-        out["verified_against"] = ("section %d: the unmodified reference binary's .anc / .mut (tests/golden/c3_full.npz)"
-                                   % w)
+        want[w] = (z["w/anc_md5"].tobytes().hex(), z["w/mut_md5"].tobytes().hex())
+        ze = np.load(os.path.join(ROOT, "tests", "golden", "c3_ends.npz"))
+        for s in (int(x) for x in ze["sections"]):
+            want[s] = (ze["s%d/anc_md5" % s].tobytes().hex(), ze["s%d/mut_md5" % s].tobytes().hex())
+        out["reference_held_sections"] = sorted(want)
+        for s, (anc, mut) in sorted(want.items()):
+            if section_md5.get("out_%d.anc" % s) == anc and section_md5.get("out_%d.mut" % s) == mut:
+                out["verified_sections"].append(s)
+        out["matches_reference"] = out["verified_sections"] == sorted(want)
+        out["verified_against"] = ("sections %s: the unmodified reference binary's .anc / .mut (tests/golden/c3_full.npz, "
+                                   "c3_ends.npz)" % sorted(want))
     except Exception as e:
         out["verify_error"] = str(e)[:120]
-    try:
-        ref = json.load(open(os.path.join(ROOT, "profiles", "r04_c3_section_md5.json")))
-        want = ref["check_md5"]
-        secs = sorted(set(int(k.split("_")[1].split(".")[0]) for k in want))
-        ok = [s for s in secs if all(section_md5.get("out_%d.%s" % (s, e)) == want["out_%d.%s" % (s, e)] for e in ("anc", "mut"))]
-        out["same_as_other_schedule"] = ok
-        out["checked_sections"] = secs
-    except Exception as e:
-        out["verify_error_other_schedule"] = str(e)[:120]
     return out
 
 
@@ -354,7 +402,8 @@ def main():
     alts = {}
     fast_report = None
     try:  # what the -m gpu tests measured for the fast modes against the REFERENCE (tests/bigtile.py record)
-        fast_report = json.load(open(os.path.join(ROOT, "profiles", "r04_fast_modes.json")))
+        import glob
+        fast_report = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_fast_modes.json")))[-1]))
     except Exception:
         pass
     if not args.no_alt:

@@ -67,6 +67,10 @@ int rl_device_count(void);
 
 /* ---------------------------------------------------------------- context */
 rl_ctx *rl_create(int device);
+/* A process that runs one stage and ends (the CLI, relate_amd/csrc/main.cpp) says so: the device blocks its contexts
+ * release then stay in the library's cache until the process is gone instead of going back to the driver one hipFree
+ * at a time (C3: ~3000 blocks, 4 s).  No reference counterpart (the reference frees with the process too). */
+void rl_keep_cache_until_exit(int on);
 void rl_destroy(rl_ctx *ctx);
 
 /* Replaces `Data::Data(chunk files)` (src/data.cpp:86-97) + the parameter
@@ -256,6 +260,13 @@ void rl_builder_destroy(rl_builder *b);
  * libstdc++'s uniform_real_distribution<double> against the library itself,
  * n draws from `seed`; returns how many differ. */
 int rl_debug_rng_mismatches(unsigned seed, int n);
+/* Measurement hook (tools/bench_builder_many.py): `builders` device builders, one host thread each, build the same tree
+ * (d, prior: N*N floats, prior may be NULL) `reps` times side by side, the matrices staying on the device, with at most
+ * `workers` resident workgroups (0: the queue's own limit).  seconds: wall-clock of all builds; mismatches: builds
+ * whose parent array differs from builder 0's of the same repetition; first_parents (may be NULL): builder 0's
+ * [reps][2N-1].  MinMatch::QuickBuild, src/tree_builder.cpp:2358-2644. */
+int rl_debug_builder_throughput(int N, double theta, int device, int builders, int reps, int workers, const float *d,
+                                const float *prior, double *seconds, int *mismatches, int *first_parents);
 
 /* Tree-sequence loop of one section, AncesTreeBuilder::BuildTopology
  * (src/anc_builder.cpp:398-656): first tree from the distance matrix at

@@ -27,6 +27,10 @@
 //       PaintSteppingStones for targets [k0, k1); only <window>'s records
 //       are kept (the others go to /dev/null): the parts of consecutive
 //       ranges concatenated ARE the reference's relate_<window>.bin
+//   ref_harness paint_windows <outdir> <chunk> <k0> <k1> <prefix> w [w ...]
+//       as paint_window for SEVERAL windows from one painting of the targets
+//       (a target is painted over the whole chunk whatever is kept):
+//       window w's records go to <prefix>_<w>.bin
 //   ref_harness repaint_targets <outdir> <chunk> <window> <dump.bin> k [k ...]
 //       as repaint, for the listed targets only (ascending)
 //
@@ -184,7 +188,7 @@ int main(int argc, char **argv) {
     return 0;
   }
 
-  if (mode == "paint_targets" || mode == "paint_window") {
+  if (mode == "paint_targets" || mode == "paint_window" || mode == "paint_windows") {
     std::string out = argv[2];
     int chunk = atoi(argv[3]);
     int N, L;
@@ -221,6 +225,31 @@ int main(int argc, char **argv) {
         fflush(fo);
       }
       fclose(fo);
+      return 0;
+    }
+    if (mode == "paint_windows") {
+      const int k0 = atoi(argv[4]), k1 = atoi(argv[5]);
+      const std::string prefix = argv[6];
+      FILE *fnull = fopen("/dev/null", "wb");
+      if (!fnull || argc < 8) return 1;
+      std::vector<FILE *> pfiles(W, fnull), mine;
+      for (int a = 7; a < argc; a++) {
+        const int w = atoi(argv[a]);
+        if (w < 0 || w >= W || pfiles[w] != fnull) return 1;
+        pfiles[w] = fopen((prefix + "_" + std::to_string(w) + ".bin").c_str(), "wb");
+        if (!pfiles[w]) return 1;
+        mine.push_back(pfiles[w]);
+      }
+      for (int k = k0; k < k1; k++) {
+        FastPainting painter(data);
+        painter.PaintSteppingStones(data, wb, pfiles, k);
+        if ((k - k0) % 25 == 0) {
+          for (FILE *f : mine) fflush(f);
+          fprintf(stderr, "[paint_windows] %d/%d\n", k - k0, k1 - k0);
+        }
+      }
+      for (FILE *f : mine) fclose(f);
+      fclose(fnull);
       return 0;
     }
     int window = atoi(argv[4]), k0 = atoi(argv[5]), k1 = atoi(argv[6]);

@@ -19,6 +19,12 @@
 namespace rl {
 
 void set_error(const char *fmt, ...);
+// RELATE_AMD_TIMING: 0 / unset -- quiet; 1 -- where the wall-clock goes, on stderr; 2 -- also the tree builder's
+// progress marks (which worker holds which tree, the merge and phase a waiting build has reached)
+inline int timing_level() {
+  static const int level = getenv("RELATE_AMD_TIMING") ? (atoi(getenv("RELATE_AMD_TIMING")) >= 2 ? 2 : 1) : 0;
+  return level;
+}
 
 #define RL_HIP(call)                                                              \
   do {                                                                            \
@@ -60,14 +66,6 @@ void device_cache_trim();
 // launches of tree-builder workers that are alive (minmatch_gpu.hip): while any is, a failed allocation does not
 // trim the cache (hipFree would wait for the workers) -- it takes a larger cached block, or waits for them to leave
 extern std::atomic<int> g_worker_launches;
-// section threads waiting for their turn at a context's RePaint lane right now (window.cpp): the tree builder's
-// launcher follows it -- RePaint runs on the CUs the workers leave, and past a certain worker count its queue, not
-// the workers, is what the sections wait in
-extern std::atomic<int> g_repaint_waiting;
-// at most this many workgroups for the two kernels of a bounded window's part launch (0: one per target): set by a
-// stage whose trees are built by resident workers -- the CUs they leave are shared by RePaint and the sections' own
-// small kernels, and a part launch that fills every free CU (2 x 254 registers per SIMD) leaves those no room
-extern std::atomic<int> g_repaint_grid_cap;
 // bytes of `device`'s memory the cache holds for re-use in blocks of at least min_block bytes (cache_alloc hands out
 // whole blocks only: smaller ones are no room for a request of min_block)
 size_t device_cache_held(int device, size_t min_block);
@@ -158,7 +156,6 @@ struct rl_ctx {
   float *h_alpha = nullptr, *h_beta = nullptr;
   rl::DevBuf d_k2_scratch;  // RePaint's checkpoint rows and side records of one launch, shared by the context's
                             // windows (window.cpp)
-  rl::DevBuf d_k2_dstate;   // ... and where the descent kernel of a bounded window's launch leaves its state
   // The fused Paint + BuildTopology stage owns the stones and nobody reads them after the windows: a window
   // quantises ITS slice where it lies (once: stone_quantised[w]) and re-paints from there, instead of keeping a
   // 2 N^2-float copy per open section.
@@ -176,7 +173,7 @@ struct rl_ctx {
     std::mutex m;
     hipStream_t s = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    rl::DevBuf scratch, dstate;
+    rl::DevBuf scratch;
   } lane2;
   bool two_lanes = false;
   std::atomic<long long> repaint_launches{0};  // RePaint launches of the context's windows

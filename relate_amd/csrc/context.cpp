@@ -60,9 +60,8 @@ struct BlockCache {
 };
 BlockCache g_dev_cache, g_pin_cache;
 }  // namespace
+std::atomic<bool> g_keep_cache{false};
 std::atomic<int> g_worker_launches{0};
-std::atomic<int> g_repaint_waiting{0};
-std::atomic<int> g_repaint_grid_cap{0};
 namespace {
 
 template <typename AllocFn>
@@ -85,7 +84,7 @@ void *cache_alloc(BlockCache &c, size_t bytes, size_t *got, AllocFn raw_alloc) {
   // Out of memory: give the cached blocks back and try once more.  While the tree builder's workers are resident
   // hipFree would wait for them (for as long as any section has a tree in flight), so first ANY cached block that is
   // large enough will do -- the windows of a stage differ by up to 2 x in their rows, more than the eighth above --
-  // and only then the trim, after the workers have left (they do, 50 ms after the last tree; a minute at most here).
+  // and only then the trim, after the workers have left (they do, 50 ms after the last tree; 5 s at most here).
   if (!p) {
     {
       std::lock_guard<std::mutex> lk(c.m);
@@ -522,24 +521,21 @@ int rl_device_count(void) {
   return n;
 }
 
+void rl_keep_cache_until_exit(int on) { rl::g_keep_cache.store(on != 0); }
+
 rl_ctx *rl_create(int device) {
   int n = rl_device_count();
   if (n <= 0 || device < 0 || device >= n) {
     set_error("no usable HIP device (visible devices: %d, requested %d)", n, device);
     return nullptr;
   }
-  // RELATE_AMD_BLOCKING_SYNC=1 (experiment): waits for the device block instead of spinning -- a stage keeps ~140 host
-  // threads in hipStreamSynchronize / hipEventSynchronize, and a host that gives the process 16 cores' worth of CPU
-  // (the GPU box's quota) has none to spare for spinning
-  if (const char *e = getenv("RELATE_AMD_BLOCKING_SYNC"))
-    if (atoi(e) != 0) (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
   if (hipSetDevice(device) != hipSuccess) {
     set_error("hipSetDevice(%d) failed", device);
     return nullptr;
   }
   rl_ctx *ctx = new rl_ctx();
   ctx->device = device;
-  if (make_stream(&ctx->s0, false, getenv("RELATE_AMD_K2_HIGH") && atoi(getenv("RELATE_AMD_K2_HIGH")) != 0) != hipSuccess ||
+  if (make_stream(&ctx->s0, false) != hipSuccess ||
       make_stream(&ctx->s1, false) != hipSuccess ||
       hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
       hipEventCreate(&ctx->ev2) != hipSuccess) {
@@ -565,9 +561,8 @@ void rl_destroy(rl_ctx *ctx) {
   if (ctx->h_beta) (void)hipHostFree(ctx->h_beta);
   delete ctx;
   // (the context's buffers went to the cache: back to the driver -- unless the process says it is about to end,
-  //  RELATE_AMD_KEEP_CACHE=1, the command-line tool: the blocks stay reusable, and the exit releases them at once)
-  static const bool keep = getenv("RELATE_AMD_KEEP_CACHE") && atoi(getenv("RELATE_AMD_KEEP_CACHE")) != 0;
-  if (!keep)
+  //  rl_keep_cache_until_exit, the command-line tool: the blocks stay reusable, and the exit releases them at once)
+  if (!g_keep_cache.load())
     rl::device_cache_trim();
   else
     (void)hipDeviceSynchronize();  // (as the trim's hipFree does: the tree builder's idle workers have left when this returns)
@@ -880,9 +875,8 @@ int rl_paint(rl_ctx *ctx, int sum_mode, float *kernel_ms) {
   p.ls_beta = ctx->d_lsb.as<float>();
   p.sum_mode = sum_mode;
   p.merge_order = 0;
-  if (const char *e = getenv("RELATE_AMD_PAINT_ORDER")) p.merge_order = atoi(e);  // experiments
   p.stats = nullptr;
-  if (getenv("RELATE_AMD_STATS")) {  // experiment builds (-DRL_STATS): 16 counters, see tools/exp_stats.py
+  if (getenv("RELATE_AMD_TEST_STATS")) {  // experiment builds (-DRL_STATS): 16 counters, see tools/exp_stats.py
     if ((rc = ctx->d_stats.alloc(32 * sizeof(unsigned long long)))) return rc;
     RL_HIP(hipMemset(ctx->d_stats.p, 0, 32 * sizeof(unsigned long long)));
     p.stats = ctx->d_stats.as<unsigned long long>();
@@ -1074,7 +1068,6 @@ static int write_paint_files(rl_ctx *ctx, const char *paint_dir, int only_window
   // file system work of different windows overlap.  Each holds ~ (2*4 + 8) * N^2 bytes of buffers.
   const size_t per_thread = (size_t)N * N * 8 + (size_t)N * maxrec;
   int nthreads = (int)std::max<size_t>(1, std::min<size_t>({(size_t)W, (size_t)4, ((size_t)6 << 30) / per_thread}));
-  if (const char *e = getenv("RELATE_AMD_WRITER_THREADS")) nthreads = std::max(1, atoi(e));
   if (only_window >= 0) nthreads = 1;
   std::mutex gpu_mutex;
   std::atomic<int> failed{0};

@@ -96,7 +96,6 @@ struct RepaintParams {
   int sum_mode;
   int partial;                // the logscales of every row are in place (an earlier launch of this window wrote them):
   int nostrip;                // a part launch's backward kernel without the LDS strip, two waves a SIMD (repaint_kernels.hip)
-  int grid_cap;               // ... and at most this many workgroups for its two kernels (0: one per target)
                               // the forward pass may stop below row_hi, the backward pass at row_lo
   // A bounded window keeps ONE state of the backward pass per target -- beta (doubles, register-major like a
   // checkpoint row), the step's factor and the running logscale as they stand before row r is done -- so that a
@@ -108,10 +107,6 @@ struct RepaintParams {
   // ... and ONE of the forward pass: alpha, the step's factor and the logscales as they stand behind row r, a
   // multiple of the checkpoint interval -- where the rows of the next part begin, so that its launch starts there
   // instead of at the window's first row.  fsave_row / fstart_row as above.
-  // The beta-only descent of a launch as a kernel of its own (repaint_descent_kernel): it leaves the state before row
-  // row_hi - 1 here (scratch of the launch: one buffer per RePaint lane), dscal[t] = {cfac, prev_ls, that row or -1, -}
-  double *dstate;             // [nloc][waves][S*64], or null: no descent kernel
-  double *dscal;              // [nloc][4]
   double *fstate;             // [nloc][waves][S*64], or null
   double *fscal;              // [nloc][4]: cfac, prev_ls, lsf
   const int32_t *fstart_row, *fsave_row;  // [nloc]

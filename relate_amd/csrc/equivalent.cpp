@@ -356,7 +356,8 @@ struct BranchMatcher {
       chain.clear();
       for (int b = median_leaf(v); b != -1; b = ref_tree.parent[b]) {
         const int s2 = ref.size[b];
-        if (b == nodes - 1 || s2 >= N) break;
+        if (s2 >= N) break;
+        if (b == nodes - 1) continue;  // (skipped, not the end of the chain: a root need not be labelled nodes - 1)
         if (near(n1, s2)) chain.push_back(b);
       }
       std::sort(chain.begin(), chain.end(), [&](int a, int b) { return rank[a] < rank[b]; });

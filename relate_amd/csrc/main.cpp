@@ -38,7 +38,7 @@ int main(int argc, char **argv) {
   setenv("GPU_MAX_HW_QUEUES", "12", 0);
   // This process runs one stage and ends: the blocks its contexts release stay in the library's cache until the
   // process is gone instead of going back to the driver one hipFree at a time (C3: ~3000 blocks, 4 s)
-  setenv("RELATE_AMD_KEEP_CACHE", "1", 0);
+  rl_keep_cache_until_exit(1);
   // option table of Relate.cpp:19-45 restricted to what the two modes read
   const std::map<std::string, bool> known = {  // name -> takes a value
       {"mode", true}, {"chunk_index", true}, {"first_section", true}, {"last_section", true},

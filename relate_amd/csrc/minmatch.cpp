@@ -29,9 +29,9 @@ static inline double now_s() {
 // ---- helper threads --------------------------------------------------------
 static std::atomic<int> g_build_threads{1};
 void set_build_threads(int T) { g_build_threads = T < 1 ? 1 : (T > 64 ? 64 : T); }
-// fewer live clusters than this: a merge is too short to be worth a hand-off (RELATE_AMD_BUILD_MIN)
+// fewer live clusters than this: a merge is too short to be worth a hand-off (RELATE_AMD_TEST_BUILD_MIN)
 static int build_min_clusters() {
-  const char *e = getenv("RELATE_AMD_BUILD_MIN");
+  const char *e = getenv("RELATE_AMD_TEST_BUILD_MIN");
   const int v = e ? atoi(e) : 512;
   return v < 2 ? 2 : v;
 }

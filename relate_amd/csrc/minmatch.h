@@ -221,6 +221,8 @@ class DeviceMinMatch {
   // with sample ages (`--sample_ages`): the builder whose state this one takes and puts back is a MinMatchAges
   int build(MinMatchAges &tb, const std::vector<double> &sample_ages, const float *d, const float *prior, HostTree &tree);
   int build_resident(MinMatchAges &tb, const std::vector<double> &sample_ages, bool with_prior, HostTree &tree);
+  // (measurement hook) the matrices of the next build_resident() copied from device memory into the staging pair
+  int stage_from_device(const float *dD, const float *dCF);
   void forget_ages();  // the next build with sample ages comes with other ages: their table goes to the device again
   // the buffers a build keeps for itself (the woven matrix, 16 N^2 B, and small ones), allocated now: 0 or < 0
   int reserve(bool ages = false);

@@ -38,48 +38,35 @@ namespace rl {
 
 namespace {
 
-#ifndef MM_BLOCK_N
-#define MM_BLOCK_N 512
-#endif
-constexpr int MM_BLOCK = MM_BLOCK_N;   // (8 waves: 256 registers per lane -- a thread keeps ~10 clusters of a merge in registers)
+constexpr int MM_BLOCK = 512;   // (8 waves; a thread keeps ~10 clusters of a merge in registers.  256 threads: 166 ms per N = 5000 tree, 1024: 156, 512: 110)
 constexpr int MM_WAVES = MM_BLOCK / 64;
-#ifndef MM_ROWS_N
-#define MM_ROWS_N 2  // (3: 119 ms per N = 5000 tree, 2: 110, 4: 134 -- registers)
-#endif
-constexpr int MM_ROWS = MM_ROWS_N;  // rows of rebuilt clusters scanned per pass of a merge (2 once a thread holds > 10 clusters)
-constexpr int MM_HITS = 64;       // mutually close pairs per row pairscan_kernel keeps; more: the host builds the tree
-constexpr int MM_UPD_MAX = 512;   // rebuilt clusters of one merge (list in LDS); more: the host builds the tree
-constexpr int MM_PAIRS_LDS = 768; // feasible pairs of one merge kept in LDS; more go through global scratch
+constexpr int MM_HITS = 64;       // mutually close pairs per row the weave keeps; more: the host builds the tree
+constexpr int MM_UPD_MAX = 512;   // rebuilt clusters of one merge; more: the host builds the tree (the AGES build keeps a longer list)
+constexpr int MM_UPD_LDS = 256;   // ... of which this many in LDS, the rest in global memory
+constexpr int MM_PAIRS_LDS = 320; // feasible pairs of one merge kept in LDS (8 per merge on average); more go through global scratch
 constexpr int MM_BUCKET_MIN = 2048;  // (the AGES build) more pairs than this are put in order bucket by bucket
 // M is stored in column panels of 64: element (a, b) at ((b / 64) * N + a) * 64 + b % 64.  A row is N / 64 runs of
 // 1 KB (a wavefront's 64 consecutive clusters: one run), 64 * N elements apart; a COLUMN -- what a merge scatters its
 // one store per cluster down -- strides by 1 KB inside one panel of N KB, a few 2 MB pages, instead of by a whole
 // row (80 KB at N = 5000: every store on another page, the address translation of 2500 pages per merge).
+// (Rows in blocks of 128, so that a row spans fewer pages: no gain, DESIGN_NOTES.md 5.)
 constexpr int MM_PANEL = 64;
-// MM_RBLOCK > 0 (experiment): the rows in blocks of MM_RBLOCK -- element (a, b) at
-// (((a / R) * P + b / 64) * R + a % R) * 64 + b % 64, P panels: a row's 1 KB runs lie R KB apart (a row spans P * R KB
-// instead of P * N KB), a column's stores fall into N / R regions.  Pages of 2 MB a merge touches at N = 5000 (two rows
-// read, ~3 rows rescanned, one column stored): ~390 in the panel layout, ~70 with R = 128.
-#ifndef MM_RBLOCK
-#define MM_RBLOCK 0
-#endif
 __host__ __device__ inline unsigned mm_index(unsigned a, unsigned b, unsigned N) {
-#if MM_RBLOCK > 0
-  const unsigned P = (N + MM_PANEL - 1) / MM_PANEL;
-  return (((a / MM_RBLOCK) * P + b / MM_PANEL) * MM_RBLOCK + a % MM_RBLOCK) * MM_PANEL + (b % MM_PANEL);
-#else
   return ((b / MM_PANEL) * N + a) * MM_PANEL + (b % MM_PANEL);
-#endif
 }
-__host__ __device__ inline size_t mm_elements(size_t N) {
-#if MM_RBLOCK > 0
-  return ((N + MM_RBLOCK - 1) / MM_RBLOCK) * MM_RBLOCK * ((N + MM_PANEL - 1) / MM_PANEL) * MM_PANEL;
-#else
-  return ((N + MM_PANEL - 1) / MM_PANEL) * N * MM_PANEL;
-#endif
-}
+__host__ __device__ inline size_t mm_elements(size_t N) { return ((N + MM_PANEL - 1) / MM_PANEL) * N * MM_PANEL; }
 constexpr int MM_MAXN = 10240;    // one thread holds up to 20 clusters of a merge in registers
-constexpr int MM_Q_LDS = 5120 / MM_BLOCK, MM_Q_GLOB = MM_MAXN / MM_BLOCK;  // register slots per thread: state in LDS / global
+constexpr int MM_Q_LDS = 5120 / MM_BLOCK, MM_Q_GLOB = MM_MAXN / MM_BLOCK;  // register slots per thread: N <= 5120 / N <= 10240
+constexpr int MM_Q_SMALL = 2048 / MM_BLOCK;                                // ... and N <= 2048
+// Where the per-cluster state of a build lives:
+//   L_HOT    (the plain build, every N): what a merge reads or writes for EVERY cluster or on the ordered part's path --
+//            the candidate (dist, dist2, lin1, lin2) and the rebuilt mark, 13 bytes per cluster -- in LDS; the rest
+//            (row minima of both matrices, sizes, the live list) in global memory, read with the rows of a merge or
+//            kept in registers.  65 KB at N = 5000: TWO workgroups per CU, 130 KB at N = 10,000;
+//   L_LDS    (the AGES build, N <= 4100) everything in LDS, 33 bytes per cluster;
+//   L_GLOBAL (the AGES build above that) everything in the global arrays of MMParams.
+//   L_WARM   L_HOT with the row minima of both matrices in LDS too (21 bytes per cluster): one workgroup per CU.
+enum { L_LDS = 0, L_GLOBAL = 1, L_HOT = 2, L_WARM = 3 };
 
 // A tree's parameters.  The matrices of a build, woven: M[a][b] = (d(a,b), d(b,a), cf(a,b), cf(b,a)).  A merge needs,
 // per cluster k, the entries (i,k), (k,i), (j,k), (k,j) of both matrices: two 16-byte loads along the rows of i and j
@@ -95,11 +82,10 @@ constexpr int MM_Q_LDS = 5120 / MM_BLOCK, MM_Q_GLOB = MM_MAXN / MM_BLOCK;  // re
 // merge overlap exactly these two.
 #define MM_PARAM_FIELDS(PTR)                                                                                         \
   int N;                                                                                                             \
-  int lds_state; /* the per-cluster state lives in LDS for the build (it fits: N <= ~5200) */                        \
+  int layout; /* L_LDS / L_GLOBAL / L_HOT: where the per-cluster state lives for the build */                       \
   float threshold, threshold_CF;                                                                                     \
   PTR(MM_F4) M; /* [N*N] destroyed */                                                                                \
   int has_prior; /* the cf halves of M are in use */                                                                 \
-  int debug;     /* experiments (RELATE_AMD_MM_DEBUG): 1 = never the one-pass form of B */                           \
   PTR(const float) rowmin_D; /* [N] minimum of each row off the diagonal */                                          \
   PTR(const float) rowmin_CF;                                                                                        \
   /* the mutually close pairs (a, b > a) of the untouched matrix, row by row in order, from pairscan_kernel */       \
@@ -118,6 +104,10 @@ constexpr int MM_Q_LDS = 5120 / MM_BLOCK, MM_Q_GLOB = MM_MAXN / MM_BLOCK;  // re
   PTR(int) mcs_lin2;                                                                                                 \
   PTR(float) min_values; /* min_values_CF, mc_lin1, mc_lin2: carried from tree to tree (in and out) */               \
   PTR(float) min_values_CF;                                                                                          \
+  /* (pinned host memory; L_LDS and L_HOT) where the worker reads the carried state and leaves it again: candidate  \
+     indices [2N], min_values_CF [N] -- L_GLOBAL: the host copies to and from the arrays above */                    \
+  PTR(int) io_lin;                                                                                                   \
+  PTR(float) io_mvcf;                                                                                                \
   PTR(float) mc_dist;                                                                                                \
   PTR(float) mc_dist2;                                                                                               \
   PTR(int) mc_lin1;                                                                                                  \
@@ -136,7 +126,7 @@ constexpr int MM_Q_LDS = 5120 / MM_BLOCK, MM_Q_GLOB = MM_MAXN / MM_BLOCK;  // re
   PTR(volatile int) host_done;                                                                                       \
   long long pair_cap;                                                                                                \
   PTR(long long) timers; /* optional: 100 MHz ticks per phase (RELATE_AMD_TIMING) */                                 \
-  PTR(unsigned) trace;   /* optional (RELATE_AMD_MM_TRACE): [0] merge, [1] phase the workgroup has reached */     \
+  PTR(unsigned) trace;   /* optional (RELATE_AMD_TIMING=2): [0] merge, [1] phase the workgroup has reached */     \
   /* --sample_ages (the AGES build): the candidates' draw as a double and their third key as the INDEX of the age   \
      among the sorted distinct sample ages (MM_AGE_EMPTY: no candidate); per cluster the index of its oldest sample \
      (age_lvl0: as the samples are, age_lvl: the build's own copy); the distinct ages, how many samples have each */ \
@@ -148,8 +138,8 @@ constexpr int MM_Q_LDS = 5120 / MM_BLOCK, MM_Q_GLOB = MM_MAXN / MM_BLOCK;  // re
   PTR(const int) ages_count;                                                                                         \
   int n_levels;                                                                                                      \
   int Ne; /* pipeline/BuildTopology.cpp:36 */                                                                        \
-  /* the rebuilt clusters of a merge beyond MM_UPD_MAX (there a renamed candidate follows its lineage up the tree,  \
-     :2342, and a merge of that lineage sends every cluster holding one through the rebuilding branch) */          \
+  /* the rebuilt clusters of a merge beyond MM_UPD_LDS (with sample ages a renamed candidate follows its lineage up  \
+     the tree, :2342, and a merge of that lineage sends every cluster holding one through the rebuilding branch) */  \
   PTR(unsigned) upd_g; /* [N] */                                                                                     \
   PTR(float) updv_g;   /* [N] */                                                                                     \
   /* ... and, for a merge with thousands of feasible pairs, the pairs per later cluster: counts / fill marks and    \
@@ -157,11 +147,7 @@ constexpr int MM_Q_LDS = 5120 / MM_BLOCK, MM_Q_GLOB = MM_MAXN / MM_BLOCK;  // re
   PTR(int) bucket;     /* [N + 1] */                                                                                 \
   PTR(int) bucket_off; /* [N + 1] */
 #define MM_HOST_PTR(T) T *
-#ifdef MM_FLAT  // (experiment: pointers of unknown address space, as before round 3)
-#define MM_GLOBAL_PTR(T) T *
-#else
 #define MM_GLOBAL_PTR(T) __attribute__((address_space(1))) T *
-#endif
 // (a class type -- HIP's float4 -- has no member functions outside the generic address space: the device struct
 //  takes the elements of M as native vectors)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -245,7 +231,8 @@ struct Best {
   int lin1, lin2;
 };
 
-constexpr int MM_PARAM_WORDS = 96;  // sizeof(MMParams) / 4 rounded up (static_assert below)
+constexpr int MM_PARAM_WORDS = 104;  // sizeof(MMParams) / 4 rounded up (static_assert below)
+constexpr int MM_ROWS_MAX = 2;       // rows of rebuilt clusters a pass of a merge scans at most (build_tree: ROWS)
 struct Shared {
   unsigned praw[MM_PARAM_WORDS];  // the tree's parameters as the worker read them from the queue
   unsigned ticket;
@@ -264,40 +251,53 @@ struct Shared {
   int wave_i3[MM_WAVES];
   float wave_f2[MM_WAVES];
   float lex_d[MM_WAVES], lex_d2[MM_WAVES];
-  int lex_p[MM_WAVES];
+  int lex_p[MM_WAVES], lex_k[MM_WAVES];
   double lex_d2d[MM_WAVES];  // (the AGES build: the draw is a double)
   int a_lw;                  // ... and the last age level its clock has reached, for all waves
-  int guess_i, guess_j;      // (MM_PREFETCH) the likely next pair: the best of the clusters that keep their candidate
-#ifdef MM_PREFETCH_LDS
-  unsigned pf_dump[64];      // ... and where the words asked for ahead land (nobody reads them)
-#endif
   int rowcount[MM_WAVES];
   float sym_dist;
-  float red_f[MM_ROWS][MM_WAVES];
-  int red_a[MM_ROWS][MM_WAVES], red_b[MM_ROWS][MM_WAVES];
-  unsigned upd[MM_UPD_MAX];  // rebuilt clusters of the merge: position | rescan << 16, any order
-  float updv[MM_UPD_MAX];    // ... and their new d(k, j), which is not in memory until the end of the merge
+  float red_f[MM_ROWS_MAX][MM_WAVES];
+  int red_a[MM_ROWS_MAX][MM_WAVES], red_b[MM_ROWS_MAX][MM_WAVES];
+  // the live list lives in the threads' registers (position t + 512 q in slot q of thread t): when a cluster leaves,
+  // the positions behind it move up by one -- a lane takes its neighbour's, the last lane of a wave the first of the
+  // next wave's from here
+  short edge[MM_WAVES][MM_Q_GLOB];
+  // rebuilt clusters of the merge, any order: position | cluster << 14 | rescan << 28; their new d(k, j), which is not
+  // in memory until the end of the merge; their row minimum (+ threshold), as it was and then as the rescan leaves it
+  unsigned upd[MM_UPD_LDS];
+  float updv[MM_UPD_LDS];
+  float updmv[MM_UPD_LDS];
   // feasible pairs of the merge, [0]: as found, [1]: in the reference's order
   unsigned pk[2][MM_PAIRS_LDS];   // key: position of the later cluster << 16 | position of the earlier one
   unsigned pxy[2][MM_PAIRS_LDS];  // later cluster << 16 | earlier cluster
   float psym[2][MM_PAIRS_LDS];    // symmetric distance of the pair (0 if the prior makes it a certain pair)
 };
 
-// The per-cluster state of a build: in LDS when it fits (25 bytes per cluster; indices as shorts), else in the
-// global arrays of MMParams.
-template <bool LDS>
+// The per-cluster state of a build and where each field lives (L_LDS / L_GLOBAL / L_HOT above).  HOT fields: read or
+// written for every cluster of every merge from LDS or on the ordered part's path; COLD fields: read with the rows of
+// a merge (row minima), by a few threads (sizes, min_values_CF of a pair) or from registers (the live list: `ci` is its
+// mirror in memory, kept for the symmetric fallback and the AGES walk).
+template <int LAY>
 struct State {
-  typedef typename std::conditional<LDS, short, int>::type idx_t;
+  static constexpr bool hot_lds = LAY != L_GLOBAL, cold_lds = LAY == L_LDS, warm_lds = LAY == L_LDS || LAY == L_WARM;
+  typedef typename std::conditional<hot_lds, short, int>::type hidx_t;
+  typedef typename std::conditional<cold_lds, short, int>::type cidx_t;
   template <typename T>
-  using ptr = typename std::conditional<LDS, T *, MM_GLOBAL_PTR(T)>::type;  // (LDS: inferred)
-  ptr<float> mv, mvcf, mcd, mcd2;  // min_values, min_values_CF, candidate (dist, dist2)
-  ptr<idx_t> lin1, lin2;           // candidate pair (stale indices are part of the carried state)
-  ptr<idx_t> ci;                   // the live clusters in order
-  ptr<idx_t> csz;                  // cluster sizes (floats in the reference: exact integers)
-  ptr<unsigned char> flag;         // rebuilt in this merge
+  using hot = typename std::conditional<hot_lds, T *, MM_GLOBAL_PTR(T)>::type;  // (LDS: inferred)
+  template <typename T>
+  using warm = typename std::conditional<warm_lds, T *, MM_GLOBAL_PTR(T)>::type;
+  template <typename T>
+  using cold = typename std::conditional<cold_lds, T *, MM_GLOBAL_PTR(T)>::type;
+  hot<float> mcd, mcd2;      // candidate (dist, dist2)
+  hot<hidx_t> lin1, lin2;    // candidate pair (stale indices are part of the carried state)
+  hot<unsigned char> flag;   // rebuilt in this merge
+  warm<float> mv, mvcf;      // min_values, min_values_CF
+  cold<cidx_t> ci;           // the live clusters in order (mirror of the threads' registers)
+  cold<cidx_t> csz;          // cluster sizes (floats in the reference: exact integers)
   // the AGES build: the candidate's draw as a double and its age level, the cluster's own age level
-  ptr<double> d2d;
-  ptr<idx_t> lv, alv;
+  hot<double> d2d;
+  hot<hidx_t> lv;
+  cold<cidx_t> alv;
 };
 
 // Wave reductions on the DPP crossbar (quad swaps, half-row and row mirrors, the two row broadcasts: the total
@@ -453,6 +453,9 @@ __device__ inline double ages_step(int k, int Ne) {
 // (32-bit element offsets from a scalar base -- N <= 10240: one address register per load instead of two)
 #define MM(a, b) p.M[mm_index((unsigned)(a), (unsigned)(b), (unsigned)N)]
 #define MM2(a, b) (((MM_GLOBAL_PTR(const f32x2))(p.M + mm_index((unsigned)(a), (unsigned)(b), (unsigned)N)))[0])  // (d(a,b), d(b,a))
+// (one half of a pair only: d(a,b) -- the first filter of a test runs on it, the few survivors fetch d(b,a))
+#define MM1(a, b) (((MM_GLOBAL_PTR(const float))(p.M + mm_index((unsigned)(a), (unsigned)(b), (unsigned)N)))[0])
+#define MMY(a, b) (((MM_GLOBAL_PTR(const float))(p.M + mm_index((unsigned)(a), (unsigned)(b), (unsigned)N)))[1])
 #define SS(a, b) symm[(unsigned)(a) * (unsigned)N + (unsigned)(b)]
 
 // One workgroup per tree: workgroup b builds the tree of params[b].
@@ -482,16 +485,18 @@ __device__ inline double ages_step(int k, int Ne) {
 // clock takes an EMPTY place only, one within the clock displaces it whatever its distance), so wave 0 walks the
 // live list once per merge, the pairs applied at their clusters' turns: exact, and slower (data sets with ancient
 // samples are small).  The per-cluster state of that build lives in global memory.
-template <bool LDS, int MAXQ, bool AGES = false>
+template <int LAY, int MAXQ, bool AGES, int ROWS>
 __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, unsigned char *dyn) {
-  typedef typename State<LDS>::idx_t idx_t;
-  constexpr int ROWS = MAXQ * MM_ROWS > 64 ? 64 / MAXQ : MM_ROWS;  // rows of rebuilt clusters per pass (ROWS * MAXQ <= 64 bits of survivors)
+  typedef typename State<LAY>::hidx_t hidx_t;
+  typedef typename State<LAY>::cidx_t cidx_t;
+  static_assert(ROWS <= MM_ROWS_MAX && ROWS * MAXQ <= 64, "ROWS * MAXQ bits of survivors per pass");
+  static_assert((LAY != L_HOT && LAY != L_WARM) || !AGES, "the AGES build keeps all of its state in one place");
   const int N = p.N;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float INF = INFINITY;
   const float threshold = p.threshold, threshold_CF = p.threshold_CF;
-  State<LDS> st;
-  if constexpr (LDS && AGES) {  // 33 bytes per cluster (the float draw of the plain build has no place here)
+  State<LAY> st;
+  if constexpr (LAY == L_LDS && AGES) {  // 33 bytes per cluster (the float draw of the plain build has no place here)
     st.d2d = reinterpret_cast<double *>(dyn);
     float *f = reinterpret_cast<float *>(st.d2d + N);
     st.mv = f;
@@ -506,7 +511,7 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
     st.lv = s + 4 * (size_t)N;
     st.alv = s + 5 * (size_t)N;
     st.flag = reinterpret_cast<unsigned char *>(s + 6 * (size_t)N);
-  } else if constexpr (LDS) {
+  } else if constexpr (LAY == L_LDS) {
     float *f = reinterpret_cast<float *>(dyn);
     st.mv = f;
     st.mvcf = f + N;
@@ -518,6 +523,24 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
     st.ci = s + 2 * (size_t)N;
     st.csz = s + 3 * (size_t)N;
     st.flag = reinterpret_cast<unsigned char *>(s + 4 * (size_t)N);
+  } else if constexpr (LAY == L_HOT || LAY == L_WARM) {  // 13 / 21 bytes per cluster in LDS
+    float *f = reinterpret_cast<float *>(dyn);
+    st.mcd = f;
+    st.mcd2 = f + N;
+    if constexpr (LAY == L_WARM) {
+      st.mv = f + 2 * (size_t)N;
+      st.mvcf = f + 3 * (size_t)N;
+      f += 2 * (size_t)N;
+    } else {
+      st.mv = p.min_values;
+      st.mvcf = p.min_values_CF;
+    }
+    short *s = reinterpret_cast<short *>(f + 2 * (size_t)N);
+    st.lin1 = s;
+    st.lin2 = s + N;
+    st.flag = reinterpret_cast<unsigned char *>(s + 2 * (size_t)N);
+    st.ci = p.cluster_index;
+    st.csz = p.cluster_size;
   } else {
     st.d2d = p.mc_dist2d;
     st.lv = p.mc_lvl;
@@ -568,25 +591,31 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
   if (tid == 0) sh.sym_slot = -1;
 
   // ---- QuickBuild set-up (:1061-1100)
+  // (L_HOT: the list's mirror in memory is written when the symmetric fallback first needs it)
+  constexpr bool CI_ALWAYS = LAY != L_HOT && LAY != L_WARM;
   for (int c = tid; c < N; c += MM_BLOCK) {
-    st.ci[c] = (idx_t)c;
-    st.csz[c] = (idx_t)1;
-    st.mv[c] = INF;
+    if constexpr (CI_ALWAYS) st.ci[c] = (cidx_t)c;
+    st.csz[c] = (cidx_t)1;
     st.mcd[c] = INF;
     st.flag[c] = 0;
     if constexpr (AGES) {
       st.d2d[c] = (double)INF;
-      st.lv[c] = (idx_t)MM_AGE_EMPTY;
-      st.alv[c] = (idx_t)p.age_lvl0[c];
+      st.lv[c] = (hidx_t)MM_AGE_EMPTY;
+      st.alv[c] = (cidx_t)p.age_lvl0[c];
     } else {
       st.mcd2[c] = INF;
     }
-    if constexpr (LDS) {  // the state carried from tree to tree comes in
-      st.lin1[c] = (idx_t)p.mc_lin1[c];
-      st.lin2[c] = (idx_t)p.mc_lin2[c];
-      st.mvcf[c] = p.min_values_CF[c];
+    if constexpr (LAY != L_GLOBAL) {  // the state carried from tree to tree comes in (pinned host memory)
+      st.lin1[c] = (hidx_t)p.io_lin[c];
+      st.lin2[c] = (hidx_t)p.io_lin[(size_t)N + c];
+      // (L_HOT: min_values_CF as carried over is in the device array already -- the weave reads it there)
+      if constexpr (LAY != L_HOT) st.mvcf[c] = p.io_mvcf[c];
     }
   }
+  // the live list: position t + MM_BLOCK q in slot q of thread t, for the whole build
+  int a_k[MAXQ];
+#pragma unroll
+  for (int q = 0; q < MAXQ; q++) a_k[q] = q * MM_BLOCK + tid < N ? q * MM_BLOCK + tid : -1;
   if (tid == 0) {
     rng_seed(sh.rng, 1u);
     sh.best.dist = INF;
@@ -689,18 +718,18 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
     if (ty) ys = c;
     if (lane == 0) {
       if (tx) {
-        st.lin1[x] = (idx_t)x;
-        st.lin2[x] = (idx_t)y;
+        st.lin1[x] = (hidx_t)x;
+        st.lin2[x] = (hidx_t)y;
         st.mcd[x] = sym;
         st.d2d[x] = rnd;
-        st.lv[x] = (idx_t)clv;
+        st.lv[x] = (hidx_t)clv;
       }
       if (ty) {
-        st.lin1[y] = (idx_t)x;
-        st.lin2[y] = (idx_t)y;
+        st.lin1[y] = (hidx_t)x;
+        st.lin2[y] = (hidx_t)y;
         st.mcd[y] = sym;
         st.d2d[y] = rnd;
-        st.lv[y] = (idx_t)clv;
+        st.lv[y] = (hidx_t)clv;
       }
     }
   };
@@ -715,14 +744,14 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
     const float ad = st.mcd[x], ad2 = st.mcd2[x], bdd = st.mcd[y], bdd2 = st.mcd2[y];
     if (lane == 0) {
       if (ad > sym || (ad == sym && ad2 > rnd)) {
-        st.lin1[x] = (idx_t)x;
-        st.lin2[x] = (idx_t)y;
+        st.lin1[x] = (hidx_t)x;
+        st.lin2[x] = (hidx_t)y;
         st.mcd[x] = sym;
         st.mcd2[x] = rnd;
       }
       if (bdd > sym || (bdd == sym && bdd2 > rnd)) {
-        st.lin1[y] = (idx_t)x;
-        st.lin2[y] = (idx_t)y;
+        st.lin1[y] = (hidx_t)x;
+        st.lin2[y] = (hidx_t)y;
         st.mcd[y] = sym;
         st.mcd2[y] = rnd;
       }
@@ -830,9 +859,6 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
   // behind this call, and an exit the compiler takes for divergent -- it hangs on values read from LDS -- is laid
   // out as a loop in which a wave passes the caller's barriers once per group of lanes.
   int bail = -1;
-#ifdef MM_PREFETCH
-  int pf_sink = 0;
-#endif
   for (int num_nodes = N; num_nodes < 2 * N - 1; num_nodes++) {
     const int n = sh.n;
     if (sh.best.dist == INF && !sh.use_sym) {
@@ -856,6 +882,12 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
         break;
       }
       symm = p.SYM + (size_t)slot * N * N;
+      if constexpr (!CI_ALWAYS) {  // the live list as it stands in the registers: from here on it is kept in memory too
+#pragma unroll
+        for (int q = 0; q < MAXQ; q++)
+          if (a_k[q] >= 0) st.ci[q * MM_BLOCK + tid] = (cidx_t)a_k[q];
+        __syncthreads();
+      }
       float bs = INF;
       int bs_pos = n;
       for (int ia = wave; ia < n; ia += MM_WAVES) {
@@ -923,29 +955,22 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
     };
     // (the live list shrinks from N to 2: the register slots past it are skipped by wave-uniform branches, not by
     //  predication -- half of all slots over a build)
-#ifdef MM_NO_SKIP
-    const int nq = MAXQ;
-#else
     const int nq = (n + MM_BLOCK - 1) / MM_BLOCK;
-#endif
-    int a_k[MAXQ];
+    float mvreg[MAXQ];  // the row minima (+ threshold) of this thread's clusters as the merge finds them
     float mv_cf = INF, mvj = INF, bd = INF, bd2 = INF;
     double bd2d = (double)INF;  // (AGES)
     const int lw_all = AGES ? sh.a_lw : 0;
-    int bpos = n;
-#pragma unroll
-    for (int q = 0; q < MAXQ; q++) {
-      const int ik = q * MM_BLOCK + tid;
-      a_k[q] = ik < n ? (int)st.ci[ik] : -1;
-    }
-#ifndef MM_QC
-#define MM_QC 5
+    int bpos = n, bk = -1;
+#ifndef MM_QC20
+#define MM_QC20 4
 #endif
-    constexpr int QC = MM_QC;  // clusters per pass (ten at once cost more in spilled registers than the second round trip)
+    // clusters per pass (ten at once cost more in spilled registers than the second round trip)
+    constexpr int QC = MAXQ == MM_Q_GLOB ? MM_QC20 : MAXQ % 5 == 0 ? 5 : 4;
 #pragma unroll
     for (int q0 = 0; q0 < MAXQ; q0 += QC) {
       if (q0 * MM_BLOCK >= n) break;
-      // every load of the pass first: the two rows from memory, then -- under their latency -- the clusters' state
+      // every load of the pass from memory first: the two rows and the clusters' row minima; what lives in LDS is read
+      // cluster by cluster under their latency (state in global memory: asked for with the rows)
       f32x4 ei[QC], ej[QC];
 #pragma unroll
       for (int qq = 0; qq < QC; qq++) {
@@ -954,21 +979,24 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
         ei[qq] = MM(i, k);
         ej[qq] = MM(j, k);
       }
-      float s_mv[QC], s_d1[QC], s_d2[QC];
-      int s_l1[QC], s_l2[QC];
-      double s_d2d[AGES ? QC : 1];
-      int s_lv[AGES ? QC : 1];
+      constexpr bool JIT = State<LAY>::hot_lds;  // the candidate's fields come from LDS: at the cluster's turn
+      float s_d1[JIT ? 1 : QC], s_d2[JIT ? 1 : QC];
+      int s_l1[JIT ? 1 : QC], s_l2[JIT ? 1 : QC];
+      double s_d2d[AGES && !JIT ? QC : 1];
+      int s_lv[AGES && !JIT ? QC : 1];
 #pragma unroll
       for (int qq = 0; qq < QC; qq++) {
-        const int k = a_k[q0 + qq] >= 0 ? a_k[q0 + qq] : 0;
-        s_mv[qq] = st.mv[k];
-        s_l1[qq] = st.lin1[k];
-        s_l2[qq] = st.lin2[k];
-        s_d1[qq] = st.mcd[k];
-        if constexpr (!AGES) s_d2[qq] = st.mcd2[k];
-        if constexpr (AGES) {
-          s_d2d[qq] = st.d2d[k];
-          s_lv[qq] = st.lv[k];
+        const unsigned k = a_k[q0 + qq] >= 0 ? (unsigned)a_k[q0 + qq] : 0u;
+        mvreg[q0 + qq] = st.mv[k];
+        if constexpr (!JIT) {
+          s_l1[qq] = st.lin1[k];
+          s_l2[qq] = st.lin2[k];
+          s_d1[qq] = st.mcd[k];
+          if constexpr (!AGES) s_d2[qq] = st.mcd2[k];
+          if constexpr (AGES) {
+            s_d2d[qq] = st.d2d[k];
+            s_lv[qq] = st.lv[k];
+          }
         }
       }
 #pragma unroll
@@ -996,18 +1024,25 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
         if (dki != dkj) nkj = over_added(csi * dki + csj * dkj);
         // (written whether changed or not: the same bits where the reference leaves the entry alone)
         MM(j, k) = f32x4{njk, nkj, ncjk, nckj};
-#ifdef MM_NT_COLUMN  // (experiment: the scattered store past the caches)
-        if (!(p.debug & 2)) __builtin_nontemporal_store(f32x4{nkj, njk, nckj, ncjk}, &MM(k, j));
-#else
-        if (!(p.debug & 2)) MM(k, j) = f32x4{nkj, njk, nckj, ncjk};  // (2: timing experiment, wrong trees)
-#endif
+        MM(k, j) = f32x4{nkj, njk, nckj, ncjk};
         if (njk < mvj) mvj = njk;
         bool rescan = false;
+        const float mvk = mvreg[q];
         if (dkj != dki) {
-          const float mvk = s_mv[qq];
           rescan = (double)fabsf(mvk - threshold - dkj) < 1e-4 || (double)fabsf(mvk - threshold - dki) < 1e-4;
         }
-        const int l1 = s_l1[qq], l2 = s_l2[qq];
+        const int sq = JIT ? 0 : qq;
+        if constexpr (JIT) {
+          s_l1[0] = st.lin1[k];
+          s_l2[0] = st.lin2[k];
+          s_d1[0] = st.mcd[k];
+          if constexpr (!AGES) s_d2[0] = st.mcd2[k];
+          if constexpr (AGES) {
+            s_d2d[0] = st.d2d[k];
+            s_lv[0] = st.lv[k];
+          }
+        }
+        const int l1 = s_l1[sq], l2 = s_l2[sq];
         const bool touches = l1 == j || l2 == j || l1 == i || l2 == i;
         if (p.timers && rescan && !touches) atomicAdd(&sh.cnt_rescan_only, 1);
         // (AGES with a prior: a candidate that touches i or j alone does not send k through the rebuilding branch
@@ -1019,47 +1054,53 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
           st.mcd[k] = INF;
           if constexpr (AGES) {
             st.d2d[k] = (double)INF;
-            st.lv[k] = (idx_t)MM_AGE_EMPTY;
+            st.lv[k] = (hidx_t)MM_AGE_EMPTY;
           } else {
             st.mcd2[k] = INF;
           }
           const int slot = atomicAdd(&sh.nupd, 1);
-          if (slot < MM_UPD_MAX) {
-            sh.upd[slot] = (unsigned)ik | (rescan ? 0x10000u : 0u);
+          const unsigned rec = (unsigned)ik | ((unsigned)k << 14) | (rescan ? 1u << 28 : 0u);
+          if (slot < MM_UPD_LDS) {
+            sh.upd[slot] = rec;
             sh.updv[slot] = nkj;
-          } else if constexpr (AGES) {
-            p.upd_g[slot - MM_UPD_MAX] = (unsigned)ik | (rescan ? 0x10000u : 0u);
-            p.updv_g[slot - MM_UPD_MAX] = nkj;
+            sh.updmv[slot] = mvk;
+          } else if (AGES || slot < MM_UPD_MAX) {  // (the tail of a long list: the row minimum stays in memory)
+            p.upd_g[slot - MM_UPD_LDS] = rec;
+            p.updv_g[slot - MM_UPD_LDS] = nkj;
           }
         } else if constexpr (AGES) {
-          if (l1 == i) st.lin1[k] = (idx_t)j;
-          if (l2 == i) st.lin2[k] = (idx_t)j;
+          if (l1 == i) st.lin1[k] = (hidx_t)j;
+          if (l2 == i) st.lin2[k] = (hidx_t)j;
           // k keeps its candidate.  The running best (:230-237) takes the first candidate WITHIN the clock with a
           // finite distance from whatever it holds, from then on nothing but a smaller one of that kind, and a slot
           // leaves that kind only for a smaller one of it: if one of the clusters that keep theirs holds such a
           // candidate, the best of the merge is the smallest (dist, dist2) among them all -- a reduction.  If none
           // does, wave 0 walks the list (below).
-          const float d1 = s_d1[qq];
-          const double d2 = s_d2d[qq];
-          if (s_lv[qq] <= lw_all && d1 < INF && (bd > d1 || (bd == d1 && bd2d > d2))) {
+          const float d1 = s_d1[sq];
+          const double d2 = s_d2d[sq];
+          if (s_lv[sq] <= lw_all && d1 < INF && (bd > d1 || (bd == d1 && bd2d > d2))) {
             bd = d1;
             bd2d = d2;
             bpos = ik;
+            bk = k;
           }
         } else {  // k keeps its candidate: what the reference's running best sees at k's turn
-          const float d1 = s_d1[qq], d2 = s_d2[qq];
+          const float d1 = s_d1[sq], d2 = s_d2[sq];
           if (bd > d1 || (bd == d1 && bd2 > d2)) {  // (ascending positions per thread: the first one wins)
             bd = d1;
             bd2 = d2;
             bpos = ik;
+            bk = k;
           }
         }
       }
     }
     mvj = wave_min_f(mvj);
     mv_cf = wave_min_f(mv_cf);
+    const int bpos_mine = bpos;
     if constexpr (AGES) wave_lex_min_d(bd, bd2d, bpos);
     else wave_lex_min(bd, bd2, bpos);
+    if (bpos < n && bpos_mine == bpos) sh.lex_k[wave] = bk;  // (one lane: positions are unique)
     if (lane == 0) {
       sh.wave_f[wave] = mvj;
       sh.wave_f2[wave] = mv_cf;
@@ -1083,21 +1124,17 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
       bail = 2;
       break;
     }
-    // (the AGES build keeps the list's tail in global memory)
-    auto upd_at = [&](int u) -> unsigned {
-      if constexpr (AGES) return u < MM_UPD_MAX ? sh.upd[u] : p.upd_g[u - MM_UPD_MAX];
-      else return sh.upd[u];
-    };
-    auto updv_at = [&](int u) -> float {
-      if constexpr (AGES) return u < MM_UPD_MAX ? sh.updv[u] : p.updv_g[u - MM_UPD_MAX];
-      else return sh.updv[u];
-    };
+    // (a list longer than MM_UPD_LDS has its tail in global memory; there the row minimum is read where it lives)
+    auto upd_at = [&](int u) -> unsigned { return u < MM_UPD_LDS ? sh.upd[u] : p.upd_g[u - MM_UPD_LDS]; };
+    auto updv_at = [&](int u) -> float { return u < MM_UPD_LDS ? sh.updv[u] : p.updv_g[u - MM_UPD_LDS]; };
+    auto updmv_at = [&](int u, int k) -> float { return u < MM_UPD_LDS ? sh.updmv[u] : st.mv[k]; };
+    auto rec_pos = [](unsigned e) -> int { return (int)(e & 0x3fffu); };
+    auto rec_k = [](unsigned e) -> int { return (int)((e >> 14) & 0x3fffu); };
+    auto rec_rescan = [](unsigned e) -> bool { return (e >> 28) != 0; };
     if (p.timers && tid == 0) {
       sh.tacc[12] += nupd * 100;
       sh.tacc[13] += sh.cnt_rescan_only * 100;
-#ifndef MM_EXP_GUESS
       sh.tacc[14] += nupd == 0 ? 100 : 0;
-#endif
       sh.tacc[15] += sh.cnt_rescan_only > 0 ? 100 : 0;
       sh.cnt_rescan_only = 0;
     }
@@ -1107,14 +1144,14 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
     // any smaller entry, else the row's minimum", three reductions finished by one wave per row --, then the
     // candidate tests of every pair a rebuilt cluster is part of (:1893-1911 for the clusters before it, :1913-2018
     // for the ones behind it), on the same registers when the merge has no more than ROWS rebuilt clusters.
-    f32x2 cj[MAXQ];  // row j of M as this thread wrote it in A, (d(j,k), d(k,j)): asked for now, used in C
+    float cj[MAXQ];  // row j of M as this thread wrote it in A, d(j,k): asked for now, used in C
 #pragma unroll
     for (int q = 0; q < MAXQ; q++) {
       if (q >= nq) break;
       const int k = a_k[q];
-      cj[q] = (k >= 0 && k != i && k != j) ? MM2(j, k) : f32x2{INF, INF};
+      cj[q] = (k >= 0 && k != i && k != j) ? MM1(j, k) : INF;
     }
-    float v[ROWS][MAXQ], w[ROWS][MAXQ];
+    float v[ROWS][MAXQ];  // d(k, l) along the rows of the rebuilt clusters k
     auto load_rows = [&](const int (&ks)[ROWS]) {
 #pragma unroll
       for (int r = 0; r < ROWS; r++) {
@@ -1122,19 +1159,18 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
 #pragma unroll
         for (int q = 0; q < MAXQ; q++) {
           if (q >= nq) break;
-          const f32x2 e = a_k[q] >= 0 ? MM2(ks[r], a_k[q]) : f32x2{INF, INF};
-          v[r][q] = e.x;
-          w[r][q] = e.y;
+          v[r][q] = a_k[q] >= 0 ? MM1(ks[r], a_k[q]) : INF;
         }
       }
     };
-    // rescans of the rows ks[r] >= 0 held in v; patch[r]: the row's new entry at column j (not in memory yet)
-    auto rescan_rows = [&](const int (&ks)[ROWS], const float (&patch)[ROWS]) {
+    // rescans of the rows ks[r] >= 0 (entries us[r] of the list) held in v; patch[r]: the row's new entry at column j
+    // (not in memory yet).  The new minimum goes to memory and, for the tests, to the list.
+    auto rescan_rows = [&](const int (&ks)[ROWS], const int (&us)[ROWS], const float (&patch)[ROWS]) {
 #pragma unroll
       for (int r = 0; r < ROWS; r++) {
         const int k = ks[r];
         if (k < 0) continue;
-        const float old = st.mv[k] - threshold;
+        const float old = updmv_at(us[r], k) - threshold;
         float fm = INF;
         int pos_old = n, pos_less = n;
 #pragma unroll
@@ -1157,10 +1193,13 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
         }
       }
       __syncthreads();
-      int myk = -1;  // one wave finishes one row
+      int myk = -1, myu = 0;  // one wave finishes one row
 #pragma unroll
       for (int r = 0; r < ROWS; r++)
-        if (wave == r) myk = ks[r];
+        if (wave == r) {
+          myk = ks[r];
+          myu = us[r];
+        }
       if (myk >= 0) {
         float fm = lane < MM_WAVES ? sh.red_f[wave][lane] : INF;
         int pos_old = lane < MM_WAVES ? sh.red_a[wave][lane] : n;
@@ -1168,9 +1207,11 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
         fm = wave_min_f(fm);
         pos_old = wave_min_i(pos_old);
         pos_less = wave_min_i(pos_less);
+        const float old = updmv_at(myu, myk) - threshold;
         if (lane == 0) {
-          const float old = st.mv[myk] - threshold;
-          st.mv[myk] = ((pos_old < n && pos_old < pos_less) ? old : fm) + threshold;
+          const float nv = ((pos_old < n && pos_old < pos_less) ? old : fm) + threshold;
+          st.mv[myk] = nv;
+          if (myu < MM_UPD_LDS) sh.updmv[myu] = nv;
         }
       }
       __syncthreads();
@@ -1188,88 +1229,103 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
         g[1] = ((unsigned)x << 16) | (unsigned)y;
       }
     };
+    // (slot q of this thread's registers for a q known at run time only -- the few survivors of a test: a chain of
+    //  selects, not an indexed array, which would live in scratch memory)
+    auto slot_k = [&](int q) -> int {
+      int k = -1;
+#pragma unroll
+      for (int x = 0; x < MAXQ; x++) k = x == q ? a_k[x] : k;
+      return k;
+    };
+    // this thread's cluster k in slot q: its row minimum as A found it, or -- rebuilt in this merge -- as the rescans left it
+    auto mv_now = [&](int q, int k) -> float {
+      if (st.flag[k]) return st.mv[k];
+      float x = INF;
+#pragma unroll
+      for (int y = 0; y < MAXQ; y++) x = y == q ? mvreg[y] : x;
+      return x;
+    };
     // candidate tests of the rows u0 .. u0+ROWS-1 of the list, held in v / w
     auto test_rows = [&](int u0) {
-      unsigned long long surv = 0;  // bit r * MAXQ + q: (row r, this thread's cluster q) is a feasible pair
 #pragma unroll
       for (int r = 0; r < ROWS; r++) {
         if (u0 + r >= nupd) continue;
-        const int up = (int)(upd_at(u0 + r) & 0xffffu);
-        const int ku = st.ci[up];
-        const float mvk = st.mv[ku];
+        const unsigned rec = upd_at(u0 + r);
+        const int up = rec_pos(rec), ku = rec_k(rec);
+        const float mvk = updmv_at(u0 + r, ku);
+        unsigned surv = 0;  // bit q: (row r, this thread's cluster q) passes the row's half of the test
 #pragma unroll
         for (int q = 0; q < MAXQ; q++) {
           if (q >= nq) break;
           const int l = a_k[q];
-          bool ok = l >= 0 && l != i && l != j && l != ku && v[r][q] <= mvk;
-          if (ok) {
-            // a later cluster meets the rebuilt ones before it; a rebuilt one meets them from its own row
-            if (q * MM_BLOCK + tid > up && st.flag[l]) ok = false;
-            if (!(w[r][q] <= st.mv[l])) ok = false;
-          }
-          surv |= ok ? 1ull << (r * MAXQ + q) : 0ull;
+          const bool ok = l >= 0 && l != i && l != j && l != ku && v[r][q] <= mvk;
+          surv |= ok ? 1u << q : 0u;
+        }
+        while (surv) {  // (few)
+          const int q = __ffs((int)surv) - 1;
+          surv &= surv - 1;
+          const int il = q * MM_BLOCK + tid, l = slot_k(q);
+          // a later cluster meets the rebuilt ones before it; a rebuilt one meets them from its own row
+          if (il > up && st.flag[l]) continue;
+          if (!(MMY(ku, l) <= mv_now(q, l))) continue;  // d(l, ku): the other half of the pair, from memory
+          if (il < up)  // the rebuilt cluster meets the clusters before it
+            append_pair(((unsigned)up << 16) | (unsigned)il, ku, l);
+          else
+            append_pair(((unsigned)il << 16) | (unsigned)up, l, ku);
         }
       }
-      while (surv) {  // (few)
-        const int bit = __ffsll((long long)surv) - 1;
-        surv &= surv - 1;
-        const int r = bit / MAXQ, q = bit - r * MAXQ;
-        const int il = q * MM_BLOCK + tid, l = st.ci[il];
-        const int up = (int)(upd_at(u0 + r) & 0xffffu), ku = st.ci[up];
-        if (il < up)  // the rebuilt cluster meets the clusters before it
-          append_pair(((unsigned)up << 16) | (unsigned)il, ku, l);
-        else
-          append_pair(((unsigned)il << 16) | (unsigned)up, l, ku);
-      }
     };
-    if (nupd <= ROWS && !(p.debug & 1)) {  // (the usual case) one pass
-      int ks[ROWS], kres[ROWS];
+    if (nupd <= ROWS) {  // (the usual case) one pass
+      int ks[ROWS], kres[ROWS], us[ROWS];
       float patch[ROWS];
       bool anyres = false;
 #pragma unroll
       for (int r = 0; r < ROWS; r++) {
         const unsigned e = r < nupd ? sh.upd[r] : 0u;
-        ks[r] = r < nupd ? (int)st.ci[e & 0xffffu] : -1;
-        kres[r] = (r < nupd && (e >> 16)) ? ks[r] : -1;
+        ks[r] = r < nupd ? rec_k(e) : -1;
+        kres[r] = (r < nupd && rec_rescan(e)) ? ks[r] : -1;
+        us[r] = r;
         patch[r] = r < nupd ? sh.updv[r] : INF;
         anyres |= kres[r] >= 0;
       }
       load_rows(ks);
-      if (anyres) rescan_rows(kres, patch);
+      if (anyres) rescan_rows(kres, us, patch);
       LAP(3);
       test_rows(0);
     } else {
       for (int u = 0; u < nupd;) {  // the flagged rows, ROWS at a time
-        int ks[ROWS];
+        int ks[ROWS], us[ROWS];
         float patch[ROWS];
         int cnt = 0;
 #pragma unroll
         for (int r = 0; r < ROWS; r++) {
           ks[r] = -1;
+          us[r] = 0;
           patch[r] = INF;
         }
         for (; u < nupd && cnt < ROWS; u++) {
           const unsigned e = upd_at(u);
-          if (!(e >> 16)) continue;
-          const int k = st.ci[e & 0xffffu];
+          if (!rec_rescan(e)) continue;
+          const int k = rec_k(e);
           const float pv = updv_at(u);
 #pragma unroll
           for (int r = 0; r < ROWS; r++)
             if (r == cnt) {
               ks[r] = k;
+              us[r] = u;
               patch[r] = pv;
             }
           cnt++;
         }
         if (cnt == 0) break;
         load_rows(ks);
-        rescan_rows(ks, patch);
+        rescan_rows(ks, us, patch);
       }
       LAP(3);
       for (int u0 = 0; u0 < nupd; u0 += ROWS) {
         int ks[ROWS];
 #pragma unroll
-        for (int r = 0; r < ROWS; r++) ks[r] = u0 + r < nupd ? (int)st.ci[upd_at(u0 + r) & 0xffffu] : -1;
+        for (int r = 0; r < ROWS; r++) ks[r] = u0 + r < nupd ? rec_k(upd_at(u0 + r)) : -1;
         load_rows(ks);
         test_rows(u0);
       }
@@ -1281,14 +1337,14 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
       for (int q = 0; q < MAXQ; q++) {
         if (q >= nq) break;
         const int k = a_k[q];
-        const bool ok = k >= 0 && k != i && k != j && cj[q].x <= min_value_j && cj[q].y <= st.mv[k];
+        const bool ok = k >= 0 && k != i && k != j && cj[q] <= min_value_j;
         cand |= ok ? 1u << q : 0u;
       }
       while (cand) {  // (few)
         const int q = __ffs((int)cand) - 1;
         cand &= cand - 1;
-        const int ik = q * MM_BLOCK + tid;
-        append_pair(0x80000000u | (unsigned)ik, st.ci[ik], j);
+        const int k = slot_k(q);
+        if (MMY(j, k) <= mv_now(q, k)) append_pair(0x80000000u | (unsigned)(q * MM_BLOCK + tid), k, j);
       }
     }
     __syncthreads();
@@ -1420,22 +1476,36 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
     // ordered part, which names clusters, not positions, from here on (the symmetric path, rare, keeps the list
     // until it is through)
     const bool sym_now = AGES || sh.use_sym != 0;  // (the AGES walk names positions: the list stays until it is through)
-    int nxt[MAXQ];
+    // The positions behind i move up by one: a lane takes its neighbour's cluster, the last lane of a wave the first
+    // lane's of the next wave (sh.edge, written before the barrier between the two halves).
     auto erase_read = [&]() {
-      const int ipos = sh.ipos;
+      if (lane == 0) {
 #pragma unroll
-      for (int q = 0; q < MAXQ; q++) {
-        nxt[q] = -1;
-        if (q >= nq) continue;
-        const int ik = q * MM_BLOCK + tid;
-        nxt[q] = (ik >= ipos && ik + 1 < n) ? (int)st.ci[ik + 1] : -1;
+        for (int q = 0; q < MAXQ; q++) {
+          if (q >= nq) break;
+          sh.edge[wave][q] = (short)a_k[q];
+        }
       }
-      for (int u = tid; u < nupd; u += MM_BLOCK) st.flag[st.ci[upd_at(u) & 0xffffu]] = 0;
+      for (int u = tid; u < nupd; u += MM_BLOCK) st.flag[rec_k(upd_at(u))] = 0;
     };
     auto erase_write = [&]() {
+      const int ipos = sh.ipos;
+      const bool mirror = CI_ALWAYS || sh.use_sym != 0;
 #pragma unroll
-      for (int q = 0; q < MAXQ; q++)
-        if (nxt[q] >= 0) st.ci[q * MM_BLOCK + tid] = (idx_t)nxt[q];
+      for (int q = 0; q < MAXQ; q++) {
+        if (q >= nq) break;
+        const int ik = q * MM_BLOCK + tid;
+        int nx = __shfl_down(a_k[q], 1, 64);
+        if (lane == 63) {
+          if (wave + 1 < MM_WAVES) nx = sh.edge[wave + 1][q];
+          else if (q + 1 < MAXQ) nx = sh.edge[0][q + 1];
+          else nx = -1;
+        }
+        if (ik >= ipos) {
+          a_k[q] = ik + 1 < n ? nx : -1;
+          if (mirror && ik + 1 < n) st.ci[ik] = (cidx_t)nx;
+        }
+      }
       if (tid == 0) sh.n = n - 1;
     };
     // The best among the clusters that keep their candidate (a copy taken before the draws: they may still
@@ -1447,76 +1517,25 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
       ud = lane < MM_WAVES ? sh.lex_d[lane] : INF;
       ud2 = lane < MM_WAVES ? sh.lex_d2[lane] : INF;
       upos = lane < MM_WAVES ? sh.lex_p[lane] : n;
+      const int upos_mine = upos;
       if constexpr (AGES) {
         ud2d = lane < MM_WAVES ? sh.lex_d2d[lane] : (double)INF;
         wave_lex_min_d(ud, ud2d, upos);
       } else {
         wave_lex_min(ud, ud2, upos);
       }
-      if (upos < n) {
-        const int kb = st.ci[upos];
+      if (upos < n) {  // (the cluster at that position: its wave left it in lex_k)
+        const unsigned long long from = __ballot(lane < MM_WAVES && upos_mine == upos);
+        const int kb = sh.lex_k[__builtin_ctzll(from)];
         bl1 = st.lin1[kb];
         bl2 = st.lin2[kb];
       }
-#ifdef MM_PREFETCH
-      if (lane == 0) {
-        sh.guess_i = upos < n ? bl1 : -1;
-        sh.guess_j = upos < n ? bl2 : -1;
-      }
-#endif
     }
     if (!sym_now) {
       erase_read();
       __syncthreads();
       erase_write();
     }
-#ifdef MM_PREFETCH
-    // (experiment, off: -DMM_PREFETCH) While wave 0 is in the ordered part the other seven ask for the rows of the LIKELY
-    // next pair -- the best of the clusters that keep their candidate is the next pair in 56 % of the merges
-    // (-DMM_EXP_GUESS counts them) -- so that phase A of the next merge finds them in the L2.  Measured on three real
-    // N = 5000 builds (tools/bench_builder_variants.sh): A 29.6 -> 25.4 ms per tree either way, but (1) into a register
-    // the loads have to land before the register is anybody else's, and that wait at the end of the merge costs 9.6 ms:
-    // 112.9 -> 119.4 ms per tree; (2) -DMM_PREFETCH_LDS: straight into LDS (global_load_lds_dword, nothing to wait for)
-    // with a bare s_barrier at the end of the merge -- issuing the ~23 loads per thread and their addresses costs what
-    // A gains (the ordered part, which shares its SIMD with a prefetching wave, +1.5 ms, the wait for the seven waves
-    // +2.1): 113.0 -> 112.9 ms per tree.
-    if constexpr (LDS && !AGES) {
-      const int gi = sh.guess_i, gj = sh.guess_j;
-      if (wave != 0 && !sym_now && gi >= 0 && gj >= 0 && gi != i && gj != i && gi < N && gj < N) {
-#ifdef MM_PREFETCH_LDS
-        const unsigned dump = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void *)sh.pf_dump;
-#endif
-        auto ask = [&](int row, int k) {
-          MM_GLOBAL_PTR(const f32x4) ptr = p.M + mm_index((unsigned)row, (unsigned)k, (unsigned)N);
-#ifdef MM_PREFETCH_LDS
-          // straight into LDS: no register to keep, nothing to wait for (the compiler does not know of these loads;
-          // its own waits are for younger ones and the counter runs in order)
-          asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dword %0, off" : : "v"(ptr), "s"(dump) : "memory", "m0");
-#else
-          pf_sink ^= ((MM_GLOBAL_PTR(const int))ptr)[0];
-#endif
-        };
-#pragma unroll
-        for (int q = 0; q < MAXQ; q++) {
-          if (q >= nq) break;
-          const int k = a_k[q];
-          if (k >= 0) {
-            ask(gi, k);
-            ask(gj, k);
-          }
-          if (q % (MM_WAVES - 1) == wave - 1) {  // wave 0's columns, dealt to the others
-            const int pos0 = q * MM_BLOCK + lane;
-            if (pos0 < n - 1) {
-              const int k0 = st.ci[pos0];
-              ask(gi, k0);
-              ask(gj, k0);
-            }
-          }
-        }
-        asm volatile("" : "+v"(pf_sink));  // (the loads are waited for here)
-      }
-    }
-#endif
     if (p.timers && tid == 0) sh.tacc[10] += wall_clock64() - sh.tmark;  // (of "ordered": before the first draw)
     if constexpr (AGES) {
       if (wave == 0) {
@@ -1603,7 +1622,7 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
           if (p.has_prior) st.mvcf[j] = mvcf_j;
           st.mcd[j] = INF;
           st.d2d[j] = (double)INF;
-          st.lv[j] = (idx_t)MM_AGE_EMPTY;
+          st.lv[j] = (hidx_t)MM_AGE_EMPTY;
         }
         AgeCand js{INF, (double)INF, MM_AGE_EMPTY, -1, -1};
         while (e < m) {
@@ -1632,12 +1651,12 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
         if (!(a_age >= before)) a_lw = -1;  // (0 or 1 lineages: the step is not a number the clock can add)
         clock_reaches();
         if (lane == 0) {
-          st.alv[j] = (idx_t)newl;
+          st.alv[j] = (cidx_t)newl;
           sh.a_lw = a_lw;
           sh.best.dist = abest.d;
           sh.best.lin1 = abest.l1;
           sh.best.lin2 = abest.l2;
-          st.csz[j] = (idx_t)(szi + szj);
+          st.csz[j] = (cidx_t)(szi + szj);
           sh.nupd = 0;
           sh.npairs = 0;
         }
@@ -1698,7 +1717,6 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
           pos = spos;
         }
       }
-      const int szi = st.csz[i], szj = st.csz[j];
       if (lane == 0) {
         st.mv[j] = min_value_j;
         if (p.has_prior) st.mvcf[j] = mvcf_j;
@@ -1719,11 +1737,8 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
         b.lin2 = st.lin2[j];
       }
       if (lane == 0) {
-#ifdef MM_EXP_GUESS  // (experiment: how often the best of the clusters that keep their candidate is the next pair)
-        if (p.timers) sh.tacc[14] += (upos < n && b.lin1 == bl1 && b.lin2 == bl2) ? 100 : 0;
-#endif
         sh.best = b;
-        st.csz[j] = (idx_t)(szi + szj);
+        st.csz[j] = (cidx_t)(int)added;  // (exact integers in floats)
         sh.nupd = 0;
         sh.npairs = 0;
       }
@@ -1835,22 +1850,15 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
       erase_write();
     }
     LAP(7);
-#ifdef MM_PREFETCH_LDS
-    // (a bare barrier: the fence of __syncthreads would wait for the words asked for ahead; nothing global is written
-    //  between the erase's barrier and this one when the state lives in LDS, the LDS writes are waited for)
-    if (LDS && !AGES && !sym_now) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else __syncthreads();
-#else
     __syncthreads();
-#endif
     LAP(8);
   }
   if (bail < 0) {
-    if constexpr (LDS) {  // the carried state goes out
+    if constexpr (LAY != L_GLOBAL) {  // the carried state goes out (pinned host memory)
       for (int c = tid; c < N; c += MM_BLOCK) {
-        p.mc_lin1[c] = (int)st.lin1[c];
-        p.mc_lin2[c] = (int)st.lin2[c];
-        p.min_values_CF[c] = st.mvcf[c];
+        p.io_lin[c] = (int)st.lin1[c];
+        p.io_lin[(size_t)N + c] = (int)st.lin2[c];
+        p.io_mvcf[c] = st.mvcf[c];
       }
     }
     if (tid == 0 && p.timers) {
@@ -1876,6 +1884,7 @@ __device__ inline void params_from_words(MMParamsDev &p, const unsigned *w) {
 
 // The builders' requests of one device and tree size, in pinned host memory: the host writes a request's words, then
 // `tail`; workers claim tickets from `head` (device memory) and read the words of their ticket.
+constexpr int MM_STAGING = 32;      // staging pairs (row-major distance matrix + clade prior of a tree, K3 -> weave) per device
 constexpr int MM_QUEUE_CAP = 1024;  // requests in flight <= builders alive (a section has one tree in flight)
 constexpr int MM_LAUNCHES = 6;      // worker launches alive at once (a stream, i.e. a hardware queue, each)
 constexpr int MM_XCDS = 8;          // a launch's workgroups are dealt to the XCDs in turn
@@ -1883,8 +1892,6 @@ struct WorkQueue {
   unsigned tail;
   unsigned pad[15];
   unsigned gone[16];  // per launch: workers that have left (the host counts a launch's LIVE workers, not its size)
-  unsigned retire[16];  // per launch: its workers leave after the tree they are building (the launcher, when RePaint
-                        // needs the CUs more than the trees do)
   unsigned words[MM_QUEUE_CAP][MM_PARAM_WORDS];
 };
 // device memory: the ticket counter, and per launch how many of its workers are building and when one last was
@@ -1906,14 +1913,15 @@ static_assert(sizeof(MMParams) % 4 == 0 && sizeof(MMParams) / 4 <= MM_PARAM_WORD
 // its last workgroup is gone, so workers that trickled away one by one would leave streams occupied by a few
 // stragglers and no way to bring the others back.  Nothing a worker waits for can fail to arrive: the only loop
 // without a tree in it is the idle one, bounded by the clock.
-template <bool LDS, int MAXQ, bool AGES = false>
-__global__ void __launch_bounds__(MM_BLOCK, 1)
+// OCC workgroups per CU: 2 * OCC waves per SIMD, 256 / OCC registers per lane (the plain build at N <= 5120: two).
+template <int LAY, int MAXQ, bool AGES, int OCC>
+__global__ void __launch_bounds__(MM_BLOCK) __attribute__((amdgpu_waves_per_eu(2 * OCC, 2 * OCC)))
     minmatch_worker(WorkQueue *q, WorkerState *ws, int launch, long long idle_ticks, int trace) {
   __shared__ Shared sh;
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
   const int tid = threadIdx.x;
   auto &mine = ws->launch[launch];
-  // (progress marks for RELATE_AMD_MM_TRACE, in the queue's spare words: workers started / tickets claimed / trees
+  // (progress marks for RELATE_AMD_TIMING=2, in the queue's spare words: workers started / tickets claimed / trees
   //  left / workers gone)
   auto mark = [&](int which) {
     if (trace && tid == 0) __hip_atomic_fetch_add(&q->pad[which], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1936,7 +1944,6 @@ __global__ void __launch_bounds__(MM_BLOCK, 1)
       unsigned seen = __hip_atomic_load(&mine.activity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       long long since = wall_clock64();
       for (;;) {
-        if (__hip_atomic_load(&q->retire[launch], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) break;  // (the launch is sent home)
         const unsigned h = __hip_atomic_load(&ws->head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned t = __hip_atomic_load(&q->tail, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
         if ((int)(t - h) > 0) {
@@ -1977,7 +1984,9 @@ __global__ void __launch_bounds__(MM_BLOCK, 1)
     __syncthreads();
     MMParamsDev p;
     params_from_words(p, sh.praw);
-    build_tree<LDS, MAXQ, AGES>(p, sh, dyn);
+    // rows of rebuilt clusters per pass of a merge: two while the registers allow (2: 110 ms per N = 5000 tree, 3: 119,
+    // 4: 134 with 256 registers per lane)
+    build_tree<LAY, MAXQ, AGES, (OCC > 1 || MAXQ > MM_Q_LDS) ? 1 : 2>(p, sh, dyn);
     __syncthreads();  // (sh is the next tree's)
     had_tree = true;
   }
@@ -2030,9 +2039,9 @@ __global__ void __launch_bounds__(256) rowmin_penalty_kernel(float *__restrict__
 // them (a wave reads 256 contiguous bytes of a row), d(b,a) and cf(b,a) -- 64 rows b, 32 columns -- through LDS;
 // a wave's store is 1 KB of M's panel.  The next panel's loads are in flight while this one is woven.
 constexpr int WV_ROWS = 32;
-// (TWO_WAY = false: every strip walks ALL panels and weaves its own rows only -- each element read twice, no
-//  512-byte runs; kept for A/B runs, RELATE_AMD_WEAVE_ONE_WAY=1)
-template <bool PRIOR, bool TWO_WAY = true>
+// (Every strip walking ALL panels and weaving its own rows only -- each element read twice, no 512-byte runs -- was
+//  within the noise of this in the C3 stage: removed, DESIGN_NOTES.md 11.)
+template <bool PRIOR>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) weave_kernel(const float *__restrict__ D, const float *__restrict__ CF,
                                                     float4 *__restrict__ M, int N, const float *__restrict__ rowmin_D,
                                                     const float *__restrict__ rowmin_CF,
@@ -2099,9 +2108,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) w
   // the diagonal panel is woven both ways -- M[a][b] for the strip's rows, a wave's store 1 KB of panel pb, and
   // M[b][a] = (d(b,a), d(a,b), cf(b,a), cf(a,b)) for the panel's 64 rows b at the strip's 32 columns, 512 B runs of
   // panel pa -- so nobody reads the tiles left of its diagonal.
-  const int pa = TWO_WAY ? a0 / 64 : 0;
+  const int pa = a0 / 64;
   auto weave = [&](int pb, const Panel &q) {
-    const bool both = TWO_WAY && pb > pa;  // (wave-uniform)
+    const bool both = pb > pa;  // (wave-uniform)
 #pragma unroll
     for (int k = 0; k < 8; k++) {
       tD[trow][tcol + k] = q.td[k];
@@ -2226,22 +2235,60 @@ int rng_restatement_mismatches(unsigned seed, int n) {
 }
 
 // ---- host side
-// dynamic LDS of a build whose per-cluster state lives there: 4 floats, 4 shorts and a flag per cluster
-// (with sample ages: the draw as a double instead of a float, two more shorts -- 33 bytes)
-static size_t lds_state_bytes(int N, bool ages = false) { return (((size_t)(ages ? 33 : 25) * N) + 255) & ~(size_t)255; }
-// ... and whether it fits next to the kernel's static LDS (160 KB per workgroup on gfx950)
-static bool lds_state_fits(int N, bool ages = false) {
-  static std::atomic<size_t> fixed[2];  // (a property of the code object, the same on every device)
-  size_t f = fixed[ages].load();
-  if (!f) {
-    hipFuncAttributes a;
-    const void *fn = ages ? reinterpret_cast<const void *>(&minmatch_worker<true, MM_Q_LDS, true>)
-                          : reinterpret_cast<const void *>(&minmatch_worker<true, MM_Q_LDS>);
-    if (hipFuncGetAttributes(&a, fn) != hipSuccess) return false;
-    fixed[ages].store(f = a.sharedSizeBytes);
-  }
-  return N <= MM_Q_LDS * MM_BLOCK && f + lds_state_bytes(N, ages) <= (size_t)160 * 1024;
+// The worker kernel for trees of N leaves: where the state lives, register slots per thread, workgroups per CU.
+//   plain build: L_HOT for every N -- 13 bytes of LDS per cluster next to ~14 KB of lists: two workgroups per CU up to
+//                N = 5120 (4 slots per thread up to N = 2048, 10 above), one with 20 slots up to N = 10,240;
+//   AGES build:  everything in LDS (33 bytes per cluster) up to N = 4100, in global memory above.
+struct WorkerKind {
+  int layout, maxq, occ;
+  bool ages;
+  const void *fn;
+  size_t dyn;  // dynamic LDS per workgroup
+};
+static size_t lds_state_bytes(int layout, int N) {
+  const size_t per = layout == L_LDS ? 33 : layout == L_HOT ? 13 : layout == L_WARM ? 21 : 0;
+  return (per * (size_t)N + 255) & ~(size_t)255;
 }
+static size_t static_lds(const void *fn) {
+  hipFuncAttributes a;
+  return hipFuncGetAttributes(&a, fn) == hipSuccess ? a.sharedSizeBytes : (size_t)1 << 30;
+}
+static WorkerKind worker_kind(int N, bool ages) {
+  const size_t lds_cu = (size_t)160 * 1024;
+  WorkerKind k{};
+  k.ages = ages;
+  if (ages) {
+    const void *f_lds = reinterpret_cast<const void *>(&minmatch_worker<L_LDS, MM_Q_LDS, true, 1>);
+    if (N <= MM_Q_LDS * MM_BLOCK && static_lds(f_lds) + lds_state_bytes(L_LDS, N) <= lds_cu)
+      k = WorkerKind{L_LDS, MM_Q_LDS, 1, true, f_lds, lds_state_bytes(L_LDS, N)};
+    else if (N <= MM_Q_LDS * MM_BLOCK)
+      k = WorkerKind{L_GLOBAL, MM_Q_LDS, 1, true, reinterpret_cast<const void *>(&minmatch_worker<L_GLOBAL, MM_Q_LDS, true, 1>), 0};
+    else
+      k = WorkerKind{L_GLOBAL, MM_Q_GLOB, 1, true, reinterpret_cast<const void *>(&minmatch_worker<L_GLOBAL, MM_Q_GLOB, true, 1>), 0};
+    return k;
+  }
+  const size_t dyn = lds_state_bytes(L_HOT, N);
+  // Two workgroups per CU (128 registers per lane) pay where HBM holds hundreds of sections' trees at once (small N);
+  // at N = 5000 a stage has ~134 sections open and a tree's latency decides: one per CU at 256 registers per lane
+  // (profiles/r06_builder_many.jsonl).  RELATE_AMD_BUILD_OCC=1 / 2 decides otherwise.
+  static const int occ_env = getenv("RELATE_AMD_BUILD_OCC") ? atoi(getenv("RELATE_AMD_BUILD_OCC")) : 0;
+  const int occ_max = occ_env > 0 ? occ_env : (N <= MM_Q_SMALL * MM_BLOCK ? 2 : 1);
+  if (N <= MM_Q_SMALL * MM_BLOCK && occ_max >= 2) {
+    const void *f = reinterpret_cast<const void *>(&minmatch_worker<L_HOT, MM_Q_SMALL, false, 2>);
+    if (2 * (static_lds(f) + dyn) <= lds_cu) return WorkerKind{L_HOT, MM_Q_SMALL, 2, false, f, dyn};
+  }
+  if (N <= MM_Q_LDS * MM_BLOCK && occ_max >= 2) {
+    const void *f = reinterpret_cast<const void *>(&minmatch_worker<L_HOT, MM_Q_LDS, false, 2>);
+    if (2 * (static_lds(f) + dyn) <= lds_cu) return WorkerKind{L_HOT, MM_Q_LDS, 2, false, f, dyn};
+  }
+  if (N <= MM_Q_LDS * MM_BLOCK) {  // one per CU: the row minima in LDS too
+    const void *f = reinterpret_cast<const void *>(&minmatch_worker<L_WARM, MM_Q_LDS, false, 1>);
+    return WorkerKind{L_WARM, MM_Q_LDS, 1, false, f, lds_state_bytes(L_WARM, N)};  // (107 + 15 KB at N = 5120)
+  }
+  return WorkerKind{L_HOT, MM_Q_GLOB, 1, false, reinterpret_cast<const void *>(&minmatch_worker<L_HOT, MM_Q_GLOB, false, 1>), dyn};
+}
+// workgroups of a tree's worker kernel a CU holds
+int device_builder_workers_per_cu(int N, bool ages) { return worker_kind(N, ages).occ; }
 
 static int env_int(const char *name, int fallback, int lo, int hi) {
   const char *e = getenv(name);
@@ -2320,7 +2367,7 @@ class DeviceShare {
   void sym_pool(int N, float **base, int **locks, int *slots) {
     std::lock_guard<std::mutex> lk(m_);
     if (sym_n_ < N) {
-      int want = env_int("RELATE_AMD_BUILD_SYM_SLOTS", 8, 0, 64);
+      int want = env_int("RELATE_AMD_TEST_SYM_SLOTS", 8, 0, 64);
       DevBuf nb, nl;
       while (want > 0 && nb.alloc((size_t)want * N * N * 4)) want /= 2;
       if (want > 0 && !nl.alloc(64 * 4) && hipMemset(nl.p, 0, 64 * 4) == hipSuccess) {
@@ -2356,12 +2403,12 @@ class DeviceShare {
   }
   // bytes of HBM the shared pools take for trees of N leaves (the stage's admission counts them once)
   static double bytes(int N) {
-    return (double)env_int("RELATE_AMD_BUILD_STAGING", 32, 1, 128) * 8.0 * N * N +
-           (double)env_int("RELATE_AMD_BUILD_SYM_SLOTS", 8, 0, 64) * 4.0 * N * N;
+    return (double)MM_STAGING * 8.0 * N * N +
+           (double)env_int("RELATE_AMD_TEST_SYM_SLOTS", 8, 0, 64) * 4.0 * N * N;
   }
 
  private:
-  DeviceShare() : cap_(env_int("RELATE_AMD_BUILD_STAGING", 32, 1, 128)) {}
+  DeviceShare() : cap_(MM_STAGING) {}
   std::mutex m_;
   std::condition_variable cv_;
   std::vector<Staging *> free_;
@@ -2393,10 +2440,9 @@ class BuildQueue {
     static std::mutex gm;
     static std::vector<BuildQueue *> *all = new std::vector<BuildQueue *>();
     std::lock_guard<std::mutex> lk(gm);
-    const bool lds = lds_state_fits(N, ages);
     for (BuildQueue *q : *all)
       if (q->device_ == device && q->N_ == N && q->ages_ == ages) return q;
-    BuildQueue *q = new BuildQueue(device, N, lds, ages);
+    BuildQueue *q = new BuildQueue(device, N, ages);
     if (!q->ok_) return nullptr;
     all->push_back(q);
     return q;
@@ -2413,7 +2459,7 @@ class BuildQueue {
       std::lock_guard<std::mutex> lk(m_);
       const unsigned t = published_++;
       MMParams pp = p;
-      pp.trace = getenv("RELATE_AMD_MM_TRACE") ? &q_->pad[8] : nullptr;
+      pp.trace = timing_level() >= 2 ? &q_->pad[8] : nullptr;
       memcpy(q_->words[t % MM_QUEUE_CAP], &pp, sizeof(MMParams));
       __atomic_store_n(&q_->tail, published_, __ATOMIC_RELEASE);
       outstanding_++;
@@ -2421,7 +2467,7 @@ class BuildQueue {
     cv_.notify_one();
     int rc = 0;
     const auto t0 = std::chrono::steady_clock::now();
-    static const bool trace = getenv("RELATE_AMD_MM_TRACE") != nullptr;
+    static const bool trace = (timing_level() >= 2);
     auto last_trace = t0;
     for (unsigned spins = 0;; spins++) {
       if (__atomic_load_n(p.host_done, __ATOMIC_ACQUIRE) != -1) break;
@@ -2456,7 +2502,7 @@ class BuildQueue {
   }
 
  private:
-  BuildQueue(int device, int N, bool lds, bool ages) : device_(device), N_(N), lds_(lds), ages_(ages) {
+  BuildQueue(int device, int N, bool ages) : device_(device), N_(N), ages_(ages), kind_(worker_kind(N, ages)) {
     if (hipSetDevice(device) != hipSuccess) return;
     if (hipHostMalloc(reinterpret_cast<void **>(&q_), sizeof(WorkQueue), hipHostMallocCoherent) != hipSuccess) return;
     memset(q_, 0, sizeof(WorkQueue));
@@ -2464,11 +2510,10 @@ class BuildQueue {
     int cus = 256;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-    // a worker has a CU to itself (150 KB of LDS, 8 waves of 256 registers); an eighth of the chip stays free for
-    // the stage's short kernels (RePaint, distance matrices, weave)
-    cap_ = env_int("RELATE_AMD_BUILD_WORKERS", cus - cus / 8, 1, 1024);
+    // `occ` workers share a CU; an eighth of the chip stays free for the stage's short kernels (RePaint, distance
+    // matrices, weave) unless the stage says otherwise (expect())
+    cap_ = env_int("RELATE_AMD_BUILD_WORKERS", kind_.occ * (cus - cus / 8), 1, 1024);
     cap_from_env_ = getenv("RELATE_AMD_BUILD_WORKERS") != nullptr;
-    idle_ms_ = env_int("RELATE_AMD_BUILD_IDLE_MS", 50, 1, 10000);
     ok_ = true;
     std::thread([this] { launcher(); }).detach();
   }
@@ -2484,42 +2529,18 @@ class BuildQueue {
         failed_.store(true);
         return;
       }
-    size_t dyn = 0;
-    if (lds_) {  // the per-cluster state of a build in LDS: more than the default 64 KB of dynamic LDS
-      const void *fn = ages_ ? reinterpret_cast<const void *>(&minmatch_worker<true, MM_Q_LDS, true>)
-                             : reinterpret_cast<const void *>(&minmatch_worker<true, MM_Q_LDS>);
-      hipFuncAttributes a;
-      if (hipFuncGetAttributes(&a, fn) != hipSuccess ||
-          hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)a.sharedSizeBytes) != hipSuccess) {
-        failed_.store(true);
-        return;
-      }
-      dyn = lds_state_bytes(N_, ages_);
+    const size_t dyn = kind_.dyn;
+    // (the per-cluster state of a build in LDS: more than the default 64 KB of dynamic LDS)
+    if (dyn > 0 && hipFuncSetAttribute(kind_.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) {
+      failed_.store(true);
+      return;
     }
     const bool verbose = getenv("RELATE_AMD_TIMING") != nullptr;
-    // RELATE_AMD_ADAPTIVE_WORKERS=lo:start:hi (experiment): the worker count follows RePaint's queue.  RePaint and the
-    // per-tree kernels run on the CUs the workers leave; with too many workers every section waits seconds for its
-    // window's next part, with too few the trees wait for a worker -- and where the edge lies moves with the box and
-    // the phase of the stage (C3: 143 s and 185 s from the same 124 workers).  Every 2 s: more than `hi_wait` section
-    // threads waiting for the lane on average -> the smallest launch is sent home (its workers leave after their
-    // tree); fewer than `lo_wait` -> eight more workers may come.
-    int a_lo = 0, a_start = 0, a_hi = 0, dyn_goal = 1 << 30;
-    if (const char *e = getenv("RELATE_AMD_ADAPTIVE_WORKERS"))
-      if (sscanf(e, "%d:%d:%d", &a_lo, &a_start, &a_hi) == 3 && a_lo > 0 && a_lo <= a_start && a_start <= a_hi) dyn_goal = a_start;
-    const double hi_wait = getenv("RELATE_AMD_ADAPTIVE_HI") ? atof(getenv("RELATE_AMD_ADAPTIVE_HI")) : 8.0;
-    const double lo_wait = getenv("RELATE_AMD_ADAPTIVE_LO") ? atof(getenv("RELATE_AMD_ADAPTIVE_LO")) : 2.0;
-    double wait_sum = 0.0;
-    long long wait_n = 0;
-    auto wait_t0 = std::chrono::steady_clock::now();
-    bool retiring[MM_LAUNCHES] = {};
-    int ceiling = 1 << 30;
-    const int hold_s = getenv("RELATE_AMD_ADAPTIVE_HOLD") ? atoi(getenv("RELATE_AMD_ADAPTIVE_HOLD")) : 30;
-    auto ceiling_until = std::chrono::steady_clock::now();
     for (;;) {
       int demand = 0, goal = 0;
       {
         std::unique_lock<std::mutex> lk(m_);
-        static const bool trace = getenv("RELATE_AMD_MM_TRACE") != nullptr;
+        static const bool trace = (timing_level() >= 2);
         while (trace && !cv_.wait_for(lk, std::chrono::milliseconds(500), [&] { return outstanding_ > 0; })) {
           fprintf(stderr, "[mm trace] N=%d idle: published %u, workers started %u, tickets claimed %u, trees left %u, workers "
                   "gone %u; streams busy:", N_, __atomic_load_n(&q_->tail, __ATOMIC_ACQUIRE),
@@ -2550,8 +2571,6 @@ class BuildQueue {
         // (the stage's word, expect(), is a limit -- it knows what RePaint needs of the chip; RELATE_AMD_BUILD_WORKERS
         //  overrides it)
         goal = (expected_ > 0 && !cap_from_env_) ? std::min(cap_, expected_) : cap_;
-        // (adaptive: the stage's word -- its rule of thumb for bounded windows -- gives way to what RePaint's queue says)
-        if (a_hi > 0) goal = std::min(cap_, dyn_goal);
         // whole rounds of the XCDs (below): the goal too
         if (goal >= MM_XCDS) goal -= goal % MM_XCDS;
       }
@@ -2561,60 +2580,10 @@ class BuildQueue {
           size[l] = 0;
           g_worker_launches.fetch_sub(1);
         }
-        if (size[l] == 0 && retiring[l]) {  // (sent home and gone: the stream can carry a launch again)
-          retiring[l] = false;
-          __atomic_store_n(&q_->retire[l], 0u, __ATOMIC_RELEASE);
-        }
         // (workers decide to leave one by one -- idle past the limit and nobody of the launch building --, so a late
         //  claim can keep one of them at work while its peers are gone: a launch counts for the workers it still has)
-        if (!retiring[l]) alive += size[l] - std::min(size[l], (int)__atomic_load_n(&q_->gone[l], __ATOMIC_ACQUIRE));
+        alive += size[l] - std::min(size[l], (int)__atomic_load_n(&q_->gone[l], __ATOMIC_ACQUIRE));
         if (size[l] == 0 && free_stream < 0) free_stream = l;
-      }
-      if (a_hi > 0) {
-        wait_sum += (double)g_repaint_waiting.load();
-        wait_n++;
-        const auto nowt = std::chrono::steady_clock::now();
-        if (nowt - wait_t0 > std::chrono::seconds(2)) {
-          const double avg = wait_sum / (double)std::max<long long>(1, wait_n);
-          wait_sum = 0.0;
-          wait_n = 0;
-          wait_t0 = nowt;
-          bool sent_home = false;
-          if (avg > hi_wait && alive > a_lo) {
-            int pick = -1;
-            for (int l = 0; l < MM_LAUNCHES; l++) {
-              const int live = size[l] - std::min(size[l], (int)__atomic_load_n(&q_->gone[l], __ATOMIC_ACQUIRE));
-              if (size[l] > 0 && !retiring[l] && live > 0 && alive - live >= a_lo &&
-                  (pick < 0 || size[l] < size[pick]))
-                pick = l;
-            }
-            if (pick >= 0) {
-              const int live = size[pick] - std::min(size[pick], (int)__atomic_load_n(&q_->gone[pick], __ATOMIC_ACQUIRE));
-              retiring[pick] = true;
-              __atomic_store_n(&q_->retire[pick], 1u, __ATOMIC_RELEASE);
-              // (the count at which the queue formed is remembered for a while: the edge is sharp -- one section
-              //  waiting on average at 112 workers, twenty at 120 -- and every visit beyond it costs all sections seconds)
-              ceiling = std::max(a_lo, std::min(dyn_goal, alive) - MM_XCDS);
-              ceiling_until = nowt + std::chrono::seconds(hold_s);
-              dyn_goal = std::max(a_lo, alive - live);
-              alive -= live;
-              sent_home = true;
-              if (verbose) {
-                fprintf(stderr, "[tree builder workers] %.1f sections waiting for RePaint: launch %d (%d workers) sent home, goal %d, "
-                        "no more than %d for %d s\n", avg, pick, live, dyn_goal, ceiling, hold_s);
-                fflush(stderr);
-              }
-            }
-          }
-          const int limit = nowt < ceiling_until ? std::min(a_hi, ceiling) : a_hi;
-          if (!sent_home && avg < lo_wait && dyn_goal < limit && alive + MM_XCDS > dyn_goal) {
-            dyn_goal = std::min(limit, dyn_goal + MM_XCDS);
-            if (verbose) {
-              fprintf(stderr, "[tree builder workers] %.1f sections waiting for RePaint: goal %d\n", avg, dyn_goal);
-              fflush(stderr);
-            }
-          }
-        }
       }
       // Workers follow the trees that are waiting or being built, not the sections that exist: a section spends half
       // of its time outside the build (distance matrix, RePaint, mapping), and a worker without a tree still holds
@@ -2641,22 +2610,15 @@ class BuildQueue {
         const int l = free_stream;
         __atomic_store_n(&q_->gone[l], 0u, __ATOMIC_RELEASE);  // (the stream's previous launch is through)
         const long long idle = (long long)idle_ms_ * 100000LL;
-        const int trace_flag = getenv("RELATE_AMD_MM_TRACE") ? 1 : 0;
-        if (ages_ && lds_)
-          hipLaunchKernelGGL((minmatch_worker<true, MM_Q_LDS, true>), dim3((unsigned)n), dim3(MM_BLOCK), dyn, streams[l], q_,
-                             d_state_.as<WorkerState>(), l, idle, trace_flag);
-        else if (ages_ && N_ <= MM_Q_LDS * MM_BLOCK)
-          hipLaunchKernelGGL((minmatch_worker<false, MM_Q_LDS, true>), dim3((unsigned)n), dim3(MM_BLOCK), 0, streams[l], q_,
-                             d_state_.as<WorkerState>(), l, idle, trace_flag);
-        else if (ages_)
-          hipLaunchKernelGGL((minmatch_worker<false, MM_Q_GLOB, true>), dim3((unsigned)n), dim3(MM_BLOCK), 0, streams[l], q_,
-                             d_state_.as<WorkerState>(), l, idle, trace_flag);
-        else if (lds_)
-          hipLaunchKernelGGL((minmatch_worker<true, MM_Q_LDS>), dim3((unsigned)n), dim3(MM_BLOCK), dyn, streams[l], q_,
-                             d_state_.as<WorkerState>(), l, idle, trace_flag);
-        else
-          hipLaunchKernelGGL((minmatch_worker<false, MM_Q_GLOB>), dim3((unsigned)n), dim3(MM_BLOCK), 0, streams[l], q_,
-                             d_state_.as<WorkerState>(), l, idle, trace_flag);
+        const int trace_flag = timing_level() >= 2 ? 1 : 0;
+        {
+          WorkQueue *a_q = q_;
+          WorkerState *a_ws = d_state_.as<WorkerState>();
+          int a_l = l, a_trace = trace_flag;
+          long long a_idle = idle;
+          void *args[] = {&a_q, &a_ws, &a_l, &a_idle, &a_trace};
+          (void)hipLaunchKernel(kind_.fn, dim3((unsigned)n), dim3(MM_BLOCK), args, dyn, streams[l]);
+        }
         if (hipGetLastError() != hipSuccess) {
           // (this thread ends: the launches it still counted alive are nobody's to take off the count any more --
           //  the memory cache would wait for them on every failed allocation, and never trim)
@@ -2680,7 +2642,8 @@ class BuildQueue {
     }
   }
   int device_, N_;
-  bool lds_, ages_, ok_ = false;
+  bool ages_, ok_ = false;
+  WorkerKind kind_;
   WorkQueue *q_ = nullptr;
   DevBuf d_state_;
   int cap_ = 224, idle_ms_ = 50;
@@ -2786,6 +2749,19 @@ float *DeviceMinMatch::device_matrix() {
   return m.staging ? m.staging->D.as<float>() : nullptr;
 }
 
+int DeviceMinMatch::stage_from_device(const float *dD, const float *dCF) {
+  Impl &m = *impl;
+  RL_HIP(hipSetDevice(m.device));
+  if (!m.stream) RL_HIP(make_stream(&m.stream, false, true));
+  if (!m.staging) m.staging = DeviceShare::of(m.device).take(m.N);
+  if (!m.staging) return -1;
+  const size_t bytes = (size_t)m.N * m.N * 4;
+  RL_HIP(hipMemcpyAsync(m.staging->D.p, dD, bytes, hipMemcpyDeviceToDevice, m.stream));
+  if (dCF) RL_HIP(hipMemcpyAsync(m.staging->CF.p, dCF, bytes, hipMemcpyDeviceToDevice, m.stream));
+  m.rowmin_d_ready = m.rowmin_cf_ready = false;
+  return 0;
+}
+
 float *DeviceMinMatch::rowmin_device() {
   Impl &m = *impl;
   if (hipSetDevice(m.device) != hipSuccess || m.d_f.alloc((size_t)8 * m.N * 4)) return nullptr;
@@ -2876,7 +2852,7 @@ int DeviceMinMatch::reserve(bool ages) {
   int rc = m.d_M.alloc(mm_elements(N) * 16);
   rc = rc ? rc : m.d_hits.alloc(((size_t)N + (size_t)2 * N * MM_HITS) * 4);
   rc = rc ? rc : m.d_f.alloc((size_t)8 * N * 4);  // min_values, min_values_CF, mc_dist, mc_dist2, 2 of the symmetric path, 2 row minima
-  rc = rc ? rc : m.d_i.alloc(((size_t)12 * N + 8) * 4);  // ints, see build_impl
+  rc = rc ? rc : m.d_i.alloc(((size_t)14 * N + 8) * 4);  // ints, see build_impl
   rc = rc ? rc : m.d_feas.alloc((size_t)pair_cap * 6 * 4);
   rc = rc ? rc : m.d_rowlist.alloc((size_t)MM_WAVES * N * 4);
   rc = rc ? rc : m.d_status.alloc(16 + 16 * 8);
@@ -2921,7 +2897,7 @@ int DeviceMinMatch::build_impl(TB &tb, const std::vector<double> *sample_ages, c
   }
   if (N < 2 || N > MM_MAXN) return 1;  // (the painting kernels stop at N = 10240 too)
   if (resident) {  // tests: every k-th resident build is handed to the host, as a tree with too many tied candidates is
-    static const int every = getenv("RELATE_AMD_BUILDER_HANDOVER_EVERY") ? atoi(getenv("RELATE_AMD_BUILDER_HANDOVER_EVERY")) : 0;
+    static const int every = getenv("RELATE_AMD_TEST_HANDOVER_EVERY") ? atoi(getenv("RELATE_AMD_TEST_HANDOVER_EVERY")) : 0;
     if (every > 0 && ++m.builds % every == 0) return 2;
   }
   RL_HIP(hipSetDevice(m.device));
@@ -2949,12 +2925,12 @@ int DeviceMinMatch::build_impl(TB &tb, const std::vector<double> *sample_ages, c
   MMParams p;
   memset(&p, 0, sizeof(p));
   p.N = N;
-  p.lds_state = lds_state_fits(N, ages) ? 1 : 0;
+  const WorkerKind kind = worker_kind(N, ages);
+  p.layout = kind.layout;
   p.threshold = tb.threshold;
   p.threshold_CF = tb.threshold_CF;
   p.M = m.d_M.as<float4>();
   p.has_prior = prior ? 1 : 0;
-  p.debug = getenv("RELATE_AMD_MM_DEBUG") ? atoi(getenv("RELATE_AMD_MM_DEBUG")) : 0;
   float *f = m.d_f.as<float>();
   p.rowmin_D = f + 6 * (size_t)N;
   p.rowmin_CF = f + 7 * (size_t)N;
@@ -2979,6 +2955,8 @@ int DeviceMinMatch::build_impl(TB &tb, const std::vector<double> *sample_ages, c
   p.mcs_lin2 = q + 7 * (size_t)N;
   p.merge_i = q + 8 * (size_t)N;           // [N-1]
   p.merge_j = q + 9 * (size_t)N;           // [N-1]
+  p.upd_g = reinterpret_cast<unsigned *>(q + 12 * (size_t)N);  // (the AGES build: a list of its own, below)
+  p.updv_g = reinterpret_cast<float *>(q + 13 * (size_t)N);
   p.kflag = m.d_flags.as<unsigned char>();
   p.pair_g = m.d_feas.as<unsigned>();
   p.pair_cap = pair_cap;
@@ -3041,14 +3019,13 @@ int DeviceMinMatch::build_impl(TB &tb, const std::vector<double> *sample_ages, c
   // (min_values_CF as carried over is also what pairscan_kernel tests the prior with: that copy goes to the device)
   const float *mvcf_dev = p.min_values_CF;
   RL_HIP(hipMemcpyAsync(p.min_values_CF, mvcf, (size_t)N * 4, hipMemcpyHostToDevice, m.stream));
-  if (p.lds_state) {
+  if (p.layout != L_GLOBAL) {
     // The worker reads the carried state from the pinned block and leaves it there again together with the merges:
     // 100 KB across PCIe per tree instead of three copies and a stream synchronisation behind the build (16 ms per
     // tree with a hundred sections sharing the hardware queues).  The system-scope fences around a tree in the worker
     // order them with the request and with "done".
-    p.mc_lin1 = lin;
-    p.mc_lin2 = lin + N;
-    p.min_values_CF = mvcf;
+    p.io_lin = lin;
+    p.io_mvcf = mvcf;
     p.merge_i = tr;
     p.merge_j = tr + N;
   } else {  // (the state lives in these arrays throughout the build: device memory)
@@ -3069,12 +3046,7 @@ int DeviceMinMatch::build_impl(TB &tb, const std::vector<double> *sample_ages, c
       hipLaunchKernelGGL(rowmin_penalty_kernel, dim3(N), dim3(256), 0, m.stream, dCF, N, (const unsigned char *)nullptr, 0.0f,
                          f + 7 * (size_t)N);
     const dim3 grid((N + WV_ROWS - 1) / WV_ROWS);
-    static const bool one_way = getenv("RELATE_AMD_WEAVE_ONE_WAY") && atoi(getenv("RELATE_AMD_WEAVE_ONE_WAY")) != 0;
-    if (prior && one_way)
-      hipLaunchKernelGGL((weave_kernel<true, false>), grid, dim3(256), 0, m.stream, dD, dCF, p.M, N, p.rowmin_D, p.rowmin_CF, mvcf_dev,
-                         ages ? 1 : 0, p.threshold, p.threshold_CF, hits, reinterpret_cast<unsigned *>(hits + N),
-                         reinterpret_cast<float *>(hits + N + (size_t)N * MM_HITS));
-    else if (prior)
+    if (prior)
       hipLaunchKernelGGL(weave_kernel<true>, grid, dim3(256), 0, m.stream, dD, dCF, p.M, N, p.rowmin_D, p.rowmin_CF, mvcf_dev,
                          ages ? 1 : 0, p.threshold, p.threshold_CF, hits, reinterpret_cast<unsigned *>(hits + N),
                          reinterpret_cast<float *>(hits + N + (size_t)N * MM_HITS));
@@ -3084,11 +3056,11 @@ int DeviceMinMatch::build_impl(TB &tb, const std::vector<double> *sample_ages, c
                          reinterpret_cast<float *>(hits + N + (size_t)N * MM_HITS));
     RL_HIP(hipGetLastError());
   }
-  static const bool trace = getenv("RELATE_AMD_MM_TRACE") != nullptr;
+  static const bool trace = (timing_level() >= 2);
   if (trace) fprintf(stderr, "[mm trace] N=%d inputs submitted\n", N), fflush(stderr);
   RL_HIP(hipStreamSynchronize(m.stream));  // inputs in place
   if (trace) fprintf(stderr, "[mm trace] N=%d inputs in place\n", N), fflush(stderr);
-  if (const char *dump = getenv("RELATE_AMD_MM_DUMP")) {
+  if (const char *dump = getenv("RELATE_AMD_TEST_MM_DUMP")) {
     // (tools/bench_builder_variants.py) the matrices of builds first..last of this builder, as the kernel gets them:
     // "<dir>:<first>:<last>"; the process ends behind the last one
     char dir[512];
@@ -3134,7 +3106,7 @@ int DeviceMinMatch::build_impl(TB &tb, const std::vector<double> *sample_ages, c
   }
   // out: the tree and the carried state
   // (merge_i [N), merge_j [N) lie back to back)
-  if (!p.lds_state) {
+  if (p.layout == L_GLOBAL) {
     RL_HIP(hipMemcpyAsync(tr, p.merge_i, ((size_t)2 * N - 1) * 4, hipMemcpyDeviceToHost, m.stream));
     RL_HIP(hipMemcpyAsync(lin, p.mc_lin1, (size_t)2 * N * 4, hipMemcpyDeviceToHost, m.stream));
     RL_HIP(hipMemcpyAsync(mvcf, p.min_values_CF, (size_t)N * 4, hipMemcpyDeviceToHost, m.stream));
@@ -3243,5 +3215,63 @@ int rl_builder_set_sample_ages(rl_builder *b, const double *ages, int n) {
 int rl_builder_last_on_gpu(const rl_builder *b) { return b ? b->last_on_gpu : RL_EINVAL; }
 
 int rl_debug_rng_mismatches(unsigned seed, int n) { return rl::rng_restatement_mismatches(seed, n); }
+
+// (measurement hook, tools/bench_builder_many.py) `builders` device builders, a host thread each, build the SAME tree
+// `reps` times side by side -- the matrices stay on the device: a copy per build into the builder's staging pair, as
+// K3 and the prior kernel would leave them -- with `workers` resident workgroups at most (0: the queue's own limit).
+// seconds: wall-clock from the first submit to the last tree; mismatches: builds whose parent array differs from
+// builder 0's of the same repetition (0 expected: every builder carries the same state through the same trees).
+int rl_debug_builder_throughput(int N, double theta, int device, int builders, int reps, int workers, const float *d,
+                                const float *prior, double *seconds, int *mismatches, int *first_parents) {
+  using namespace rl;
+  if (N < 2 || builders < 1 || reps < 1 || !d || !seconds || !mismatches) return RL_EINVAL;
+  RL_HIP(hipSetDevice(device));
+  const size_t NN = (size_t)N * N;
+  DevBuf masterD, masterCF;
+  if (masterD.alloc(NN * 4) || (prior && masterCF.alloc(NN * 4))) return RL_ENOMEM;
+  RL_HIP(hipMemcpy(masterD.p, d, NN * 4, hipMemcpyHostToDevice));
+  if (prior) RL_HIP(hipMemcpy(masterCF.p, prior, NN * 4, hipMemcpyHostToDevice));
+  std::vector<std::unique_ptr<MinMatch>> tbs;
+  std::vector<std::unique_ptr<DeviceMinMatch>> devs;
+  for (int b = 0; b < builders; b++) {
+    tbs.emplace_back(new MinMatch(N, theta));
+    devs.emplace_back(new DeviceMinMatch(N, device));
+    if (devs.back()->reserve(false)) return RL_ENOMEM;
+  }
+  if (device_builder_expect(device, N, workers, false)) return RL_EHIP;
+  std::vector<std::vector<int>> parents((size_t)builders * reps);
+  std::atomic<int> ready(0), failed(0);
+  std::atomic<bool> go(false);
+  std::vector<std::thread> th;
+  for (int b = 0; b < builders; b++)
+    th.emplace_back([&, b] {
+      (void)hipSetDevice(device);
+      ready.fetch_add(1);
+      while (!go.load()) std::this_thread::sleep_for(std::chrono::microseconds(50));
+      for (int r = 0; r < reps && !failed.load(); r++) {
+        HostTree t;
+        if (devs[b]->stage_from_device(masterD.as<float>(), prior ? masterCF.as<float>() : nullptr) ||
+            devs[b]->build_resident(*tbs[b], prior != nullptr, t) != 0) {
+          failed.store(1);
+          break;
+        }
+        parents[(size_t)b * reps + r].assign(t.parent.begin(), t.parent.begin() + (2 * N - 1));
+      }
+    });
+  while (ready.load() < builders) std::this_thread::sleep_for(std::chrono::microseconds(100));
+  const auto t0 = std::chrono::steady_clock::now();
+  go.store(true);
+  for (auto &x : th) x.join();
+  *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  (void)device_builder_expect(device, N, 0, false);
+  if (failed.load()) return RL_EHIP;
+  int bad = 0;
+  for (int b = 1; b < builders; b++)
+    for (int r = 0; r < reps; r++) bad += parents[(size_t)b * reps + r] != parents[r];
+  *mismatches = bad;
+  if (first_parents)
+    for (int r = 0; r < reps; r++) memcpy(first_parents + (size_t)r * (2 * N - 1), parents[r].data(), ((size_t)2 * N - 1) * 4);
+  return RL_OK;
+}
 
 }  // extern "C"

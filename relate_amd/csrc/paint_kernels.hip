@@ -351,8 +351,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) paint_kernel(const PaintParams 
 template <int S, int TAIL, int WAVES>
 static hipError_t launch_paint_t(const PaintParams &p, int dir, hipStream_t stream) {
   const dim3 grid(dir == 2 ? 2 * p.nloc : p.nloc), block(64 * WAVES);
-  // experiments: extra LDS per workgroup caps the waves a SIMD holds (RELATE_AMD_PAINT_LDS bytes)
-  static const int lds = getenv("RELATE_AMD_PAINT_LDS") ? atoi(getenv("RELATE_AMD_PAINT_LDS")) : 0;
+  const int lds = 0;
   if (dir == 2)
     hipLaunchKernelGGL((paint_kernel<S, TAIL, RL_MODE, WAVES, 2>), grid, block, lds, stream, p);
   else if (dir == 1)

@@ -307,11 +307,9 @@ RL_DEV void product_steps(const HeldRow<S, NS> &ck, int lane, const double (&b)[
   }
 }
 
-// DESCENT: the beta-only part of a bounded window's launch as a kernel of its own -- from the window's last row, or
-// from the state an earlier launch kept, down to the first row ABOVE the part, where it leaves its state for the
-// product kernel (p.dstate).  No posterior rows up there, so no checkpoint strip: two waves share a SIMD instead of
-// one (the same loops run 1.77 x slower one wave a SIMD, §4 K2), and a launch of a part is mostly descent.
-template <int S, int TAIL, int MODE, int WAVES, bool DESCENT = false, bool NOSTRIP = false>
+// (The beta-only descent of a part launch as a kernel of its own, two waves a SIMD, was built and measured in round 5:
+//  waits halved, same wall-clock -- removed, DESIGN_NOTES.md 11.)
+template <int S, int TAIL, int MODE, int WAVES, bool NOSTRIP = false>
 RL_DEV void repaint_backward(const RepaintParams &p, int n, float *stage, double *strip, WaveLink<WAVES> &lk) {
   const int wv = lk.w;
   PaintLane<S> pl;
@@ -361,23 +359,8 @@ RL_DEV void repaint_backward(const RepaintParams &p, int n, float *stage, double
   int jstart = (p.bstate && p.partial) ? __builtin_amdgcn_readfirstlane(p.start_row[t]) : -1;
   const int jsave = p.bstate ? __builtin_amdgcn_readfirstlane(p.save_row[t]) : -1;
   double *__restrict__ bst = p.bstate ? p.bstate + ((size_t)t * WAVES + wv) * (S * 64) + pl.lane : nullptr;
-  double *__restrict__ dst = p.dstate ? p.dstate + ((size_t)t * WAVES + wv) * (S * 64) + pl.lane : nullptr;
   const double *__restrict__ state_from = bst;          // where a start from a kept state loads from ...
   const double *__restrict__ scal_from = p.bscal ? p.bscal + (size_t)t * 2 : nullptr;  // ... and its two scalars
-  if constexpr (DESCENT) {
-    // nothing to come down: the pass starts inside or below the part (or the part reaches the window's last row)
-    if ((jstart < 0 ? D - 2 : jstart) < row_hi) {
-      if (pl.lane == 0 && wv == 0) p.dscal[(size_t)t * 4 + 2] = -1.0;
-      return;
-    }
-  } else if (p.dstate) {
-    const int r = (int)__builtin_amdgcn_readfirstlane((int)p.dscal[(size_t)t * 4 + 2]);
-    if (r >= 0) {  // the descent kernel of this launch stands before row r
-      jstart = r;
-      state_from = dst;
-      scal_from = p.dscal + (size_t)t * 4;
-    }
-  }
   float lsf = 0.0f;
   if (jstart < 0) {
     lsf = (float)lane_value(rec, (D - 1 - cpb) * REPAINT_SIDE + 2);  // the forward pass's last logscale
@@ -396,7 +379,7 @@ RL_DEV void repaint_backward(const RepaintParams &p, int n, float *stage, double
 #pragma unroll
   for (int i = 0; i < (HeldRow<S, NOSTRIP>::VREG > 0 ? HeldRow<S, NOSTRIP>::VREG : 1); i++) ck.v[i] = 0.0;
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-  if constexpr (!DESCENT) {  // the checkpoint row of the block the first row to be done belongs to
+  {  // the checkpoint row of the block the first row to be done belongs to
     const int first_row = jstart < 0 ? D - 1 : jstart;
     const int blk = first_row - first_row % CK;
     if (block_kept(blk)) ck.request(ckrows + (int64_t)(blk / CK) * ROW - pl.lane, pl.lane);
@@ -404,7 +387,6 @@ RL_DEV void repaint_backward(const RepaintParams &p, int n, float *stage, double
   MaskRow rows[CK];
   double cfs[CK], dvs[CK];
   auto open_block = [&]() {
-    if constexpr (DESCENT) return;  // (the rows' rebuild constants: nothing is rebuilt up here)
 #pragma unroll
     for (int q = 1; q < CK; q++) {
       rows[q] = site_row(p.masks, S, p.L, __builtin_amdgcn_readlane(sit, q), WAVES, wv);
@@ -414,7 +396,6 @@ RL_DEV void repaint_backward(const RepaintParams &p, int n, float *stage, double
   };
   open_block();
   auto product_row = [&](int j, bool first) {
-    if constexpr (DESCENT) return;
     const int r = j - cpb;
     const bool kept = j >= row_lo && j < row_hi;  // (uniform over the workgroup)
     float *__restrict__ trow = top + (int64_t)(j - row_lo) * TROW;
@@ -444,7 +425,7 @@ RL_DEV void repaint_backward(const RepaintParams &p, int n, float *stage, double
   };
   // (a later launch of a bounded window: the logscales are in place, the forward pass stopped below row_hi -- its
   //  records above are not there -- and nothing below row_lo is asked for)
-  const int jstop = DESCENT ? row_hi : (p.partial ? max(0, row_lo) : 0), jls = p.partial ? row_hi : D;
+  const int jstop = p.partial ? max(0, row_lo) : 0, jls = p.partial ? row_hi : D;
   const int jtop = jstart < 0 ? D - 2 : jstart;  // the first row the loop does
   // at the top of row j: s0 = site j + 1, s1 = site j, s2 = site j - 1
   int s0 = st[jtop + 1], s1 = jtop >= 0 ? st[jtop] : 0, s2 = jtop >= 1 ? st[jtop - 1] : 0;
@@ -537,14 +518,6 @@ RL_DEV void repaint_backward(const RepaintParams &p, int n, float *stage, double
     if (pl.lane == 0 && wv == 0 && j < jls) lsout[j] = lsf;
   }
   retire_touch(touched);
-  if constexpr (DESCENT) {  // the state before row row_hi - 1: where the product kernel goes on
-    store_row<S>(dst, b);
-    if (pl.lane == 0 && wv == 0) {
-      p.dscal[(size_t)t * 4] = cfac;
-      p.dscal[(size_t)t * 4 + 1] = prev_ls;
-      p.dscal[(size_t)t * 4 + 2] = (double)(row_hi - 1);
-    }
-  }
 }
 
 template <int S, int TAIL, int MODE, int WAVES>
@@ -554,12 +527,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) repaint_fwd_kernel(const Repain
   WaveLink<WAVES> lk;
   lk.s = &link;
   lk.w = WAVES > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
-  // (a part launch may come with fewer workgroups than targets -- p.grid_cap, window.cpp --: a workgroup then takes
-  //  every gridDim.x-th target of the longest-first order)
-  for (int idx = blockIdx.x; idx < p.nloc; idx += gridDim.x) {
-    repaint_forward<S, TAIL, MODE, WAVES>(p, p.order[idx], stage[lk.w], lk);
-    if (WAVES > 1) __syncthreads();
-  }
+  repaint_forward<S, TAIL, MODE, WAVES>(p, p.order[blockIdx.x], stage[lk.w], lk);
 }
 // One wave per SIMD (the LDS strips decide that): beta in registers, the block's checkpoint row in LDS.  The strips
 // are dynamic LDS so that the compiler budgets registers for two waves per SIMD (256 VGPRs, no AGPR copies).
@@ -586,35 +554,8 @@ __global__ void __launch_bounds__(64 * WAVES, 2) repaint_bwd_nostrip_kernel(cons
   WaveLink<WAVES> lk;
   lk.s = &link;
   lk.w = WAVES > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
-  repaint_backward<S, TAIL, MODE, WAVES, false, true>(p, p.order[blockIdx.x], stage[lk.w], nullptr, lk);
-}
-// ... with fewer workgroups than targets (p.grid_cap): a kernel of its own -- the loop around the pass costs the
-// compiler 108 bytes of scratch per lane, which the one-workgroup-per-target kernel does not pay
-template <int S, int TAIL, int MODE, int WAVES>
-__global__ void __launch_bounds__(64 * WAVES, 2) repaint_bwd_nostrip_loop_kernel(const RepaintParams p) {
-  __shared__ float stage[WAVES][16 * 64];
-  __shared__ WaveLinkStorage link;
-  WaveLink<WAVES> lk;
-  lk.s = &link;
-  lk.w = WAVES > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
-#pragma clang loop unroll(disable)
-  for (int idx = blockIdx.x; idx < p.nloc; idx += gridDim.x) {
-    const int n = __builtin_amdgcn_readfirstlane(p.order[__builtin_amdgcn_readfirstlane(idx)]);
-    repaint_backward<S, TAIL, MODE, WAVES, false, true>(p, n, stage[lk.w], nullptr, lk);
-    if (WAVES > 1) __syncthreads();
-  }
-}
-
-template <int S, int TAIL, int MODE, int WAVES>
-__global__ void __launch_bounds__(64 * WAVES, 2) repaint_descent_kernel(const RepaintParams p) {
-  __shared__ float stage[WAVES][16 * 64];
-  __shared__ WaveLinkStorage link;
-  WaveLink<WAVES> lk;
-  lk.s = &link;
-  lk.w = WAVES > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
   repaint_backward<S, TAIL, MODE, WAVES, true>(p, p.order[blockIdx.x], stage[lk.w], nullptr, lk);
 }
-
 template <int S, int TAIL, int WAVES>
 static hipError_t launch_repaint_t(const RepaintParams &p, hipStream_t stream) {
   constexpr size_t strips = (size_t)WAVES * strip_doubles<S>() * sizeof(double);
@@ -632,17 +573,9 @@ static hipError_t launch_repaint_t(const RepaintParams &p, hipStream_t stream) {
       if (dev <= 127) done[(dev >> 6) & 1].fetch_or(bit, std::memory_order_release);
     }
   }
-  // (part launches of the strip-less kind may be capped: the two kernels then leave room on the CUs for the sections'
-  //  own small kernels, whose latency is on every tree's path)
-  const int capped = (p.partial && p.nostrip && p.grid_cap > 0) ? std::min(p.nloc, p.grid_cap) : p.nloc;
-  hipLaunchKernelGGL((repaint_fwd_kernel<S, TAIL, RL_MODE, WAVES>), dim3(capped), dim3(64 * WAVES), 0, stream, p);
-  // (the descent reads nothing the forward kernel writes in a partial launch -- the records above row_hi are not made --
-  //  but in a window's first launch it takes the forward logscales from them: behind the forward kernel, same stream)
-  if (p.dstate)
-    hipLaunchKernelGGL((repaint_descent_kernel<S, TAIL, RL_MODE, WAVES>), dim3(p.nloc), dim3(64 * WAVES), 0, stream, p);
-  if (p.partial && p.nostrip && capped < p.nloc)
-    hipLaunchKernelGGL((repaint_bwd_nostrip_loop_kernel<S, TAIL, RL_MODE, WAVES>), dim3(capped), dim3(64 * WAVES), 0, stream, p);
-  else if (p.partial && p.nostrip)
+  hipLaunchKernelGGL((repaint_fwd_kernel<S, TAIL, RL_MODE, WAVES>), dim3(p.nloc), dim3(64 * WAVES), 0, stream, p);
+  // nostrip = 1: the part launches of a bounded window without the strip; 2: whole windows too
+  if (p.nostrip > 1 || (p.partial && p.nostrip))
     hipLaunchKernelGGL((repaint_bwd_nostrip_kernel<S, TAIL, RL_MODE, WAVES>), dim3(p.nloc), dim3(64 * WAVES), 0, stream, p);
   else
     hipLaunchKernelGGL((repaint_bwd_kernel<S, TAIL, RL_MODE, WAVES>), dim3(p.nloc), dim3(64 * WAVES), strips, stream, p);

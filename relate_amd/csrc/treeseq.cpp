@@ -813,6 +813,13 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
     rl_destroy(ctx);
     return rc;
   }
+  // rl_stage_opts.find_equivalent_branches: checked before any device or builder set-up
+  const bool want_feb = knob("RELATE_AMD_FUSED_FEB", o.find_equivalent_branches, true, 0) != 0;
+  if (want_feb && (first_section != 0 || last_section != W - 1 || W < 2)) {
+    set_error("find_equivalent_branches needs a call that covers all %d sections of the chunk (and at least two)", W);
+    rl_destroy(ctx);
+    return RL_EINVAL;
+  }
   std::cerr << "---------------------------------------------------------" << std::endl;
   std::cerr << "Estimating topologies of AncesTrees in sections " << first_section << "-" << last_section << "..."
             << std::endl;
@@ -955,6 +962,8 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
   // core stalls every merge, so they get a quarter of the physical cores at most: measured on 2 x 64 cores with 8
   // sections open, 4 helpers each finished in 109 s, 8 in 177 s, none in 165 s.
   set_build_threads(std::min(8, std::max(1, host_threads() / (8 * std::max(1, concurrent)))));
+  // (test hook, read once per stage: tests/test_stage_gpu.py)
+  std::atomic<int> fail_opens{getenv("RELATE_AMD_TEST_FAIL_OPENS") ? atoi(getenv("RELATE_AMD_TEST_FAIL_OPENS")) : 0};
   std::atomic<int> open_sections(0);
   int most_open = 0;            // (under g_gpu_mutex)
   const auto stage_t0 = std::chrono::steady_clock::now();
@@ -988,14 +997,7 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
   std::atomic<int> next_slot(0);
   // rl_stage_opts.find_equivalent_branches: the stage downstream on the trees while they are in memory (equivalent.cpp)
   FebJob *feb = nullptr;
-  if (knob("RELATE_AMD_FUSED_FEB", o.find_equivalent_branches, true, 0) != 0) {
-    if (first_section != 0 || last_section != W - 1 || W < 2) {
-      set_error("find_equivalent_branches needs a call that covers all %d sections of the chunk (and at least two)", W);
-      rl_destroy(ctx);
-      return RL_EINVAL;
-    }
-    feb = feb_job_create(ctx->N, W, std::max(4, std::min(32, host_threads() / 8)));
-  }
+  if (want_feb) feb = feb_job_create(ctx->N, W, std::max(4, std::min(32, host_threads() / 8)));
   auto worker = [&]() {
     cpu_set_t before;
     CPU_ZERO(&before);
@@ -1021,7 +1023,7 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
       rl_treeseq_set_build_device(ts, device);
       if (ctx->nloc == ctx->N) {
         rl_treeseq_set_device_matrix(ts, win_matrix_dev);
-        if (!getenv("RELATE_AMD_NO_K3_FUSION")) rl_treeseq_set_device_matrix_ex(ts, win_matrix_dev_ex);
+        rl_treeseq_set_device_matrix_ex(ts, win_matrix_dev_ex);
       }
     }
     for (;;) {
@@ -1042,7 +1044,7 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
       const size_t min_block = (size_t)(0.85 * (cap_rows > 0 && cap_rows < rows_of[section]
                                                     ? std::min(kept_rows * row_bytes, bstate_bytes / 4.0)
                                                     : kept_rows * row_bytes));
-      int open_rc = RL_EIO, oom_alone = 0;
+      int open_rc = RL_EIO, oom_alone = 0, oom_total = 0;
       for (;;) {  // admission: wait until the window fits next to the ones that are open or being opened
         bool admitted = false;
         {
@@ -1062,7 +1064,6 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
           // (test hook, RELATE_AMD_TEST_FAIL_OPENS=k: k > 0 -- the next k admitted opens that happen while another
           //  section is open fail as if the device were out of memory; k < 0 -- the next |k| opens whatever else is
           //  open.  The retry below is otherwise reached only when the allocator really runs dry)
-          static std::atomic<int> fail_opens{getenv("RELATE_AMD_TEST_FAIL_OPENS") ? atoi(getenv("RELATE_AMD_TEST_FAIL_OPENS")) : 0};
           bool injected = false;
           if (fail_opens.load() > 0 && open_sections.load() > 0) injected = fail_opens.fetch_sub(1) > 0;
           else if (fail_opens.load() < 0) injected = fail_opens.fetch_add(1) < 0;
@@ -1094,7 +1095,9 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
           // Out of memory although admitted (the estimate counts bytes, the allocator needs blocks): not the
           // stage's failure while other sections hold memory they will give back -- wait for one to close and ask
           // again.  Alone on the device it IS the failure.
-          if (tl_alloc_failures != oom_before && others && !first_error.load()) {
+          // (bounded: two threads that keep failing while each sees the other's reservation would otherwise retry for
+          //  ever -- after 20 admitted-but-failed opens of this section it IS the stage's failure)
+          if (tl_alloc_failures != oom_before && others && !first_error.load() && ++oom_total <= 20) {
             open_rc = RL_ENOMEM;
             const int open_then = open_sections.load();
             for (int i = 0; i < 1200 && open_sections.load() >= open_then && open_sections.load() > 0 &&
@@ -1152,7 +1155,6 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
     for (auto &x : th) x.join();
   }
   if (gpu_build) (void)device_builder_expect(device, ctx->N, 0, !sample_ages.empty());
-  g_repaint_grid_cap.store(0);
   rc = first_error.load();
   if (rc) set_error("%s", first_message.c_str());
   if (feb) {

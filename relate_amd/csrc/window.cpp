@@ -91,15 +91,6 @@ static int repaint_rows(rl_window *win, float *kernel_ms) {
   // (the second lane's strips are sized for partial launches: a window's first, whole pass takes the first lane)
   const bool first_lane_only = !win->have_logscales || scratch_bytes > ctx->lane2.scratch.bytes;
   const auto t_ask = std::chrono::steady_clock::now();
-  g_repaint_waiting.fetch_add(1);
-  struct Waiting {  // (counted until the lane is this thread's, whichever way the function leaves)
-    bool on = true;
-    void off() {
-      if (on) g_repaint_waiting.fetch_sub(1);
-      on = false;
-    }
-    ~Waiting() { off(); }
-  } waiting;
   // (whichever lane is free; with both taken, the windows queue up behind the two in turn)
   static std::atomic<unsigned> turn{0};
   std::unique_lock<std::mutex> one_at_a_time(ctx->repaint_mutex, std::defer_lock);
@@ -123,7 +114,6 @@ static int repaint_rows(rl_window *win, float *kernel_ms) {
   hipEvent_t e0 = second ? ctx->lane2.e0 : ctx->ev0, e1 = second ? ctx->lane2.e1 : ctx->ev2;
   rl::DevBuf &scratch = second ? ctx->lane2.scratch : ctx->d_k2_scratch;
   const auto t_got = std::chrono::steady_clock::now();
-  waiting.off();
   win->t_turn += std::chrono::duration<double>(t_got - t_ask).count();
   int rc = scratch.alloc(scratch_bytes);
   if (rc) return rc;
@@ -169,32 +159,14 @@ static int repaint_rows(rl_window *win, float *kernel_ms) {
   // HeldRow NOSTRIP): a part is ~6 rows per target behind ~40 beta-only steps of descent, the checkpoint rows are read
   // where they lie (through the L2), and two waves share a SIMD.  C3, 116 workers, same boxes, alternating: 147.6 /
   // 147.1 / 144.6 s against 161.6 / 148.0 / 150.4 s with the strip; RePaint 57-68 s on the device instead of 77-120,
-  // a section waits 1-2 s per window for its turn (profiles/r05_c3_runs.json).  RELATE_AMD_REPAINT_NOSTRIP=0: the strip.
-  static const bool nostrip = !(getenv("RELATE_AMD_REPAINT_NOSTRIP") && atoi(getenv("RELATE_AMD_REPAINT_NOSTRIP")) == 0);
-  p.nostrip = nostrip ? 1 : 0;
-  // (at most so many workgroups per part launch: the stage's word, common.h; RELATE_AMD_REPAINT_GRID=n overrides, 0 =
-  //  one per target)
-  static const int grid_env = getenv("RELATE_AMD_REPAINT_GRID") ? atoi(getenv("RELATE_AMD_REPAINT_GRID")) : -1;
-  p.grid_cap = grid_env >= 0 ? grid_env : g_repaint_grid_cap.load();
+  // a section waits 1-2 s per window for its turn (profiles/r05_c3_runs.json).  RELATE_AMD_REPAINT_NOSTRIP=0: the strip
+  // everywhere; 2: no strip for whole windows either.
+  static const int nostrip = getenv("RELATE_AMD_REPAINT_NOSTRIP") ? atoi(getenv("RELATE_AMD_REPAINT_NOSTRIP")) : 1;
+  p.nostrip = nostrip;
   p.bstate = win->d_bstate.as<double>();
   p.bscal = win->d_bscal.as<double>();
   p.fstate = win->d_fstate.as<double>();
   p.fscal = win->d_fscal.as<double>();
-  // a bounded window's launch is mostly the way DOWN to its part: that goes first, as a kernel of its own at two waves
-  // a SIMD (repaint_kernels.hip: repaint_descent_kernel), through a state buffer of the lane
-  p.dstate = nullptr;
-  p.dscal = nullptr;
-  // (Built and measured in round 4, NOT the default: on one box, alternating, the C3 stage took 162.0 / 157.6 s with
-  //  it and 157.1 / 157.0 s without -- a third kernel per launch and 0.4 GB of state written and read back cost what
-  //  the second wave per SIMD gains.  RELATE_AMD_DESCENT_KERNEL=1 turns it on.)
-  static const bool descent = getenv("RELATE_AMD_DESCENT_KERNEL") && atoi(getenv("RELATE_AMD_DESCENT_KERNEL")) != 0;
-  if (descent && win->cap_rows < win->top_off[nloc]) {
-    rl::DevBuf &ds = second ? ctx->lane2.dstate : ctx->d_k2_dstate;
-    const size_t state_bytes = (size_t)nloc * S * 64 * waves * sizeof(double);
-    if ((rc = ds.alloc(state_bytes + (size_t)nloc * 4 * sizeof(double)))) return rc;
-    p.dstate = ds.as<double>();
-    p.dscal = reinterpret_cast<double *>(ds.as<unsigned char>() + state_bytes);
-  }
   (void)N;
   bool ok = hipMemcpyAsync(win->d_place.p, win->h_place, (size_t)nloc * 48, hipMemcpyHostToDevice, stream) == hipSuccess;
   ok = ok && hipEventRecord(e0, stream) == hipSuccess;
@@ -294,8 +266,7 @@ static int place_rows(rl_window *win, int snp, float *kernel_ms) {
     rc = RL_ENOMEM;
   }
   if (rc) return rc;
-  const bool keep_state = win->cap_rows < all_rows &&
-                          !(getenv("RELATE_AMD_WINDOW_BSTATE") && atoi(getenv("RELATE_AMD_WINDOW_BSTATE")) == 0);
+  const bool keep_state = win->cap_rows < all_rows;
   win->start_row.assign(nloc, -1);
   win->save_row.assign(nloc, -1);
   win->fstart_row.assign(nloc, -1);
@@ -372,8 +343,7 @@ static int place_rows(rl_window *win, int snp, float *kernel_ms) {
     // doubles, 0.6 GB at C3: what lets a SECOND lane of RePaint launches cost no sections (round 4).
     int64_t *ck = reinterpret_cast<int64_t *>(hp + (size_t)nloc * 40);
     constexpr int CKR = REPAINT_CHECKPOINT;
-    static const bool compact = !(getenv("RELATE_AMD_COMPACT_STRIPS") && atoi(getenv("RELATE_AMD_COMPACT_STRIPS")) == 0);
-    if (!win->have_logscales || !compact) {
+    if (!win->have_logscales) {
       for (int t = 0; t < nloc; t++) ck[t] = win->ck_off[t];
       win->ck_rows_launch = win->ck_off[nloc];
     } else {

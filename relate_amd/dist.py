@@ -435,10 +435,13 @@ def run_chunk_by_targets(out_dir, chunk_index=0, painting=None, device=None, sec
                         send[maxrows, 0] = 1.0
                     fab.all_gather_rows(send, recv)
                     served += 1
-                    bad = [int(x) for x in torch.nonzero(recv[maxrows::stride, 0].cpu()).flatten()]
-                    if bad and abort is None:  # (every rank sees the same flags: all stop in the next tick)
-                        abort = RuntimeError("run_chunk_by_targets: rows of section %d at SNP %d failed on rank%s %s"
-                                             % (section, snp, "s" if len(bad) > 1 else "", bad))
+                    # (the ok-flag rows: only the rank that CONSUMES the matrix looks at them -- a device-to-host copy and a
+                    #  wait per tree, not per tree and rank; its `abort` reaches the others through the next tick's table)
+                    if r == rank and abort is None:
+                        bad = [int(x) for x in torch.nonzero(recv[maxrows::stride, 0].cpu()).flatten()]
+                        if bad:
+                            abort = RuntimeError("run_chunk_by_targets: rows of section %d at SNP %d failed on rank%s %s"
+                                                 % (section, snp, "s" if len(bad) > 1 else "", bad))
                 elif kind == REQ_RELEASE:
                     try:
                         shard.release_section(section)

@@ -148,7 +148,7 @@ def test_builders_side_by_side_with_hand_overs_and_the_symmetric_pool(monkeypatc
     need the symmetric matrix at the same time with ONE in the device's pool: one takes it, the other's tree goes to
     the host (status 1).  Every tree equals the host builder's."""
     import threading
-    monkeypatch.setenv("RELATE_AMD_BUILD_SYM_SLOTS", "1")
+    monkeypatch.setenv("RELATE_AMD_TEST_SYM_SLOTS", "1")
     N = 1300
     rng = np.random.RandomState(11)
     flat = np.full((N, N), 2.5, np.float32)

@@ -12,7 +12,12 @@ N = 5000 x L = 500,000, seed 1, --memory 20, 267 windows).  test
 
 Here: ONE Paint of the whole chunk on the device (1.4 s) and everything above compared bit for bit; 16 more
 (seeded) targets against the oracle at full length; the fused stage for section 133 with both tree builders, the
-device builder with bounded windows as the whole-chunk stage runs them."""
+device builder with bounded windows as the whole-chunk stage runs them.
+
+tests/golden/c3_ends.npz (tools/make_golden_full.py c3_ends; round 6): the two BOUNDARY windows, 0
+(boundarySNP_begin = 0) and 266 (boundarySNP_end = L - 1, the last SNP's no-carrier quirk) -- the windows with
+special-case code in fast_painting.cpp:60-69, :98-107, :150 -- as the reference wrote them: its complete paint file
+of each and BuildTopology of each section."""
 import ctypes as C
 import os
 import struct
@@ -244,3 +249,56 @@ def test_fused_stage_of_that_section_writes_the_references_files(c3, chunk_dir, 
     opts = api.stage_opts(gpu_build=0 if builder == "host" else 1, window_rows=rows if rows else -1)
     api.stage_build_topology_ex(os.path.join(chunk_dir, "out"), 0, w, w, opts, fused=True)
     check_section(z, os.path.join(chunk_dir, "out"), w)
+
+
+ENDS = os.path.join(ROOT, "tests", "golden", "c3_ends.npz")
+
+
+@pytest.fixture(scope="module")
+def ends(c3):
+    z = np.load(ENDS)
+    zc, ctx, _ = c3
+    assert [int(x) for x in z["meta"]] == [int(x) for x in zc["meta"]] and np.array_equal(z["wb"], zc["wb"])
+    for key in z.files:  # (the same chunk files as c3_full's reference runs were given)
+        if key.startswith("in_md5/"):
+            assert np.array_equal(z[key], zc[key]), key
+    return z
+
+
+@pytest.mark.parametrize("which", [0, 1])
+def test_paint_files_of_the_boundary_windows_are_the_references(c3, ends, tmp_path, which):
+    _, ctx, _ = c3
+    w = int(ends["sections"][which])
+    assert w in (0, ctx.W - 1)
+    fn = str(tmp_path / "relate_w.bin")
+    ctx.write_paint_file(w, fn)
+    assert os.path.getsize(fn) == int(ends["s%d/paint_size" % w][0])
+    assert np.array_equal(md5(open(fn, "rb").read()), ends["s%d/paint_md5" % w])
+
+
+def check_end_section(z, out_dir, w):
+    anc = os.path.join(out_dir, "chunk_0", "out_%d.anc" % w)
+    mut = open(os.path.join(out_dir, "chunk_0", "out_%d.mut" % w), "rb").read()
+    _, trees = rlutil.parse_anc(anc)
+    assert [t[0] for t in trees] == list(z["s%d/tree_pos" % w]), "tree positions"
+    for t, (tr, want) in enumerate(zip(trees, z["s%d/tree_parent_md5" % w])):
+        assert np.array_equal(md5(tr[1].astype("<i4").tobytes()), want), "parent array of tree %d" % t
+    assert mut == z["s%d/mut" % w].tobytes()
+    assert os.path.getsize(anc) == int(z["s%d/anc_size" % w][0])
+    assert np.array_equal(md5(open(anc, "rb").read()), z["s%d/anc_md5" % w])
+    os.remove(anc)
+    os.remove(os.path.join(out_dir, "chunk_0", "out_%d.mut" % w))
+
+
+@pytest.mark.parametrize("which", [0, 1])
+def test_fused_stage_of_the_boundary_sections_writes_the_references_files(c3, ends, chunk_dir, which):
+    """Relate --mode PaintBuildTopology for section 0 / 266 alone, the device's workers, 1/32 of the window's rows
+    resident: the reference's out_<w>.anc / out_<w>.mut"""
+    _, ctx, _ = c3
+    w = int(ends["sections"][which])
+    win = ctx.open_window(w, None, int(ends["wb"][w]))
+    rows = sum(win.rows(n) for n in range(ctx.N)) // 32
+    win.close()
+    opts = api.stage_opts(gpu_build=1, window_rows=rows)
+    api.stage_build_topology_ex(os.path.join(chunk_dir, "out"), 0, w, w, opts, fused=True)
+    check_end_section(ends, os.path.join(chunk_dir, "out"), w)

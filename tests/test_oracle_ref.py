@@ -113,7 +113,7 @@ def test_quickbuild_random_matrices_match_reference_binary(tmp_path, monkeypatch
     subprocess.run(args, check=True)
     ref = np.fromfile(str(tmp_path / "p.bin"), dtype=np.int32)
     monkeypatch.setenv("RELATE_AMD_BUILD_THREADS", str(threads))
-    monkeypatch.setenv("RELATE_AMD_BUILD_MIN", "4")
+    monkeypatch.setenv("RELATE_AMD_TEST_BUILD_MIN", "4")
     got = api.quickbuild(d.copy(), 0.001, prior)
     assert np.array_equal(got, ref)
 

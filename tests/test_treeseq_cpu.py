@@ -68,7 +68,7 @@ def test_anc_mut_byte_identical_to_reference(tmp_path, oracle, name):
 def test_helper_threads_do_not_change_the_trees(tmp_path, oracle, monkeypatch):
     """a tree builder with helper threads (parallel distance updates inside a merge) writes the same bytes"""
     monkeypatch.setenv("RELATE_AMD_BUILD_THREADS", "3")
-    monkeypatch.setenv("RELATE_AMD_BUILD_MIN", "4")
+    monkeypatch.setenv("RELATE_AMD_TEST_BUILD_MIN", "4")
     fx = Fixture("synth70", tmp_path)
     for w in (0, fx.W // 2, fx.W - 1):
         anc, mut, nt = build_section(fx, w, tmp_path, oracle)
@@ -90,7 +90,7 @@ def test_quickbuild_same_tree_with_helper_threads(monkeypatch, seed, with_prior)
     monkeypatch.setenv("RELATE_AMD_BUILD_THREADS", "1")
     ref = api.quickbuild(d.copy(), 0.001, None if prior is None else prior.copy())
     monkeypatch.setenv("RELATE_AMD_BUILD_THREADS", "4")
-    monkeypatch.setenv("RELATE_AMD_BUILD_MIN", "4")
+    monkeypatch.setenv("RELATE_AMD_TEST_BUILD_MIN", "4")
     got = api.quickbuild(d.copy(), 0.001, None if prior is None else prior.copy())
     for a, b in zip(ref, got):
         assert np.array_equal(a, b)
