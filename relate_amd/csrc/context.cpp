@@ -596,6 +596,39 @@ int rl_park_stones(rl_ctx *ctx) {
   return RL_OK;
 }
 
+// Room for the stepping stones of a Paint: in HBM -- unless the two buffers would take most of what is free (config
+// #5 with all targets on one GPU: 2 x 144 GB): then they are painted straight into pinned host memory, the kernel's
+// stores crossing PCIe (seconds, once per chunk), and every window of the stage copies its slice in when it opens,
+// as it does for stones parked by rl_park_stones.  (The stores are the only traffic: nothing of the stones is read
+// back by the painting.)
+static int alloc_stones(rl_ctx *ctx) {
+  const size_t bytes = (size_t)ctx->W * ctx->nloc * ctx->N * sizeof(float);
+  if (ctx->h_alpha) {  // (stones of an earlier pass parked on the host)
+    (void)hipHostFree(ctx->h_alpha);
+    (void)hipHostFree(ctx->h_beta);
+    ctx->h_alpha = ctx->h_beta = nullptr;
+  }
+  size_t free_b = 0, total_b = 0;
+  const bool have = ctx->d_alpha.p && ctx->d_alpha.bytes >= bytes && ctx->d_beta.p && ctx->d_beta.bytes >= bytes;
+  if (!have && hipMemGetInfo(&free_b, &total_b) == hipSuccess && 2.0 * (double)bytes > 0.6 * (double)free_b) {
+    ctx->d_alpha.release();
+    ctx->d_beta.release();
+    float *a = nullptr, *b = nullptr;
+    if (hipHostMalloc(reinterpret_cast<void **>(&a), bytes, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void **>(&b), bytes, hipHostMallocDefault) != hipSuccess) {
+      if (a) (void)hipHostFree(a);
+      (void)hipGetLastError();
+      set_error("the stepping stones (2 x %.1f GB) fit neither the device nor pinned host memory", 1e-9 * (double)bytes);
+      return RL_ENOMEM;
+    }
+    ctx->h_alpha = a;
+    ctx->h_beta = b;
+    return RL_OK;
+  }
+  int rc = ctx->d_alpha.alloc(bytes);
+  return rc ? rc : ctx->d_beta.alloc(bytes);
+}
+
 static int set_common(rl_ctx *ctx, int N, int L, const double *r, const double *rpos, const int *wb, int W) {
   if (!ctx || N < 2 || L < 2 || W < 1 || !r || !rpos || !wb) {
     set_error("rl_set_chunk: bad arguments");
@@ -816,13 +849,7 @@ int rl_prepare(rl_ctx *ctx) {
   int rc = upload_plan(ctx);
   if (rc) return rc;
   const size_t N = ctx->N, W = ctx->W, nloc = ctx->nloc;  // stones: this context's target rows only
-  if (ctx->h_alpha) {  // (stones of an earlier pass parked on the host)
-    (void)hipHostFree(ctx->h_alpha);
-    (void)hipHostFree(ctx->h_beta);
-    ctx->h_alpha = ctx->h_beta = nullptr;
-  }
-  if ((rc = ctx->d_alpha.alloc(W * nloc * N * sizeof(float)))) return rc;
-  if ((rc = ctx->d_beta.alloc(W * nloc * N * sizeof(float)))) return rc;
+  if ((rc = alloc_stones(ctx))) return rc;
   if ((rc = ctx->d_lsa.alloc(W * nloc * sizeof(float)))) return rc;
   if ((rc = ctx->d_lsb.alloc(W * nloc * sizeof(float)))) return rc;
   RL_HIP(hipDeviceSynchronize());
@@ -842,13 +869,7 @@ int rl_paint(rl_ctx *ctx, int sum_mode, float *kernel_ms) {
   int rc = upload_plan(ctx);
   if (rc) return rc;
   const size_t N = ctx->N, W = ctx->W, nloc = ctx->nloc;  // stones: this context's target rows only
-  if (ctx->h_alpha) {  // (stones of an earlier pass parked on the host)
-    (void)hipHostFree(ctx->h_alpha);
-    (void)hipHostFree(ctx->h_beta);
-    ctx->h_alpha = ctx->h_beta = nullptr;
-  }
-  if ((rc = ctx->d_alpha.alloc(W * nloc * N * sizeof(float)))) return rc;
-  if ((rc = ctx->d_beta.alloc(W * nloc * N * sizeof(float)))) return rc;
+  if ((rc = alloc_stones(ctx))) return rc;
   if ((rc = ctx->d_lsa.alloc(W * nloc * sizeof(float)))) return rc;
   if ((rc = ctx->d_lsb.alloc(W * nloc * sizeof(float)))) return rc;
 
@@ -869,8 +890,8 @@ int rl_paint(rl_ctx *ctx, int sum_mode, float *kernel_ms) {
   p.stone_ie = ctx->d_ie.as<int32_t>();
   p.binit = ctx->d_binit.as<double>();
   p.order = ctx->d_order.as<int32_t>();
-  p.alpha = ctx->d_alpha.as<float>();
-  p.beta = ctx->d_beta.as<float>();
+  p.alpha = ctx->h_alpha ? ctx->h_alpha : ctx->d_alpha.as<float>();
+  p.beta = ctx->h_alpha ? ctx->h_beta : ctx->d_beta.as<float>();
   p.ls_alpha = ctx->d_lsa.as<float>();
   p.ls_beta = ctx->d_lsb.as<float>();
   p.sum_mode = sum_mode;

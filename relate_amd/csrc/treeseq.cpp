@@ -343,6 +343,30 @@ rl_treeseq *treeseq_borrowing(int N, int L, const uint32_t *bits, int row_words,
 }
 }  // namespace rl
 
+// How many resident tree-builder workers a stage asks for.  The reference's unit of parallelism is a section job
+// (scripts/RelateParallel/RelateParallel.sh:231-257: one process per section range); here a section has at most ONE tree
+// in flight, so:
+//   * never more workers than open sections (what HBM admits: ~134 at N = 5000, ~70 at N = 10,000, 256 at N = 2000);
+//   * whole windows resident (RePaint runs once per window, then the chip is the trees'): a worker per section, up to
+//     7/8 of the worker slots -- an eighth of the CUs stays with the sections' own short kernels;
+//   * bounded windows (RePaint runs all through the stage, on the CUs the workers leave, and every section waits in
+//     its queue): 29/64 of the CUs.  Measured at C3 over three rounds (profiles/r03..r05_c3_*): 3/8 -> 13/32 -> 29/64
+//     as the per-tree kernels got lighter; past ~31/64 the stage is bistable (RePaint's lane saturates and the
+//     sections fall into a convoy: 143 s and 185 s from the same 124 workers), so the rule stays a whole XCD round
+//     (8 workers) below that edge.  profiles/r06_worker_rule.json: the rule against 0.75x / 1.25x / 1.5x of it at
+//     N = 2000, 5000 and 10,000;
+//   * `per_cu` worker slots per CU (two for the small-N kernel, minmatch_gpu.hip worker_kind): the CU share above is a
+//     share of CUs, the slots on them follow.
+// (The trees themselves are bound by the memory system, not by CUs -- profiles/r06_builder_many.jsonl: 128 workers
+//  build 495 trees/s side by side, 256 build 361 --, which is why more workers than this do not pay even where HBM
+//  would admit the sections.)
+namespace rl {
+int stage_worker_goal(int cus, int open_sections, bool bounded_windows, int per_cu) {
+  const int share = bounded_windows ? 29 * cus / 64 : cus - cus / 8;
+  return std::max(1, std::min(open_sections, share * std::max(1, per_cu)));
+}
+}  // namespace rl
+
 extern "C" {
 
 int rl_treeseq_build(rl_treeseq *ts, int start, int end, rl_matrix_fn matrix, rl_advance_fn advance, void *user,
@@ -934,28 +958,14 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
       nthreads = std::min(nthreads, concurrent);
     }
   }
+  int asked_workers = 0;
   if (gpu_build) {
-    // One worker per open section -- unless the windows are bounded: then RePaint runs all through the stage, on the
-    // CUs the workers do not hold (a worker has a CU to itself), and it is the queue every section waits in.  At C3
-    // (134 sections, 37 launches per window): 110 workers 207 s, 100 workers 177 s, 90 workers 190 s (RePaint 168 /
-    // 100 / 92 s busy; trees waiting 5 / 36 / 55 ms for a worker): the workers got 3/8 of the CUs in round 3.  Round 4
-    // (prior_kernel through LDS: RePaint waits 3-4 s per window instead of 9-12): 96 workers 165.7 s, 104 workers
-    // 161.9 s, 112 workers 182.8 s (profiles/r04_c3_workers.json): 13/32 of the CUs.  Round 5 (six passes of per-tree
-    // kernels fused into three; 22 runs in profiles/r05_c3_runs.json): 104 workers 154-156 s, 116 workers 146-152 s,
-    // 124 workers 143-185 s, 132 workers 150-173 s, 140-148 workers 171-179 s -- past ~120 workers the stage is bistable
-    // (RePaint's lane is ~134 launches of 14 ms per 1.9 s part: at the edge of saturation any slow-down becomes a
-    // convoy of sections waiting 15 s per window): 29/64 of the CUs.
-    int workers = nthreads, cus = 256;
-    if (cap_rows > 0) {
-      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 8) cus = 256;
-      workers = std::min(nthreads, 29 * cus / 64);
-    }
+    int cus = 256;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 8) cus = 256;
+    int workers = stage_worker_goal(cus, nthreads, cap_rows > 0, device_builder_workers_per_cu(ctx->N, !sample_ages.empty()));
     if (o.workers > 0) workers = o.workers;  // (RELATE_AMD_BUILD_WORKERS overrides either, minmatch_gpu.hip)
     (void)device_builder_expect(device, ctx->N, workers, !sample_ages.empty());
-    // (RePaint's part launches can be capped to a share of the wave slots the workers leave -- g_repaint_grid_cap,
-    //  RELATE_AMD_REPAINT_GRID=n -- so that the sections' own kernels keep CUs to run on: 124 workers + 768 workgroups
-    //  gave 142.2 s once and 146.2 / 157.0 s on another box against 143.6-148.7 s for 116 workers uncapped
-    //  (profiles/r05_c3_runs.json): not the default)
+    asked_workers = workers;
   }
   // Host threads left over by the sections help inside each tree build (minmatch.h BuildThreads).  Helpers are the
   // less efficient use of a core (a merge is split 8 ways for a 2.5x shorter build) and a helper that loses its
@@ -1165,9 +1175,9 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
   }
   if (getenv("RELATE_AMD_TIMING"))
     fprintf(stderr, "[stage] sections %d..%d on %d threads, up to %d open at once, %lld of at most %.0f posterior rows "
-            "resident per window, %lld RePaint launches (%.1f s on the device), %s tree builder, %.1f s\n", first_section,
-            last_section, nthreads, most_open, cap_rows > 0 ? cap_rows : (long long)max_rows, max_rows,
-            ctx->repaint_launches.load(), 1e-6 * (double)ctx->repaint_us.load(), gpu_build ? "GPU" : "host",
+            "resident per window, %lld RePaint launches (%.1f s on the device), %s tree builder (%d workers asked for), %.1f s\n",
+            first_section, last_section, nthreads, most_open, cap_rows > 0 ? cap_rows : (long long)max_rows, max_rows,
+            ctx->repaint_launches.load(), 1e-6 * (double)ctx->repaint_us.load(), gpu_build ? "GPU" : "host", asked_workers,
             std::chrono::duration<double>(std::chrono::steady_clock::now() - stage_t0).count());
   const auto destroy_t0 = std::chrono::steady_clock::now();
   rl_destroy(ctx);
