@@ -574,8 +574,8 @@ static hipError_t launch_repaint_t(const RepaintParams &p, hipStream_t stream) {
     }
   }
   hipLaunchKernelGGL((repaint_fwd_kernel<S, TAIL, RL_MODE, WAVES>), dim3(p.nloc), dim3(64 * WAVES), 0, stream, p);
-  // nostrip = 1: the part launches of a bounded window without the strip; 2: whole windows too
-  if (p.nostrip > 1 || (p.partial && p.nostrip))
+  // the part launches of a bounded window without the strip, whole windows with it
+  if (p.partial && p.nostrip)
     hipLaunchKernelGGL((repaint_bwd_nostrip_kernel<S, TAIL, RL_MODE, WAVES>), dim3(p.nloc), dim3(64 * WAVES), 0, stream, p);
   else
     hipLaunchKernelGGL((repaint_bwd_kernel<S, TAIL, RL_MODE, WAVES>), dim3(p.nloc), dim3(64 * WAVES), strips, stream, p);

@@ -159,10 +159,9 @@ static int repaint_rows(rl_window *win, float *kernel_ms) {
   // HeldRow NOSTRIP): a part is ~6 rows per target behind ~40 beta-only steps of descent, the checkpoint rows are read
   // where they lie (through the L2), and two waves share a SIMD.  C3, 116 workers, same boxes, alternating: 147.6 /
   // 147.1 / 144.6 s against 161.6 / 148.0 / 150.4 s with the strip; RePaint 57-68 s on the device instead of 77-120,
-  // a section waits 1-2 s per window for its turn (profiles/r05_c3_runs.json).  RELATE_AMD_REPAINT_NOSTRIP=0: the strip
-  // everywhere; 2: no strip for whole windows either.
-  static const int nostrip = getenv("RELATE_AMD_REPAINT_NOSTRIP") ? atoi(getenv("RELATE_AMD_REPAINT_NOSTRIP")) : 1;
-  p.nostrip = nostrip;
+  // a section waits 1-2 s per window for its turn (profiles/r05_c3_runs.json).  A WHOLE window keeps the strip: every
+  // one of a block's six rows would re-read the checkpoint row, 15.7 ms against 14.9 ms (profiles/r06_k2_whole_window_strip.json).
+  p.nostrip = 1;
   p.bstate = win->d_bstate.as<double>();
   p.bscal = win->d_bscal.as<double>();
   p.fstate = win->d_fstate.as<double>();
