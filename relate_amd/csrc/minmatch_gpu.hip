@@ -979,7 +979,9 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
         ei[qq] = MM(i, k);
         ej[qq] = MM(j, k);
       }
-      constexpr bool JIT = State<LAY>::hot_lds;  // the candidate's fields come from LDS: at the cluster's turn
+      // the candidate's fields from LDS: all of the pass at once while the registers allow (256 per lane: 2 ms of a
+      // tree under load), at the cluster's turn in the 128-register kernels
+      constexpr bool JIT = State<LAY>::hot_lds && ROWS == 1;
       float s_d1[JIT ? 1 : QC], s_d2[JIT ? 1 : QC];
       int s_l1[JIT ? 1 : QC], s_l2[JIT ? 1 : QC];
       double s_d2d[AGES && !JIT ? QC : 1];
@@ -1495,7 +1497,8 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
       for (int q = 0; q < MAXQ; q++) {
         if (q >= nq) break;
         const int ik = q * MM_BLOCK + tid;
-        int nx = __shfl_down(a_k[q], 1, 64);
+        // (lane l takes lane l + 1's: one DPP move across the wave, wave_shl:1; lane 63 -- it keeps -1 -- from the edge)
+        int nx = __builtin_amdgcn_update_dpp(-1, a_k[q], 0x130, 0xf, 0xf, false);
         if (lane == 63) {
           if (wave + 1 < MM_WAVES) nx = sh.edge[wave + 1][q];
           else if (q + 1 < MAXQ) nx = sh.edge[0][q + 1];

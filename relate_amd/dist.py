@@ -308,12 +308,25 @@ def run_chunk_by_targets(out_dir, chunk_index=0, painting=None, device=None, sec
         # the sections it owns need ~17 N^2 bytes each on the device; 0.7 of what is left for the rows
         window_rows = 0
         if on_device_rows(fab):
-            free_b = torch.cuda.mem_get_info(fab.device)[0]
-            free_b -= (17.0 * N * N * min(max(1, int(in_flight)), max(1, len(deal_sections(
+            nloc = shard.k_end - shard.k_begin
+            n_win = max(1, int(in_flight)) * world
+            mine_n = min(max(1, int(in_flight)), max(1, len(deal_sections(
                 list(range(shard.W if num_sections is None else num_sections)) if sections is None else list(sections),
-                rank, world)))) if build_on_gpu else 0.0)
-            window_rows = max(3 * (shard.k_end - shard.k_begin) + 64,
-                              int(0.7 * max(free_b, 0.0) / (max(1, int(in_flight)) * world * 4.2 * N)))
+                rank, world))))
+            free_b = float(torch.cuda.mem_get_info(fab.device)[0])
+            row_b = 4.2 * N
+            # next to its rows a bounded window keeps one forward and one backward RePaint state per target (doubles:
+            # 4 rows' worth of bytes each) and its slice of the stepping stones (2 N floats per target); RePaint's
+            # strips for a window's first, whole pass are one buffer of the context (a sixth of the rows, doubles)
+            per_window = 4.0 * row_b * nloc + 8.0 * N * nloc + 48e6
+            avail = 0.85 * free_b - (17.0 * N * N * mine_n if build_on_gpu else 0.0) - n_win * per_window
+            min_rows = 3 * nloc + 64
+            if avail < n_win * min_rows * row_b:
+                raise ValueError("run_chunk_by_targets: %d windows in flight (in_flight %d x %d ranks) do not fit the %.0f GB "
+                                 "free on the device next to %d tree builders -- fewer in flight" %
+                                 (n_win, in_flight, world, free_b / 1e9, mine_n))
+            # (a third of what is left goes to the strips of the whole passes)
+            window_rows = max(min_rows, int(0.67 * avail / (n_win * row_b)))
     if window_rows:
         shard.set_window_rows(window_rows)
     todo = list(range(shard.W if num_sections is None else num_sections)) if sections is None else list(sections)

@@ -35,7 +35,7 @@ if os.environ.get("C5_SKIP_FUSED") != "1":
           file=sys.stderr, flush=True)
 if route_sections > 0:
     out["by_targets_one_rank"] = run([os.path.join(ROOT, "tools", "chunk_c5_sharded.py"), str(N), str(L), str(MEM),
-                                      str(route_sections), str(in_flight), "-1", "1"])
+                                      str(route_sections), str(in_flight), os.environ.get("C5_ROUTE_FRACTION", "0.05"), "1"])
 f = out.get("fused_stage") or {}
 if f.get("wall_s"):
     trees = f.get("trees_built") or f.get("trees_kept")

@@ -36,7 +36,7 @@ try:
                                     r.ctypes.data_as(C.c_void_p), rpos.ctypes.data_as(C.c_void_p),
                                     wb.ctypes.data_as(C.c_void_p), W) == 0
     del seq
-    exe = os.path.join(ROOT, "relate_amd", "Relate")
+    exe = os.environ.get("RELATE_EXE") or os.path.join(ROOT, "relate_amd", "Relate")  # (RELATE_EXE: another build, A/B runs)
     t0 = time.time()
     # C3_FUSED_FEB=1: FindEquivalentBranches fused behind the stage (every .anc written once, as that stage leaves it)
     fused_feb = ["--find_equivalent_branches"] if os.environ.get("C3_FUSED_FEB") and sections == W else []

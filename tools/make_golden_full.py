@@ -11,9 +11,11 @@
            -> tests/golden/full_c2.npz
   c4       one chunk of config #4 as bench.py makes it (N = 2000 x L = 121,000, seed 1, --memory 1): the same
            -> tests/golden/full_c4.npz
+  c5_first config #5 (N = 10,000 x L = 200,000, seed 1, --memory 25): the reference's complete paint file of window 0 and
+           BuildTopology of section 0 (hours of the reference) -> tests/golden/c5_first.npz
 
 Runs only in the build container (needs oracle/_ref, `make -C oracle ref`).  Resumable: every step leaves its output
-in the work directory.   python tools/make_golden_full.py <c3_ends|c2|c4> [workdir] [procs]
+in the work directory.   python tools/make_golden_full.py <c3_ends|c2|c4|c5_first> [workdir] [procs]
 """
 import ctypes as C
 import hashlib
@@ -33,6 +35,7 @@ CONFIGS = {
     "c3_ends": dict(N=5000, L=500000, mem=20.0, seed=1, work="/tmp/c3ref", out="c3_ends.npz", sections=None),
     "c2": dict(N=1000, L=100000, mem=5.0, seed=1, work="/tmp/c2ref", out="full_c2.npz", sections="first_mid_last"),
     "c4": dict(N=2000, L=121000, mem=1.0, seed=1, work="/tmp/c4ref", out="full_c4.npz", sections="first_mid_last"),
+    "c5_first": dict(N=10000, L=200000, mem=25.0, seed=1, work="/tmp/c5ref", out="c5_first.npz", sections=None),
 }
 
 
@@ -184,8 +187,8 @@ if __name__ == "__main__":
     chunk(work, cfg["N"], cfg["L"], cfg["mem"], cfg["seed"])
     W, wb = windows_of(work)
     print("[%s] chunk: W = %d, %.0f s" % (name, W, time.time() - t0), flush=True)
-    if name == "c3_ends":
-        sections = [0, W - 1]
+    if name in ("c3_ends", "c5_first"):
+        sections = [0, W - 1] if name == "c3_ends" else [0]
         paint_windows(work, cfg["N"], sections, procs)
         print("[%s] paint files of windows %s: %.0f s" % (name, sections, time.time() - t0), flush=True)
         all_windows = False
