@@ -448,8 +448,8 @@ def main():
     roofline_k2 = None
     pmc = None
     pmc_file = None
-    for cand in ("r05_pmc_c3.json", "r04_pmc_c3.json", "r03_pmc_c3.json", "r02_pmc_c3.json"):  # HBM bytes per launch: separate rocprofv3 --pmc runs
-        try:                                              # (tools/gpu_profile_r05.sh), committed summary
+    for cand in ("r06_pmc_c3.json", "r05_pmc_c3.json", "r04_pmc_c3.json", "r03_pmc_c3.json", "r02_pmc_c3.json"):  # HBM bytes per launch: separate rocprofv3 --pmc runs
+        try:                                              # (tools/gpu_r06_i.sh), committed summary
             pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))
             if pmc["N"] != N or pmc["L"] != L or by_target or args.workload != "c3":
                 pmc = None

@@ -343,7 +343,7 @@ typedef struct rl_stage_opts {
   long long window_rows;    /* posterior rows a window keeps resident; 0: from the HBM that is free; < 0: all      */
   int window_parts;         /* a window keeps at least 1/window_parts of its rows (0: 32)                          */
   int section_threads;      /* sections open at once at most (0: from HBM and the device)                          */
-  int workers;              /* tree-builder workgroups on the device (0: one per open section, 29/64 of the CUs when the windows are bounded) */
+  int workers;              /* tree-builder workgroups on the device (0: the rule of treeseq.cpp stage_worker_goal -- one per open section, 29/64 of the CUs when the windows are bounded, times the kernel's workgroups per CU) */
   int repaint_lanes;        /* RePaint launches side by side: 1 or 2 (0: 1)                                        */
   int park_stones;          /* fused stage: stepping stones to pinned host memory after Paint (rl_park_stones)     */
   int pin_threads;          /* section threads pinned to L3 groups: 1 / 0 (-1: 1)                                  */

@@ -206,14 +206,19 @@ class TorchFabric:
         return out.cpu().numpy().reshape((self.world,) + tuple(t.shape))
 
     def all_gather_rows(self, send, recv):
-        if not self.live or self.world == 1:
-            recv.copy_(send)
-        else:
-            dist.all_gather_into_tensor(recv, send)
-        if recv.is_cuda:
-            # (the stream the collective was ordered on, NOT the device: a device-wide wait also waits for the tree
+        self.all_gather_rows_many([send], [recv])
+
+    def all_gather_rows_many(self, sends, recvs):
+        """the blocks of SEVERAL matrices: the collectives queue up behind one another, ONE wait for all of them"""
+        for send, recv in zip(sends, recvs):
+            if not self.live or self.world == 1:
+                recv.copy_(send)
+            else:
+                dist.all_gather_into_tensor(recv, send)
+        if recvs and recvs[0].is_cuda:
+            # (the stream the collectives were ordered on, NOT the device: a device-wide wait also waits for the tree
             #  builder's resident workers, i.e. for every other section's tree -- 0.6 s per matrix at N = 10,000)
-            torch.cuda.current_stream(recv.device).synchronize()
+            torch.cuda.current_stream(recvs[0].device).synchronize()
 
 
 class ThreadFabric:
@@ -246,15 +251,20 @@ class ThreadFabric:
         return np.stack(self._exchange(np.array(table, dtype=np.int64)))
 
     def all_gather_rows(self, send, recv):
-        blocks = self._exchange(send)
-        n = send.shape[0]
-        for r, b in enumerate(blocks):
-            recv[r * n:(r + 1) * n].copy_(b)
-        if recv.is_cuda:
-            # (the stream the collective was ordered on, NOT the device: a device-wide wait also waits for the tree
+        self.all_gather_rows_many([send], [recv])
+
+    def all_gather_rows_many(self, sends, recvs):
+        """the blocks of several matrices with ONE exchange, one wait and one closing barrier"""
+        blocks = self._exchange(list(sends))
+        for i, recv in enumerate(recvs):
+            n = sends[i].shape[0]
+            for r, b in enumerate(blocks):
+                recv[r * n:(r + 1) * n].copy_(b[i])
+        if recvs and recvs[0].is_cuda:
+            # (the stream the copies were ordered on, NOT the device: a device-wide wait also waits for the tree
             #  builder's resident workers, i.e. for every other section's tree -- 0.6 s per matrix at N = 10,000)
-            torch.cuda.current_stream(recv.device).synchronize()
-        self.hub.barrier.wait()  # (nobody overwrites its send block while another rank still copies from it)
+            torch.cuda.current_stream(recvs[0].device).synchronize()
+        self.hub.barrier.wait()  # (nobody overwrites its send blocks while another rank still copies from them)
 
 
 def on_device_rows(fab):
@@ -336,9 +346,13 @@ def run_chunk_by_targets(out_dir, chunk_index=0, painting=None, device=None, sec
     # a block = this rank's rows + one row whose first float says whether they are good (1.0 = shard.rows failed on
     # that rank and the block is stale: the owner must not build from it)
     stride = maxrows + 1
-    send = fab.buffer(stride, N)
-    recv = fab.buffer(world * stride, N)
-    on_device = send.is_cuda
+    # the matrices of a tick are exchanged `lanes` at a time: every rank computes its rows of up to `lanes` requests,
+    # the collectives queue up behind one another and ONE wait covers them (a wait per matrix serialised ~1.5 ms of
+    # exchange per tree; two ranks as threads of one process paid two barriers per matrix)
+    lanes = max(1, min(4, Q * world))
+    sends = [fab.buffer(stride, N) for _ in range(lanes)]
+    recvs = [fab.buffer(world * stride, N) for _ in range(lanes)]
+    on_device = sends[0].is_cuda
     gpu_build = bool(build_on_gpu and on_device)
     if gpu_build:
         shard.expect_builders(min(Q, max(1, len(mine))))
@@ -391,7 +405,7 @@ def run_chunk_by_targets(out_dir, chunk_index=0, painting=None, device=None, sec
     for t in threads:
         t.start()
 
-    def deliver(req):
+    def deliver(req, recv):
         _, _, _, ptr, to_device, _, _ = req
         for r in range(world):
             a, b = target_range(r, world, N)
@@ -432,43 +446,63 @@ def run_chunk_by_targets(out_dir, chunk_index=0, painting=None, device=None, sec
             if owns_shard:
                 shard.close()
             raise err
-        busy = False
+        # the tick's requests in (rank, slot) order; runs of matrix requests go `lanes` at a time
+        reqs = []
         for r in range(world):
             for q in range(Q):
                 kind, section, snp = (int(x) for x in tables[r, q])
-                if kind == REQ_NONE:
-                    continue
-                busy = True
-                if kind == REQ_MATRIX:
-                    try:
-                        if abort is None:
-                            shard.rows(section, snp, send.data_ptr())
-                    except BaseException as e:  # (keep the collectives aligned; the next tick stops the job)
-                        abort = e
-                        send[maxrows, 0] = 1.0
-                    fab.all_gather_rows(send, recv)
-                    served += 1
-                    # (the ok-flag rows: only the rank that CONSUMES the matrix looks at them -- a device-to-host copy and a
-                    #  wait per tree, not per tree and rank; its `abort` reaches the others through the next tick's table)
-                    if r == rank and abort is None:
-                        bad = [int(x) for x in torch.nonzero(recv[maxrows::stride, 0].cpu()).flatten()]
-                        if bad:
-                            abort = RuntimeError("run_chunk_by_targets: rows of section %d at SNP %d failed on rank%s %s"
-                                                 % (section, snp, "s" if len(bad) > 1 else "", bad))
-                elif kind == REQ_RELEASE:
-                    try:
-                        shard.release_section(section)
-                    except BaseException as e:
-                        abort = e
-                if r == rank:
-                    req = snapshot[q]
-                    if kind == REQ_MATRIX and abort is None:
-                        deliver(req)
-                    elif kind == REQ_MATRIX:  # (no tree from a matrix with stale rows in it)
-                        req[6] = abort
-                    with lock:
-                        pending[q] = None
-                    req[5].set()
+                if kind != REQ_NONE:
+                    reqs.append((r, q, kind, section, snp))
+        busy = bool(reqs)
+
+        def complete(r, q, error=None):
+            if r == rank:
+                req = snapshot[q]
+                if error is not None:
+                    req[6] = error
+                with lock:
+                    pending[q] = None
+                req[5].set()
+        i = 0
+        while i < len(reqs):
+            r, q, kind, section, snp = reqs[i]
+            if kind == REQ_RELEASE:
+                try:
+                    shard.release_section(section)
+                except BaseException as e:
+                    abort = e
+                complete(r, q)
+                i += 1
+                continue
+            group = []
+            while i < len(reqs) and reqs[i][2] == REQ_MATRIX and len(group) < lanes:
+                group.append(reqs[i])
+                i += 1
+            for lane, (r, q, kind, section, snp) in enumerate(group):
+                sends[lane][maxrows, 0] = 0.0
+                try:
+                    if abort is None:
+                        shard.rows(section, snp, sends[lane].data_ptr())
+                    else:
+                        sends[lane][maxrows, 0] = 1.0  # (nothing computed: the block is stale)
+                except BaseException as e:  # (keep the collectives aligned; the next tick stops the job)
+                    abort = e
+                    sends[lane][maxrows, 0] = 1.0
+            fab.all_gather_rows_many(sends[:len(group)], recvs[:len(group)])
+            served += len(group)
+            for lane, (r, q, kind, section, snp) in enumerate(group):
+                # (the ok-flag rows: only the rank that CONSUMES the matrix looks at them -- a device-to-host copy per tree
+                #  it owns; its `abort` reaches the others through the next tick's table)
+                if r == rank and abort is None:
+                    bad = [int(x) for x in torch.nonzero(recvs[lane][maxrows::stride, 0].cpu()).flatten()]
+                    if bad:
+                        abort = RuntimeError("run_chunk_by_targets: rows of section %d at SNP %d failed on rank%s %s"
+                                             % (section, snp, "s" if len(bad) > 1 else "", bad))
+                if r == rank and abort is None:
+                    deliver(snapshot[q], recvs[lane])
+                    complete(r, q)
+                else:
+                    complete(r, q, abort)  # (no tree from a matrix with stale rows in it)
         if not busy:
             if (tables[:, Q, 0] == 1).all():
                 break

@@ -35,7 +35,7 @@ CONFIGS = {
     "c3_ends": dict(N=5000, L=500000, mem=20.0, seed=1, work="/tmp/c3ref", out="c3_ends.npz", sections=None),
     "c2": dict(N=1000, L=100000, mem=5.0, seed=1, work="/tmp/c2ref", out="full_c2.npz", sections="first_mid_last"),
     "c4": dict(N=2000, L=121000, mem=1.0, seed=1, work="/tmp/c4ref", out="full_c4.npz", sections="first_mid_last"),
-    "c5_first": dict(N=10000, L=200000, mem=25.0, seed=1, work="/tmp/c5ref", out="c5_first.npz", sections=None),
+    "c5_first": dict(N=10000, L=200000, mem=25.0, seed=1, work="/tmp/c5ref", out="c5_first.npz", sections=None, records=True),
 }
 
 
@@ -151,6 +151,22 @@ def pack(cfg, work, sections, all_windows):
         elif os.path.exists(os.path.join(work, "paint_md5_%d.npy" % s)):
             data["s%d/paint_md5" % s] = np.load(os.path.join(work, "paint_md5_%d.npy" % s))
             data["s%d/paint_size" % s] = np.load(os.path.join(work, "paint_size_%d.npy" % s))
+        if cfg.get("records") and os.path.exists(pf):  # every target's record of the window, so that a test can check a subset
+            import struct
+            buf = open(pf, "rb").read()
+            pos, lens, md5s = 0, [], []
+            for _ in range(cfg["N"]):
+                q = pos + 8
+                for _stone in range(2):
+                    one, n, bsnp, ls, K = struct.unpack_from("<QQifi", buf, q)
+                    assert one == 1 and n == cfg["N"]
+                    q += 28 + 8 * K
+                lens.append(q - pos)
+                md5s.append(md5(buf[pos:q]))
+                pos = q
+            assert pos == len(buf)
+            data["s%d/record_len" % s] = np.array(lens, dtype=np.int32)
+            data["s%d/record_md5" % s] = np.stack(md5s)
         anc = os.path.join(d, "chunk_0", "out_%d.anc" % s)
         mut = open(os.path.join(d, "chunk_0", "out_%d.mut" % s), "rb").read()
         data["s%d/anc_md5" % s] = md5_file(anc)
