@@ -253,6 +253,7 @@ int device_builder_reserve_shared(int device, int N);
 // how many builders of trees of N leaves will ask the device's workers at the same time (0: unknown)
 // (ages: the builders with sample ages -- their workers are another kernel)
 int device_builder_expect(int device, int N, int builders, bool ages = false);
+int device_builder_expect_add(int device, int N, int delta, bool ages = false);
 // workgroups of the worker kernel for trees of N leaves a CU holds (1 or 2)
 int device_builder_workers_per_cu(int N, bool ages = false);
 // the stage's rule for how many resident workers to ask for (treeseq.cpp)

@@ -2456,6 +2456,12 @@ class BuildQueue {
     std::lock_guard<std::mutex> lk(m_);
     expected_ = builders;
   }
+  // ... of SEVERAL callers that share the device (target ranges as threads of one process, shard.cpp): each adds what
+  // it asks for and takes it off again
+  void expect_add(int delta) {
+    std::lock_guard<std::mutex> lk(m_);
+    expected_ = std::max(0, expected_ + delta);
+  }
   // Publishes the tree and returns when ITS worker says it is out (p.host_done, -1 until then): 0, or RL_EHIP.
   int run(const MMParams &p) {
     {
@@ -2662,6 +2668,13 @@ int device_builder_expect(int device, int N, int builders, bool ages) {
   BuildQueue *q = BuildQueue::of(device, N, ages);
   if (!q) return -1;
   q->expect(builders);
+  return 0;
+}
+int device_builder_expect_add(int device, int N, int delta, bool ages) {
+  if (hipSetDevice(device) != hipSuccess) return -1;
+  BuildQueue *q = BuildQueue::of(device, N, ages);
+  if (!q) return -1;
+  q->expect_add(delta);
   return 0;
 }
 

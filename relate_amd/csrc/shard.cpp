@@ -35,7 +35,7 @@ namespace rl {
 rl_treeseq *treeseq_borrowing(int N, int L, const uint32_t *bits, int row_words, const double *rpos, const int *bp_pos,
                               const int *state, double theta);
 int device_builder_reserve_shared(int device, int N);
-int device_builder_expect(int device, int N, int builders, bool ages = false);
+int device_builder_expect_add(int device, int N, int delta, bool ages = false);
 }  // namespace rl
 
 using namespace rl;
@@ -127,7 +127,7 @@ void rl_shard_close(rl_shard *s) {
   for (auto &kv : s->open)
     if (kv.second->win) rl_window_close(kv.second->win);
   s->open.clear();
-  if (s->expected > 0) (void)device_builder_expect(s->device, s->ctx->N, 0);
+  if (s->expected > 0) (void)device_builder_expect_add(s->device, s->ctx->N, -s->expected);
   rl_destroy(s->ctx);
   delete s;
 }
@@ -215,8 +215,11 @@ int rl_shard_release_section(rl_shard *s, int section) {
 int rl_shard_expect_builders(rl_shard *s, int builders) {
   if (!s || builders < 0) return RL_EINVAL;
   if (builders > 0 && device_builder_reserve_shared(s->device, s->ctx->N)) return RL_ENOMEM;
+  // (added to what the other shards of this process on this device ask for: two target ranges as threads of one
+  //  process each asking for 4 workers used to leave 4 for their 8 trees -- the later word won)
+  const int delta = builders - s->expected;
   s->expected = builders;
-  return device_builder_expect(s->device, s->ctx->N, builders) ? RL_EHIP : RL_OK;
+  return device_builder_expect_add(s->device, s->ctx->N, delta) ? RL_EHIP : RL_OK;
 }
 
 int rl_shard_build_section(rl_shard *s, int section, int flags, int fb, int build_device, rl_matrix_fn matrix,

@@ -55,4 +55,15 @@ if f.get("wall_s"):
                        "on its owner rank, the sections dealt evenly, so the trees split eightfold too; every tree costs one "
                        "all-gather of N^2 floats, overlapped with the other sections' builds -- the job takes the longer of "
                        "the two plus start-up.  Never run on more than one GPU from this environment."}
+# section 0 against the REFERENCE where its fixture is there (tests/golden/c5_first.npz, tools/make_golden_full.py c5_first)
+try:
+    import numpy as np
+    z = np.load(os.path.join(ROOT, "tests", "golden", "c5_first.npz"))
+    want = {"out_0.anc": z["s0/anc_md5"].tobytes().hex(), "out_0.mut": z["s0/mut_md5"].tobytes().hex()}
+    for leg in ("fused_stage", "by_targets_one_rank"):
+        got = (out.get(leg) or {}).get("section_md5") or (out.get(leg) or {}).get("md5") or {}
+        if got:
+            out[leg]["section_0_matches_reference"] = all(got.get(k) == v for k, v in want.items())
+except Exception as e:
+    out["reference_fixture"] = "not compared: %s" % str(e)[:100]
 print(json.dumps(out))
