@@ -8,8 +8,8 @@
 //     line per cluster: on a host dozens of open sections are bound by DRAM (DESIGN_NOTES.md 5), in HBM one
 //     workgroup per tree leaves the other 255 CUs to the trees of the other sections;
 //   * the parts that are order-free (distance updates, row-minimum rescans, candidate tests, reductions) run
-//     on all 1024 threads; the random draws -- one per feasible pair, in the reference's order -- and the
-//     candidate bookkeeping run on thread 0 over lists the parallel parts leave in order;
+//     on all 512 threads; the random draws -- one per feasible pair, in the reference's order -- and the
+//     candidate bookkeeping run on wave 0 over lists the parallel parts leave in order;
 //   * std::mt19937 (seed 1 per build) and libstdc++'s generate_canonical<double, 53> are restated below.
 // The symmetric fallback (no mutually closest pair left, :255-293 / :968-1058) is here too: "the first cluster in
 // scan order that reaches the minimum" is a lexicographic (value, position) reduction.  The state both builders
@@ -73,7 +73,8 @@ enum { L_LDS = 0, L_GLOBAL = 1, L_HOT = 2, L_WARM = 3 };
 // instead of four loads along rows and four down columns (a scattered 4-byte access costs one CU ~3.5 cycles:
 // measured 3.7 us per column of 2500 clusters, six of them per merge in the plain layout); what stays scattered is
 // ONE 16-byte store per cluster, M[k][j], which waits for nobody.  Packed from the distance matrix (K3 + carrier
-// penalty) and the clade prior by pack_kernel; row minima of both by rowmin_kernel.
+// penalty) and the clade prior by weave_kernel; row minima of both by the penalty / prior passes (rowmin_penalty_kernel,
+// prior_kernel).
 //
 // One field list, two structs of the same layout: MMParams (plain pointers: what the host fills in) and MMParamsDev
 // (GLOBAL pointers: what the build kernel works with).  A worker reads its parameters from a queue, not from
@@ -88,7 +89,7 @@ enum { L_LDS = 0, L_GLOBAL = 1, L_HOT = 2, L_WARM = 3 };
   int has_prior; /* the cf halves of M are in use */                                                                 \
   PTR(const float) rowmin_D; /* [N] minimum of each row off the diagonal */                                          \
   PTR(const float) rowmin_CF;                                                                                        \
-  /* the mutually close pairs (a, b > a) of the untouched matrix, row by row in order, from pairscan_kernel */       \
+  /* the mutually close pairs (a, b > a) of the untouched matrix, row by row in order, from weave_kernel   */       \
   PTR(const int) hit_cnt;    /* [N] (more than MM_HITS: not all kept) */                                             \
   PTR(const unsigned) hit_b; /* [N][MM_HITS] */                                                                      \
   PTR(const float) hit_sym;  /* [N][MM_HITS] symmetric distance of the pair (0: the prior makes it a certain pair) */ \
@@ -232,7 +233,7 @@ struct Best {
 };
 
 constexpr int MM_PARAM_WORDS = 104;  // sizeof(MMParams) / 4 rounded up (static_assert below)
-constexpr int MM_ROWS_MAX = 2;       // rows of rebuilt clusters a pass of a merge scans at most (build_tree: ROWS)
+constexpr int MM_ROWS_MAX = 2;       // rows of rebuilt clusters a pass of a merge scans at most (build_tree: ROWS; 3: 119 ms per N = 5000 tree, 2: 110, 4: 134)
 struct Shared {
   unsigned praw[MM_PARAM_WORDS];  // the tree's parameters as the worker read them from the queue
   unsigned ticket;
@@ -460,19 +461,22 @@ __device__ inline double ages_step(int k, int Ne) {
 
 // One workgroup per tree: workgroup b builds the tree of params[b].
 //
-// A merge (i into j) on the workgroup, thread t holding the clusters at positions t, t + 1024, ... of the live list:
-//   A. every thread: the four entries (k,j), (k,i), (i,k), (j,k) of both matrices for its clusters k (all loads
-//      issued at once), the size-weighted updates written back and KEPT in registers; which clusters rebuild their
+// A merge (i into j) on the workgroup, thread t holding the clusters at positions t, t + 512, ... of the live list IN
+// ITS REGISTERS for the whole build (a_k; the positions behind a cluster that leaves move up by one lane):
+//   A. every thread: the four entries (k,j), (k,i), (i,k), (j,k) of both matrices for its clusters k (all loads of a
+//      pass issued at once, with the clusters' row minima, which stay in registers to the end of the merge), the
+//      size-weighted updates written back; which clusters rebuild their
 //      candidates (row minimum on a changed entry, or candidate touching i or j: appended to a list in LDS, their
 //      candidates reset); partial minima of the merged cluster's row (both matrices) and the best candidate among
 //      the clusters that keep theirs, (dist, dist2, position)-lexicographic -- one exchange for all of it;
-//   B. the rows of the rebuilt clusters, MM_ROWS at a time, an element per thread and position: first the
-//      row-minimum rescans (the reference's scan with early exit = "the old minimum if it occurs before any smaller
-//      entry, else the row's minimum": three reductions, finished by one wave per row), then, on the values still
-//      in registers, the row half of the candidate test of every pair the rebuilt cluster is part of; the few
-//      survivors fetch the column half (and the prior's entries) themselves and append the feasible pairs,
-//      keyed by (position of the later cluster, position of the earlier one), to a list in LDS;
-//   C. the merged cluster's own pairs from the registers of A, keyed behind all others;
+//   B. the rows of the rebuilt clusters, ROWS at a time, d(k,l) per thread and position (one half of a pair: 4 of an
+//      element's 16 bytes): first the row-minimum rescans (the reference's scan with early exit = "the old minimum if
+//      it occurs before any smaller entry, else the row's minimum": three reductions, finished by one wave per row),
+//      then, on the values still in registers, the row half of the candidate test of every pair the rebuilt cluster
+//      is part of; the few survivors fetch the other half, d(l,k), themselves and append the feasible pairs, keyed by
+//      (position of the later cluster, position of the earlier one), to a list in LDS;
+//   C. the merged cluster's own pairs from its row as A left it (d(j,k) read back, in flight since the start of B; the
+//      survivors fetch d(k,j)), keyed behind all others;
 //   D. the pairs sorted by key (rank = number of smaller keys) -- the order in which the reference meets them --
 //      and ONE lane draws the random numbers and updates the candidates in that order, then settles the running
 //      best: per cluster the candidate it holds at its turn of the reference's loop, smallest (dist, dist2),
@@ -484,12 +488,12 @@ __device__ inline double ages_step(int k, int Ne) {
 // reduction above -- the running best over the clusters in order -- is order-dependent there (a candidate beyond the
 // clock takes an EMPTY place only, one within the clock displaces it whatever its distance), so wave 0 walks the
 // live list once per merge, the pairs applied at their clusters' turns: exact, and slower (data sets with ancient
-// samples are small).  The per-cluster state of that build lives in global memory.
+// samples are small).  Its per-cluster state lives in one place: LDS up to N = 4100 (L_LDS), global memory above.
 template <int LAY, int MAXQ, bool AGES, int ROWS>
 __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, unsigned char *dyn) {
   typedef typename State<LAY>::hidx_t hidx_t;
   typedef typename State<LAY>::cidx_t cidx_t;
-  static_assert(ROWS <= MM_ROWS_MAX && ROWS * MAXQ <= 64, "ROWS * MAXQ bits of survivors per pass");
+  static_assert(ROWS <= MM_ROWS_MAX && ROWS <= MM_WAVES, "a wave finishes a row's rescan");
   static_assert((LAY != L_HOT && LAY != L_WARM) || !AGES, "the AGES build keeps all of its state in one place");
   const int N = p.N;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -630,7 +634,7 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
   }
   __syncthreads();
 
-  // ---- Initialize (:59-146 / :1647-1735): row minima (+ threshold); the minima themselves come from rowmin_kernel
+  // ---- Initialize (:59-146 / :1647-1735): row minima (+ threshold); the minima themselves come from the penalty / prior passes
   for (int a = tid; a < N; a += MM_BLOCK) {
     st.mv[a] = p.rowmin_D[a] + threshold;
     if (p.has_prior) {
@@ -758,7 +762,7 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
     }
     return rnd;
   };
-  // mutually close pairs in (a, b) order (:1690-1722): pairscan_kernel has found them; MM_BLOCK rows at a time they
+  // mutually close pairs in (a, b) order (:1690-1722): weave_kernel has found them; MM_BLOCK rows at a time they
   // are staged in LDS in order and wave 0 draws
   auto draw_staged = [&](int count) {  // wave 0: the staged pairs sh.pxy[0] / sh.psym[0] in order (:1704-1722)
     if constexpr (AGES) {  // (:205-237)
@@ -1989,6 +1993,8 @@ __global__ void __launch_bounds__(MM_BLOCK) __attribute__((amdgpu_waves_per_eu(2
     params_from_words(p, sh.praw);
     // rows of rebuilt clusters per pass of a merge: two while the registers allow (2: 110 ms per N = 5000 tree, 3: 119,
     // 4: 134 with 256 registers per lane)
+    // (three / four rows, possible since a row costs 10 registers instead of 20: 114.2 / 114.4 ms per tree against 115.0
+    //  -- the tests gain what the ordered part loses to spills: profiles/r06_rows_per_pass.json)
     build_tree<LAY, MAXQ, AGES, (OCC > 1 || MAXQ > MM_Q_LDS) ? 1 : 2>(p, sh, dyn);
     __syncthreads();  // (sh is the next tree's)
     had_tree = true;
@@ -2301,7 +2307,7 @@ static int env_int(const char *name, int fallback, int lo, int hi) {
 // What the builders of one device share.
 //
 // * Staging: the row-major distance matrix (K3 writes it, the carrier penalty edits it) and clade prior of a tree
-//   are needed from K3 until the weave (pack_kernel) -- ~30 ms of a tree's ~0.2 s with a hundred sections sharing
+//   are needed from K3 until the weave (weave_kernel) -- ~30 ms of a tree's ~0.2 s with a hundred sections sharing
 //   the hardware queues: 32 pairs (12 were a queue of their own at 134 sections: 11 s of every section's 60).  A builder takes a pair from
 //   a small pool for that time instead of owning 8 N^2 bytes for life (200 MB of the 725 MB a section used to pin
 //   at N = 5000: why 91 sections were all that fitted).
@@ -3032,7 +3038,7 @@ int DeviceMinMatch::build_impl(TB &tb, const std::vector<double> *sample_ages, c
     lin[(size_t)N + c] = tb.mc[c].lin2;
     mvcf[c] = tb.min_values_CF[c];
   }
-  // (min_values_CF as carried over is also what pairscan_kernel tests the prior with: that copy goes to the device)
+  // (min_values_CF as carried over is also what weave_kernel tests the prior with: that copy goes to the device)
   const float *mvcf_dev = p.min_values_CF;
   RL_HIP(hipMemcpyAsync(p.min_values_CF, mvcf, (size_t)N * 4, hipMemcpyHostToDevice, m.stream));
   if (p.layout != L_GLOBAL) {

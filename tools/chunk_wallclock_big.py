@@ -34,7 +34,7 @@ with tempfile.TemporaryDirectory() as work:
                                     r.ctypes.data_as(C.c_void_p), rpos.ctypes.data_as(C.c_void_p),
                                     wb.ctypes.data_as(C.c_void_p), W) == 0
     del seq
-    exe = os.path.join(ROOT, "relate_amd", "Relate")
+    exe = os.environ.get("RELATE_EXE") or os.path.join(ROOT, "relate_amd", "Relate")  # (RELATE_EXE: another build, A/B runs)
     if len(sys.argv) > 5 and sys.argv[5] == "ref":  # the unmodified reference binary on the same chunk (container only)
         exe = rlutil.REF_RELATE
     t0 = time.time()
