@@ -267,6 +267,11 @@ int rl_debug_rng_mismatches(unsigned seed, int n);
  * [reps][2N-1].  MinMatch::QuickBuild, src/tree_builder.cpp:2358-2644. */
 int rl_debug_builder_throughput(int N, double theta, int device, int builders, int reps, int workers, const float *d,
                                 const float *prior, double *seconds, int *mismatches, int *first_parents);
+/* Test hook (host only): the stage's rule for how many resident tree-builder workgroups it asks for -- never more
+ * than open sections (a section has one tree in flight: the unit of parallelism of
+ * scripts/RelateParallel/RelateParallel.sh:231-257); 7/8 of the worker slots with whole windows resident, 29/64 of the
+ * CUs (times the kernel's workgroups per CU) when the windows are bounded and RePaint runs all through the stage. */
+int rl_debug_stage_worker_goal(int cus, int open_sections, int bounded_windows, int workers_per_cu);
 
 /* Tree-sequence loop of one section, AncesTreeBuilder::BuildTopology
  * (src/anc_builder.cpp:398-656): first tree from the distance matrix at

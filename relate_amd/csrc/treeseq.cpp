@@ -1195,6 +1195,10 @@ static int build_sections(rl_ctx *ctx, const char *out_dir, int chunk_index, int
   return rc;
 }
 
+int rl_debug_stage_worker_goal(int cus, int open_sections, int bounded_windows, int workers_per_cu) {
+  return rl::stage_worker_goal(cus, open_sections, bounded_windows != 0, workers_per_cu);
+}
+
 void rl_stage_opts_init(rl_stage_opts *o) {
   if (!o) return;
   memset(o, 0, sizeof(*o));
