@@ -2277,9 +2277,11 @@ static WorkerKind worker_kind(int N, bool ages) {
     return k;
   }
   const size_t dyn = lds_state_bytes(L_HOT, N);
-  // Two workgroups per CU (128 registers per lane) pay where HBM holds hundreds of sections' trees at once (small N);
-  // at N = 5000 a stage has ~134 sections open and a tree's latency decides: one per CU at 256 registers per lane
-  // (profiles/r06_builder_many.jsonl).  RELATE_AMD_BUILD_OCC=1 / 2 decides otherwise.
+  // Two workgroups per CU (128 registers per lane) hold half the CUs for the same workers -- the default where HBM
+  // holds hundreds of sections' trees at once (small N; no measurable difference on a C4 chunk either way); at
+  // N = 5000 a stage has ~134 sections open and a tree's latency decides: one per CU at 256 registers per lane, 1.33 x
+  // faster per tree (profiles/r06_builder_many.jsonl, r06_c4_chunk_occ.json).  RELATE_AMD_BUILD_OCC=1 / 2 decides
+  // otherwise.
   static const int occ_env = getenv("RELATE_AMD_BUILD_OCC") ? atoi(getenv("RELATE_AMD_BUILD_OCC")) : 0;
   const int occ_max = occ_env > 0 ? occ_env : (N <= MM_Q_SMALL * MM_BLOCK ? 2 : 1);
   if (N <= MM_Q_SMALL * MM_BLOCK && occ_max >= 2) {

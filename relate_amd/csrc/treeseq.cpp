@@ -357,9 +357,8 @@ rl_treeseq *treeseq_borrowing(int N, int L, const uint32_t *bits, int row_words,
 //     N = 2000, 5000 and 10,000;
 //   * `per_cu` worker slots per CU (two for the small-N kernel, minmatch_gpu.hip worker_kind): the CU share above is a
 //     share of CUs, the slots on them follow.
-// (The trees themselves are bound by the memory system, not by CUs -- profiles/r06_builder_many.jsonl: 128 workers
-//  build 495 trees/s side by side, 256 build 361 --, which is why more workers than this do not pay even where HBM
-//  would admit the sections.)
+// (A tree's time in the stage does not depend on the worker count -- 142-150 ms from 116 to 148 workers,
+//  profiles/r05_c3_runs.json --; past the share above it is RePaint, on the CUs left, that every section waits for.)
 namespace rl {
 int stage_worker_goal(int cus, int open_sections, bool bounded_windows, int per_cu) {
   const int share = bounded_windows ? 29 * cus / 64 : cus - cus / 8;
