@@ -1,5 +1,5 @@
 """SQ counters of the Paint launches per forward + backward step pair (one target at one visited site, both passes), from
-tools/gpu_r06_a.sh: the merged launch of each summation mode (the dispatches of the timed step AND of bench.py's
+tools/archive/gpu_r06_a.sh: the merged launch of each summation mode (the dispatches of the timed step AND of bench.py's
 split-direction measurement are in the trace: the merged ones are the kernels with DIR = 2).
     python tools/sq_report.py <dir> <label>"""
 import glob, json, sqlite3, sys
