@@ -969,7 +969,10 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
 #define MM_QC20 4
 #endif
     // clusters per pass (ten at once cost more in spilled registers than the second round trip)
-    constexpr int QC = MAXQ == MM_Q_GLOB ? MM_QC20 : MAXQ % 5 == 0 ? 5 : 4;
+#ifndef MM_QC10
+#define MM_QC10 5
+#endif
+    constexpr int QC = MAXQ == MM_Q_GLOB ? MM_QC20 : MAXQ % 5 == 0 ? (ROWS == 1 ? 5 : MM_QC10) : 4;
 #pragma unroll
     for (int q0 = 0; q0 < MAXQ; q0 += QC) {
       if (q0 * MM_BLOCK >= n) break;
@@ -985,7 +988,7 @@ __device__ __forceinline__ void build_tree(const MMParamsDev &p, Shared &sh, uns
       }
       // the candidate's fields from LDS: all of the pass at once while the registers allow (256 per lane: 2 ms of a
       // tree under load), at the cluster's turn in the 128-register kernels
-      constexpr bool JIT = State<LAY>::hot_lds && ROWS == 1;
+      constexpr bool JIT = State<LAY>::hot_lds && (ROWS == 1 || QC > 5);
       float s_d1[JIT ? 1 : QC], s_d2[JIT ? 1 : QC];
       int s_l1[JIT ? 1 : QC], s_l2[JIT ? 1 : QC];
       double s_d2d[AGES && !JIT ? QC : 1];
