@@ -50,7 +50,8 @@ constexpr int MM_BUCKET_MIN = 2048;  // (the AGES build) more pairs than this ar
 // one store per cluster down -- strides by 1 KB inside one panel of N KB, a few 2 MB pages, instead of by a whole
 // row (80 KB at N = 5000: every store on another page, the address translation of 2500 pages per merge).
 // (Rows in blocks of 128, so that a row spans fewer pages: no gain, DESIGN_NOTES.md 5.)
-constexpr int MM_PANEL = 64;
+constexpr int MM_PANEL = 64;  // (narrower panels -- a column's stores 128 / 256 / 512 B apart instead of 1 KB -- are no faster:
+                              //  118.1 / 115.5 / 114.9 ms per tree against 114.7, profiles/r06_panel_width.json)
 __host__ __device__ inline unsigned mm_index(unsigned a, unsigned b, unsigned N) {
   return ((b / MM_PANEL) * N + a) * MM_PANEL + (b % MM_PANEL);
 }
