@@ -189,3 +189,32 @@ def test_builders_side_by_side_with_hand_overs_and_the_symmetric_pool(monkeypatc
         d.close()
     assert on_gpu[0] == 2 and on_gpu[3] == 2  # the flat matrices went to the host, the others stayed
     assert 2 <= on_gpu[1] + on_gpu[2] <= 4    # with one symmetric matrix in the pool a circulant tree may be the host's
+
+
+@pytest.mark.parametrize("N,builders", [(300, 6), (2100, 3)])
+def test_many_builders_side_by_side_build_the_same_trees(N, builders):
+    """rl_debug_builder_throughput (the measurement hook of tools/bench_builder_many.py): several device builders, a host
+    thread each, build one matrix (with a prior) three times side by side, the matrices staged from device memory --
+    every builder's trees are builder 0's, and builder 0's first tree is the one a lone builder builds (N = 300: two
+    workers per CU, N = 2100: one)"""
+    import ctypes as C
+    rng = np.random.RandomState(11)
+    d = coalescent_matrix(rng, N)
+    pr = (np.floor(rng.rand(N, N) * 3) * 6.9).astype(np.float32)
+    lib = api.lib()
+    lib.rl_debug_builder_throughput.argtypes = [C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                                C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p]
+    secs, bad = C.c_double(0), C.c_int(-1)
+    reps = 3
+    first = np.zeros((reps, 2 * N - 1), np.int32)
+    dd = np.ascontiguousarray(d, dtype=np.float32)
+    rc = lib.rl_debug_builder_throughput(N, 0.001, 0, builders, reps, 0, dd.ctypes.data_as(C.c_void_p),
+                                         pr.ctypes.data_as(C.c_void_p), C.byref(secs), C.byref(bad),
+                                         first.ctypes.data_as(C.c_void_p))
+    assert rc == 0, lib.rl_last_error().decode()
+    assert bad.value == 0 and secs.value > 0.0
+    b = api.Builder(N, device=0)
+    for r in range(reps):  # (a builder carries its state from tree to tree: the same sequence)
+        want = b.build(d.copy(), pr)[0]
+        assert np.array_equal(first[r], want), "repetition %d" % r
+    b.close()
