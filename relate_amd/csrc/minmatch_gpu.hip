@@ -1899,6 +1899,7 @@ constexpr int MM_STAGING = 32;      // staging pairs (row-major distance matrix 
 constexpr int MM_QUEUE_CAP = 1024;  // requests in flight <= builders alive (a section has one tree in flight)
 constexpr int MM_LAUNCHES = 6;      // worker launches alive at once (a stream, i.e. a hardware queue, each)
 constexpr int MM_XCDS = 8;          // a launch's workgroups are dealt to the XCDs in turn
+constexpr int MM_WHOLE_ROUNDS = 64; // from this many workers on, launches and the goal are whole rounds of the XCDs
 struct WorkQueue {
   unsigned tail;
   unsigned pad[15];
@@ -2592,8 +2593,9 @@ class BuildQueue {
         // (the stage's word, expect(), is a limit -- it knows what RePaint needs of the chip; RELATE_AMD_BUILD_WORKERS
         //  overrides it)
         goal = (expected_ > 0 && !cap_from_env_) ? std::min(cap_, expected_) : cap_;
-        // whole rounds of the XCDs (below): the goal too
-        if (goal >= MM_XCDS) goal -= goal % MM_XCDS;
+        // whole rounds of the XCDs (below): the goal too -- where the workers are many enough for their spread over the
+        // XCDs to matter (a stage of 43 sections lost 3 of its workers to the rounding: config #5 on one GPU)
+        if (goal >= MM_WHOLE_ROUNDS) goal -= goal % MM_XCDS;
       }
       int alive = 0, free_stream = -1;
       for (int l = 0; l < MM_LAUNCHES; l++) {
@@ -2617,8 +2619,8 @@ class BuildQueue {
         // their remainders on the low XCDs (six launches: up to six workers more there than on XCD 7), and a RePaint
         // launch -- its workgroups dealt to the XCDs in the same round-robin -- lasts as long as the XCD with the
         // fewest CUs left.  Whole rounds only.
-        n = (n + MM_XCDS - 1) / MM_XCDS * MM_XCDS;
-        if (goal >= MM_XCDS) {
+        if (goal >= MM_WHOLE_ROUNDS) {
+          n = (n + MM_XCDS - 1) / MM_XCDS * MM_XCDS;
           // (`alive` counts live workers since round 4, so what is missing need not be a whole round: wait until it is)
           n = std::min(n, (goal - alive) / MM_XCDS * MM_XCDS);
           if (n <= 0) {

@@ -362,7 +362,11 @@ rl_treeseq *treeseq_borrowing(int N, int L, const uint32_t *bits, int row_words,
 namespace rl {
 int stage_worker_goal(int cus, int open_sections, bool bounded_windows, int per_cu) {
   const int share = bounded_windows ? 29 * cus / 64 : cus - cus / 8;
-  return std::max(1, std::min(open_sections, share * std::max(1, per_cu)));
+  int goal = std::max(1, std::min(open_sections, share * std::max(1, per_cu)));
+  // (whole rounds of the 8 XCDs once the workers are many -- a launch's workgroups go to the XCDs in turn, and RePaint
+  //  lasts as long as the XCD with the fewest CUs left: C3's 116 are 112 alive)
+  if (goal >= 64) goal -= goal % 8;
+  return goal;
 }
 }  // namespace rl
 
